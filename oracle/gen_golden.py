@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the LIVE reference (runs only where /root/reference exists).
+
+Test infrastructure.  The reference is imported read-only from /root/reference/src with import
+stubs for ROS / open3d / pytorch3d / tensorboard (none of them touches hot-path arithmetic, SURVEY
+8c).  The single arithmetic stub is pytorch3d.transforms.axis_angle_to_matrix, replaced by the
+oracle's restatement of the published algorithm (recorded in each fixture's ``meta``).
+
+Before a fixture is written, the oracle restatement (oracle/dc_oracle.py) is run on the same inputs
+and asserted equal to the reference's outputs, so a committed fixture certifies both.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn}.npz, about 5 MB)
+"""
+import os
+import sys
+import tempfile
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import dc_oracle as O                                                     # noqa: E402
+from depth_correction_amd.dataset import PlaneDataset, RoomBoxDataset, KittiLikeDataset, add_depth_noise  # noqa: E402
+
+for m in ['pytorch3d', 'pytorch3d.io', 'pytorch3d.structures', 'pytorch3d.ops', 'pytorch3d.ops.knn',
+          'pytorch3d.transforms', 'pytorch3d.renderer', 'open3d', 'ros_numpy', 'rospy', 'sensor_msgs',
+          'sensor_msgs.msg', 'geometry_msgs', 'geometry_msgs.msg', 'nav_msgs', 'nav_msgs.msg', 'std_msgs',
+          'std_msgs.msg', 'tf', 'tf.transformations', 'tf2_msgs', 'tf2_msgs.msg', 'torch.utils.tensorboard']:
+    sys.modules[m] = MagicMock()
+sys.modules['pytorch3d.transforms'].axis_angle_to_matrix = O.axis_angle_to_matrix
+sys.modules['rospy'].is_shutdown.return_value = False
+np.object = object                                   # removed numpy alias used at nearest_neighbors.py:69
+sys.path.insert(0, '/root/reference/src')
+
+import depth_correction.config as RC                                      # noqa: E402
+RC.cmd_out = lambda *a, **k: ('unknown', '')          # config.py:160 shells out to git
+from depth_correction.config import Config, PoseCorrection                # noqa: E402
+from depth_correction.depth_cloud import DepthCloud                       # noqa: E402
+from depth_correction.dataset import PlaneDataset as RefPlaneDataset      # noqa: E402
+from depth_correction.eval import eval_loss_clouds                        # noqa: E402
+from depth_correction.loss import create_loss, point_to_plane_dist        # noqa: E402
+from depth_correction.model import ScaledPolynomial, Polynomial           # noqa: E402
+from depth_correction.nearest_neighbors import nearest_neighbors          # noqa: E402
+from depth_correction.preproc import (establish_neighborhoods, global_cloud, global_cloud_mask,
+                                      local_feature_cloud)                # noqa: E402
+from depth_correction.transform import xyz_axis_angle_to_matrix          # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+META = ('reference: ctu-vras/depth_correction @ /root/reference; torch %s; scipy %s; numpy %s; '
+        'pytorch3d.axis_angle_to_matrix substituted by oracle restatement (unpinned)'
+        % (torch.__version__, __import__('scipy').__version__, np.__version__))
+
+
+def npy(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def compact(x):
+    """Indices as int32 (values < 2^31), everything else untouched."""
+    x = npy(x)
+    return x.astype(np.int32) if x.dtype == np.int64 else x
+
+
+def close(a, b, rtol=1e-9, atol=1e-12, what=''):
+    a, b = npy(a), npy(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ok = np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+    assert ok, '%s: max abs diff %.3g' % (what, np.nanmax(np.abs(a - b)))
+
+
+def xyz_of(cloud):
+    return np.stack([cloud[f] for f in 'xyz'], axis=1).astype(np.float64)
+
+
+def base_cfg(**kw):
+    cfg = Config()
+    cfg.log_dir = tempfile.mkdtemp()
+    cfg.min_depth, cfg.max_depth, cfg.grid_res = 0.0, float('inf'), 0.0
+    cfg.nn_r = None
+    cfg.log_filters = False
+    cfg.from_dict(kw)
+    return cfg
+
+
+def oracle_scans(ref_clouds):
+    return [dict(vps=c.vps.detach(), dirs=c.dirs.detach(), depth=c.depth.detach(), inc=c.inc_angles.detach(),
+                 mask=None if c.mask is None else c.mask) for c in ref_clouds]
+
+
+def run_sequence(name, scans_xyz, poses_np, cfg, w0, exponent, model_cls, variants, pose_deltas0=None,
+                 out=None, prefix='', grad_points_for=2):
+    """Drive the reference exactly like train.py:94-215 (set-up) and eval.py:85-112 (iteration).
+
+    With ``out``/``prefix`` given, only the variant results are added to an existing fixture dict
+    (same scans, poses and neighbourhoods as the base run)."""
+    base = out is None
+    if base:
+        out = dict(meta=np.array(META), cfg_nn_k=cfg.nn_k, cfg_min_valid_neighbors=cfg.min_valid_neighbors,
+                   eigenvalue_ratio_bounds=np.array(cfg.eigenvalue_ratio_bounds, dtype=np.float64),
+                   vp_dispersion_bounds=np.array(cfg.vp_dispersion_bounds, dtype=np.float64),
+                   poses=poses_np, n_scans=len(scans_xyz))
+    out[prefix + 'w'], out[prefix + 'exponent'] = np.array(w0), np.array(exponent)
+    out[prefix + 'model'] = np.array(model_cls.__name__)
+    clouds = [local_feature_cloud(xyz.copy(), cfg) for xyz in scans_xyz]             # train.py:94-104
+    poses = torch.as_tensor(poses_np)
+    for s, (xyz, c) in enumerate(zip(scans_xyz, clouds)):
+        if not base:
+            break
+        out['scan%d_xyz' % s] = xyz_of(xyz)
+        for f in ('dirs', 'depth', 'neighbors', 'eigvals', 'inc_angles', 'mask') + (('mean', 'cov') if s == 0 else ()):
+            out['scan%d_%s' % (s, f)] = compact(getattr(c, f))
+        out['scan%d_absdot' % s] = npy((c.dirs * c.normals).sum(-1).abs())
+        # restatement check: local features
+        dist_o, ind_o = O.knn_ckdtree(npy(c.points), cfg.nn_k)
+        assert np.array_equal(ind_o, npy(c.neighbors)), 'local knn'
+        f = O.features(c.points, c.neighbors, c.dirs)
+        for k in ('mean', 'cov', 'eigvals', 'inc_angles'):
+            close(f[k], getattr(c, k), what='local ' + k)
+        m = O.local_mask(c.eigvals, cfg.eigenvalue_bounds, cfg.eigenvalue_ratio_bounds)
+        assert torch.equal(m, c.mask), 'local mask'
+
+    g0 = global_cloud(clouds=clouds, poses=poses)                                   # train.py:166
+    ns = establish_neighborhoods(cloud=g0, cfg=cfg)                                 # train.py:172
+    mask = global_cloud_mask(g0, g0.mask if hasattr(g0, 'mask') else None, cfg)     # train.py:212
+    if base:
+        out['g_neighbors'] = compact(ns[0])
+        assert torch.equal(ns[1], (ns[0] >= 0).double()[..., None])                 # weights are implied
+        out['g_mask'] = npy(mask)
+        out['g0_points'], out['g0_eigvals'] = npy(g0.points), npy(g0.eigvals)
+        out['g0_vp_dispersion'] = npy(g0.vp_dispersion())
+        out['g0_dir_dispersion'] = npy(g0.dir_dispersion())
+    # restatement check: global neighbourhoods and mask
+    _, ind_o = O.knn_ckdtree(npy(g0.points), cfg.nn_k)
+    assert np.array_equal(ind_o, npy(ns[0])), 'global knn'
+    _, ind_b = O.knn_bruteforce(npy(g0.points), cfg.nn_k)
+    assert np.array_equal(ind_b, npy(ns[0])), 'global knn vs brute force'
+    lm = torch.cat([c.mask for c in clouds])
+    m_o = O.global_mask(lm, ns[0], g0.eigvals, vps=g0.vps, dirs=g0.dirs, weights=ns[1],
+                        min_valid_neighbors=cfg.min_valid_neighbors, eigenvalue_bounds=cfg.eigenvalue_bounds,
+                        eigenvalue_ratio_bounds=cfg.eigenvalue_ratio_bounds,
+                        dir_dispersion_bounds=cfg.dir_dispersion_bounds, vp_dispersion_bounds=cfg.vp_dispersion_bounds)
+    assert torch.equal(m_o, mask), 'global mask'
+    print('%s: N=%d, masked=%d' % (name, len(g0), int(mask.sum())))
+
+    for tag, loss_name, loss_kwargs in variants:
+        cfg.loss = loss_name
+        cfg.loss_kwargs.update(loss_kwargs)
+        cfg.pose_correction = PoseCorrection.pose if pose_deltas0 is not None else PoseCorrection.none
+        loss_fun = create_loss(cfg)
+        model = model_cls(w=list(w0), exponent=list(exponent))
+        pd = None
+        if pose_deltas0 is not None:
+            pd = torch.tensor(pose_deltas0, dtype=torch.float64, requires_grad=True)
+        loss, loss_clouds, poses_upd, feat = eval_loss_clouds([clouds], [poses], [pd], [mask], [ns], model,
+                                                              loss_fun, cfg)   # eval.py:85
+        fc = feat[0]
+        fc.points.retain_grad()
+        loss.backward()
+        tag = prefix + tag
+        out['%s_loss' % tag] = npy(loss)
+        out['%s_pointwise' % tag] = npy(loss_clouds[0].loss)
+        out['%s_grad_w' % tag] = npy(model.w.grad)
+        if grad_points_for > 0:
+            out['%s_grad_points' % tag] = npy(fc.points.grad)
+            grad_points_for -= 1
+        if pd is not None:
+            out['%s_grad_pose_deltas' % tag] = npy(pd.grad)
+            out[prefix + 'pose_deltas'] = np.array(pose_deltas0)
+            out[prefix + 'poses_upd'] = npy(poses_upd[0])
+        if tag == prefix + variants[0][0]:
+            for f in ('points', 'eigvals') + (('mean', 'cov', 'inc_angles') if base else ()):
+                out[prefix + 'g_' + f] = npy(getattr(fc, f))
+            if base:
+                out['g_absdot'] = npy((fc.dirs * fc.normals).sum(-1).abs())
+
+        # restatement check: the whole iteration through the oracle, autograd backward
+        w = torch.tensor([list(w0)], dtype=torch.float64, requires_grad=True)
+        e = torch.tensor([list(exponent)], dtype=torch.float64)
+        pdo = None if pd is None else torch.tensor(pose_deltas0, dtype=torch.float64, requires_grad=True)
+        lo, fo = O.eval_sequence(oracle_scans(clouds), poses, w, e, ns[0], mask, kind=loss_name,
+                                 model=model_cls.__name__, normalization=cfg.loss_kwargs['normalization'],
+                                 sqrt=cfg.loss_kwargs['sqrt'], pose_deltas=pdo, reduction='mean')
+        fo['points'].retain_grad()
+        lo.backward()
+        close(lo, loss, what=tag + ' loss')
+        close(w.grad, model.w.grad, rtol=1e-8, what=tag + ' grad_w')
+        close(fo['points'].grad, fc.points.grad, rtol=1e-8, atol=1e-14, what=tag + ' grad_points')
+        close(fo['eigvals'], fc.eigvals, what=tag + ' eigvals')
+        if pd is not None:
+            close(pdo.grad, pd.grad, rtol=1e-8, atol=1e-14, what=tag + ' grad_pose')
+        # closed form vs the reference's autograd
+        cf = O.closed_form_backward(npy(fc.points), npy(ns[0]), npy(mask), kind=loss_name,
+                                    normalization=cfg.loss_kwargs['normalization'], sqrt=cfg.loss_kwargs['sqrt'])
+        close(cf['loss'], loss, what=tag + ' closed-form loss')
+        close(cf['grad_points'], fc.points.grad, rtol=1e-6, atol=1e-13, what=tag + ' closed-form grad')
+        print('  %-22s loss=%.9g grad_w=%s' % (tag, loss.item(), npy(model.w.grad).ravel()))
+
+    if name:
+        np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
+    return out
+
+
+def gen_c0_plane():
+    """BASELINE config 0: PlaneDataset(10 000, 2 poses), nn_k=4, fp64, min_eigval_loss."""
+    ref_ds = RefPlaneDataset(n_pts=10_000, n_poses=2)
+    our_ds = PlaneDataset(n_pts=10_000, n_poses=2)
+    scans, poses = [], []
+    rng = np.random.default_rng(7)
+    for (rc, rp), (oc, op) in zip(ref_ds, our_ds):
+        close(xyz_of(rc), xyz_of(oc), what='PlaneDataset cloud')        # generator restatement check
+        close(rp, op, what='PlaneDataset pose')
+        scans.append(add_depth_noise(oc, 0.01, rng))
+        poses.append(op)
+    cfg = base_cfg(nn_k=4, min_valid_neighbors=4)
+    variants = [('mineig_norm', 'min_eigval_loss', dict(normalization=True, sqrt=False)),
+                ('mineig_raw', 'min_eigval_loss', dict(normalization=False, sqrt=False))]
+    run_sequence('c0_plane', scans, np.stack(poses), cfg, (-0.002, 0.001), (2.0, 4.0), ScaledPolynomial, variants)
+
+
+def gen_room():
+    """Room-box scans (configs 1-3 shape, reduced to 4 x 5000 points), nn_k=10, all loss variants,
+    then the same with per-pose corrections (model_poses_learning pattern)."""
+    ds = RoomBoxDataset(n_pts=2000, n_poses=4)
+    scans = [c for c, _ in ds]
+    poses = np.stack([p for _, p in ds])
+    cfg = base_cfg(nn_k=10, min_valid_neighbors=5, vp_dispersion_bounds=[])
+    variants = [('mineig_norm', 'min_eigval_loss', dict(normalization=True, sqrt=False)),
+                ('mineig_raw', 'min_eigval_loss', dict(normalization=False, sqrt=False)),
+                ('mineig_norm_sqrt', 'min_eigval_loss', dict(normalization=True, sqrt=True)),
+                ('mineig_raw_sqrt', 'min_eigval_loss', dict(normalization=False, sqrt=True)),
+                ('trace', 'trace_loss', dict(sqrt=False)),
+                ('trace_sqrt', 'trace_loss', dict(sqrt=True))]
+    out = run_sequence(None, scans, poses, cfg, (1e-3, 2e-3), (2.0, 4.0), ScaledPolynomial, variants)
+
+    rng = np.random.default_rng(11)
+    pd = np.concatenate([0.02 * rng.normal(size=(4, 3)), 0.01 * rng.normal(size=(4, 3))], axis=1)
+    pd[0] = 0.0                                                   # zero delta: the small-angle branch
+    cfg = base_cfg(nn_k=10, min_valid_neighbors=5, vp_dispersion_bounds=[])
+    variants = [('mineig_norm', 'min_eigval_loss', dict(normalization=True, sqrt=False)),
+                ('trace', 'trace_loss', dict(sqrt=False))]
+    run_sequence(None, scans, poses, cfg, (1e-3, 2e-3), (2.0, 4.0), ScaledPolynomial, variants,
+                 pose_deltas0=pd, out=out, prefix='poses_', grad_points_for=1)
+    cfg = base_cfg(nn_k=10, min_valid_neighbors=5, vp_dispersion_bounds=[])
+    variants = [('mineig_norm', 'min_eigval_loss', dict(normalization=True, sqrt=False))]
+    run_sequence('room_k10', scans, poses, cfg, (2e-3, -1e-3), (1.0, 3.0), Polynomial, variants,
+                 out=out, prefix='poly_', grad_points_for=0)
+
+
+def gen_icp():
+    """Config 4 shape reduced: KITTI-like ring scans, point-to-plane with precomputed correspondences
+    (train.py:178-210), gradient w.r.t. model weights and per-pose corrections."""
+    ds = KittiLikeDataset(n_poses=3, n_rings=16, n_azimuth=512)
+    cfg = base_cfg(nn_k=8, min_valid_neighbors=5, vp_dispersion_bounds=[])
+    clouds = [local_feature_cloud(c, cfg) for c, _ in ds]
+    poses = torch.as_tensor(np.stack([p for _, p in ds]))
+    ratio = 0.3
+    masks = []
+    for j in range(len(clouds) - 1):
+        p1 = npy(clouds[j].transform(poses[j]).to_points())
+        p2 = npy(clouds[j + 1].transform(poses[j + 1]).to_points())
+        m1, m2, _ = O.nn1_correspondences(p1, p2, ratio)
+        masks.append((m1, m2))
+    rng = np.random.default_rng(5)
+    pd0 = np.concatenate([0.02 * rng.normal(size=(3, 3)), 0.005 * rng.normal(size=(3, 3))], axis=1)
+    model = ScaledPolynomial(w=[1e-3, 2e-3], exponent=[2.0, 4.0])
+    pd = torch.tensor(pd0, dtype=torch.float64, requires_grad=True)
+    poses_upd = torch.matmul(poses, xyz_axis_angle_to_matrix(pd))
+    tc = [model(c).transform(p) for c, p in zip(clouds, poses_upd)]                 # loss.py:381-386
+    loss = point_to_plane_dist(tc, icp_inlier_ratio=ratio, masks=masks)
+    loss.backward()
+    out = dict(meta=np.array(META), poses=npy(poses), pose_deltas=pd0, w=npy(model.w), exponent=npy(model.exponent),
+               loss=npy(loss), grad_w=npy(model.w.grad), grad_pose_deltas=npy(pd.grad), n_scans=len(clouds),
+               ratio=ratio)
+    for s, c in enumerate(clouds):
+        for f in ('vps', 'dirs', 'depth', 'inc_angles', 'mask', 'normals'):
+            out['scan%d_%s' % (s, f)] = npy(getattr(c, f))
+    for j, (m1, m2) in enumerate(masks):
+        out['pair%d_mask1' % j], out['pair%d_idx2' % j] = m1, m2
+    # restatement check
+    w = torch.tensor(npy(model.w), requires_grad=True)
+    pdo = torch.tensor(pd0, dtype=torch.float64, requires_grad=True)
+    pu = torch.matmul(poses, O.xyz_axis_angle_to_matrix(pdo))
+    pts, nrm = [], []
+    for c, T in zip(clouds, pu):
+        d = O.model_apply(c.depth, c.inc_angles, c.mask, w, model.exponent.detach())
+        v, r, n = O.transform_cloud(c.vps, c.dirs, T, normals=c.normals.detach())
+        pts.append(O.points_from(v, r, d)), nrm.append(n)
+    lo = O.point_to_plane(pts, nrm, masks)
+    lo.backward()
+    close(lo, loss, what='icp loss')
+    close(w.grad, model.w.grad, rtol=1e-6, what='icp grad_w')
+    close(pdo.grad, pd.grad, rtol=1e-6, atol=1e-12, what='icp grad_pose')
+    print('icp_pairs: loss=%.9g grad_w=%s' % (loss.item(), npy(model.w.grad).ravel()))
+    np.savez_compressed(os.path.join(GOLD, 'icp_pairs.npz'), **out)
+
+
+def gen_knn():
+    """nearest_neighbors() itself: k, k within r, r only (nearest_neighbors.py:22-80)."""
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-2, 2, size=(2000, 3)) * [1, 1, 0.02],
+                          rng.uniform(-1, 1, size=(1000, 3))]).astype(np.float32).astype(np.float64)
+    p = torch.as_tensor(pts)
+    out = dict(meta=np.array(META), points=pts)
+    d, i = nearest_neighbors(p, p, k=10)
+    out['k10_dist'], out['k10_ind'] = npy(d), npy(i)
+    do, io = O.knn_bruteforce(pts, 10)
+    assert np.array_equal(io, npy(i))
+    close(do, d, what='knn dist')
+    d, i = nearest_neighbors(p, p, k=8, r=0.15)
+    out['k8_r015_dist'], out['k8_r015_ind'] = npy(d), npy(i)
+    do, io = O.knn_bruteforce(pts, 8, r=0.15)
+    assert np.array_equal(io, npy(i)), 'k within r'
+    close(np.where(np.isinf(do), -1, do), np.where(np.isinf(npy(d)), -1, npy(d)), what='knn r dist')
+    _, i = nearest_neighbors(p, p, r=0.12)
+    out['r012_ind'] = npy(i)
+    assert np.array_equal(O.radius_bruteforce(pts, 0.12), npy(i)), 'radius'
+    assert np.array_equal(O.radius_ckdtree(pts, 0.12), npy(i)), 'radius ckdtree'
+    print('knn: k10 / k8+r / r ok, Kmax(r=0.12)=%d' % npy(i).shape[1])
+    np.savez_compressed(os.path.join(GOLD, 'knn.npz'), **out)
+
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['knn', 'c0', 'room', 'icp']
+    if 'knn' in which:
+        gen_knn()
+    if 'c0' in which:
+        gen_c0_plane()
+    if 'room' in which:
+        gen_room()
+    if 'icp' in which:
+        gen_icp()
