@@ -1,0 +1,115 @@
+"""ctypes binding of libdc_hip.so (include/dc_hip.h) on torch device tensors.
+
+Thin and explicit: every wrapper checks shapes / dtypes / devices on the host (a kernel that reads
+out of bounds can take the whole GPU down), passes raw device pointers plus torch's current HIP
+stream, and raises on a non-zero status.  There is NO fallback: if the library cannot be loaded the
+first call raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+__all__ = ['lib', 'lib_path', 'DC_F32', 'DC_F64', 'DC_Q32', 'LOSS_KINDS', 'MODEL_KINDS']
+
+DC_F32, DC_F64, DC_Q32 = 0, 1, 2
+LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
+MODEL_KINDS = {None: 0, 'BaseModel': 0, 'Polynomial': 1, 'ScaledPolynomial': 2}
+MAX_MODEL_TERMS = 8
+
+_LIB = None
+_vp, _i32, _i64, _f64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
+
+_SIGNATURES = {
+    'dc_version': (ctypes.c_int, []),
+    'dc_knn_workspace_bytes': (_sz, [_i64, _i64]),
+    'dc_knn_build': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _sz, _vp]),
+    'dc_radius_count': (_i32, [_vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
+    'dc_radius_fill': (_i32, [_i64, _f64, _i32, _vp, _vp, _sz, _vp]),
+    'dc_knn_transpose_workspace_bytes': (_sz, [_i64, _i32]),
+    'dc_knn_transpose': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'dc_spatial_order_workspace_bytes': (_sz, [_i64]),
+    'dc_spatial_order': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
+    'dc_points_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
+                             _vp, _vp, _vp, _vp, _vp]),
+    'dc_partial_rows': (_i64, [_i64]),
+    'dc_param_grad_count': (_i32, [_i32, _i32]),
+    'dc_points_bwd': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32,
+                             _i32, _vp, _vp, _vp]),
+    'dc_features_fwd': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp]),
+    'dc_features_bwd': (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
+    'dc_consistency_bwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'dc_mask_bounds': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _f64, _f64, _vp, _vp]),
+    'dc_valid_count': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'dc_dispersion': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
+    'dc_p2plane_partial_count': (_i64, [_i64]),
+    'dc_p2plane_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
+                               _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+}
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libdc_hip.so')
+
+
+def lib():
+    """The loaded HIP library; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError('depth_correction_amd: %s is missing -- build it with `python -c "import '
+                               '__graft_entry__ as g; g.build()"` (hipcc, gfx950). There is no CPU fallback.' % path)
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError = header / library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def check(status, what):
+    if status != 0:
+        kind = {-1: 'invalid argument', -2: 'unsupported dtype', -3: 'workspace too small',
+                -4: 'unsupported size'}.get(status, 'HIP error %d' % status)
+        raise RuntimeError('%s failed: %s' % (what, kind))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return DC_F32
+    if t.dtype == torch.float64:
+        return DC_F64
+    raise TypeError('depth_correction_amd kernels take float32 or float64 tensors, got %s' % t.dtype)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def need(t, shape=None, dtype=None, name='tensor', device=None):
+    """Host-side operand check before a raw pointer goes to a kernel."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on the GPU (depth_correction_amd has no CPU path)' % name)
+    if device is not None and t.device != device:
+        raise RuntimeError('%s is on %s, expected %s' % (name, t.device, device))
+    if not t.is_contiguous():
+        raise RuntimeError('%s must be contiguous' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if shape is not None:
+        if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise ValueError('%s has shape %s, expected %s' % (name, tuple(t.shape), shape))
+    return t

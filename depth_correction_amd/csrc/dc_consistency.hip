@@ -1,0 +1,615 @@
+// Map-consistency hot path kernels (gfx950): corrected points, neighbourhood features + loss forward,
+// hand-derived backward.  C ABI at the bottom; declarations and reference citations in include/dc_hip.h.
+//
+// Data layout in HBM (all arrays owned by the caller, i.e. torch's allocator):
+//   per point (SoA): vps[N,3], dirs[N,3], depth[N], inc[N] (T = f32|f64), lmask u8[N], scan_id i32[N]
+//   points          x[N,S]  S = 3 (API layout) or 4 (padded: one 16-B gather per neighbour for f32 / q32);
+//                   point format PT = f32 | f64 | q32 (DC_Q32: int32 fixed point, x = origin + q * scale)
+//   neighbours      nbr i32[N,K] row major, -1 = missing
+//   backward record rec[N,8] = {cmean.xyz, c1, v0.xyz, c2} in the point format (32 B: two 16-B loads per edge)
+//   incoming edges  csr_ptr i32[N+1], csr_src i32[E]  (transpose of nbr, built once per neighbourhood set)
+// All arithmetic on chip is fp64 (differences against the centre point are exact, covariances and the
+// eigen-solve keep LAPACK-level accuracy); only storage is T.  No atomics: block partial sums are
+// written to a workspace and reduced in a fixed order, so every result is bitwise reproducible.
+#include "dc_common.h"
+#include "dc_device.h"
+#include "dc_pointmath.h"
+#include "dc_points_dev.h"
+
+namespace dc {
+
+// ------------------------------------------------------------------------------------------------
+// K1+K2+K3: d' = model(d, inc) on masked points, (vps, dirs) -> pose frame, x = vps' + d' dirs'.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename PT, int STRIDE>
+__global__ __launch_bounds__(kBlock) void points_fwd_kernel(PointInputs in, int64_t n, QParams qp, PT* __restrict__ x_out,
+                                                            T* __restrict__ vps_out, T* __restrict__ dirs_out,
+                                                            T* __restrict__ depth_out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  ModelParams mp;
+  load_model(in, mp);
+  double vp[3], dr[3], T12[12];
+  Row3<T, 3>::load((const T*)in.vps, i, vp, qp);
+  Row3<T, 3>::load((const T*)in.dirs, i, dr, qp);
+  const double d = (double)((const T*)in.depth)[i];
+  const bool lm = in.lmask ? in.lmask[i] != 0 : true;
+  const double inc = (mp.kind != DC_MODEL_NONE && lm) ? (double)((const T*)in.inc)[i] : 0.0;
+  const double dc_ = model_depth(mp, d, inc, lm);
+  load_pose(in, in.scan_id ? in.scan_id[i] : 0, T12);
+  double vr[3], drr[3], x[3];
+  rot3(T12, vp, vr);
+  vr[0] += T12[3]; vr[1] += T12[7]; vr[2] += T12[11];
+  rot3(T12, dr, drr);
+  x[0] = vr[0] + dc_ * drr[0]; x[1] = vr[1] + dc_ * drr[1]; x[2] = vr[2] + dc_ * drr[2];
+  Row3<PT, STRIDE>::store(x_out, i, x, qp);
+  if (vps_out) Row3<T, 3>::store(vps_out, i, vr, qp);
+  if (dirs_out) Row3<T, 3>::store(dirs_out, i, drr, qp);
+  if (depth_out) depth_out[i] = (T)dc_;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather one neighbourhood and accumulate mean / second moments about the centre point.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename PT, int STRIDE>
+__device__ __forceinline__ void gather_neighbourhood(const PT* __restrict__ x, const int32_t* __restrict__ nbr,
+                                                     const T* __restrict__ wmean, int64_t i, int k, const double* xi,
+                                                     const QParams& qp, CovAcc& acc) {
+  cov_init(acc);
+  const int32_t* row = nbr + i * k;
+  for (int q = 0; q < k; ++q) {
+    const int32_t j = row[q];
+    if (j < 0) continue;
+    double xj[3];
+    Row3<PT, STRIDE>::load(x, j, xj, qp);
+    const double wm = wmean ? (double)wmean[i * k + q] : 1.0;
+    cov_add(acc, xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2], wm);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hot-path forward: neighbourhood covariance -> smallest eigenpair -> pointwise loss + backward
+// record; block partial sums of (masked loss, mask count).
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename PT, int STRIDE>
+__global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
+    const PT* __restrict__ x, const int32_t* __restrict__ nbr, int64_t n, int k, const uint8_t* __restrict__ mask,
+    const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec, T* __restrict__ pointwise,
+    T* __restrict__ eigvals, double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / kWave) * 2];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0};
+  if (blk >= 0) {
+    const int64_t i = blk * kBlock + threadIdx.x;
+    if (i < n) {
+      double xi[3];
+      Row3<PT, STRIDE>::load(x, i, xi, qp);
+      CovAcc acc;
+      gather_neighbourhood<T, PT, STRIDE>(x, nbr, (const T*)nullptr, i, k, xi, qp, acc);
+      double moff[3], cm[3], C[6], D, omega;
+      cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
+      double lam[3], V[3][3];
+      eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
+      const bool m = mask ? mask[i] != 0 : true;
+      const double off = offset ? (double)offset[i] : 0.0;
+      const double tr = lam[0] + lam[1] + lam[2];
+      double c1, c2;
+      const double l = loss_and_coeffs(lp, lam[0], tr, D, off, m, &c1, &c2);
+      if (m) { acc2[0] = l; acc2[1] = 1.0; }
+      if (rec) {
+        const double mabs[3] = {xi[0] + cm[0], xi[1] + cm[1], xi[2] + cm[2]};
+        Rec8<PT>::store(rec, i, mabs, c1, V[0], c2, qp);
+      }
+      if (pointwise) pointwise[i] = (T)l;
+      if (eigvals) { eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2]; }
+    }
+  }
+  block_sum<2>(acc2, lds);
+  if (threadIdx.x == 0) {
+    partials[(int64_t)blockIdx.x * 2] = acc2[0];
+    partials[(int64_t)blockIdx.x * 2 + 1] = acc2[1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full neighbourhood features (DepthCloud.update_features): mean, cov, eigvals, eigvecs, normals,
+// incidence angles, valid-neighbour count, weights.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kBlock) void features_fwd_kernel(
+    const T* __restrict__ x, const int32_t* __restrict__ nbr, const T* __restrict__ wmean, const T* __restrict__ dirs,
+    int64_t n, int k, double scale, T* __restrict__ mean, T* __restrict__ cov, T* __restrict__ eigvals,
+    T* __restrict__ eigvecs, T* __restrict__ normals, T* __restrict__ inc, int32_t* __restrict__ nvalid,
+    T* __restrict__ weights_out, T* __restrict__ cmean_out, T* __restrict__ invd_out) {
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  if (blk < 0) return;
+  const int64_t i = blk * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const QParams qp{};
+  double xi[3];
+  Row3<T, STRIDE>::load(x, i, xi, qp);
+  CovAcc acc;
+  gather_neighbourhood<T, T, STRIDE>(x, nbr, wmean, i, k, xi, qp, acc);
+  double moff[3], cm[3], C[6], D, omega;
+  cov_finish(acc, scale, moff, cm, C, &D, &omega);
+  if (mean) { mean[i * 3] = (T)(xi[0] + moff[0]); mean[i * 3 + 1] = (T)(xi[1] + moff[1]); mean[i * 3 + 2] = (T)(xi[2] + moff[2]); }
+  if (cmean_out) { cmean_out[i * 3] = (T)(xi[0] + cm[0]); cmean_out[i * 3 + 1] = (T)(xi[1] + cm[1]); cmean_out[i * 3 + 2] = (T)(xi[2] + cm[2]); }
+  if (invd_out) invd_out[i] = (T)(omega / D);
+  if (cov) {
+    T* c = cov + i * 9;
+    c[0] = (T)C[0]; c[1] = (T)C[1]; c[2] = (T)C[2];
+    c[3] = (T)C[1]; c[4] = (T)C[3]; c[5] = (T)C[4];
+    c[6] = (T)C[2]; c[7] = (T)C[4]; c[8] = (T)C[5];
+  }
+  if (nvalid) nvalid[i] = (int32_t)acc.W;
+  if (weights_out) {
+    const int32_t* row = nbr + i * k;
+    for (int q = 0; q < k; ++q) weights_out[i * k + q] = row[q] >= 0 ? (T)omega : (T)0;
+  }
+  if (eigvals || eigvecs || normals || inc) {
+    double lam[3], V[3][3];
+    eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
+    if (eigvals) { eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2]; }
+    if (eigvecs) {   // torch layout: eigvecs[i, :, k] = k-th eigenvector
+      T* e = eigvecs + i * 9;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) e[r * 3 + c] = (T)V[c][r];
+    }
+    if (normals || inc) {
+      double dr[3], nrm[3], a;
+      Row3<T, 3>::load(dirs, i, dr, qp);
+      normal_and_incidence(dr, V[0], nrm, &a);
+      if (normals) Row3<T, 3>::store(normals, i, nrm, qp);
+      if (inc) inc[i] = (T)a;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward epilogue per point: dL/dx_j -> dL/dw, dL/dexponent, dL/d[R|t] of the point's scan.
+// acc layout: [0,P) grad w, [P,2P) grad exponent, then 12 per-scan slots handled by the caller.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j,
+                                                 const double* g, double* gw, double* ge, double* gT, int* scan) {
+  double vp[3], dr[3], T12[12];
+  const QParams qp0{};
+  Row3<T, 3>::load((const T*)in.vps, j, vp, qp0);
+  Row3<T, 3>::load((const T*)in.dirs, j, dr, qp0);
+  const double d = (double)((const T*)in.depth)[j];
+  const bool lm = in.lmask ? in.lmask[j] != 0 : true;
+  const int s = in.scan_id ? in.scan_id[j] : 0;
+  *scan = s;
+  load_pose(in, s, T12);
+  // dL/dd' = (R dir) . g = dir . (R^T g)
+  const double rg0 = T12[0] * g[0] + T12[4] * g[1] + T12[8] * g[2];
+  const double rg1 = T12[1] * g[0] + T12[5] * g[1] + T12[9] * g[2];
+  const double rg2 = T12[2] * g[0] + T12[6] * g[1] + T12[10] * g[2];
+  const double gd = dr[0] * rg0 + dr[1] * rg1 + dr[2] * rg2;
+  double dcorr = d;
+  if (mp.kind != DC_MODEL_NONE && lm) {
+    const double inc = (double)((const T*)in.inc)[j];
+    const double base = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d * gd : -gd;
+    double bias = 0.0;
+    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
+      if (k < mp.n_terms) {
+        const double pk = pow_term(inc, mp.e[k]);
+        bias += pk * mp.w[k];
+        gw[k] += base * pk;
+        if (ge) ge[k] += (inc > 0.0) ? base * mp.w[k] * pk * log(inc) : 0.0;
+      }
+    }
+    dcorr = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? d * (1.0 - bias) : d - bias;
+  }
+  if (gT) {
+    // x = R xl + t, xl = vps + d' dirs:  dL/dR = g xl^T, dL/dt = g
+    const double xl0 = vp[0] + dcorr * dr[0], xl1 = vp[1] + dcorr * dr[1], xl2 = vp[2] + dcorr * dr[2];
+    gT[0] = g[0] * xl0; gT[1] = g[0] * xl1; gT[2] = g[0] * xl2; gT[3] = g[0];
+    gT[4] = g[1] * xl0; gT[5] = g[1] * xl1; gT[6] = g[1] * xl2; gT[7] = g[1];
+    gT[8] = g[2] * xl0; gT[9] = g[2] * xl1; gT[10] = g[2] * xl2; gT[11] = g[2];
+  }
+}
+
+// Block-reduce the parameter gradients of one block into its partial row:
+//   [0,P) w, [P,2P) exponent, [2P, 2P + 12 S) poses.
+template <typename T>
+__device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool active, bool want_e, bool want_pose,
+                                                   double* gw, double* ge, double* gT, int scan, double* lds,
+                                                   double* __restrict__ prow) {
+  const int P = in.n_terms;
+  double v[2 * DC_MAX_MODEL_TERMS];
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) { v[k] = gw[k]; v[DC_MAX_MODEL_TERMS + k] = want_e ? ge[k] : 0.0; }
+  block_sum<2 * DC_MAX_MODEL_TERMS>(v, lds);
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < P; ++k) { prow[k] = v[k]; prow[P + k] = v[DC_MAX_MODEL_TERMS + k]; }
+  }
+  if (want_pose) {
+    // scans are interleaved after spatial sorting: reduce per scan id present in the block
+    for (int s = 0; s < in.n_scans; ++s) {
+      double t[12];
+      const bool mine = active && scan == s;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) t[q] = mine ? gT[q] : 0.0;
+      block_sum<12>(t, lds);
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) prow[2 * P + s * 12 + q] = t[q];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hot-path backward: dL/dx_j = sum over incoming edges (i -> j) of c1_i (v0_i . d) v0_i - c2_i d,
+// d = x_j - cmean_i, gathered through the transposed neighbour list; fused with the point epilogue.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename PT, int STRIDE>
+__global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
+    const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
+    const int32_t* __restrict__ csr_src, int64_t n, PointInputs in, QParams qp, int want_e, int want_pose,
+    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+  __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  ModelParams mp;
+  load_model(in, mp);
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
+  int scan = -1;
+  bool active = false;
+  if (blk >= 0) {
+    const int64_t j = blk * kBlock + threadIdx.x;
+    if (j < n) {
+      active = true;
+      double xj[3], g[3] = {0.0, 0.0, 0.0};
+      Row3<PT, STRIDE>::load(x, j, xj, qp);
+      const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
+      for (int32_t e = beg; e < end; ++e) {
+        double m[3], v[3], c1, c2;
+        Rec8<PT>::load(rec, csr_src[e], m, &c1, v, &c2, qp);
+        const double d0 = xj[0] - m[0], d1 = xj[1] - m[1], d2 = xj[2] - m[2];
+        const double t = c1 * (v[0] * d0 + v[1] * d1 + v[2] * d2);
+        g[0] += t * v[0] - c2 * d0;
+        g[1] += t * v[1] - c2 * d1;
+        g[2] += t * v[2] - c2 * d2;
+      }
+      if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
+      if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, want_e ? ge : nullptr, want_pose ? gT : nullptr, &scan);
+    }
+  }
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + (int64_t)blockIdx.x * n_acc);
+}
+
+// Stand-alone point epilogue for the un-fused API path (grad of points given).
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict__ grad_x, int64_t n, PointInputs in,
+                                                            int want_e, int want_pose, double* __restrict__ partials,
+                                                            int n_acc) {
+  __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  ModelParams mp;
+  load_model(in, mp);
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
+  int scan = -1;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = j < n;
+  if (active) {
+    double g[3];
+    Row3<T, STRIDE>::load(grad_x, j, g, QParams{});
+    points_bwd_point<T>(in, mp, j, g, gw, want_e ? ge : nullptr, want_pose ? gT : nullptr, &scan);
+  }
+  reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + (int64_t)blockIdx.x * n_acc);
+}
+
+// Generic neighbourhood-features backward for the un-fused API path:
+//   dL/dx_j = sum_{i -> j} [ Gs_i (x_j - cmean_i) + gm_i ],  grec[N,12] = {cmean.xyz, Gs(xx xy xz yy yz zz), gm.xyz}
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kBlock) void features_bwd_kernel(const T* __restrict__ x, const T* __restrict__ grec,
+                                                              const int32_t* __restrict__ csr_ptr,
+                                                              const int32_t* __restrict__ csr_src, int64_t n,
+                                                              T* __restrict__ grad_points) {
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  if (blk < 0) return;
+  const int64_t j = blk * kBlock + threadIdx.x;
+  if (j >= n) return;
+  double xj[3], g[3] = {0.0, 0.0, 0.0};
+  Row3<T, STRIDE>::load(x, j, xj, QParams{});
+  const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
+  for (int32_t e = beg; e < end; ++e) {
+    const T* r = grec + (int64_t)csr_src[e] * 12;
+    const double d0 = xj[0] - (double)r[0], d1 = xj[1] - (double)r[1], d2 = xj[2] - (double)r[2];
+    const double xx = r[3], xy = r[4], xz = r[5], yy = r[6], yz = r[7], zz = r[8];
+    g[0] += xx * d0 + xy * d1 + xz * d2 + (double)r[9];
+    g[1] += xy * d0 + yy * d1 + yz * d2 + (double)r[10];
+    g[2] += xz * d0 + yz * d1 + zz * d2 + (double)r[11];
+  }
+  Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
+}
+
+// Build the generic backward record from upstream gradients of (mean, cov, eigvals):
+//   G = V diag(ge) V^T + sym(gcov);  Gs = 2 (omega / D) G;  gm = gmean / W.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void features_grec_kernel(const T* __restrict__ cmean, const T* __restrict__ invd,
+                                                               const int32_t* __restrict__ nvalid,
+                                                               const T* __restrict__ eigvecs, const T* __restrict__ g_mean,
+                                                               const T* __restrict__ g_cov, const T* __restrict__ g_eig,
+                                                               int64_t n, T* __restrict__ grec) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double G[6] = {0, 0, 0, 0, 0, 0};
+  if (g_eig) {
+    const T* e = eigvecs + i * 9;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double ge = (double)g_eig[i * 3 + k];
+      const double v0 = e[0 * 3 + k], v1 = e[1 * 3 + k], v2 = e[2 * 3 + k];
+      G[0] += ge * v0 * v0; G[1] += ge * v0 * v1; G[2] += ge * v0 * v2;
+      G[3] += ge * v1 * v1; G[4] += ge * v1 * v2; G[5] += ge * v2 * v2;
+    }
+  }
+  if (g_cov) {
+    const T* c = g_cov + i * 9;
+    G[0] += (double)c[0]; G[1] += 0.5 * ((double)c[1] + (double)c[3]); G[2] += 0.5 * ((double)c[2] + (double)c[6]);
+    G[3] += (double)c[4]; G[4] += 0.5 * ((double)c[5] + (double)c[7]); G[5] += (double)c[8];
+  }
+  const double f = 2.0 * (double)invd[i];
+  T* r = grec + i * 12;
+  r[0] = cmean[i * 3]; r[1] = cmean[i * 3 + 1]; r[2] = cmean[i * 3 + 2];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) r[3 + q] = (T)(f * G[q]);
+  const double w = (double)nvalid[i];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) r[9 + q] = g_mean ? (T)((double)g_mean[i * 3 + q] / w) : (T)0;
+}
+
+// Sum block partial rows [n_rows, n_acc] in a fixed order into out[n_acc].
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n_rows,
+                                                                 int n_acc, double* __restrict__ out) {
+  __shared__ double lds[kBlock / kWave];
+  const int a = blockIdx.x;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < n_rows; r += kBlock) s += partials[r * n_acc + a];
+  double v[1] = {s};
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) out[a] = v[0];
+}
+
+}  // namespace dc
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+using namespace dc;
+
+#define DC_CHECK_LAUNCH()                                  \
+  do {                                                     \
+    hipError_t err__ = hipGetLastError();                  \
+    if (err__ != hipSuccess) return (int)err__;            \
+  } while (0)
+
+static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
+
+extern "C" {
+
+int dc_version(void) { return 100; }
+
+int64_t dc_partial_rows(int64_t n) { return xcd_grid(n_blocks(n)); }
+
+int dc_param_grad_count(int n_terms, int n_scans) { return 2 * n_terms + 12 * n_scans; }
+
+static PointInputs make_inputs(const void* vps, const void* dirs, const void* depth, const void* inc,
+                               const uint8_t* lmask, const int32_t* scan_id, const double* poses, int n_scans,
+                               int model_kind, int n_terms, const double* w, const double* e) {
+  PointInputs in;
+  in.vps = vps; in.dirs = dirs; in.depth = depth; in.inc = inc; in.lmask = lmask; in.scan_id = scan_id;
+  in.poses = poses; in.w = w; in.e = e; in.model_kind = model_kind; in.n_terms = n_terms; in.n_scans = n_scans;
+  return in;
+}
+
+static int check_model(int model_kind, int n_terms, const void* inc, const double* w, const double* e) {
+  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
+  if (model_kind != DC_MODEL_NONE) {
+    if (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !inc || !w || !e) return DC_ERR_ARG;
+  }
+  return DC_OK;
+}
+
+static int make_qparams(int point_fmt, int dtype, int stride, const double* qparams, QParams* qp) {
+  *qp = QParams{};
+  if (point_fmt == DC_Q32) {
+    if (!qparams || stride != 4 || dtype != DC_F32 || !(qparams[3] > 0.0)) return DC_ERR_ARG;
+    qp->origin[0] = qparams[0]; qp->origin[1] = qparams[1]; qp->origin[2] = qparams[2];
+    qp->scale = qparams[3];
+    qp->inv_scale = 1.0 / qparams[3];
+    return DC_OK;
+  }
+  return point_fmt == dtype ? DC_OK : DC_ERR_DTYPE;      // float / double points share the inputs' dtype
+}
+
+// Dispatch over (input dtype, point format, row stride).
+#define DC_DISPATCH_FMT(dtype, fmt, stride, LAUNCH)                       \
+  do {                                                                    \
+    if ((fmt) == DC_Q32) { LAUNCH(float, q32, 4); }                       \
+    else if ((dtype) == DC_F32) { if ((stride) == 3) { LAUNCH(float, float, 3); } else { LAUNCH(float, float, 4); } } \
+    else if ((dtype) == DC_F64) { if ((stride) == 3) { LAUNCH(double, double, 3); } else { LAUNCH(double, double, 4); } } \
+    else return DC_ERR_DTYPE;                                             \
+  } while (0)
+
+int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                  const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
+                  const double* w, const double* e, int64_t n, int dtype, int point_fmt, const double* qparams,
+                  int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, hipStream_t stream) {
+  if (n < 0 || !vps || !dirs || !depth || !points_out || (out_stride != 3 && out_stride != 4)) return DC_ERR_ARG;
+  if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
+  int rc = check_model(model_kind, n_terms, inc, w, e);
+  if (rc) return rc;
+  QParams qp;
+  rc = make_qparams(point_fmt, dtype, out_stride, qparams, &qp);
+  if (rc) return rc;
+  if (n == 0) return DC_OK;
+  if (model_kind == DC_MODEL_NONE) n_terms = 0;
+  PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
+  dim3 grid((unsigned)n_blocks(n)), block(kBlock);
+#define LAUNCH(T, PT, S) \
+  hipLaunchKernelGGL((points_fwd_kernel<T, PT, S>), grid, block, 0, stream, in, n, qp, (PT*)points_out, (T*)vps_out, (T*)dirs_out, (T*)depth_out)
+  DC_DISPATCH_FMT(dtype, point_fmt, out_stride, LAUNCH);
+#undef LAUNCH
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
+                       const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
+                       int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
+                       double* sums_out, hipStream_t stream) {
+  if (n < 0 || k < 1 || !points || !nbr || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
+  if (loss_kind != DC_LOSS_MIN_EIGVAL && loss_kind != DC_LOSS_TRACE) return DC_ERR_ARG;
+  QParams qp;
+  int rc = make_qparams(point_fmt, dtype, stride, qparams, &qp);
+  if (rc) return rc;
+  if (n == 0) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
+  LossParams lp{loss_kind, normalization, sqrt_};
+  const int64_t rows = xcd_grid(n_blocks(n));
+  dim3 grid((unsigned)rows), block(kBlock);
+#define LAUNCH(T, PT, S) \
+  hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, nbr, n, k, mask, \
+                     (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws)
+  DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH);
+#undef LAUNCH
+  DC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), block, 0, stream, partials_ws, rows, 2, sums_out);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
+                       const int32_t* csr_ptr, const int32_t* csr_src, int64_t n, const void* vps, const void* dirs,
+                       const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+                       const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
+                       int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
+                       double* grads_out, hipStream_t stream) {
+  if (n < 0 || !points || !rec || !csr_ptr || !csr_src || (stride != 3 && stride != 4)) return DC_ERR_ARG;
+  const bool params = dirs != nullptr;
+  if (!params && !grad_points) return DC_ERR_ARG;
+  if (params) {
+    if (!vps || !depth || !partials_ws || !grads_out) return DC_ERR_ARG;
+    if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
+    if (want_pose_grad && n_scans < 1) return DC_ERR_ARG;
+    int rc = check_model(model_kind, n_terms, inc, w, e);
+    if (rc) return rc;
+  }
+  QParams qp;
+  int rc = make_qparams(point_fmt, dtype, stride, qparams, &qp);
+  if (rc) return rc;
+  if (model_kind == DC_MODEL_NONE) n_terms = 0;
+  const int n_acc = 2 * n_terms + 12 * n_scans;
+  if (n == 0) return params ? (int)hipMemsetAsync(grads_out, 0, n_acc * sizeof(double), stream) : DC_OK;
+  PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
+  const int64_t rows = xcd_grid(n_blocks(n));
+  dim3 grid((unsigned)rows), block(kBlock);
+  if (params && !want_pose_grad && n_scans > 0) {
+    // pose slots are not produced: keep them zero
+    hipError_t err = hipMemsetAsync(partials_ws, 0, (size_t)rows * n_acc * sizeof(double), stream);
+    if (err != hipSuccess) return (int)err;
+  }
+#define LAUNCH(T, PT, S) \
+  hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, (const PT*)rec, csr_ptr, \
+                     csr_src, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc)
+  DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH);
+#undef LAUNCH
+  DC_CHECK_LAUNCH();
+  if (params && n_acc > 0) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), block, 0, stream, partials_ws, rows, n_acc, grads_out);
+    DC_CHECK_LAUNCH();
+  }
+  return DC_OK;
+}
+
+int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, const void* vps, const void* dirs,
+                  const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+                  const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
+                  int want_exponent_grad, int want_pose_grad, double* partials_ws, double* grads_out,
+                  hipStream_t stream) {
+  if (n < 0 || !grad_points || !vps || !dirs || !depth || !partials_ws || !grads_out || (stride != 3 && stride != 4))
+    return DC_ERR_ARG;
+  if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
+  int rc = check_model(model_kind, n_terms, inc, w, e);
+  if (rc) return rc;
+  if (model_kind == DC_MODEL_NONE) n_terms = 0;
+  const int n_acc = 2 * n_terms + 12 * n_scans;
+  if (n_acc == 0) return DC_OK;
+  if (n == 0) return (int)hipMemsetAsync(grads_out, 0, n_acc * sizeof(double), stream);
+  PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
+  const int64_t rows = n_blocks(n);
+  dim3 grid((unsigned)rows), block(kBlock);
+  if (!want_pose_grad && n_scans > 0) {
+    hipError_t err = hipMemsetAsync(partials_ws, 0, (size_t)rows * n_acc * sizeof(double), stream);
+    if (err != hipSuccess) return (int)err;
+  }
+#define LAUNCH(T, S) \
+  hipLaunchKernelGGL((points_bwd_kernel<T, S>), grid, block, 0, stream, (const T*)grad_points, n, in, \
+                     want_exponent_grad, want_pose_grad, partials_ws, n_acc)
+  if (dtype == DC_F32) { if (stride == 3) LAUNCH(float, 3); else LAUNCH(float, 4); }
+  else if (dtype == DC_F64) { if (stride == 3) LAUNCH(double, 3); else LAUNCH(double, 4); }
+  else return DC_ERR_DTYPE;
+#undef LAUNCH
+  DC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), block, 0, stream, partials_ws, rows, n_acc, grads_out);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nbr, int64_t n, int k,
+                    const void* mean_weights, double scale, const void* dirs, void* mean, void* cov, void* eigvals,
+                    void* eigvecs, void* normals, void* inc_angles, int32_t* nvalid, void* weights_out,
+                    void* cmean_out, void* invd_out, hipStream_t stream) {
+  if (n < 0 || k < 1 || !points || !nbr || (stride != 3 && stride != 4)) return DC_ERR_ARG;
+  if ((normals || inc_angles) && !dirs) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  dim3 grid((unsigned)xcd_grid(n_blocks(n))), block(kBlock);
+#define LAUNCH(T, S) \
+  hipLaunchKernelGGL((features_fwd_kernel<T, S>), grid, block, 0, stream, (const T*)points, nbr, (const T*)mean_weights, \
+                     (const T*)dirs, n, k, scale, (T*)mean, (T*)cov, (T*)eigvals, (T*)eigvecs, (T*)normals, \
+                     (T*)inc_angles, nvalid, (T*)weights_out, (T*)cmean_out, (T*)invd_out)
+  if (dtype == DC_F32) { if (stride == 3) LAUNCH(float, 3); else LAUNCH(float, 4); }
+  else if (dtype == DC_F64) { if (stride == 3) LAUNCH(double, 3); else LAUNCH(double, 4); }
+  else return DC_ERR_DTYPE;
+#undef LAUNCH
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* csr_ptr, const int32_t* csr_src,
+                    int64_t n, const void* cmean, const void* invd, const int32_t* nvalid, const void* eigvecs,
+                    const void* grad_mean, const void* grad_cov, const void* grad_eigvals, void* grec_ws,
+                    void* grad_points, hipStream_t stream) {
+  if (n < 0 || !points || !csr_ptr || !csr_src || !cmean || !invd || !nvalid || !grec_ws || !grad_points) return DC_ERR_ARG;
+  if (stride != 3 && stride != 4) return DC_ERR_ARG;
+  if (grad_eigvals && !eigvecs) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  dim3 block(kBlock);
+#define LAUNCH(T, S) \
+  do { \
+    hipLaunchKernelGGL((features_grec_kernel<T>), dim3((unsigned)n_blocks(n)), block, 0, stream, (const T*)cmean, \
+                       (const T*)invd, nvalid, (const T*)eigvecs, (const T*)grad_mean, (const T*)grad_cov, \
+                       (const T*)grad_eigvals, n, (T*)grec_ws); \
+    hipLaunchKernelGGL((features_bwd_kernel<T, S>), dim3((unsigned)xcd_grid(n_blocks(n))), block, 0, stream, \
+                       (const T*)points, (const T*)grec_ws, csr_ptr, csr_src, n, (T*)grad_points); \
+  } while (0)
+  if (dtype == DC_F32) { if (stride == 3) LAUNCH(float, 3); else LAUNCH(float, 4); }
+  else if (dtype == DC_F64) { if (stride == 3) LAUNCH(double, 3); else LAUNCH(double, 4); }
+  else return DC_ERR_DTYPE;
+#undef LAUNCH
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// Device-side helpers shared by the kernels: typed loads/stores, wave64 / block reductions,
+// XCD-aware block remap.  gfx950 only (wavefront = 64 lanes, 8 XCDs).
+#pragma once
+#include "dc_common.h"
+
+namespace dc {
+
+constexpr int kBlock = 256;          // 4 waves, one per SIMD
+constexpr int kWave = 64;
+constexpr int kXcds = 8;
+
+// Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Give every XCD one contiguous
+// range of the point array, so the neighbour gathers of spatially sorted points stay in that XCD's L2.
+// Returns the logical block index, or -1 for the padding blocks of the last round.
+__device__ __forceinline__ int64_t xcd_block(int64_t n_logical) {
+  const int64_t per = (n_logical + kXcds - 1) / kXcds;
+  const int64_t b = blockIdx.x;
+  const int64_t logical = (b % kXcds) * per + b / kXcds;
+  return logical < n_logical ? logical : -1;
+}
+inline int64_t xcd_grid(int64_t n_logical) { return ((n_logical + kXcds - 1) / kXcds) * kXcds; }
+
+// ---- xyz rows: element stride 3 (API tensors) or 4 (padded internal layout) ------------------------
+// Point formats: float, double, or q32 (fixed point, DC_Q32).  All loads return fp64 absolute coordinates.
+struct q32 { int32_t v; };
+struct QParams { double origin[3]; double scale; double inv_scale; };
+
+template <typename T> struct Scalar { typedef T type; };          // element type of derived float outputs
+template <> struct Scalar<q32> { typedef float type; };
+
+template <typename T, int STRIDE> struct Row3;
+template <typename T> struct Row3<T, 3> {
+  static __device__ __forceinline__ void load(const T* p, int64_t i, double* o, const QParams&) {
+    const T* q = p + i * 3;
+    o[0] = (double)q[0]; o[1] = (double)q[1]; o[2] = (double)q[2];
+  }
+  static __device__ __forceinline__ void store(T* p, int64_t i, const double* v, const QParams&) {
+    T* q = p + i * 3;
+    q[0] = (T)v[0]; q[1] = (T)v[1]; q[2] = (T)v[2];
+  }
+};
+template <> struct Row3<float, 4> {
+  static __device__ __forceinline__ void load(const float* p, int64_t i, double* o, const QParams&) {
+    const float4 v = reinterpret_cast<const float4*>(p)[i];
+    o[0] = (double)v.x; o[1] = (double)v.y; o[2] = (double)v.z;
+  }
+  static __device__ __forceinline__ void store(float* p, int64_t i, const double* v, const QParams&) {
+    reinterpret_cast<float4*>(p)[i] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.f);
+  }
+};
+template <> struct Row3<double, 4> {
+  static __device__ __forceinline__ void load(const double* p, int64_t i, double* o, const QParams&) {
+    const double2* q = reinterpret_cast<const double2*>(p) + 2 * i;
+    const double2 a = q[0], b = q[1];
+    o[0] = a.x; o[1] = a.y; o[2] = b.x;
+  }
+  static __device__ __forceinline__ void store(double* p, int64_t i, const double* v, const QParams&) {
+    double2* q = reinterpret_cast<double2*>(p) + 2 * i;
+    q[0] = make_double2(v[0], v[1]);
+    q[1] = make_double2(v[2], 0.0);
+  }
+};
+__device__ __forceinline__ int32_t quantize(double x, double origin, double inv_scale) {
+  double q = rint((x - origin) * inv_scale);
+  q = q > 2147483520.0 ? 2147483520.0 : (q < -2147483520.0 ? -2147483520.0 : q);   // saturate, NaN -> below
+  return (q == q) ? (int32_t)q : (int32_t)0x80000000;
+}
+template <> struct Row3<q32, 4> {
+  static __device__ __forceinline__ void load(const q32* p, int64_t i, double* o, const QParams& qp) {
+    const int4 v = reinterpret_cast<const int4*>(p)[i];
+    o[0] = qp.origin[0] + (double)v.x * qp.scale;
+    o[1] = qp.origin[1] + (double)v.y * qp.scale;
+    o[2] = qp.origin[2] + (double)v.z * qp.scale;
+  }
+  static __device__ __forceinline__ void store(q32* p, int64_t i, const double* v, const QParams& qp) {
+    reinterpret_cast<int4*>(p)[i] = make_int4(quantize(v[0], qp.origin[0], qp.inv_scale),
+                                              quantize(v[1], qp.origin[1], qp.inv_scale),
+                                              quantize(v[2], qp.origin[2], qp.inv_scale), 0);
+  }
+};
+
+// ---- backward record rows [N,8] = {cmean.xyz, c1, v0.xyz, c2} in the point format ----------------------
+template <typename T> struct Rec8 {
+  static __device__ __forceinline__ void store(T* rec, int64_t i, const double* m, double c1, const double* v, double c2,
+                                               const QParams&) {
+    T* r = rec + i * 8;
+    r[0] = (T)m[0]; r[1] = (T)m[1]; r[2] = (T)m[2]; r[3] = (T)c1;
+    r[4] = (T)v[0]; r[5] = (T)v[1]; r[6] = (T)v[2]; r[7] = (T)c2;
+  }
+  static __device__ __forceinline__ void load(const T* rec, int64_t i, double* m, double* c1, double* v, double* c2,
+                                              const QParams&) {
+    const T* r = rec + i * 8;
+    m[0] = (double)r[0]; m[1] = (double)r[1]; m[2] = (double)r[2]; *c1 = (double)r[3];
+    v[0] = (double)r[4]; v[1] = (double)r[5]; v[2] = (double)r[6]; *c2 = (double)r[7];
+  }
+};
+template <> struct Rec8<float> {
+  static __device__ __forceinline__ void store(float* rec, int64_t i, const double* m, double c1, const double* v,
+                                               double c2, const QParams&) {
+    float4* r = reinterpret_cast<float4*>(rec) + 2 * i;
+    r[0] = make_float4((float)m[0], (float)m[1], (float)m[2], (float)c1);
+    r[1] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)c2);
+  }
+  static __device__ __forceinline__ void load(const float* rec, int64_t i, double* m, double* c1, double* v, double* c2,
+                                              const QParams&) {
+    const float4* r = reinterpret_cast<const float4*>(rec) + 2 * i;
+    const float4 a = r[0], b = r[1];
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; *c1 = a.w; v[0] = b.x; v[1] = b.y; v[2] = b.z; *c2 = b.w;
+  }
+};
+template <> struct Rec8<q32> {
+  static __device__ __forceinline__ void store(q32* rec, int64_t i, const double* m, double c1, const double* v,
+                                               double c2, const QParams& qp) {
+    int4* r = reinterpret_cast<int4*>(rec) + 2 * i;
+    r[0] = make_int4(quantize(m[0], qp.origin[0], qp.inv_scale), quantize(m[1], qp.origin[1], qp.inv_scale),
+                     quantize(m[2], qp.origin[2], qp.inv_scale), __float_as_int((float)c1));
+    reinterpret_cast<float4*>(r)[1] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)c2);
+  }
+  static __device__ __forceinline__ void load(const q32* rec, int64_t i, double* m, double* c1, double* v, double* c2,
+                                              const QParams& qp) {
+    const int4* r = reinterpret_cast<const int4*>(rec) + 2 * i;
+    const int4 a = r[0];
+    const float4 b = reinterpret_cast<const float4*>(r)[1];
+    m[0] = qp.origin[0] + (double)a.x * qp.scale; m[1] = qp.origin[1] + (double)a.y * qp.scale;
+    m[2] = qp.origin[2] + (double)a.z * qp.scale; *c1 = (double)__int_as_float(a.w);
+    v[0] = b.x; v[1] = b.y; v[2] = b.z; *c2 = b.w;
+  }
+};
+
+// ---- reductions ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Sum `NV` per-thread doubles over the block; thread 0 receives the totals in `v`.
+// `lds` must hold (kBlock / kWave) * NV doubles.  Fixed order => bitwise reproducible.
+template <int NV>
+__device__ __forceinline__ void block_sum(double* v, double* lds) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double s = wave_sum(v[q]);
+    if (lane == 0) lds[wave * NV + q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      double s = 0.0;
+      for (int wv = 0; wv < kBlock / kWave; ++wv) s += lds[wv * NV + q];
+      v[q] = s;
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace dc

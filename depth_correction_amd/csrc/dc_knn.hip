@@ -1,0 +1,657 @@
+// Neighbourhood builder on the GPU (gfx950): k-NN / k-within-radius / radius / cross-cloud 1-NN over lidar
+// points, plus the transposed neighbour list used by the backward and the spatial (Morton) order used
+// to lay a sequence out in HBM.  Replaces scipy.spatial.cKDTree at reference nearest_neighbors.py:46-51
+// (and loss.py:442-443, train.py:188-189).  C ABI at the bottom; see include/dc_hip.h.
+//
+// Contract reproduced from cKDTree (fp64 tree even for fp32 input): neighbours ordered by ascending
+// fp64 squared distance s = ((dx*dx + dy*dy) + dz*dz) evaluated WITHOUT fused multiply-add, query()
+// keeps d2 < r*r, query_ball_point() keeps d2 <= r*r and returns ascending indices, missing -> -1 / inf.
+// Exact distance ties are outside the contract (cKDTree orders them by tree traversal); here they are
+// ordered by index, so results are deterministic.
+//
+// Structure: points are binned into a uniform grid whose cell keys are 63-bit Morton codes; a radix
+// sort (rocPRIM) groups the cells, an open-addressing hash table maps key -> [begin, end) in the sorted
+// array.  One lane per query walks cube shells of cells outwards until the k-th best distance is
+// provably final.  Queries are processed in Morton order, so the lanes of a wavefront read the same
+// few cells (L1/L2 hits) and the sorted coordinates they stream are contiguous.
+#include <cstring>
+#include <cstdlib>
+#include "dc_common.h"
+#include "dc_device.h"
+#include <rocprim/rocprim.hpp>
+
+namespace dc {
+
+struct Grid {
+  double origin[3];
+  double h, inv_h;
+  int32_t dim[3];
+};
+
+constexpr uint64_t kEmptyKey = ~0ull;
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__device__ __forceinline__ uint64_t morton3(int32_t x, int32_t y, int32_t z) {
+  return spread21((uint32_t)x) | (spread21((uint32_t)y) << 1) | (spread21((uint32_t)z) << 2);
+}
+__device__ __forceinline__ void cell_of(const Grid& g, const double* p, int32_t* c) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double f = floor((p[a] - g.origin[a]) * g.inv_h);
+    int32_t ci = (f > 0.0) ? ((f < (double)(g.dim[a] - 1)) ? (int32_t)f : g.dim[a] - 1) : 0;   // NaN -> 0
+    c[a] = ci;
+  }
+}
+__device__ __forceinline__ uint32_t hash_key(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_xyz(const T* p, int64_t i, int stride, double* o) {
+  const T* q = p + i * stride;
+  o[0] = (double)q[0]; o[1] = (double)q[1]; o[2] = (double)q[2];
+}
+
+// ---- bounding box (finite points only) ----------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const T* __restrict__ xyz, int stride, int64_t n,
+                                                              double* __restrict__ part) {
+  __shared__ double lds[(kBlock / kWave) * 6];
+  double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    double p[3];
+    load_xyz(xyz, i, stride, p);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (isfinite(p[a])) { v[a] = fmin(v[a], p[a]); v[3 + a] = fmax(v[3 + a], p[a]); }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    double s = v[q];
+    for (int off = 32; off > 0; off >>= 1) {
+      double o = __shfl_down(s, off, 64);
+      s = q < 3 ? fmin(s, o) : fmax(s, o);
+    }
+    if (lane == 0) lds[wave * 6 + q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int q = threadIdx.x;
+    double s = lds[q];
+    for (int wv = 1; wv < kBlock / kWave; ++wv) s = q < 3 ? fmin(s, lds[wv * 6 + q]) : fmax(s, lds[wv * 6 + q]);
+    part[(int64_t)blockIdx.x * 6 + q] = s;
+  }
+}
+
+// One thread: finish the bounding box and choose the cell size.
+//   cell_hint > 0 : use it (radius searches use r).
+//   otherwise     : lidar points lie on surfaces; with areal density sigma ~ N / A(bbox) a cell of edge
+//                   h holds ~ sigma h^2 points and a ball of radius h ~ pi sigma h^2, so h = sqrt(A k / (2N))
+//                   lets most queries finish after the first shell.
+__global__ void grid_setup_kernel(const double* __restrict__ part, int n_part, int64_t n, int k, double cell_hint,
+                                  Grid* __restrict__ g) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int b = 0; b < n_part; ++b)
+    for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], part[b * 6 + a]); hi[a] = fmax(hi[a], part[b * 6 + 3 + a]); }
+  double L[3], Lmax = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    if (!(hi[a] >= lo[a])) { lo[a] = 0.0; hi[a] = 0.0; }
+    L[a] = hi[a] - lo[a];
+    Lmax = fmax(Lmax, L[a]);
+  }
+  double h = cell_hint;
+  if (!(h > 0.0)) {
+    const double area = 2.0 * (L[0] * L[1] + L[1] * L[2] + L[0] * L[2]);
+    const double kk = k > 1 ? (double)k : 2.0;
+    h = area > 0.0 ? sqrt(area * kk / (2.0 * (double)(n > 0 ? n : 1))) : Lmax / 16.0;
+    if (!(h > 0.0)) h = 1.0;
+  }
+  const double hmin = Lmax / 2097150.0;          // at most 2^21 - 1 cells per axis
+  if (h < hmin) h = hmin;
+  g->h = h;
+  g->inv_h = 1.0 / h;
+  for (int a = 0; a < 3; ++a) {
+    g->origin[a] = lo[a];
+    double d = floor(L[a] / h) + 1.0;
+    g->dim[a] = d < 2097151.0 ? (int32_t)d : 2097151;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__ xyz, int stride, int64_t n,
+                                                           const Grid* __restrict__ gp, uint64_t* __restrict__ keys,
+                                                           int32_t* __restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const Grid g = *gp;
+  double p[3];
+  int32_t c[3];
+  load_xyz(xyz, i, stride, p);
+  cell_of(g, p, c);
+  keys[i] = morton3(c[0], c[1], c[2]);
+  ids[i] = (int32_t)i;
+}
+
+// Fine Morton key over the bounding box (21 bits per axis) for the spatial layout order.
+__global__ void box_finish_kernel(const double* __restrict__ part, int n_part, double* __restrict__ box) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int b = 0; b < n_part; ++b)
+    for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], part[b * 6 + a]); hi[a] = fmax(hi[a], part[b * 6 + 3 + a]); }
+  double Lmax = 0.0;
+  for (int a = 0; a < 3; ++a) { if (!(hi[a] >= lo[a])) { lo[a] = hi[a] = 0.0; } Lmax = fmax(Lmax, hi[a] - lo[a]); }
+  box[0] = lo[0]; box[1] = lo[1]; box[2] = lo[2];
+  box[3] = Lmax > 0.0 ? 2097151.0 / Lmax : 0.0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fine_keys_kernel(const T* __restrict__ xyz, int stride, int64_t n,
+                                                           const double* __restrict__ box,
+                                                           uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double s = box[3];
+  double p[3];
+  int32_t c[3];
+  load_xyz(xyz, i, stride, p);
+  for (int a = 0; a < 3; ++a) {
+    double f = (p[a] - box[a]) * s;
+    c[a] = (f > 0.0) ? (f < 2097151.0 ? (int32_t)f : 2097151) : 0;
+  }
+  keys[i] = morton3(c[0], c[1], c[2]);
+  ids[i] = (int32_t)i;
+}
+
+// Gather the sorted fp64 coordinates and insert every cell's first position into the hash table.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restrict__ xyz, int stride, int64_t n,
+                                                               const uint64_t* __restrict__ skeys,
+                                                               const int32_t* __restrict__ sids,
+                                                               double* __restrict__ sp, uint64_t* __restrict__ tab_key,
+                                                               int32_t* __restrict__ tab_beg, uint32_t tab_mask) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  double x[3];
+  load_xyz(xyz, sids[p], stride, x);
+  sp[p * 3] = x[0]; sp[p * 3 + 1] = x[1]; sp[p * 3 + 2] = x[2];
+  const uint64_t key = skeys[p];
+  if (p == 0 || skeys[p - 1] != key) {
+    uint32_t slot = hash_key(key) & tab_mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&tab_key[slot], (unsigned long long)kEmptyKey,
+                                                (unsigned long long)key);
+      if (prev == kEmptyKey || prev == key) { tab_beg[slot] = (int32_t)p; break; }
+      slot = (slot + 1) & tab_mask;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const uint64_t* __restrict__ skeys,
+                                                          const uint64_t* __restrict__ tab_key,
+                                                          int32_t* __restrict__ tab_end, uint32_t tab_mask) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t key = skeys[p];
+  if (p == n - 1 || skeys[p + 1] != key) {
+    uint32_t slot = hash_key(key) & tab_mask;
+    while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
+    tab_end[slot] = (int32_t)(p + 1);
+  }
+}
+
+struct CellTable {
+  const uint64_t* key;
+  const int32_t* beg;
+  const int32_t* end;
+  uint32_t mask;
+};
+
+__device__ __forceinline__ bool find_cell(const CellTable& t, uint64_t key, int32_t* b, int32_t* e) {
+  uint32_t slot = hash_key(key) & t.mask;
+  while (true) {
+    const uint64_t k = t.key[slot];
+    if (k == key) { *b = t.beg[slot]; *e = t.end[slot]; return true; }
+    if (k == kEmptyKey) return false;
+    slot = (slot + 1) & t.mask;
+  }
+}
+
+// cKDTree's squared distance: products and sums individually rounded, in axis order.
+__device__ __forceinline__ double sqdist(const double* a, const double* b) {
+  const double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+  double s = __dmul_rn(d0, d0);
+  s = __dadd_rn(s, __dmul_rn(d1, d1));
+  s = __dadd_rn(s, __dmul_rn(d2, d2));
+  return s;
+}
+
+// Visit the cells of the cube shell at Chebyshev distance r around cell c.
+template <typename F>
+__device__ __forceinline__ void for_shell(const Grid& g, const int32_t* c, int r, F&& f) {
+  const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+  const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+  const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+  for (int z = z0; z <= z1; ++z) {
+    const bool zf = (z == c[2] - r) || (z == c[2] + r);
+    for (int y = y0; y <= y1; ++y) {
+      const bool yf = zf || (y == c[1] - r) || (y == c[1] + r);
+      if (yf) {
+        for (int x = x0; x <= x1; ++x) f(x, y, z);
+      } else {
+        if (c[0] - r >= 0) f(c[0] - r, y, z);
+        if (r > 0 && c[0] + r <= g.dim[0] - 1) f(c[0] + r, y, z);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool shell_in_grid(const Grid& g, const int32_t* c, int r) {
+  return c[0] - r >= 0 || c[1] - r >= 0 || c[2] - r >= 0 || c[0] + r < g.dim[0] || c[1] + r < g.dim[1] ||
+         c[2] + r < g.dim[2];
+}
+
+// Lower bound on the distance from q (in cell c) to any point outside the shells 0..r.
+__device__ __forceinline__ double shell_bound(const Grid& g, const double* q, const int32_t* c, int r) {
+  double fmin_ = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double lo = g.origin[a] + (double)c[a] * g.h, hi = lo + g.h;
+    fmin_ = fmin(fmin_, fmin(q[a] - lo, hi - q[a]));
+  }
+  if (!(fmin_ > 0.0)) fmin_ = 0.0;
+  const double b = (double)r * g.h + fmin_ - 1e-7 * g.h;      // guard against cell-assignment rounding
+  return b > 0.0 ? b : 0.0;
+}
+
+// ---- k nearest neighbours ---------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                           const double* __restrict__ queries,
+                                                           const int32_t* __restrict__ qids, int64_t n_query,
+                                                           const Grid* __restrict__ gp, CellTable tab, int k, double r_max,
+                                                           int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_query) return;
+  const Grid g = *gp;
+  const double q[3] = {queries[t * 3], queries[t * 3 + 1], queries[t * 3 + 2]};
+  const int64_t row = qids ? qids[t] : t;
+  double bd[KMAX];
+  int32_t bi[KMAX];
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+  const double ub2 = r_max > 0.0 ? r_max * r_max : INFINITY;
+  double worst_d = INFINITY;
+  int32_t worst_i = 0x7fffffff;
+  int32_t c[3];
+  cell_of(g, q, c);
+  const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+  for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+    for_shell(g, c, r, [&](int x, int y, int z) {
+      int32_t b, e;
+      if (!find_cell(tab, morton3(x, y, z), &b, &e)) return;
+      for (int32_t p = b; p < e; ++p) {
+        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
+        double d = sqdist(pp, q);
+        int32_t id = sids[p];
+        if (!(d < ub2)) continue;
+        if (!(d < worst_d || (d == worst_d && id < worst_i))) continue;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+          const bool lt = (d < bd[s]) || (d == bd[s] && id < bi[s]);
+          const double td = bd[s];
+          const int32_t ti = bi[s];
+          bd[s] = lt ? d : td; bi[s] = lt ? id : ti;
+          d = lt ? td : d; id = lt ? ti : id;
+        }
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) if (s == k - 1) { worst_d = bd[s]; worst_i = bi[s]; }
+      }
+    });
+    const double bound = shell_bound(g, q, c, r);
+    const double b2 = bound * bound;
+    if (worst_d < b2) break;              // k-th best is closer than anything unvisited
+    if (b2 >= ub2) break;                 // everything unvisited is beyond the radius
+  }
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    if (s < k) {
+      const bool ok = bi[s] != 0x7fffffff;
+      idx_out[row * k + s] = ok ? bi[s] : -1;
+      if (dist_out) dist_out[row * k + s] = ok ? sqrt(bd[s]) : INFINITY;
+    }
+  }
+}
+
+// ---- radius search: count, then fill (ascending index, -1 padded) ------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                        int64_t n, const Grid* __restrict__ gp, CellTable tab, double rad,
+                                                        int32_t* __restrict__ count, int32_t* __restrict__ idx_out,
+                                                        int kmax) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n) return;
+  const Grid g = *gp;
+  const double q[3] = {sp[t * 3], sp[t * 3 + 1], sp[t * 3 + 2]};
+  const int64_t row = sids[t];
+  const double r2 = rad * rad;
+  int32_t c[3];
+  cell_of(g, q, c);
+  int32_t cnt = 0;
+  int32_t* out = FILL ? idx_out + row * kmax : nullptr;
+  const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+  for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+    for_shell(g, c, r, [&](int x, int y, int z) {
+      int32_t b, e;
+      if (!find_cell(tab, morton3(x, y, z), &b, &e)) return;
+      for (int32_t p = b; p < e; ++p) {
+        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
+        if (sqdist(pp, q) <= r2) {
+          if (FILL) {
+            // insertion into the ascending row (rows are short)
+            const int32_t id = sids[p];
+            int32_t s = cnt;
+            while (s > 0 && out[s - 1] > id) { out[s] = out[s - 1]; --s; }
+            out[s] = id;
+          }
+          ++cnt;
+        }
+      }
+    });
+    const double bound = shell_bound(g, q, c, r);
+    if (bound > rad) break;
+  }
+  if (FILL) {
+    for (int32_t s = cnt; s < kmax; ++s) out[s] = -1;
+  } else {
+    count[row] = cnt;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void to_f64_kernel(const T* __restrict__ xyz, int stride, int64_t n,
+                                                        double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double p[3];
+  load_xyz(xyz, i, stride, p);
+  out[i * 3] = p[0]; out[i * 3 + 1] = p[1]; out[i * 3 + 2] = p[2];
+}
+
+// ---- transposed neighbour list ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void edge_keys_kernel(const int32_t* __restrict__ nbr, int64_t n_edges, int k,
+                                                           int32_t n, uint32_t* __restrict__ keys,
+                                                           int32_t* __restrict__ src) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n_edges) return;
+  const int32_t j = nbr[e];
+  keys[e] = (j >= 0 && j < n) ? (uint32_t)j : (uint32_t)n;      // missing neighbours sort to the end
+  src[e] = (int32_t)(e / k);
+}
+
+__global__ __launch_bounds__(kBlock) void csr_ptr_kernel(const uint32_t* __restrict__ skeys, int64_t n_edges, int32_t n,
+                                                         int32_t* __restrict__ ptr) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j > n) return;
+  int64_t lo = 0, hi = n_edges;             // first position with key >= j
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (skeys[mid] < (uint32_t)j) lo = mid + 1; else hi = mid;
+  }
+  ptr[j] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(kBlock) void max_i32_kernel(const int32_t* __restrict__ v, int64_t n, int32_t* __restrict__ out) {
+  int32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) m = max(m, v[i]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// ---- workspace carving -------------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* b) : base((char*)b), off(0) {}
+  template <typename U> U* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    U* p = base ? (U*)(base + off) : nullptr;
+    off += count * sizeof(U);
+    return p;
+  }
+};
+
+constexpr int kBoxBlocks = 256;
+
+static uint32_t table_size(int64_t n) {
+  uint64_t s = 1024;
+  while (s < (uint64_t)(2 * n + 2)) s <<= 1;
+  return (uint32_t)s;
+}
+
+struct GridWs {
+  double* part; Grid* grid; uint64_t* keys; uint64_t* skeys; int32_t* ids; int32_t* sids; double* sp;
+  uint64_t* tab_key; int32_t* tab_beg; int32_t* tab_end; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
+  double* qf64; size_t total;
+};
+
+static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
+  GridWs g;
+  Carver c(ws);
+  g.part = c.take<double>(kBoxBlocks * 6);
+  g.grid = c.take<Grid>(1);
+  g.keys = c.take<uint64_t>(n);
+  g.skeys = c.take<uint64_t>(n);
+  g.ids = c.take<int32_t>(n);
+  g.sids = c.take<int32_t>(n);
+  g.sp = c.take<double>(3 * n);
+  g.tab_n = table_size(n);
+  g.tab_key = c.take<uint64_t>(g.tab_n);
+  g.tab_beg = c.take<int32_t>(g.tab_n);
+  g.tab_end = c.take<int32_t>(g.tab_n);
+  g.qf64 = c.take<double>(3 * n_query_extra);
+  g.sort_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr,
+                            (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0, 63, (hipStream_t)0);
+  g.sort_tmp = c.take<char>(g.sort_bytes);
+  g.total = c.off + 256;
+  return g;
+}
+
+#define DC_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+template <typename T>
+static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hint, GridWs& w, hipStream_t st) {
+  const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL((bbox_partial_kernel<T>), dim3(kBoxBlocks), dim3(kBlock), 0, st, xyz, stride, n, w.part);
+  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1), 0, st, w.part, kBoxBlocks, n, k, cell_hint, w.grid);
+  hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.grid, w.keys, w.ids);
+  DC_HIP(rocprim::radix_sort_pairs(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, 63, st));
+  DC_HIP(hipMemsetAsync(w.tab_key, 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
+  hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp,
+                     w.tab_key, w.tab_beg, w.tab_n - 1);
+  hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, w.tab_key, w.tab_end, w.tab_n - 1);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+static int launch_knn(int k, const double* sp, const int32_t* sids, const double* q, const int32_t* qids, int64_t nq,
+                      const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, hipStream_t st) {
+  const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
+#define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist)
+  if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
+#undef LK
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+extern "C" {
+
+size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
+  if (n < 0 || n_query < 0) return 0;
+  return carve_grid(nullptr, n, n_query).total;
+}
+
+// Self k-NN (query == NULL) or cross-cloud k-NN of `query` in `points`.
+int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride, int64_t n_query,
+                 int k, double r, double cell_hint, int32_t* idx_out, double* dist_out, void* ws, size_t ws_bytes,
+                 hipStream_t stream) {
+  if (!points || n < 0 || k < 1 || k > 64 || !idx_out || !ws || stride < 3) return DC_ERR_ARG;
+  if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  if (query && (n_query < 0 || q_stride < 3)) return DC_ERR_ARG;
+  const int64_t nq = query ? n_query : 0;
+  GridWs w = carve_grid(ws, n, nq);
+  if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
+  if (n == 0) {
+    if (query && n_query > 0) {
+      DC_HIP(hipMemsetAsync(idx_out, 0xff, (size_t)n_query * k * sizeof(int32_t), stream));
+      // dist = inf is not a byte pattern; callers treat idx = -1 as authoritative
+    }
+    return DC_OK;
+  }
+  int rc;
+  if (dtype == DC_F32) rc = build_grid((const float*)points, stride, n, k, cell_hint, w, stream);
+  else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, k, cell_hint, w, stream);
+  else return DC_ERR_DTYPE;
+  if (rc) return rc;
+  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  if (!query) return launch_knn(k, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, stream);
+  if (n_query == 0) return DC_OK;
+  const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
+  else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
+  return launch_knn(k, w.sp, w.sids, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, stream);
+}
+
+// Radius search, pass 1: per-point neighbour counts and their maximum (device scalars).
+int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double r, int32_t* count_out,
+                    int32_t* kmax_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!points || n < 0 || !(r > 0.0) || !count_out || !kmax_out || !ws || stride < 3) return DC_ERR_ARG;
+  if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  GridWs w = carve_grid(ws, n, 0);
+  if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
+  DC_HIP(hipMemsetAsync(kmax_out, 0, sizeof(int32_t), stream));
+  if (n == 0) return DC_OK;
+  int rc;
+  if (dtype == DC_F32) rc = build_grid((const float*)points, stride, n, 0, r, w, stream);
+  else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, 0, r, w, stream);
+  else return DC_ERR_DTYPE;
+  if (rc) return rc;
+  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, count_out, nullptr, 0);
+  hipLaunchKernelGGL(max_i32_kernel, dim3(256), block, 0, stream, count_out, n, kmax_out);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+// Radius search, pass 2: the grid of pass 1 must still be in `ws` (same points, same r, same stream).
+int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || !(r > 0.0) || kmax < 1 || !idx_out || !ws) return DC_ERR_ARG;
+  GridWs w = carve_grid(ws, n, 0);
+  if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
+  if (n == 0) return DC_OK;
+  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, nullptr, idx_out, kmax);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+size_t dc_knn_transpose_workspace_bytes(int64_t n, int k) {
+  if (n < 0 || k < 1) return 0;
+  const int64_t ne = n * k;
+  Carver c(nullptr);
+  c.take<uint32_t>(ne); c.take<uint32_t>(ne); c.take<int32_t>(ne);
+  size_t sb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                            (size_t)(ne > 0 ? ne : 1), 0, 32, (hipStream_t)0);
+  c.take<char>(sb);
+  return c.off + 256;
+}
+
+// csr_ptr[N+1], csr_src[N*K]: for every point j the ascending list of centres i whose neighbourhood contains j.
+int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int32_t* csr_ptr, int32_t* csr_src, void* ws, size_t ws_bytes,
+                     hipStream_t stream) {
+  if (!nbr || n < 0 || k < 1 || !csr_ptr || !csr_src || !ws) return DC_ERR_ARG;
+  const int64_t ne = n * k;
+  if (ne >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  if (ws_bytes < dc_knn_transpose_workspace_bytes(n, k)) return DC_ERR_WORKSPACE;
+  if (n == 0) return (int)hipMemsetAsync(csr_ptr, 0, sizeof(int32_t), stream);
+  Carver c(ws);
+  uint32_t* keys = c.take<uint32_t>(ne);
+  uint32_t* skeys = c.take<uint32_t>(ne);
+  int32_t* src = c.take<int32_t>(ne);
+  size_t sb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                            (size_t)ne, 0, 32, (hipStream_t)0);
+  void* tmp = c.take<char>(sb);
+  int bits = 1;
+  while (((int64_t)1 << bits) <= n) ++bits;
+  const dim3 block(kBlock);
+  hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)((ne + kBlock - 1) / kBlock)), block, 0, stream, nbr, ne, k, (int32_t)n, keys, src);
+  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, src, csr_src, (size_t)ne, 0, (unsigned)bits, stream));
+  hipLaunchKernelGGL(csr_ptr_kernel, dim3((unsigned)((n + 1 + kBlock - 1) / kBlock)), block, 0, stream, skeys, ne, (int32_t)n, csr_ptr);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+size_t dc_spatial_order_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  Carver c(nullptr);
+  c.take<double>(kBoxBlocks * 6); c.take<double>(4); c.take<uint64_t>(n); c.take<uint64_t>(n); c.take<int32_t>(n);
+  size_t sb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                            (size_t)(n > 0 ? n : 1), 0, 63, (hipStream_t)0);
+  c.take<char>(sb);
+  return c.off + 256;
+}
+
+// order_out[p] = index of the point at position p of the Morton (Z-curve) order over the bounding box.
+int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32_t* order_out, void* ws, size_t ws_bytes,
+                     hipStream_t stream) {
+  if (!points || n < 0 || !order_out || !ws || stride < 3) return DC_ERR_ARG;
+  if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  if (ws_bytes < dc_spatial_order_workspace_bytes(n)) return DC_ERR_WORKSPACE;
+  if (n == 0) return DC_OK;
+  Carver c(ws);
+  double* part = c.take<double>(kBoxBlocks * 6);
+  double* box = c.take<double>(4);
+  uint64_t* keys = c.take<uint64_t>(n);
+  uint64_t* skeys = c.take<uint64_t>(n);
+  int32_t* ids = c.take<int32_t>(n);
+  size_t sb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                            (size_t)n, 0, 63, (hipStream_t)0);
+  void* tmp = c.take<char>(sb);
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32) {
+    hipLaunchKernelGGL((bbox_partial_kernel<float>), dim3(kBoxBlocks), block, 0, stream, (const float*)points, stride, n, part);
+    hipLaunchKernelGGL(box_finish_kernel, dim3(1), dim3(1), 0, stream, part, kBoxBlocks, box);
+    hipLaunchKernelGGL((fine_keys_kernel<float>), grid, block, 0, stream, (const float*)points, stride, n, box, keys, ids);
+  } else if (dtype == DC_F64) {
+    hipLaunchKernelGGL((bbox_partial_kernel<double>), dim3(kBoxBlocks), block, 0, stream, (const double*)points, stride, n, part);
+    hipLaunchKernelGGL(box_finish_kernel, dim3(1), dim3(1), 0, stream, part, kBoxBlocks, box);
+    hipLaunchKernelGGL((fine_keys_kernel<double>), grid, block, 0, stream, (const double*)points, stride, n, box, keys, ids);
+  } else return DC_ERR_DTYPE;
+  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, ids, order_out, (size_t)n, 0, 63, stream));
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+"""Operator layer: one Python function per C-ABI entry point (include/dc_hip.h), torch tensors in and out.
+
+No autograd here (see ``autograd.py``) and no CPU implementation: every function requires GPU tensors
+and the HIP library.  Shapes follow the reference's tensors (``[N,3]`` points, ``[N,K]`` neighbours ...).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as nv
+from ._native import lib, check, need, ptr, stream_ptr, dtype_code
+
+__all__ = [
+    'knn', 'radius_neighbors', 'knn_transpose', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
+    'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair',
+    'as_index32',
+]
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+
+
+def as_index32(neighbors):
+    """Reference neighbour tensors are int64 (nearest_neighbors.py:78); the kernels take int32."""
+    if neighbors.dtype == torch.int32:
+        return neighbors.contiguous()
+    assert neighbors.dtype == torch.int64
+    return neighbors.to(torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# neighbourhood builder
+# ------------------------------------------------------------------------------------------------
+def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
+    """k-NN of ``query`` (default: ``points`` itself) in ``points``: (dist f64 [M,k] | None, idx i32 [M,k])."""
+    need(points, (None, 3), name='points')
+    n = points.shape[0]
+    if not (1 <= k <= 64):
+        raise ValueError('k must be in 1..64, got %r' % (k,))
+    if query is not None:
+        need(query, (None, 3), dtype=points.dtype, name='query', device=points.device)
+    m = n if query is None else query.shape[0]
+    idx = torch.empty((m, k), dtype=torch.int32, device=points.device)
+    dist = torch.full((m, k), float('inf'), dtype=torch.float64, device=points.device) if want_dist else None
+    if n == 0:
+        idx.fill_(-1)
+        return dist, idx
+    nbytes = lib().dc_knn_workspace_bytes(n, 0 if query is None else m)
+    ws = _ws(nbytes, points.device)
+    check(lib().dc_knn_build(ptr(points), 3, dtype_code(points), n, ptr(query), 3, 0 if query is None else m, k,
+                             float(r) if r else 0.0, float(cell_hint), ptr(idx), ptr(dist), ptr(ws), nbytes,
+                             stream_ptr()), 'dc_knn_build')
+    return dist, idx
+
+
+def radius_neighbors(points, r):
+    """All neighbours within ``r`` (inclusive), ascending index, padded with -1: idx i32 [N, Kmax]."""
+    need(points, (None, 3), name='points')
+    n = points.shape[0]
+    if n == 0:
+        return torch.empty((0, 0), dtype=torch.int32, device=points.device)
+    nbytes = lib().dc_knn_workspace_bytes(n, 0)
+    ws = _ws(nbytes, points.device)
+    count = torch.empty((n,), dtype=torch.int32, device=points.device)
+    kmax = torch.zeros((1,), dtype=torch.int32, device=points.device)
+    check(lib().dc_radius_count(ptr(points), 3, dtype_code(points), n, float(r), ptr(count), ptr(kmax), ptr(ws), nbytes,
+                                stream_ptr()), 'dc_radius_count')
+    km = int(kmax.item())            # set-up phase: the padded width is needed on the host
+    idx = torch.empty((n, max(km, 1)), dtype=torch.int32, device=points.device)
+    check(lib().dc_radius_fill(n, float(r), max(km, 1), ptr(idx), ptr(ws), nbytes, stream_ptr()), 'dc_radius_fill')
+    return idx
+
+
+def knn_transpose(nbr):
+    """(csr_ptr i32 [N+1], csr_src i32 [N*K]) -- incoming edges of every point."""
+    need(nbr, (None, None), dtype=torch.int32, name='neighbors')
+    n, k = nbr.shape
+    csr_ptr = torch.empty((n + 1,), dtype=torch.int32, device=nbr.device)
+    csr_src = torch.empty((max(n * k, 1),), dtype=torch.int32, device=nbr.device)
+    nbytes = lib().dc_knn_transpose_workspace_bytes(n, k)
+    ws = _ws(nbytes, nbr.device)
+    check(lib().dc_knn_transpose(ptr(nbr), n, k, ptr(csr_ptr), ptr(csr_src), ptr(ws), nbytes, stream_ptr()),
+          'dc_knn_transpose')
+    return csr_ptr, csr_src
+
+
+def spatial_order(points):
+    need(points, (None, 3), name='points')
+    n = points.shape[0]
+    order = torch.empty((n,), dtype=torch.int32, device=points.device)
+    nbytes = lib().dc_spatial_order_workspace_bytes(n)
+    ws = _ws(nbytes, points.device)
+    check(lib().dc_spatial_order(ptr(points), 3, dtype_code(points), n, ptr(order), ptr(ws), nbytes, stream_ptr()),
+          'dc_spatial_order')
+    return order
+
+
+# ------------------------------------------------------------------------------------------------
+# points (model + pose + ray end point)
+# ------------------------------------------------------------------------------------------------
+class PointSet:
+    """Validated per-point inputs of one sequence (local scans concatenated)."""
+
+    def __init__(self, vps, dirs, depth, inc=None, lmask=None, scan_id=None):
+        need(dirs, (None, 3), name='dirs')
+        n = dirs.shape[0]
+        dev, dt = dirs.device, dirs.dtype
+        need(vps, (n, 3), dtype=dt, name='vps', device=dev)
+        depth = depth.reshape(-1)
+        need(depth, (n,), dtype=dt, name='depth', device=dev)
+        if inc is not None:
+            inc = inc.reshape(-1)
+            need(inc, (n,), dtype=dt, name='inc_angles', device=dev)
+        if lmask is not None:
+            need(lmask, (n,), dtype=torch.bool, name='mask', device=dev)
+        if scan_id is not None:
+            need(scan_id, (n,), dtype=torch.int32, name='scan_id', device=dev)
+        self.vps, self.dirs, self.depth, self.inc, self.lmask, self.scan_id = vps, dirs, depth, inc, lmask, scan_id
+        self.n, self.device, self.dtype = n, dev, dt
+
+
+def _model_args(model_kind, w, e, ps):
+    kind = nv.MODEL_KINDS[model_kind] if not isinstance(model_kind, int) else model_kind
+    if kind == 0:
+        return 0, 0, None, None
+    need(w, (None,), dtype=torch.float64, name='w', device=ps.device)
+    need(e, (w.shape[0],), dtype=torch.float64, name='exponent', device=ps.device)
+    if not (1 <= w.shape[0] <= nv.MAX_MODEL_TERMS):
+        raise ValueError('model must have 1..%d terms' % nv.MAX_MODEL_TERMS)
+    if ps.inc is None:
+        raise ValueError('the model needs incidence angles')
+    return kind, w.shape[0], w, e
+
+
+def _pose_args(poses, ps):
+    if poses is None:
+        if ps.scan_id is not None:
+            raise ValueError('scan_id given without poses')
+        return None, 0
+    need(poses, (None, 12), dtype=torch.float64, name='poses[S,12]', device=ps.device)
+    return poses, poses.shape[0]
+
+
+class QFormat:
+    """Fixed-point parameters of the DC_Q32 point format: x = origin + q * scale (q int32)."""
+
+    def __init__(self, origin, scale):
+        self.origin = [float(v) for v in origin]
+        self.scale = float(scale)
+        self._c = (ctypes.c_double * 4)(*self.origin, self.scale)
+
+    @staticmethod
+    def for_extent(lo, hi, margin=4.0):
+        """Power-of-two resolution covering `margin` x the half extent of the box [lo, hi] about its centre."""
+        import math
+        origin = [(a + b) / 2 for a, b in zip(lo, hi)]
+        half = max(max((b - a) / 2 for a, b in zip(lo, hi)), 1e-3)
+        return QFormat(origin, 2.0 ** (math.ceil(math.log2(half * margin)) - 31))
+
+
+def _fmt_args(points_dtype, qfmt):
+    """(point_fmt code, qparams pointer) for a points / rec buffer."""
+    if qfmt is not None:
+        return nv.DC_Q32, qfmt._c
+    return (nv.DC_F32 if points_dtype == torch.float32 else nv.DC_F64), None
+
+
+def _check_points(points, qfmt, name='points'):
+    need(points, (None, None), name=name)
+    if qfmt is not None:
+        need(points, (None, 4), dtype=torch.int32, name=name + ' (q32)')
+    elif points.shape[1] not in (3, 4) or not points.dtype.is_floating_point:
+        raise ValueError('%s must be float [N,3] or [N,4]' % name)
+
+
+def points_fwd(ps, poses=None, model_kind=None, w=None, e=None, stride=3, want_parts=False, qfmt=None, out=None):
+    """x = pose(vps) + model(depth) * pose(dirs); optionally also (vps', dirs', depth').
+    With ``qfmt`` the points are written as int32 fixed-point rows [N,4] (DC_Q32)."""
+    kind, nt, w, e = _model_args(model_kind, w, e, ps)
+    poses, ns = _pose_args(poses, ps)
+    if qfmt is not None:
+        stride = 4
+        if ps.dtype != torch.float32:
+            raise TypeError('the q32 point format goes with float32 inputs')
+    x = out if out is not None else torch.empty((ps.n, stride), dtype=torch.int32 if qfmt is not None else ps.dtype,
+                                                device=ps.device)
+    _check_points(x, qfmt, 'points_out')
+    assert x.shape == (ps.n, stride) and x.device == ps.device
+    fmt, qptr = _fmt_args(ps.dtype, qfmt)
+    parts = (torch.empty_like(ps.vps), torch.empty_like(ps.dirs), torch.empty_like(ps.depth)) if want_parts \
+        else (None, None, None)
+    check(lib().dc_points_fwd(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
+                              ptr(poses), ns, kind, nt, ptr(w), ptr(e), ps.n, dtype_code(ps.dirs), fmt, qptr, stride,
+                              ptr(x), ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), stream_ptr()), 'dc_points_fwd')
+    return (x,) + parts if want_parts else x
+
+
+def _grads_split(g, nt, ns):
+    return g[:nt], g[nt:2 * nt], g[2 * nt:].reshape(ns, 3, 4)
+
+
+def points_bwd(grad_points, ps, poses=None, model_kind=None, w=None, e=None, want_exponent=False, want_pose=False):
+    """(dL/dw [P], dL/dexponent [P], dL/d[R|t] [S,3,4]) for a given dL/dpoints."""
+    kind, nt, w, e = _model_args(model_kind, w, e, ps)
+    poses, ns = _pose_args(poses, ps)
+    need(grad_points, (ps.n, None), dtype=ps.dtype, name='grad_points', device=ps.device)
+    stride = grad_points.shape[1]
+    nacc = 2 * nt + 12 * ns
+    out = torch.zeros((max(nacc, 1),), dtype=torch.float64, device=ps.device)
+    if nacc == 0:
+        return _grads_split(out[:0], 0, 0)
+    rows = lib().dc_partial_rows(ps.n)
+    part = torch.empty((rows * nacc,), dtype=torch.float64, device=ps.device)
+    check(lib().dc_points_bwd(ptr(grad_points), stride, dtype_code(grad_points), ps.n, ptr(ps.vps), ptr(ps.dirs),
+                              ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id), ptr(poses), ns, kind, nt,
+                              ptr(w), ptr(e), int(want_exponent), int(want_pose), ptr(part), ptr(out), stream_ptr()),
+          'dc_points_bwd')
+    return _grads_split(out, nt, ns)
+
+
+# ------------------------------------------------------------------------------------------------
+# neighbourhood features
+# ------------------------------------------------------------------------------------------------
+def features_fwd(points, nbr, dirs=None, mean_weights=None, scale=None, want=('mean', 'cov', 'eigvals', 'eigvecs',
+                                                                             'normals', 'inc_angles'),
+                 want_saved=False, want_weights=False):
+    need(points, (None, None), name='points')
+    n, stride = points.shape
+    assert stride in (3, 4)
+    dev, dt = points.device, points.dtype
+    need(nbr, (n, None), dtype=torch.int32, name='neighbors', device=dev)
+    k = nbr.shape[1]
+    if dirs is not None:
+        need(dirs, (n, 3), dtype=dt, name='dirs', device=dev)
+    if mean_weights is not None:
+        mean_weights = mean_weights.reshape(n, k)
+        need(mean_weights, (n, k), dtype=dt, name='weights', device=dev)
+    shapes = dict(mean=(n, 3), cov=(n, 3, 3), eigvals=(n, 3), eigvecs=(n, 3, 3), normals=(n, 3), inc_angles=(n, 1))
+    out = {f: (torch.empty(shapes[f], dtype=dt, device=dev) if f in want else None) for f in shapes}
+    if (out['normals'] is not None or out['inc_angles'] is not None) and dirs is None:
+        raise ValueError('normals / incidence angles need dirs')
+    nvalid = torch.empty((n,), dtype=torch.int32, device=dev) if want_saved else None
+    cmean = torch.empty((n, 3), dtype=dt, device=dev) if want_saved else None
+    invd = torch.empty((n,), dtype=dt, device=dev) if want_saved else None
+    wout = torch.empty((n, k), dtype=dt, device=dev) if want_weights else None
+    check(lib().dc_features_fwd(ptr(points), stride, dtype_code(points), ptr(nbr), n, k, ptr(mean_weights),
+                                float(scale) if scale else 0.0, ptr(dirs), ptr(out['mean']), ptr(out['cov']),
+                                ptr(out['eigvals']), ptr(out['eigvecs']), ptr(out['normals']), ptr(out['inc_angles']),
+                                ptr(nvalid), ptr(wout), ptr(cmean), ptr(invd), stream_ptr()), 'dc_features_fwd')
+    out.update(nvalid=nvalid, cmean=cmean, invd=invd, weights=wout)
+    return out
+
+
+def features_bwd(points, csr_ptr, csr_src, cmean, invd, nvalid, eigvecs=None, grad_mean=None, grad_cov=None,
+                 grad_eigvals=None):
+    need(points, (None, None), name='points')
+    n, stride = points.shape
+    dev, dt = points.device, points.dtype
+    need(csr_ptr, (n + 1,), dtype=torch.int32, name='csr_ptr', device=dev)
+    need(csr_src, (None,), dtype=torch.int32, name='csr_src', device=dev)
+    need(cmean, (n, 3), dtype=dt, name='cmean', device=dev)
+    need(invd, (n,), dtype=dt, name='invd', device=dev)
+    need(nvalid, (n,), dtype=torch.int32, name='nvalid', device=dev)
+    for t, shp, nm in ((eigvecs, (n, 3, 3), 'eigvecs'), (grad_mean, (n, 3), 'grad_mean'), (grad_cov, (n, 3, 3), 'grad_cov'),
+                       (grad_eigvals, (n, 3), 'grad_eigvals')):
+        if t is not None:
+            need(t, shp, dtype=dt, name=nm, device=dev)
+    grec = torch.empty((n, 12), dtype=dt, device=dev)
+    gp = torch.empty((n, stride), dtype=dt, device=dev)
+    check(lib().dc_features_bwd(ptr(points), stride, dtype_code(points), ptr(csr_ptr), ptr(csr_src), n, ptr(cmean),
+                                ptr(invd), ptr(nvalid), ptr(eigvecs), ptr(grad_mean), ptr(grad_cov), ptr(grad_eigvals),
+                                ptr(grec), ptr(gp), stream_ptr()), 'dc_features_bwd')
+    return gp
+
+
+# ------------------------------------------------------------------------------------------------
+# fused consistency loss
+# ------------------------------------------------------------------------------------------------
+def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss', normalization=True, sqrt=False,
+                    rec=None, want_pointwise=False, want_eigvals=False, partials=None, sums=None, qfmt=None):
+    _check_points(points, qfmt)
+    n, stride = points.shape
+    dev = points.device
+    dt = torch.float32 if qfmt is not None else points.dtype
+    need(nbr, (n, None), dtype=torch.int32, name='neighbors', device=dev)
+    k = nbr.shape[1]
+    if mask is not None:
+        need(mask, (n,), dtype=torch.bool, name='mask', device=dev)
+    if offset is not None:
+        need(offset, (n,), dtype=dt, name='offset', device=dev)
+    if rec is None:
+        rec = torch.empty((n, 8), dtype=points.dtype, device=dev)
+    else:
+        need(rec, (n, 8), dtype=points.dtype, name='rec', device=dev)
+    fmt, qptr = _fmt_args(dt, qfmt)
+    pw = torch.empty((n,), dtype=dt, device=dev) if want_pointwise else None
+    ev = torch.empty((n, 3), dtype=dt, device=dev) if want_eigvals else None
+    rows = lib().dc_partial_rows(n)
+    if partials is None:
+        partials = torch.empty((rows * 2,), dtype=torch.float64, device=dev)
+    else:
+        need(partials, (None,), dtype=torch.float64, name='partials', device=dev)
+        assert partials.numel() >= rows * 2
+    if sums is None:
+        sums = torch.empty((2,), dtype=torch.float64, device=dev)
+    check(lib().dc_consistency_fwd(ptr(points), stride, fmt if qfmt is None else nv.DC_F32, fmt, qptr, ptr(nbr), n, k,
+                                   ptr(mask), ptr(offset), nv.LOSS_KINDS[loss], int(bool(normalization)), int(bool(sqrt)), ptr(rec), ptr(pw),
+                                   ptr(ev), ptr(partials), ptr(sums), stream_ptr()), 'dc_consistency_fwd')
+    return dict(sums=sums, rec=rec, pointwise=pw, eigvals=ev)
+
+
+def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_kind=None, w=None, e=None,
+                    want_exponent=False, want_pose=False, want_grad_points=False, partials=None, grads=None, qfmt=None):
+    _check_points(points, qfmt)
+    n, stride = points.shape
+    dev = points.device
+    dt = torch.float32 if qfmt is not None else points.dtype
+    fmt, qptr = _fmt_args(dt, qfmt)
+    dcode = nv.DC_F32 if qfmt is not None else fmt
+    need(rec, (n, 8), dtype=points.dtype, name='rec', device=dev)
+    need(csr_ptr, (n + 1,), dtype=torch.int32, name='csr_ptr', device=dev)
+    need(csr_src, (None,), dtype=torch.int32, name='csr_src', device=dev)
+    gp = torch.empty((n, stride), dtype=dt, device=dev) if want_grad_points else None
+    if ps is None:
+        assert want_grad_points
+        check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src), n,
+                                       None, None, None, None, None, None, None, 0, 0, 0, None, None, 0, 0, ptr(gp), None,
+                                       None, stream_ptr()), 'dc_consistency_bwd')
+        return gp, None
+    assert ps.n == n and ps.dtype == dt and ps.device == dev
+    kind, nt, w, e = _model_args(model_kind, w, e, ps)
+    poses, ns = _pose_args(poses, ps)
+    nacc = 2 * nt + 12 * ns
+    rows = lib().dc_partial_rows(n)
+    if partials is None:
+        partials = torch.empty((max(rows * nacc, 1),), dtype=torch.float64, device=dev)
+    else:
+        assert partials.numel() >= rows * nacc
+    if grads is None:
+        grads = torch.zeros((max(nacc, 1),), dtype=torch.float64, device=dev)
+    check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src), n,
+                                   ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
+                                   ptr(poses), ns, kind, nt, ptr(w), ptr(e), int(want_exponent), int(want_pose), ptr(gp),
+                                   ptr(partials), ptr(grads), stream_ptr()), 'dc_consistency_bwd')
+    return gp, _grads_split(grads, nt, ns)
+
+
+# ------------------------------------------------------------------------------------------------
+# masks
+# ------------------------------------------------------------------------------------------------
+def _bound(v, default):
+    if v is None:
+        return default
+    v = float(v)
+    return default if v != v else v        # config files encode "unbounded" as nan (config.py:41-43)
+
+
+def mask_bounds(mask, num, num_index=0, den=None, den_index=0, lo=None, hi=None):
+    """mask &= lo <= num[:, num_index] (/ den[:, den_index]) <= hi   (in place, returns mask)."""
+    n = mask.shape[0]
+    need(mask, (n,), dtype=torch.bool, name='mask')
+    num2 = num.reshape(n, -1)
+    need(num2, (n, None), name='values', device=mask.device)
+    den2 = None
+    if den is not None:
+        den2 = den.reshape(n, -1)
+        need(den2, (n, None), dtype=num2.dtype, name='denominator', device=mask.device)
+    check(lib().dc_mask_bounds(ptr(num2), num2.shape[1], num_index, ptr(den2), den2.shape[1] if den2 is not None else 0,
+                               den_index, dtype_code(num2), n, _bound(lo, float('-inf')), _bound(hi, float('inf')),
+                               ptr(mask), stream_ptr()), 'dc_mask_bounds')
+    return mask
+
+
+def valid_count(nbr):
+    need(nbr, (None, None), dtype=torch.int32, name='neighbors')
+    cnt = torch.empty((nbr.shape[0],), dtype=torch.int32, device=nbr.device)
+    check(lib().dc_valid_count(ptr(nbr), nbr.shape[0], nbr.shape[1], ptr(cnt), stream_ptr()), 'dc_valid_count')
+    return cnt
+
+
+def dispersion(vec, nbr, weights=None):
+    need(vec, (None, 3), name='vectors')
+    n = vec.shape[0]
+    need(nbr, (n, None), dtype=torch.int32, name='neighbors', device=vec.device)
+    k = nbr.shape[1]
+    if weights is not None:
+        weights = weights.reshape(n, k)
+        need(weights, (n, k), dtype=vec.dtype, name='weights', device=vec.device)
+    out = torch.empty((n,), dtype=vec.dtype, device=vec.device)
+    check(lib().dc_dispersion(ptr(vec), dtype_code(vec), ptr(nbr), ptr(weights), n, k, ptr(out), stream_ptr()),
+          'dc_dispersion')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# point-to-plane ICP pair
+# ------------------------------------------------------------------------------------------------
+def p2plane_pair(psa, normals_a, psb, normals_b, pose_a, pose_b, idx_a, idx_b, model_kind=None, w=None, e=None):
+    """Sums of point-to-plane distances over the correspondences of one scan pair and their gradients:
+    returns (sums f64 [2], dw [P], de [P], dTa [3,4], dTb [3,4]) for d(sum12 + sum21)."""
+    dev, dt = psa.device, psa.dtype
+    assert psb.device == dev and psb.dtype == dt
+    need(normals_a, (psa.n, 3), dtype=dt, name='normals_a', device=dev)
+    need(normals_b, (psb.n, 3), dtype=dt, name='normals_b', device=dev)
+    need(pose_a, (12,), dtype=torch.float64, name='pose_a', device=dev)
+    need(pose_b, (12,), dtype=torch.float64, name='pose_b', device=dev)
+    need(idx_a, (None,), dtype=torch.int32, name='idx_a', device=dev)
+    m = idx_a.shape[0]
+    need(idx_b, (m,), dtype=torch.int32, name='idx_b', device=dev)
+    kind, nt, w, e = _model_args(model_kind, w, e, psa)
+    if kind != 0 and psb.inc is None:
+        raise ValueError('the model needs incidence angles')
+    part = torch.empty((lib().dc_p2plane_partial_count(m),), dtype=torch.float64, device=dev)
+    out = torch.empty((2 + 2 * nt + 24,), dtype=torch.float64, device=dev)
+    check(lib().dc_p2plane_pair(ptr(psa.vps), ptr(psa.dirs), ptr(psa.depth), ptr(psa.inc), ptr(psa.lmask),
+                                ptr(normals_a), ptr(psb.vps), ptr(psb.dirs), ptr(psb.depth), ptr(psb.inc),
+                                ptr(psb.lmask), ptr(normals_b), dtype_code(psa.dirs), ptr(pose_a), ptr(pose_b), kind, nt,
+                                ptr(w), ptr(e), ptr(idx_a), ptr(idx_b), m, 1, 1, ptr(part), ptr(out), stream_ptr()),
+          'dc_p2plane_pair')
+    return out[:2], out[2:2 + nt], out[2 + nt:2 + 2 * nt], out[2 + 2 * nt:14 + 2 * nt].reshape(3, 4), \
+        out[14 + 2 * nt:].reshape(3, 4)

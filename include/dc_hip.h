@@ -1,0 +1,167 @@
+/* libdc_hip.so -- C ABI of the MI355X (gfx950) map-consistency hot path of ctu-vras/depth_correction.
+ *
+ * The reference is pure Python; this boundary is what a Python binding of its hot path (ctypes, see
+ * INTEGRATION.md) calls instead of torch / scipy / LAPACK.  Each entry point names the reference code it
+ * replaces (paths relative to the reference's src/depth_correction/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch's allocator), unless marked "host";
+ *   - float arrays have element type `dtype` (DC_F32 | DC_F64); on-chip arithmetic is always fp64;
+ *   - indices are int32, -1 = missing neighbour (the reference's int64 is converted at the Python boundary);
+ *   - every call is asynchronous on `stream` and never allocates: scratch comes from a caller workspace whose
+ *     size the *_workspace_bytes / dc_partial_rows twins report;
+ *   - return value: 0 = ok, < 0 = invalid argument (DC_ERR_*), > 0 = hipError_t;
+ *   - results are bitwise reproducible (no floating-point atomics anywhere).
+ */
+#ifndef DC_HIP_H
+#define DC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef DC_F32
+#define DC_F32 0
+#define DC_F64 1
+#define DC_Q32 2 /* internal point format: int32 fixed point rows [n,4], x = origin + q * scale (16 B / point) */
+#define DC_LOSS_MIN_EIGVAL 0
+#define DC_LOSS_TRACE 1
+#define DC_MODEL_NONE 0
+#define DC_MODEL_POLYNOMIAL 1
+#define DC_MODEL_SCALED_POLYNOMIAL 2
+#define DC_MAX_MODEL_TERMS 8
+#define DC_OK 0
+#define DC_ERR_ARG (-1)
+#define DC_ERR_DTYPE (-2)
+#define DC_ERR_WORKSPACE (-3)
+#define DC_ERR_UNSUPPORTED (-4)
+#endif
+
+typedef struct ihipStream_t* dcStream_t; /* == hipStream_t */
+
+int dc_version(void);
+
+/* ---- neighbourhood builder: nearest_neighbors.py:22-80 (scipy cKDTree), depth_cloud.py:210-215 --------- */
+
+/* Self k-NN (query == NULL) or k-NN of `query` [n_query, q_stride] in `points` [n, stride]; k <= 64.
+ * r > 0: keep only d < r (cKDTree distance_upper_bound), missing -> idx -1 / dist inf.  cell_hint <= 0: auto.
+ * idx_out int32 [rows, k], dist_out fp64 [rows, k] or NULL.  Ordering: ascending fp64 distance, self first. */
+size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query);
+int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride,
+                 int64_t n_query, int k, double r, double cell_hint, int32_t* idx_out, double* dist_out, void* ws,
+                 size_t ws_bytes, dcStream_t stream);
+
+/* Radius search (query_ball_point, nearest_neighbors.py:50-51,69-73), two passes over one workspace
+ * (size dc_knn_workspace_bytes(n, 0)): counts + their maximum, then rows of ascending indices padded with -1. */
+int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double r, int32_t* count_out,
+                    int32_t* kmax_out, void* ws, size_t ws_bytes, dcStream_t stream);
+int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, size_t ws_bytes, dcStream_t stream);
+
+/* Transposed neighbour list for the backward (replaces autograd's index_put scatter of depth_cloud.py:303-304):
+ * csr_ptr int32 [n+1], csr_src int32 [n*k] (first csr_ptr[n] entries valid, ascending centre index). */
+size_t dc_knn_transpose_workspace_bytes(int64_t n, int k);
+int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int32_t* csr_ptr, int32_t* csr_src, void* ws,
+                     size_t ws_bytes, dcStream_t stream);
+
+/* Morton (Z-curve) order of the points over their bounding box: order_out[p] = index of the p-th point.
+ * Used once per sequence to lay the global cloud out so that neighbour gathers stay cache-local. */
+size_t dc_spatial_order_workspace_bytes(int64_t n);
+int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32_t* order_out, void* ws,
+                     size_t ws_bytes, dcStream_t stream);
+
+/* ---- corrected points: model.py:243-261 (ScaledPolynomial), :181-199 (Polynomial), BaseModel.forward :76-78,
+ *      DepthCloud.transform depth_cloud.py:135-152, to_points :122-124, preproc.global_cloud :80-119 ---------
+ * d' = model(depth, inc) on points with lmask != 0 (NULL = all), scan s = scan_id[i] (NULL = 0) is moved by
+ * poses[s] (fp64 [n_scans, 12] row-major [R|t], NULL = identity), x = vps' + d' dirs'.
+ * w, e: fp64 device arrays [n_terms] (model weights / exponents).  out_stride 3 or 4 (4 = padded rows).
+ * point_fmt: format of points_out -- `dtype` itself, or DC_Q32 (dtype DC_F32, stride 4) with qparams = HOST
+ * fp64 [4] {origin.xyz, scale}: fixed-point rows with uniform resolution `scale` (fp32 traffic, ~2^8 finer
+ * than fp32 at the range limit; used for the internal buffers of the fused loss).
+ * vps_out / dirs_out [n,3], depth_out [n] are optional (NULL). */
+int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                  const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
+                  const double* w, const double* e, int64_t n, int dtype, int point_fmt, const double* qparams,
+                  int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, dcStream_t stream);
+
+/* Backward of dc_points_fwd for a given dL/dpoints: grads_out fp64 [2*n_terms + 12*n_scans] =
+ * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count]. */
+int64_t dc_partial_rows(int64_t n);
+int dc_param_grad_count(int n_terms, int n_scans);
+int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, const void* vps, const void* dirs,
+                  const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+                  const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
+                  int want_exponent_grad, int want_pose_grad, double* partials_ws, double* grads_out,
+                  dcStream_t stream);
+
+/* ---- neighbourhood features: DepthCloud.update_features depth_cloud.py:426-433 = update_mean :291-295,
+ *      update_weights :356-364, update_cov :366-369 -> utils.covs utils.py:109-149, compute_eig :376-399
+ *      (torch.linalg.eigh, CPU-forced in the reference), update_normals :401-415, update_incidence_angles :417-424.
+ * All outputs optional (NULL): mean [n,3], cov [n,3,3], eigvals [n,3] ascending, eigvecs [n,3,3] (columns),
+ * normals [n,3], inc_angles [n], nvalid int32 [n], weights_out [n,k]; cmean_out [n,3] / invd_out [n] are the
+ * saved tensors of dc_features_bwd.  mean_weights [n,k] or NULL (validity); scale <= 0: no Gaussian weights. */
+int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nbr, int64_t n, int k,
+                    const void* mean_weights, double scale, const void* dirs, void* mean, void* cov, void* eigvals,
+                    void* eigvecs, void* normals, void* inc_angles, int32_t* nvalid, void* weights_out,
+                    void* cmean_out, void* invd_out, dcStream_t stream);
+
+/* dL/dpoints from dL/d(mean, cov, eigvals) (any may be NULL); grec_ws: dtype [n,12] scratch. */
+int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* csr_ptr, const int32_t* csr_src,
+                    int64_t n, const void* cmean, const void* invd, const int32_t* nvalid, const void* eigvecs,
+                    const void* grad_mean, const void* grad_cov, const void* grad_eigvals, void* grec_ws,
+                    void* grad_points, dcStream_t stream);
+
+/* ---- fused map-consistency loss: compute_neighborhood_features preproc.py:195-217 + min_eigval_loss
+ *      loss.py:216-294 / trace_loss :297-370 + their autograd backward (train.py:300-307) ------------------------
+ * Forward: per point the covariance of its neighbourhood, smallest eigenpair, pointwise loss
+ *   l = relu(lam0 [/ clamp(sum lam, 1e-6)] - offset) [sqrt], and the 8-element backward record rec [n,8]
+ *   (same format as the points: point_fmt / qparams as in dc_points_fwd).
+ * sums_out fp64 [2] = {sum of l over mask, number of masked points}; mask u8 [n] or NULL; offset [n] or NULL;
+ * pointwise [n], eigvals [n,3] optional.  partials_ws: fp64 [dc_partial_rows(n) * 2]. */
+int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
+                       const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
+                       int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
+                       double* sums_out, dcStream_t stream);
+
+/* Backward of sum-over-mask of l: dL/dx_j gathered over incoming edges, chained in the same kernel to
+ * dL/dw, dL/dexponent, dL/d[R|t] (grads_out as in dc_points_bwd; pass dirs == NULL to get only grad_points).
+ * grad_points [n, stride] optional.  partials_ws: fp64 [dc_partial_rows(n) * dc_param_grad_count()]. */
+int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
+                       const int32_t* csr_ptr, const int32_t* csr_src, int64_t n, const void* vps, const void* dirs,
+                       const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+                       const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
+                       int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
+                       double* grads_out, dcStream_t stream);
+
+/* ---- masks: filters.py:85-113 within_bounds, :184-193 valid neighbours, :196-254 eigenvalue (ratio) bounds,
+ *      depth_cloud.py:314-326 dir / vp dispersion, preproc.py:122-164 global_cloud_mask ------------------------- */
+/* mask[i] &= lo <= num[i, num_index] (/ den[i, den_index]) <= hi; +-inf = unbounded; NaN fails. */
+int dc_mask_bounds(const void* num, int num_stride, int num_index, const void* den, int den_stride, int den_index,
+                   int dtype, int64_t n, double lo, double hi, uint8_t* mask, dcStream_t stream);
+int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, dcStream_t stream);
+/* out[i] = trace of the weighted covariance of vec[nbr[i]]; weights [n,k] or NULL (validity). */
+int dc_dispersion(const void* vec, int dtype, const int32_t* nbr, const void* weights, int64_t n, int k, void* out,
+                  dcStream_t stream);
+
+/* ---- point-to-plane ICP loss: loss.point_to_plane_dist loss.py:406-488 inside icp_loss :373-403 (model(c),
+ *      c.transform(pose) :381-386) with precomputed correspondences (train.py:178-210) ------------------------------
+ * One scan pair (A, B): idxA / idxB int32 [m] index the local points of scan A / B; poseA / poseB fp64 [12]
+ * device [R|t]; normals are the LOCAL normals (rotated by the pose inside).  Points are rounded to fp32 before
+ * the distances are formed (loss.py:436-437).  Forward and backward are one kernel:
+ *   out fp64 [2 + 2 P + 24] = { sum |nA.(xB-xA)| |nA|, sum |nB.(xA-xB)| |nB|,
+ *                               d(sum12+sum21)/dw [P], /dexponent [P], /d[R|t]_A [12], /d[R|t]_B [12] }.
+ * partials_ws: fp64 [dc_p2plane_partial_count(m)]. */
+int64_t dc_p2plane_partial_count(int64_t m);
+int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, const void* incA, const uint8_t* lmaskA,
+                    const void* normalsA, const void* vpsB, const void* dirsB, const void* depthB, const void* incB,
+                    const uint8_t* lmaskB, const void* normalsB, int dtype, const double* poseA, const double* poseB,
+                    int model_kind, int n_terms, const double* w, const double* e, const int32_t* idxA,
+                    const int32_t* idxB, int64_t m, int want_exponent_grad, int want_pose_grad, double* partials_ws,
+                    double* out, dcStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DC_HIP_H */

@@ -368,7 +368,7 @@ def eval_sequence(scans, poses, w, exponent, neighbors, mask, kind='min_eigval_l
     vps_g, dirs_g, depth_g = torch.cat(vps_g), torch.cat(dirs_g), torch.cat(depth_g)   # :118
     x = points_from(vps_g, dirs_g, depth_g)
     f = features(x, neighbors, dirs_g, weights=weights)
-    f['points'] = x
+    f['points'], f['dirs'], f['depth'] = x, dirs_g, depth_g
     loss = pointwise_loss(eigvals=f['eigvals'], cov=f['cov'], kind=kind, mask=mask, sqrt=sqrt,
                           normalization=normalization)
     return reduce_loss(loss, reduction), f

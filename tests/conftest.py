@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+                cache[name] = {k: z[k] for k in z.files}
+        return cache[name]
+    return load
+
+
+@pytest.fixture(scope='session')
+def dev():
+    return torch.device('cuda:0')

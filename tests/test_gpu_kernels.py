@@ -1,0 +1,353 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the golden fixtures generated
+from the live reference and against the oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): neighbour indices bit-exact; eigenvalues and loss within 1e-5
+relative.  fp64 device data is checked much tighter (1e-9) because the kernels compute in fp64."""
+import numpy as np
+import pytest
+import torch
+
+import dc_oracle as O
+from helpers import t, npy, scans_from_golden, concat_scans, poses12, assert_eigvals_close
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # north_star tolerance (fp32 data)
+RTOL64 = 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# K4 / K4r neighbourhood builder
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_knn_golden_bit_exact(golden, dev, dtype):
+    from depth_correction_amd import ops
+    g = golden('knn')
+    pts = t(g['points'], dev, dtype)            # fixture points are fp32-representable
+    dist, idx = ops.knn(pts, 10)
+    assert np.array_equal(npy(idx), g['k10_ind'])
+    assert np.array_equal(npy(dist), g['k10_dist'])            # fp64 sqrt of the same fp64 sums
+    dist, idx = ops.knn(pts, 8, r=0.15)
+    assert np.array_equal(npy(idx), g['k8_r015_ind'])
+    assert np.array_equal(npy(dist), g['k8_r015_dist'])        # inf where missing
+    idx = ops.radius_neighbors(pts, 0.12)
+    assert np.array_equal(npy(idx), g['r012_ind'])
+
+
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+def test_knn_global_cloud_bit_exact(golden, dev, name):
+    from depth_correction_amd import ops
+    g = golden(name)
+    _, idx = ops.knn(t(g['g0_points'], dev), int(g['cfg_nn_k']))
+    assert np.array_equal(npy(idx), g['g_neighbors'])
+    for s in range(int(g['n_scans'])):
+        _, idx = ops.knn(t(g['scan%d_xyz' % s], dev), int(g['cfg_nn_k']))
+        assert np.array_equal(npy(idx), g['scan%d_neighbors' % s])
+
+
+def test_knn_cross_cloud_and_oracle(dev):
+    from depth_correction_amd import ops
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-3, 3, size=(5000, 3)) * [1, 1, 0.05]
+    b = rng.uniform(-3.5, 3.5, size=(3000, 3)) * [1, 1, 0.05]
+    dist, idx = ops.knn(t(a, dev), 1, query=t(b, dev))
+    dref, iref = O.knn_ckdtree(a, 1, query=b)
+    assert np.array_equal(npy(idx)[:, 0], iref)
+    assert np.array_equal(npy(dist)[:, 0], dref)
+
+
+def test_knn_transpose(golden, dev):
+    from depth_correction_amd import ops
+    g = golden('knn')
+    nbr = t(g['k8_r015_ind'], dev).to(torch.int32)
+    ptr_, src = ops.knn_transpose(nbr)
+    ptr_, src = npy(ptr_), npy(src)
+    n, k = g['k8_r015_ind'].shape
+    ref = [[] for _ in range(n)]
+    for i in range(n):
+        for j in g['k8_r015_ind'][i]:
+            if j >= 0:
+                ref[j].append(i)
+    assert ptr_[0] == 0 and ptr_[-1] == sum(len(r) for r in ref)
+    for j in range(n):
+        assert list(src[ptr_[j]:ptr_[j + 1]]) == ref[j]
+
+
+def test_spatial_order_is_permutation(golden, dev):
+    from depth_correction_amd import ops
+    g = golden('room_k10')
+    order = npy(ops.spatial_order(t(g['g0_points'], dev, torch.float32)))
+    assert np.array_equal(np.sort(order), np.arange(len(order)))
+
+
+# ---------------------------------------------------------------------------------------------
+# K3, K5-K12 features
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+def test_features_golden_f64(golden, dev, name):
+    from depth_correction_amd import ops
+    g = golden(name)
+    x = t(g['g_points'], dev)
+    nbr = t(g['g_neighbors'], dev)
+    f = ops.features_fwd(x, nbr, dirs=None, want=('mean', 'cov', 'eigvals', 'eigvecs'))
+    np.testing.assert_allclose(npy(f['mean']), g['g_mean'], rtol=RTOL64, atol=1e-12)
+    np.testing.assert_allclose(npy(f['cov']), g['g_cov'], rtol=RTOL64, atol=1e-15)
+    assert_eigvals_close(npy(f['eigvals']), g['g_eigvals'], RTOL64, name)
+    # eigenvectors: residual and orthonormality (sign is arbitrary, loss.py:731-735 compares up to sign)
+    V = npy(f['eigvecs'])
+    C = g['g_cov']
+    res = np.einsum('nij,njk->nik', C, V) - V * npy(f['eigvals'])[:, None, :]
+    assert np.abs(res).max() <= 1e-12 * np.abs(C).max()
+    assert np.abs(np.einsum('nji,njk->nik', V, V) - np.eye(3)).max() < 1e-12
+
+
+def test_local_features_normals_incidence(golden, dev):
+    from depth_correction_amd import ops
+    g = golden('room_k10')
+    for s in range(int(g['n_scans'])):
+        x = t(g['scan%d_xyz' % s], dev)
+        dirs = t(g['scan%d_dirs' % s], dev)
+        nbr = t(g['scan%d_neighbors' % s], dev)
+        f = ops.features_fwd(x, nbr, dirs=dirs, want=('eigvals', 'normals', 'inc_angles'))
+        assert_eigvals_close(npy(f['eigvals']), g['scan%d_eigvals' % s], RTOL64)
+        # inc = arccos|dir . n| ; compare the cosine (arccos is ill-conditioned at 0) and the angle
+        absdot = np.abs((npy(dirs) * npy(f['normals'])).sum(-1))
+        np.testing.assert_allclose(absdot, g['scan%d_absdot' % s], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(npy(f['inc_angles']), g['scan%d_inc_angles' % s], rtol=0, atol=1e-7)
+        n = npy(f['normals'])
+        assert np.all((npy(dirs) * n).sum(-1) <= 1e-15)              # oriented towards the sensor
+
+
+def test_features_f32_vs_oracle(golden, dev):
+    """fp32 device data: same fp32 points to kernel and oracle, eigenvalues within 1e-5 relative."""
+    from depth_correction_amd import ops
+    g = golden('room_k10')
+    x32 = t(g['g_points'], dtype=torch.float32)
+    nbr = t(g['g_neighbors'])
+    ref = O.features(x32.double(), nbr.long(), torch.zeros_like(x32).double())
+    for stride in (3, 4):
+        xs = x32 if stride == 3 else torch.cat([x32, torch.zeros(len(x32), 1)], 1)
+        f = ops.features_fwd(xs.contiguous().to(dev), nbr.to(dev), want=('mean', 'cov', 'eigvals'))
+        assert_eigvals_close(npy(f['eigvals']), npy(ref['eigvals']), RTOL, 'f32 eigvals')
+        np.testing.assert_allclose(npy(f['cov']), npy(ref['cov']), rtol=RTOL, atol=1e-7 * float(ref['cov'].abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# K1-K3 points, K14/K15 loss, K18 backward
+# ---------------------------------------------------------------------------------------------
+VARIANTS = [('mineig_norm', 'min_eigval_loss', True, False), ('mineig_raw', 'min_eigval_loss', False, False),
+            ('mineig_norm_sqrt', 'min_eigval_loss', True, True), ('mineig_raw_sqrt', 'min_eigval_loss', False, True),
+            ('trace', 'trace_loss', False, False), ('trace_sqrt', 'trace_loss', False, True)]
+
+
+def _run_sequence(g, dev, dtype, prefix='', loss='min_eigval_loss', normalization=True, sqrt=False, poses=None,
+                  stride=3, q32=False):
+    from depth_correction_amd import ops
+    qfmt = None
+    if q32:
+        lo, hi = g['g0_points'].min(0), g['g0_points'].max(0)
+        qfmt = ops.QFormat.for_extent(lo, hi)
+    scans = scans_from_golden(g, dtype)
+    ps = concat_scans(scans, dev)
+    w = t(g[prefix + 'w'].reshape(-1), dev)
+    e = t(g[prefix + 'exponent'].reshape(-1), dev)
+    model = str(g[prefix + 'model'])
+    P = poses12(g['poses'] if poses is None else poses, dev)
+    x = ops.points_fwd(ps, P, model, w, e, stride=stride, qfmt=qfmt)
+    nbr = t(g['g_neighbors'], dev)
+    mask = t(g['g_mask'], dev)
+    fw = ops.consistency_fwd(x, nbr, mask=mask, loss=loss, normalization=normalization, sqrt=sqrt, want_pointwise=True,
+                             want_eigvals=True, qfmt=qfmt)
+    cp, cs = ops.knn_transpose(nbr)
+    gp, (gw, ge, gT) = ops.consistency_bwd(x, fw['rec'], cp, cs, ps, P, model, w, e, want_exponent=True, want_pose=True,
+                                           want_grad_points=True, qfmt=qfmt)
+    if q32:
+        x = torch.as_tensor(qfmt.origin, dtype=torch.float64, device=dev) + x[:, :3].double() * qfmt.scale
+    return dict(x=x, fw=fw, gp=gp, gw=gw, ge=ge, gT=gT, mask=mask, qfmt=qfmt)
+
+
+def test_points_golden(golden, dev):
+    g = golden('room_k10')
+    r = _run_sequence(g, dev, torch.float64)
+    np.testing.assert_allclose(npy(r['x']), g['g_points'], rtol=1e-13, atol=1e-13)
+    r = _run_sequence(g, dev, torch.float32, stride=4)
+    np.testing.assert_allclose(npy(r['x'])[:, :3], g['g_points'], rtol=2e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,loss,norm,sqrt', VARIANTS)
+def test_consistency_golden_f64(golden, dev, tag, loss, norm, sqrt):
+    g = golden('room_k10')
+    r = _run_sequence(g, dev, torch.float64, loss=loss, normalization=norm, sqrt=sqrt)
+    sums = npy(r['fw']['sums'])
+    M = g['g_mask'].sum()
+    assert sums[1] == M
+    np.testing.assert_allclose(sums[0] / M, g[tag + '_loss'], rtol=RTOL64)
+    np.testing.assert_allclose(npy(r['fw']['pointwise'])[g['g_mask']], g[tag + '_pointwise'], rtol=1e-7, atol=1e-15)
+    np.testing.assert_allclose(npy(r['gw']) / M, g[tag + '_grad_w'].reshape(-1), rtol=1e-7)
+    if tag + '_grad_points' in g:
+        ref = g[tag + '_grad_points']
+        np.testing.assert_allclose(npy(r['gp']) / M, ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+
+
+def _oracle_sequence(g, dtype, loss, norm, sqrt):
+    """The oracle (fp64 arithmetic) on the SAME inputs the device gets: fixture inputs rounded to `dtype`."""
+    scans = [{k: (v.double() if v.dtype.is_floating_point else v) for k, v in s.items()}
+             for s in scans_from_golden(g, dtype)]
+    w = torch.tensor(g['w'].reshape(1, -1), requires_grad=True)
+    e = torch.tensor(g['exponent'].reshape(1, -1))
+    val, f = O.eval_sequence(scans, torch.as_tensor(g['poses']), w, e, t(g['g_neighbors']).long(), t(g['g_mask']),
+                             kind=loss, normalization=norm, sqrt=sqrt, reduction='mean')
+    f['points'].retain_grad()
+    val.backward()
+    # magnitude of the terms dL/dw sums (they largely cancel): sum_j |dL/dd'_j * dd'_j/dw_k|
+    gd = (f['dirs'] * f['points'].grad).sum(-1).detach()
+    d = torch.cat([s['depth'] for s in scans]).reshape(-1)
+    inc = torch.cat([s['inc'] for s in scans]).reshape(-1)
+    lm = torch.cat([s['mask'] for s in scans])
+    terms = (lm * d * gd).abs()[:, None] * inc[:, None] ** e
+    f['grad_w_scale'] = npy(terms.sum(0))
+    return float(val.detach()), npy(w.grad).ravel(), f
+
+
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+@pytest.mark.parametrize('tag,loss,norm,sqrt', VARIANTS[:2] + VARIANTS[4:5])
+def test_consistency_f32_vs_oracle(golden, dev, name, tag, loss, norm, sqrt):
+    """fp32 device data (BASELINE config 0 and the room cloud): identical fp32 inputs to the HIP path and to
+    the oracle; loss and dL/dw within 1e-5 relative, eigenvalues within 1e-5 of the oracle's on the device's
+    own fp32 points."""
+    from depth_correction_amd import ops
+    g = golden(name)
+    ref_loss, ref_gw, ref_f = _oracle_sequence(g, torch.float32, loss, norm, sqrt)
+    M = g['g_mask'].sum()
+    xr = npy(ref_f['points'])
+    for stride, q32 in ((3, False), (4, False), (4, True)):
+        r = _run_sequence(g, dev, torch.float32, loss=loss, normalization=norm, sqrt=sqrt, stride=stride, q32=q32)
+        sums = npy(r['fw']['sums'])
+        assert sums[1] == M
+        np.testing.assert_allclose(sums[0] / M, ref_loss, rtol=RTOL)
+        x = npy(r['x'])[:, :3].astype(np.float64)
+        if q32:
+            # fixed-point internal points (the fused path's format): everything within the north-star 1e-5,
+            # end to end from the fp32 inputs, including per-point eigenvalues against the fp64 oracle
+            # dL/dw is a sum of strongly cancelling per-point terms; the fp32 fields of the backward record
+            # (unit round-off 6e-8) bound the error by a few u * sum|terms| on top of the 1e-5 relative bar
+            gw_err = np.abs(npy(r['gw']) / M - ref_gw)
+            assert np.all(gw_err <= RTOL * np.abs(ref_gw) + 2e-7 * ref_f['grad_w_scale']), (gw_err, ref_gw, ref_f['grad_w_scale'])
+            step = r['qfmt'].scale                              # 2^-25 m (3e-8 m) for these 20 m scenes
+            assert np.abs(x - xr).max() <= 0.5 * step * 1.01
+            # (a) kernel arithmetic: against the oracle on exactly the device's (dequantised) points
+            fo = O.features(torch.as_tensor(x), t(g['g_neighbors']).long(), torch.zeros(len(x), 3, dtype=torch.float64))
+            assert_eigvals_close(npy(r['fw']['eigvals']), npy(fo['eigvals']), RTOL, 'fused q32 eigvals')
+            # (b) end to end against the fp64 oracle: 1e-5 relative plus the first-order effect of moving a
+            # coordinate by one resolution step, d(lambda) = 2 sqrt(lambda) step  (3e-8 m here)
+            lam, ref = npy(r['fw']['eigvals']).astype(np.float64), npy(ref_f['eigvals'])
+            assert np.all(np.abs(lam - ref) <= RTOL * np.abs(ref) + 2 * np.sqrt(np.abs(ref)) * step)
+        else:
+            # float32 points (API layout): x is rounded to fp32 once (half an ulp), which bounds what dL/dw can
+            # agree to on a 10 000-point cloud; eigenvalues are checked on exactly the device's fp32 points
+            np.testing.assert_allclose(npy(r['gw']) / M, ref_gw, rtol=1e-4)
+            assert np.abs(x - xr).max() <= 0.5 * np.spacing(np.abs(xr).max().astype(np.float32)) * 1.01
+            fo = O.features(torch.as_tensor(x), t(g['g_neighbors']).long(), torch.zeros(len(x), 3, dtype=torch.float64))
+            assert_eigvals_close(npy(r['fw']['eigvals']), npy(fo['eigvals']), RTOL, 'fused f32 eigvals')
+
+
+def test_consistency_polynomial_model(golden, dev):
+    g = golden('room_k10')
+    r = _run_sequence(g, dev, torch.float64, prefix='poly_')
+    M = g['g_mask'].sum()
+    np.testing.assert_allclose(npy(r['fw']['sums'])[0] / M, g['poly_mineig_norm_loss'], rtol=RTOL64)
+    np.testing.assert_allclose(npy(r['gw']) / M, g['poly_mineig_norm_grad_w'].reshape(-1), rtol=1e-7)
+
+
+@pytest.mark.parametrize('tag,loss', [('poses_mineig_norm', 'min_eigval_loss'), ('poses_trace', 'trace_loss')])
+def test_pose_gradients_golden(golden, dev, tag, loss):
+    """model_poses_learning pattern: gradient w.r.t. per-pose 6-vectors chained through T = T0 Exp(delta)."""
+    g = golden('room_k10')
+    pd = torch.tensor(g['poses_pose_deltas'], dtype=torch.float64, requires_grad=True)
+    T = torch.matmul(torch.as_tensor(g['poses']), O.xyz_axis_angle_to_matrix(pd))
+    np.testing.assert_allclose(npy(T), g['poses_poses_upd'], rtol=1e-12, atol=1e-14)
+    r = _run_sequence(g, dev, torch.float64, prefix='poses_', loss=loss, normalization=True, poses=T.detach())
+    M = g['g_mask'].sum()
+    np.testing.assert_allclose(npy(r['fw']['sums'])[0] / M, g[tag + '_loss'], rtol=RTOL64)
+    np.testing.assert_allclose(npy(r['gw']) / M, g[tag + '_grad_w'].reshape(-1), rtol=1e-7)
+    gT = torch.zeros_like(T)
+    gT[:, :3, :] = r['gT'].cpu() / M
+    T.backward(gT)
+    ref = g[tag + '_grad_pose_deltas']
+    np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+
+
+def test_exponent_gradient_vs_oracle_autograd(golden, dev):
+    g = golden('room_k10')
+    r = _run_sequence(g, dev, torch.float64)
+    scans = scans_from_golden(g)
+    w = torch.tensor(g['w'].reshape(1, -1), requires_grad=True)
+    e = torch.tensor(g['exponent'].reshape(1, -1), requires_grad=True)
+    loss, _ = O.eval_sequence(scans, torch.as_tensor(g['poses']), w, e, t(g['g_neighbors']).long(), t(g['g_mask']),
+                              reduction='sum')
+    loss.backward()
+    np.testing.assert_allclose(npy(r['gw']), npy(w.grad).ravel(), rtol=1e-7)
+    np.testing.assert_allclose(npy(r['ge']), npy(e.grad).ravel(), rtol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------
+# K13 masks
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+def test_global_mask_golden(golden, dev, name):
+    from depth_correction_amd import ops
+    g = golden(name)
+    n = len(g['g_mask'])
+    nbr = t(g['g_neighbors'], dev)
+    scans = scans_from_golden(g)
+    ps = concat_scans(scans, dev)
+    x, vps, dirs, _ = ops.points_fwd(ps, poses12(g['poses'], dev), want_parts=True)
+    np.testing.assert_allclose(npy(x), g['g0_points'], rtol=1e-13, atol=1e-13)
+    ev = ops.features_fwd(x, nbr, want=('eigvals',))['eigvals']
+    mask = ps.lmask.clone()
+    cnt = ops.valid_count(nbr)
+    ops.mask_bounds(mask, cnt.to(torch.float64), lo=int(g['cfg_min_valid_neighbors']))
+    for i, j, lo, hi in g['eigenvalue_ratio_bounds']:
+        ops.mask_bounds(mask, ev, int(i), ev, int(j), lo, hi)
+    vd = ops.dispersion(vps, nbr)
+    np.testing.assert_allclose(npy(vd), g['g0_vp_dispersion'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(npy(ops.dispersion(dirs, nbr)), g['g0_dir_dispersion'], rtol=1e-9, atol=1e-15)
+    if len(g['vp_dispersion_bounds']):
+        ops.mask_bounds(mask, vd, lo=g['vp_dispersion_bounds'][0], hi=g['vp_dispersion_bounds'][1])
+    assert np.array_equal(npy(mask), g['g_mask'])
+    assert n == mask.numel()
+
+
+# ---------------------------------------------------------------------------------------------
+# K16 point-to-plane ICP
+# ---------------------------------------------------------------------------------------------
+def test_p2plane_golden(golden, dev):
+    from depth_correction_amd import ops
+    g = golden('icp_pairs')
+    ns = int(g['n_scans'])
+    pd = torch.tensor(g['pose_deltas'], dtype=torch.float64, requires_grad=True)
+    T = torch.matmul(torch.as_tensor(g['poses']), O.xyz_axis_angle_to_matrix(pd))
+    P = poses12(T.detach(), dev)
+    w, e = t(g['w'].reshape(-1), dev), t(g['exponent'].reshape(-1), dev)
+    pss, nrm = [], []
+    for s in range(ns):
+        pss.append(ops.PointSet(t(g['scan%d_vps' % s], dev), t(g['scan%d_dirs' % s], dev), t(g['scan%d_depth' % s], dev),
+                                t(g['scan%d_inc_angles' % s], dev), t(g['scan%d_mask' % s], dev)))
+        nrm.append(t(g['scan%d_normals' % s], dev))
+    loss, gw, gT = 0.0, 0.0, torch.zeros(ns, 4, 4, dtype=torch.float64)
+    for j in range(ns - 1):
+        ia = torch.nonzero(t(g['pair%d_mask1' % j])).reshape(-1).to(torch.int32).to(dev)
+        ib = t(g['pair%d_idx2' % j]).to(torch.int32).to(dev)
+        sums, dw, de, dTa, dTb = ops.p2plane_pair(pss[j], nrm[j], pss[j + 1], nrm[j + 1], P[j], P[j + 1], ia, ib,
+                                                  'ScaledPolynomial', w, e)
+        m = len(ia)
+        scale = 0.5 / m / (ns - 1)
+        loss = loss + scale * float(sums.sum())
+        gw = gw + scale * dw.cpu()
+        gT[j, :3] += scale * dTa.cpu()
+        gT[j + 1, :3] += scale * dTb.cpu()
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-6)          # reference rounds points to fp32 (loss.py:436)
+    np.testing.assert_allclose(npy(gw), g['grad_w'].reshape(-1), rtol=1e-5)
+    T.backward(gT)
+    ref = g['grad_pose_deltas']
+    np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
