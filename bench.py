@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Headline benchmark: points/sec through min_eigval_loss forward + backward (+ Adam) on MI355X.
+
+Workload (BASELINE.json configs[2], SURVEY 8d "C2"): one sequence of 10 overlapping 200k-point room-box
+scans (global cloud N = 2 M), nn_k = 10, ScaledPolynomial model (w = [1e-3, 2e-3], exponents [2, 4]),
+min_eigval_loss with normalization, masks from the default eigenvalue-ratio bounds + min 5 valid
+neighbours, Adam lr 1e-3.  One "step" = model apply -> pose transform -> global cloud -> neighbourhood
+covariance / eigen / loss -> backward -> Adam step on the whole global cloud; the k-NN build is set-up
+(amortised once, train.py:172-175) and reported separately.  With --gpus N every rank owns one such
+sequence (configs[3] shape: weak scaling, sequences are independent) and the ranks exchange
+one RCCL all-reduce of [sum loss, dL/dw] per step.
+
+Prints ONE JSON line (contract in the task statement) including `roofline` (dominant kernel, HIP-event
+timed inside the timed region) and `cpu_baseline` (the oracle = CPU restatement of the reference
+algorithm, timed on this host's cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--scans', type=int, default=10)
+    ap.add_argument('--points', type=int, default=200_000, help='points per scan')
+    ap.add_argument('--k', type=int, default=10)
+    ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
+    ap.add_argument('--cpu-scans', type=int, default=2, help='scans in the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--no-sort', action='store_true', help='keep the scan-major point order (ablation)')
+    ap.add_argument('--point-format', default='auto', choices=['auto', 'q32', 'float'])
+    return ap.parse_args()
+
+
+def algorithmic_bytes(k):
+    """SURVEY 8d accounting (fp32 data, int32 indices), bytes per point and launch."""
+    fwd = 72 + 16 * k            # whole forward incl. the raw point inputs
+    bwd = 72 + 28 * k
+    return dict(points_fwd=32 + 12, consistency_fwd=fwd - 32 + 12, consistency_bwd=bwd, path=fwd + bwd)
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands
+    one GPU's job a share of the host, oversubscribing all visible cores only slows the baseline down)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get('DC_CPU_THREADS')
+    return int(env) if env else min(n, 32)
+
+
+def cpu_baseline(scans_xyz, poses, k, n_iters, lr):
+    """The oracle (reference algorithm as written: materialised [N,K,3,3] products, torch.linalg.eigh, autograd
+    backward, torch.optim.Adam; fp64 = the reference's default float_type) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import dc_oracle as O
+    torch.set_num_threads(host_cores())
+    scans = []
+    for xyz in scans_xyz:                                   # local_feature_cloud on the CPU (set-up, untimed)
+        pts = torch.as_tensor(xyz, dtype=torch.float64)
+        depth = pts.norm(dim=-1, keepdim=True)
+        dirs = pts / depth
+        _, ind = O.knn_ckdtree(pts.numpy(), k)
+        f = O.features(pts, torch.as_tensor(ind), dirs)
+        scans.append(dict(vps=torch.zeros_like(pts), dirs=dirs, depth=depth, inc=f['inc_angles'],
+                          mask=O.local_mask(f['eigvals'], None, [[0, 1, 0.0, 0.25], [1, 2, 0.25, 1.0]])))
+    poses = torch.as_tensor(poses, dtype=torch.float64)
+    x0 = torch.cat([O.points_from(*O.transform_cloud(s['vps'], s['dirs'], T), s['depth']) for s, T in zip(scans, poses)])
+    _, nbr = O.knn_ckdtree(x0.numpy(), k)
+    nbr = torch.as_tensor(nbr)
+    f0 = O.features(x0, nbr, torch.cat([s['dirs'] for s in scans]))
+    mask = O.global_mask(torch.cat([s['mask'] for s in scans]), nbr, f0['eigvals'], min_valid_neighbors=5,
+                         eigenvalue_ratio_bounds=[[0, 1, 0.0, 0.25], [1, 2, 0.25, 1.0]])
+    del f0
+    w = torch.nn.Parameter(torch.tensor([[1e-3, 2e-3]], dtype=torch.float64))
+    e = torch.tensor([[2.0, 4.0]], dtype=torch.float64)
+    opt = torch.optim.Adam([w], lr=lr)
+    times = []
+    for it in range(n_iters + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _ = O.eval_sequence(scans, poses, w, e, nbr, mask, reduction='mean')
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    n = len(x0)
+    med = float(np.median(times[1:]))
+    return dict(value=n / med, unit='points/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d scans x %d pts (N=%d), k=%d, fp64, 1 warm-up + %d iterations, median; loss %.6g'
+                       % (len(scans), len(scans_xyz[0]), n, k, n_iters, float(loss.detach())),
+                s_per_iter=med)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from depth_correction_amd.dataset import RoomBoxDataset
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import consistency_loss
+    from depth_correction_amd import ops
+
+    dtype = getattr(torch, args.dtype)
+    ds = RoomBoxDataset(n_pts=args.points, n_poses=args.scans, seed_base=1000 + 100 * rank,
+                        dtype=np.float32 if dtype == torch.float32 else np.float64)
+    scans_xyz, poses = [], []
+    for cloud, pose in ds:
+        scans_xyz.append(np.stack([cloud[f] for f in 'xyz'], axis=1))
+        poses.append(pose)
+    poses = np.stack(poses)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, spatial_sort=not args.no_sort,
+                                point_format=args.point_format)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    # the k-NN build alone, on the global cloud (reported separately)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ops.knn(info['points0'], args.k, want_dist=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    knn_ms = ev0.elapsed_time(ev1)
+
+    n_local = plan.n
+    count = torch.tensor([plan.count], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(count)
+    total_count = float(count.item())
+
+    w = torch.nn.Parameter(torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, device=dev))
+    exponent = torch.tensor([[2.0, 4.0]], dtype=torch.float64, device=dev)
+    poses_t = info['poses']
+    opt = torch.optim.Adam([w], lr=1e-3)
+    packed = torch.zeros((1 + w.numel(),), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+    timed = dict(points_fwd=[], consistency_fwd=[], consistency_bwd=[])
+
+    def hooked(name, fn):
+        def wrapper(*a, **kw):
+            if not timing_on[0]:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            out = fn(*a, **kw)
+            e1.record(stream)
+            timed[name].append((e0, e1))
+            return out
+        return wrapper
+
+    timing_on = [False]
+    ops.points_fwd = hooked('points_fwd', ops.points_fwd)
+    ops.consistency_fwd = hooked('consistency_fwd', ops.consistency_fwd)
+    ops.consistency_bwd = hooked('consistency_bwd', ops.consistency_bwd)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        s, _ = consistency_loss(plan, w, exponent, poses_t)
+        loss = s / total_count
+        loss.backward()
+        if dist is not None:
+            # the only exchange of the path: [sum loss, dL/dw], one RCCL all-reduce per step
+            packed[0] = loss.detach()
+            packed[1:] = w.grad.reshape(-1)
+            dist.all_reduce(packed)
+            w.grad.copy_(packed[1:].reshape(w.shape))
+            loss = packed[0]
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    timing_on[0] = True
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timing_on[0] = False
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    final_loss = float(loss.detach().item()) if isinstance(loss, torch.Tensor) else float(loss)
+
+    if rank == 0:
+        ms = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in timed.items() if evs}
+        ab = algorithmic_bytes(args.k)
+        dom = max(('consistency_fwd', 'consistency_bwd'), key=lambda n_: ms.get(n_, 0.0))
+        achieved = ab[dom] * n_local / (ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            key = '%s/N%d/K%d/%s' % (dom, n_local, args.k, args.dtype)
+            traffic = tj.get(key)
+        gpu_ms = sum(ms.values())
+        value = n_local * world * args.steps / elapsed
+        out = {
+            'metric': 'points/sec through min_eigval_loss fwd+bwd (200k pts, k=10); HBM GB/s vs peak',
+            'value': value, 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C2: %d overlapping %dk-pt room-box scans per sequence (N=%d per GPU), nn_k=%d, '
+                                   'ScaledPolynomial, min_eigval_loss(normalization) fwd+bwd + Adam; one sequence per GPU'
+                                   % (args.scans, args.points // 1000, n_local, args.k),
+                       'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
+                       'masked_points': total_count, 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
+                       'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3), 'setup_s': setup_s},
+            'roofline': {'bound': 'hbm', 'kernel': 'dc_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'algorithmic_bytes_per_point': ab[dom], 'kernel_ms': ms,
+                         'path_achieved': ab['path'] * value / world / 1e9,
+                         'path_frac': ab['path'] * value / world / 1e9 / HBM_PEAK_GBPS,
+                         'gpu_kernel_ms_per_step': gpu_ms},
+        }
+        if world == 1 and args.cpu_scans > 0:
+            torch.cuda.empty_cache()
+            out['cpu_baseline'] = cpu_baseline(scans_xyz[:args.cpu_scans], poses[:args.cpu_scans], args.k,
+                                               args.cpu_iters, 1e-3)
+            out['config']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kBlock) void features_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j,
-                                                 const double* g, double* gw, double* ge, double* gT, int* scan) {
+                                                 const double* g, double* gw, double* ge, double* gT, bool want_e,
+                                                 bool want_pose, int* scan) {
   double vp[3], dr[3], T12[12];
   const QParams qp0{};
   Row3<T, 3>::load((const T*)in.vps, j, vp, qp0);
@@ -195,17 +196,18 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
     const double inc = (double)((const T*)in.inc)[j];
     const double base = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d * gd : -gd;
     double bias = 0.0;
+#pragma unroll
     for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
       if (k < mp.n_terms) {
         const double pk = pow_term(inc, mp.e[k]);
         bias += pk * mp.w[k];
         gw[k] += base * pk;
-        if (ge) ge[k] += (inc > 0.0) ? base * mp.w[k] * pk * log(inc) : 0.0;
+        if (want_e) ge[k] += (inc > 0.0) ? base * mp.w[k] * pk * log(inc) : 0.0;
       }
     }
     dcorr = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? d * (1.0 - bias) : d - bias;
   }
-  if (gT) {
+  if (want_pose) {
     // x = R xl + t, xl = vps + d' dirs:  dL/dR = g xl^T, dL/dt = g
     const double xl0 = vp[0] + dcorr * dr[0], xl1 = vp[1] + dcorr * dr[1], xl2 = vp[2] + dcorr * dr[2];
     gT[0] = g[0] * xl0; gT[1] = g[0] * xl1; gT[2] = g[0] * xl2; gT[3] = g[0];
@@ -226,7 +228,9 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) { v[k] = gw[k]; v[DC_MAX_MODEL_TERMS + k] = want_e ? ge[k] : 0.0; }
   block_sum<2 * DC_MAX_MODEL_TERMS>(v, lds);
   if (threadIdx.x == 0) {
-    for (int k = 0; k < P; ++k) { prow[k] = v[k]; prow[P + k] = v[DC_MAX_MODEL_TERMS + k]; }
+#pragma unroll
+    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k)
+      if (k < P) { prow[k] = v[k]; prow[P + k] = v[DC_MAX_MODEL_TERMS + k]; }
   }
   if (want_pose) {
     // scans are interleaved after spatial sorting: reduce per scan id present in the block
@@ -261,6 +265,8 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
   double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gT[k] = 0.0;
   int scan = -1;
   bool active = false;
   if (blk >= 0) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
         g[2] += t * v[2] - c2 * d2;
       }
       if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
-      if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, want_e ? ge : nullptr, want_pose ? gT : nullptr, &scan);
+      if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
     }
   }
   if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + (int64_t)blockIdx.x * n_acc);
@@ -297,13 +303,15 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
   double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gT[k] = 0.0;
   int scan = -1;
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool active = j < n;
   if (active) {
     double g[3];
     Row3<T, STRIDE>::load(grad_x, j, g, QParams{});
-    points_bwd_point<T>(in, mp, j, g, gw, want_e ? ge : nullptr, want_pose ? gT : nullptr, &scan);
+    points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
   reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + (int64_t)blockIdx.x * n_acc);
 }

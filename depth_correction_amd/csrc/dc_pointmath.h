@@ -41,7 +41,10 @@ DC_HD double pow_term(double g, double e) {
 
 DC_HD double model_bias(const ModelParams& mp, double inc) {
   double b = 0.0;
-  for (int k = 0; k < mp.n_terms; ++k) b += pow_term(inc, mp.e[k]) * mp.w[k];
+  // fixed trip count + predicate: keeps w[] / e[] in registers (a dynamic bound would index them through scratch)
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k)
+    if (k < mp.n_terms) b += pow_term(inc, mp.e[k]) * mp.w[k];
   return b;
 }
 

@@ -23,6 +23,7 @@ struct PointInputs {
 __device__ __forceinline__ void load_model(const PointInputs& in, ModelParams& mp) {
   mp.kind = in.model_kind;
   mp.n_terms = in.n_terms;
+#pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
     const bool on = k < in.n_terms && in.model_kind != DC_MODEL_NONE;
     mp.w[k] = on ? in.w[k] : 0.0;

@@ -1,0 +1,102 @@
+"""Set-up phase of one sequence on the GPU (what train.py:94-215 does once before the optimisation loop):
+local feature clouds -> global cloud -> global neighbourhoods -> global mask -> fused SequencePlan.
+
+Array-level functions used by ``bench.py`` and by the reference-API layer (``preproc.py``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .plan import SequencePlan
+
+__all__ = ['local_features', 'global_neighborhoods', 'global_mask', 'build_sequence', 'DEFAULT_RATIO_BOUNDS']
+
+# config.py:218 default eigenvalue_ratio_bounds
+DEFAULT_RATIO_BOUNDS = [[0, 1, 0.0, 0.25], [1, 2, 0.25, 1.0]]
+
+
+def _eig_masks(mask, eigvals, eigenvalue_bounds=None, eigenvalue_ratio_bounds=None):
+    for e, lo, hi in (eigenvalue_bounds or []):                       # filters.py:196-221
+        ops.mask_bounds(mask, eigvals, int(e), lo=lo, hi=hi)
+    for i, j, lo, hi in (eigenvalue_ratio_bounds or []):              # filters.py:224-254
+        ops.mask_bounds(mask, eigvals, int(i), eigvals, int(j), lo, hi)
+    return mask
+
+
+def local_features(xyz, k=None, r=None, vps=None, eigenvalue_bounds=None,
+                   eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, dtype=None, device='cuda:0'):
+    """local_feature_cloud (preproc.py:35-64) on raw sensor-frame points: DepthCloud.from_points
+    (depth_cloud.py:592-638) + update_all (:435-441) + the eigenvalue masks (:53-62)."""
+    pts = torch.as_tensor(np.ascontiguousarray(xyz) if isinstance(xyz, np.ndarray) else xyz, device=device)
+    if dtype is not None:
+        pts = pts.to(dtype)
+    pts = pts.contiguous()
+    vps_t = torch.zeros_like(pts) if vps is None else torch.as_tensor(vps, dtype=pts.dtype, device=pts.device).expand_as(pts).contiguous()
+    dirs = pts - vps_t
+    depth = dirs.norm(dim=-1, keepdim=True)
+    dirs = torch.where(depth > 0, dirs / depth, dirs).contiguous()
+    ps = ops.PointSet(vps_t, dirs, depth)
+    x = ops.points_fwd(ps)                                            # update_points
+    if k:
+        _, nbr = ops.knn(x, k, r=r, want_dist=False)                  # update_neighbors
+    else:
+        nbr = ops.radius_neighbors(x, r)
+    f = ops.features_fwd(x, nbr, dirs=dirs, want=('eigvals', 'normals', 'inc_angles'))
+    mask = torch.ones((len(pts),), dtype=torch.bool, device=pts.device)
+    _eig_masks(mask, f['eigvals'], eigenvalue_bounds, eigenvalue_ratio_bounds)
+    return dict(vps=vps_t, dirs=dirs, depth=depth, inc_angles=f['inc_angles'], mask=mask, normals=f['normals'],
+                eigvals=f['eigvals'], neighbors=nbr, points=x)
+
+
+def global_cloud_arrays(clouds, poses):
+    """preproc.global_cloud (preproc.py:80-119) without a model: (points, vps, dirs) of the concatenated cloud."""
+    dev = clouds[0]['dirs'].device
+    sizes = [len(c['dirs']) for c in clouds]
+    scan_id = torch.repeat_interleave(torch.arange(len(clouds), dtype=torch.int32, device=dev),
+                                      torch.as_tensor(sizes, device=dev))
+    cat = lambda f: torch.cat([c[f].reshape(len(c['dirs']), -1) for c in clouds]).contiguous()
+    ps = ops.PointSet(cat('vps'), cat('dirs'), cat('depth'), None, None, scan_id)
+    P = torch.as_tensor(poses, device=dev).to(torch.float64)[:, :3, :].reshape(len(clouds), 12).contiguous()
+    return ops.points_fwd(ps, P, want_parts=True)
+
+
+def global_neighborhoods(points, k=None, r=None):
+    """establish_neighborhoods (preproc.py:168-185) for the ball type: (neighbors i32 [N,K], weights implied)."""
+    if k:
+        return ops.knn(points, k, r=r, want_dist=False)[1]
+    return ops.radius_neighbors(points, r)
+
+
+def global_mask(local_mask, points, vps, dirs, nbr, min_valid_neighbors=5, eigenvalue_bounds=None,
+                eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, dir_dispersion_bounds=None, vp_dispersion_bounds=None):
+    """global_cloud_mask (preproc.py:122-164)."""
+    mask = torch.ones((len(points),), dtype=torch.bool, device=points.device) if local_mask is None else local_mask.clone()
+    if min_valid_neighbors:
+        ops.mask_bounds(mask, ops.valid_count(nbr).to(torch.float64), lo=min_valid_neighbors)
+    if eigenvalue_bounds or eigenvalue_ratio_bounds:
+        ev = ops.features_fwd(points, nbr, want=('eigvals',))['eigvals']
+        _eig_masks(mask, ev, eigenvalue_bounds, eigenvalue_ratio_bounds)
+    if dir_dispersion_bounds:
+        ops.mask_bounds(mask, ops.dispersion(dirs, nbr), lo=dir_dispersion_bounds[0], hi=dir_dispersion_bounds[1])
+    if vp_dispersion_bounds:
+        ops.mask_bounds(mask, ops.dispersion(vps, nbr), lo=vp_dispersion_bounds[0], hi=vp_dispersion_bounds[1])
+    return mask
+
+
+def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='cuda:0', min_valid_neighbors=5,
+                   eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, vp_dispersion_bounds=None, model_kind='ScaledPolynomial',
+                   loss='min_eigval_loss', normalization=True, sqrt=False, spatial_sort=True, point_format='auto'):
+    """Everything train.py does before its loop for one sequence; returns (plan, info)."""
+    clouds = [local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype, device=device)
+              for xyz in scans_xyz]
+    poses_t = torch.as_tensor(np.asarray(poses), dtype=torch.float64, device=device)
+    x0, vps0, dirs0, _ = global_cloud_arrays(clouds, poses_t)
+    nbr = global_neighborhoods(x0, k=k, r=r)
+    lmask = torch.cat([c['mask'] for c in clouds])
+    mask = global_mask(lmask, x0, vps0, dirs0, nbr, min_valid_neighbors=min_valid_neighbors,
+                       eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, vp_dispersion_bounds=vp_dispersion_bounds)
+    plan = SequencePlan(clouds, poses_t, nbr, mask, model_kind=model_kind, loss=loss, normalization=normalization,
+                        sqrt=sqrt, spatial_sort=spatial_sort, point_format=point_format)
+    return plan, dict(clouds=clouds, poses=poses_t, neighbors=nbr, mask=mask, points0=x0)
