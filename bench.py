@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--no-sort', action='store_true', help='keep the scan-major point order (ablation)')
     ap.add_argument('--point-format', default='auto', choices=['auto', 'q32', 'float'])
+    ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')
     return ap.parse_args()
 
 
@@ -155,73 +156,66 @@ def main():
     knn_ms = ev0.elapsed_time(ev1)
 
     n_local = plan.n
-    count = torch.tensor([plan.count], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(count)
-    total_count = float(count.item())
-
-    w = torch.nn.Parameter(torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, device=dev))
-    exponent = torch.tensor([[2.0, 4.0]], dtype=torch.float64, device=dev)
+    from depth_correction_amd.plan import SequenceTrainer, KernelTimer
+    w0, e0 = [1e-3, 2e-3], [2.0, 4.0]
     poses_t = info['poses']
-    opt = torch.optim.Adam([w], lr=1e-3)
-    packed = torch.zeros((1 + w.numel(),), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream()
-    timed = dict(points_fwd=[], consistency_fwd=[], consistency_bwd=[])
-
-    def hooked(name, fn):
-        def wrapper(*a, **kw):
-            if not timing_on[0]:
-                return fn(*a, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            out = fn(*a, **kw)
-            e1.record(stream)
-            timed[name].append((e0, e1))
-            return out
-        return wrapper
-
-    timing_on = [False]
-    ops.points_fwd = hooked('points_fwd', ops.points_fwd)
-    ops.consistency_fwd = hooked('consistency_fwd', ops.consistency_fwd)
-    ops.consistency_bwd = hooked('consistency_bwd', ops.consistency_bwd)
-
-    def step():
-        opt.zero_grad(set_to_none=False)
-        s, _ = consistency_loss(plan, w, exponent, poses_t)
-        loss = s / total_count
-        loss.backward()
+    if args.autograd:
+        # drop-in style loop: torch autograd Function + torch.optim.Adam (what train.py drives)
+        count = torch.tensor([plan.count], dtype=torch.float64, device=dev)
         if dist is not None:
-            # the only exchange of the path: [sum loss, dL/dw], one RCCL all-reduce per step
-            packed[0] = loss.detach()
-            packed[1:] = w.grad.reshape(-1)
-            dist.all_reduce(packed)
-            w.grad.copy_(packed[1:].reshape(w.shape))
-            loss = packed[0]
-        opt.step()
-        return loss
+            dist.all_reduce(count)
+        total_count = float(count.item())
+        w = torch.nn.Parameter(torch.tensor([w0], dtype=torch.float64, device=dev))
+        exponent = torch.tensor([e0], dtype=torch.float64, device=dev)
+        opt = torch.optim.Adam([w], lr=1e-3)
+        packed = torch.zeros((1 + w.numel(),), dtype=torch.float64, device=dev)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            s, _ = consistency_loss(plan, w, exponent, poses_t)
+            loss = s / total_count
+            loss.backward()
+            if dist is not None:
+                packed[0] = loss.detach()
+                packed[1:] = w.grad.reshape(-1)
+                dist.all_reduce(packed)
+                w.grad.copy_(packed[1:].reshape(w.shape))
+                loss = packed[0]
+            opt.step()
+            return loss.detach()
+    else:
+        # native loop: one host call per evaluation (dc_sequence_eval) + dc_adam_step; with several ranks the only
+        # exchange of the path is one RCCL all-reduce of [sum loss, count, dL/dw] per step
+        trainer = SequenceTrainer([plan], w0, e0, [poses_t], lr=1e-3, distributed=dist is not None)
+        total_count = trainer.count
+
+        def step():
+            acc = trainer.step()
+            return acc
 
     for _ in range(args.warmup):
         loss = step()
-    timing_on[0] = True
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timing_on[0] = False
+    with KernelTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    kernel_ms = timer.read()
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    final_loss = float(loss.detach().item()) if isinstance(loss, torch.Tensor) else float(loss)
+    loss = loss.detach().cpu()
+    final_loss = float(loss) if loss.numel() == 1 else float(loss[0] / loss[1])
 
     if rank == 0:
-        ms = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in timed.items() if evs}
+        ms = {name: v[0] for name, v in kernel_ms.items()}
         ab = algorithmic_bytes(args.k)
         dom = max(('consistency_fwd', 'consistency_bwd'), key=lambda n_: ms.get(n_, 0.0))
         achieved = ab[dom] * n_local / (ms[dom] * 1e-3) / 1e9
@@ -243,6 +237,7 @@ def main():
                                    'ScaledPolynomial, min_eigval_loss(normalization) fwd+bwd + Adam; one sequence per GPU'
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
+                       'loop': 'autograd+torch.optim.Adam' if args.autograd else 'native (dc_sequence_eval + dc_adam_step)',
                        'masked_points': total_count, 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3), 'setup_s': setup_s},
             'roofline': {'bound': 'hbm', 'kernel': 'dc_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -48,10 +48,26 @@ _SIGNATURES = {
     'dc_mask_bounds': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _f64, _f64, _vp, _vp]),
     'dc_valid_count': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'dc_dispersion': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
+    'dc_sequence_eval': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'dc_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp]),
+    'dc_profiler_enable': (_i32, [_i32]),
+    'dc_profiler_reset': (_i32, []),
+    'dc_profiler_read': (_i32, [_i32, _vp, _vp]),
     'dc_p2plane_partial_count': (_i64, [_i64]),
     'dc_p2plane_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
 }
+
+
+class SequenceDesc(ctypes.Structure):
+    """dcSequenceDesc of include/dc_hip.h."""
+    _fields_ = [('n', ctypes.c_int64), ('k', ctypes.c_int32), ('n_scans', ctypes.c_int32), ('dtype', ctypes.c_int32),
+                ('point_fmt', ctypes.c_int32), ('qparams', ctypes.c_double * 4),
+                ('vps', _vp), ('dirs', _vp), ('depth', _vp), ('inc', _vp), ('lmask', _vp), ('scan_id', _vp),
+                ('nbr', _vp), ('csr_ptr', _vp), ('csr_src', _vp), ('mask', _vp), ('x', _vp), ('rec', _vp),
+                ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
+                ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
 
 
 def lib_path():

@@ -15,6 +15,7 @@
 #include "dc_device.h"
 #include "dc_pointmath.h"
 #include "dc_points_dev.h"
+#include "../../include/dc_hip.h"
 
 namespace dc {
 
@@ -390,6 +391,21 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* _
   if (threadIdx.x == 0) out[a] = v[0];
 }
 
+// torch.optim.Adam (single-tensor path, no amsgrad) on a small fp64 parameter vector; grad is scaled first.
+__global__ void adam_kernel(double* __restrict__ p, const double* __restrict__ grad, double* __restrict__ m,
+                            double* __restrict__ v, int64_t n, double grad_scale, double lr, double b1, double b2,
+                            double eps, double weight_decay, double bias1, double bias2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double g = grad[i] * grad_scale;
+  if (weight_decay != 0.0) g += weight_decay * p[i];
+  const double mi = m[i] + (g - m[i]) * (1.0 - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+  const double vi = v[i] * b2 + (1.0 - b2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  m[i] = mi; v[i] = vi;
+  const double denom = sqrt(vi) / bias2_sqrt + eps;
+  p[i] = p[i] + (-(lr / bias1)) * (mi / denom);
+}
+
 }  // namespace dc
 
 // ================================================================================================
@@ -404,6 +420,38 @@ using namespace dc;
   } while (0)
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
+
+// ---- in-library kernel timer: HIP events recorded on the launch stream right around the main kernels ------
+namespace {
+constexpr int kProfKinds = 3;            // 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd
+constexpr int kProfCap = 4096;
+struct ProfState {
+  bool on = false;
+  int count[kProfKinds] = {0, 0, 0};
+  hipEvent_t start[kProfKinds][kProfCap];
+  hipEvent_t stop[kProfKinds][kProfCap];
+  int created[kProfKinds] = {0, 0, 0};
+} g_prof;
+
+struct ProfScope {
+  int kind, slot;
+  hipStream_t stream;
+  ProfScope(int kind_, hipStream_t s) : kind(kind_), slot(-1), stream(s) {
+    if (!g_prof.on || g_prof.count[kind] >= kProfCap) return;
+    slot = g_prof.count[kind];
+    if (slot >= g_prof.created[kind]) {
+      if (hipEventCreate(&g_prof.start[kind][slot]) != hipSuccess || hipEventCreate(&g_prof.stop[kind][slot]) != hipSuccess) { slot = -1; return; }
+      g_prof.created[kind] = slot + 1;
+    }
+    (void)hipEventRecord(g_prof.start[kind][slot], stream);
+  }
+  ~ProfScope() {
+    if (slot < 0) return;
+    (void)hipEventRecord(g_prof.stop[kind][slot], stream);
+    g_prof.count[kind] = slot + 1;
+  }
+};
+}  // namespace
 
 extern "C" {
 
@@ -468,7 +516,7 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
   dim3 grid((unsigned)n_blocks(n)), block(kBlock);
 #define LAUNCH(T, PT, S) \
   hipLaunchKernelGGL((points_fwd_kernel<T, PT, S>), grid, block, 0, stream, in, n, qp, (PT*)points_out, (T*)vps_out, (T*)dirs_out, (T*)depth_out)
-  DC_DISPATCH_FMT(dtype, point_fmt, out_stride, LAUNCH);
+  { ProfScope prof(0, stream); DC_DISPATCH_FMT(dtype, point_fmt, out_stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   return DC_OK;
@@ -490,7 +538,7 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
 #define LAUNCH(T, PT, S) \
   hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, nbr, n, k, mask, \
                      (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws)
-  DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH);
+  { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), block, 0, stream, partials_ws, rows, 2, sums_out);
@@ -531,7 +579,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
 #define LAUNCH(T, PT, S) \
   hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, (const PT*)rec, csr_ptr, \
                      csr_src, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc)
-  DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH);
+  { ProfScope prof(2, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   if (params && n_acc > 0) {
@@ -618,6 +666,64 @@ int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* cs
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   return DC_OK;
+}
+
+// ---- profiler control ---------------------------------------------------------------------------------------
+int dc_profiler_enable(int on) {
+  g_prof.on = on != 0;
+  return DC_OK;
+}
+int dc_profiler_reset(void) {
+  for (int k = 0; k < kProfKinds; ++k) g_prof.count[k] = 0;
+  return DC_OK;
+}
+// kind: 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd.  Waits for the recorded launches to finish.
+int dc_profiler_read(int kind, double* total_ms, int64_t* launches) {
+  if (kind < 0 || kind >= kProfKinds || !total_ms || !launches) return DC_ERR_ARG;
+  double tot = 0.0;
+  const int n = g_prof.count[kind];
+  for (int i = 0; i < n; ++i) {
+    hipError_t err = hipEventSynchronize(g_prof.stop[kind][i]);
+    if (err != hipSuccess) return (int)err;
+    float ms = 0.f;
+    err = hipEventElapsedTime(&ms, g_prof.start[kind][i], g_prof.stop[kind][i]);
+    if (err != hipSuccess) return (int)err;
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = n;
+  return DC_OK;
+}
+
+int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t step,
+                 double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 hipStream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  const double bias1 = 1.0 - pow(beta1, (double)step);
+  const double bias2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
+                     grad_scale, lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+// One evaluation of a whole sequence (eval.py:85-112 + backward) from a caller-filled descriptor: three kernels
+// (+ two fixed-order reductions).  out fp64 [2 + 2 P + 12 S] = {sum loss over mask, mask count, grads of the sum}.
+int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
+                     int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream) {
+  if (!d || !out || !poses) return DC_ERR_ARG;
+  const int stride = 4;
+  int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
+                         d->n_terms, w, e, d->n, d->dtype, d->point_fmt, d->qparams, stride, d->x, nullptr, nullptr,
+                         nullptr, stream);
+  if (rc) return rc;
+  rc = dc_consistency_fwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->n, d->k, d->mask, nullptr,
+                          d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, d->partials, out, stream);
+  if (rc || !want_grad) return rc;
+  return dc_consistency_bwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->n,
+                            d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
+                            d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, d->partials, out + 2, stream);
 }
 
 }  // extern "C"

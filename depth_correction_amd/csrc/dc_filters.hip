@@ -3,6 +3,7 @@
 // depth_cloud.py:314-326 (dir / vp dispersion), preproc.py:122-164 (global_cloud_mask).
 // HBM-bound elementwise passes; one lane per point, coalesced.
 #include "dc_common.h"
+#include "../../include/dc_hip.h"
 #include "dc_device.h"
 
 namespace dc {

@@ -4,6 +4,7 @@
 // one kernel: the loss is a sum of |n . (x2 - x1)| terms, so every correspondence contributes its gradient
 // straight to the model weights and to the two scan poses (block partial sums, fixed-order reduction).
 #include "dc_common.h"
+#include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include "dc_pointmath.h"
 #include "dc_points_dev.h"

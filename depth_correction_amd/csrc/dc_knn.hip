@@ -17,6 +17,7 @@
 #include <cstring>
 #include <cstdlib>
 #include "dc_common.h"
+#include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include <rocprim/rocprim.hpp>
 

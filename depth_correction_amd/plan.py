@@ -19,12 +19,15 @@ Results are reported in the caller's point order; per-point outputs are un-permu
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import ops
-from ._native import need
+from . import _native as nv
+from ._native import need, lib, check, ptr, stream_ptr
 
-__all__ = ['SequencePlan', 'consistency_loss']
+__all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer']
 
 
 class SequencePlan:
@@ -95,6 +98,46 @@ class SequencePlan:
         nacc = 2 * ops.nv.MAX_MODEL_TERMS + 12 * self.n_scans
         self.partials = torch.empty((rows * max(nacc, 2),), dtype=torch.float64, device=dev)
         self.version = 0
+        self._desc = None
+
+    # ------------------------------------------------------------------------------------------------
+    def desc(self, n_terms):
+        """dcSequenceDesc for the one-call native evaluation (dc_sequence_eval)."""
+        if self._desc is None or self._desc.n_terms != n_terms:
+            d = nv.SequenceDesc()
+            d.n, d.k, d.n_scans = self.n, self.k, self.n_scans
+            d.dtype = nv.DC_F32 if self.dtype == torch.float32 else nv.DC_F64
+            d.point_fmt = nv.DC_Q32 if self.qfmt is not None else d.dtype
+            if self.qfmt is not None:
+                for i in range(4):
+                    d.qparams[i] = self.qfmt._c[i]
+            p = lambda t: None if t is None else t.data_ptr()
+            ps = self.ps
+            d.vps, d.dirs, d.depth, d.inc, d.lmask, d.scan_id = p(ps.vps), p(ps.dirs), p(ps.depth), p(ps.inc), p(ps.lmask), p(ps.scan_id)
+            d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(self.csr_ptr), p(self.csr_src), p(self.mask)
+            d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
+            d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
+            d.n_terms = n_terms
+            d.loss_kind, d.normalization, d.sqrt_ = nv.LOSS_KINDS[self.loss], int(self.normalization), int(self.sqrt)
+            if d.model_kind != 0 and ps.inc is None:
+                raise ValueError('the model needs incidence angles')
+            self._desc = d
+        return self._desc
+
+    def eval_native(self, w, exponent, poses12, out, want_grad=True, want_exponent=False, want_pose=False):
+        """One host call per evaluation.  w, exponent: fp64 device vectors [P]; poses12: fp64 device [S,12];
+        out: fp64 device [2 + 2P + 12S] <- {sum loss, count, d/dw, d/dexponent, d/d[R|t]}."""
+        nt = 0 if w is None else w.numel()
+        d = self.desc(nt)
+        need(poses12, (self.n_scans, 12), dtype=torch.float64, name='poses12', device=self.device)
+        need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        if nt:
+            need(w, (nt,), dtype=torch.float64, name='w', device=self.device)
+            need(exponent, (nt,), dtype=torch.float64, name='exponent', device=self.device)
+        check(lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
+                                     int(want_exponent), int(want_pose), ptr(out), stream_ptr()), 'dc_sequence_eval')
+        self.version += 1
+        return out
 
     # ------------------------------------------------------------------------------------------------
     def poses12(self, poses):
@@ -173,3 +216,74 @@ class _ConsistencyLoss(torch.autograd.Function):
 def consistency_loss(plan, w, exponent, poses):
     """(sum of pointwise loss over the mask, mask count) of one sequence; the sum carries the autograd graph."""
     return _ConsistencyLoss.apply(plan, w, exponent, poses), plan.count
+
+
+class KernelTimer:
+    """HIP-event timing of the three hot kernels, recorded inside the library on the launch stream."""
+    KINDS = ('points_fwd', 'consistency_fwd', 'consistency_bwd')
+
+    def __enter__(self):
+        check(lib().dc_profiler_reset(), 'dc_profiler_reset')
+        check(lib().dc_profiler_enable(1), 'dc_profiler_enable')
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().dc_profiler_enable(0), 'dc_profiler_enable')
+
+    def read(self):
+        """{kernel: (mean ms per launch, launches)}; waits for the recorded launches."""
+        out = {}
+        for i, name in enumerate(self.KINDS):
+            tot, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+            check(lib().dc_profiler_read(i, ctypes.byref(tot), ctypes.byref(cnt)), 'dc_profiler_read')
+            if cnt.value:
+                out[name] = (tot.value / cnt.value, cnt.value)
+        return out
+
+
+class SequenceTrainer:
+    """The per-iteration body of train.py:220-312 for ball neighbourhoods and the min-eigenvalue / trace loss,
+    without Python in the loop: dc_sequence_eval (fwd + bwd) and dc_adam_step (torch.optim.Adam semantics) on
+    device-resident fp64 parameters.  Sequences are independent: with torch.distributed initialised,
+    one all-reduce of [sum loss, count, dL/dw] per step joins the ranks."""
+
+    def __init__(self, plans, w, exponent, poses, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 process_group=None, distributed=False):
+        self.plans = list(plans)
+        dev = self.plans[0].device
+        self.w = torch.as_tensor(w, dtype=torch.float64).reshape(-1).to(dev).contiguous()
+        self.exponent = torch.as_tensor(exponent, dtype=torch.float64).reshape(-1).to(dev).contiguous()
+        self.nt = self.w.numel()
+        self.poses12 = [p.poses12(T) for p, T in zip(self.plans, poses)]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(self.w)
+        self.exp_avg_sq = torch.zeros_like(self.w)
+        self.t = 0
+        self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
+        self.acc = torch.zeros((2 + self.nt,), dtype=torch.float64, device=dev)       # [sum loss, count, dL/dw]
+        self.distributed, self.group = distributed, process_group
+        self.count = sum(p.count for p in self.plans)
+        if distributed:
+            import torch.distributed as dist
+            c = torch.tensor([self.count], dtype=torch.float64, device=dev)
+            dist.all_reduce(c, group=process_group)
+            self.count = float(c.item())
+
+    def step(self):
+        """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
+        (mean loss = acc[0] / acc[1]).  No host synchronisation."""
+        for plan, P, out in zip(self.plans, self.poses12, self.outs):
+            plan.eval_native(self.w, self.exponent, P, out)
+        if len(self.outs) == 1:
+            acc = self.outs[0][:2 + self.nt]
+        else:
+            acc = self.acc
+            torch.stack([o[:2 + self.nt] for o in self.outs]).sum(0, out=acc)
+        if self.distributed:
+            import torch.distributed as dist
+            dist.all_reduce(acc, group=self.group)
+        self.t += 1
+        check(lib().dc_adam_step(ptr(self.w), ctypes.c_void_p(acc.data_ptr() + 16), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                 self.nt, self.t, 1.0 / self.count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                 self.weight_decay, stream_ptr()), 'dc_adam_step')
+        return acc

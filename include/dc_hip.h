@@ -161,6 +161,41 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
                     const int32_t* idxB, int64_t m, int want_exponent_grad, int want_pose_grad, double* partials_ws,
                     double* out, dcStream_t stream);
 
+/* ---- whole-sequence evaluation + optimiser step (train.py:220-312 per-iteration body for one sequence) ----------
+ * The caller fills a descriptor with the device arrays of one sequence (SequencePlan in Python) once; every
+ * iteration is then ONE host call that launches dc_points_fwd, dc_consistency_fwd and dc_consistency_bwd.
+ * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_partial_rows(n) * max(2, 2 P + 12 S)] are scratch. */
+typedef struct dcSequenceDesc {
+  int64_t n;
+  int32_t k, n_scans, dtype, point_fmt;
+  double qparams[4];
+  const void *vps, *dirs, *depth, *inc;
+  const uint8_t* lmask;
+  const int32_t* scan_id;
+  const int32_t *nbr, *csr_ptr, *csr_src;
+  const uint8_t* mask;
+  void *x, *rec;
+  double* partials;
+  int32_t model_kind, n_terms, loss_kind, normalization, sqrt_, reserved;
+} dcSequenceDesc;
+
+/* out fp64 [2 + 2 P + 12 S] = {sum of pointwise loss over mask, mask count, d(sum)/dw, /dexponent, /d[R|t]};
+ * w, e, poses: device fp64 (model weights [P], exponents [P], poses [S,12]). */
+int dc_sequence_eval(const dcSequenceDesc* desc, const double* w, const double* e, const double* poses, int want_grad,
+                     int want_exponent_grad, int want_pose_grad, double* out, dcStream_t stream);
+
+/* torch.optim.Adam step (train.py:139-149,312) on a device fp64 vector; grad is multiplied by grad_scale first
+ * (1 / number of masked points of all sequences = the reference's mean reduction, loss.py:205-213). */
+int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t step,
+                 double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 dcStream_t stream);
+
+/* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
+ * bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them. */
+int dc_profiler_enable(int on);
+int dc_profiler_reset(void);
+int dc_profiler_read(int kind, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif
