@@ -1,0 +1,140 @@
+"""Loss evaluation over sequences with the reference's signatures (eval.py:31-112).
+
+``eval_loss_clouds`` is the body of one training iteration.  When the configuration is the one the fused kernels
+cover (ball neighbourhoods on the GPU, min-eigenvalue or trace loss without quantile inliers / offsets / distance
+weights, (Scaled)Polynomial or no model) every sequence is evaluated by its cached ``SequencePlan`` -- three kernel
+launches -- and the returned loss carries the hand-derived backward to ``model.w`` / ``model.exponent`` / the pose
+corrections.  Any other configuration goes through the un-fused DepthCloud operators with identical results.
+"""
+from __future__ import annotations
+
+import torch
+
+from .config import Config, NeighborhoodType, PoseCorrection
+from .depth_cloud import DepthCloud
+from .plan import SequencePlan, consistency_loss
+from .preproc import (compute_neighborhood_features, global_cloud, global_cloud_mask, local_feature_cloud,
+                      offset_cloud)
+from .transform import xyz_axis_angle_to_matrix
+
+__all__ = ['create_corrected_poses', 'eval_loss_clouds', 'initialize_pose_corrections', 'fused_supported',
+           'PlanCloud']
+
+
+def initialize_pose_corrections(datasets, cfg: Config):
+    """Zero 6-vector corrections per cfg.pose_correction (eval.py:31-65); lengths of ``datasets`` are used."""
+    kwargs = dict(dtype=cfg.torch_float_type(), device=cfg.device, requires_grad=True)
+    deltas = []
+    for ds in datasets:
+        if cfg.pose_correction == PoseCorrection.common:
+            delta = deltas[0] if deltas else torch.zeros((1, 6), **kwargs)
+        elif cfg.pose_correction == PoseCorrection.sequence:
+            delta = torch.zeros((1, 6), **kwargs)
+        elif cfg.pose_correction == PoseCorrection.pose:
+            delta = torch.zeros((len(ds), 6), **kwargs)
+        else:
+            delta = None
+        deltas.append(delta)
+    return deltas
+
+
+def create_corrected_poses(poses, pose_deltas, cfg: Config):
+    """T_s = T0_s * [Exp(axis-angle) | xyz] (eval.py:68-82)."""
+    if cfg.pose_correction == PoseCorrection.none:
+        return poses
+    assert len(poses) == len(pose_deltas)
+    if cfg.pose_correction == PoseCorrection.common:
+        assert all(d is pose_deltas[0] for d in pose_deltas[1:])
+    return [torch.matmul(p, xyz_axis_angle_to_matrix(d)) for p, d in zip(poses, pose_deltas)]
+
+
+def fused_supported(clouds, model, cfg: Config):
+    kw = cfg.loss_kwargs
+    return (getattr(cfg, 'fused', True) and cfg.nn_type == NeighborhoodType.ball
+            and cfg.loss in ('min_eigval_loss', 'trace_loss') and not cfg.loss_offset and not cfg.nn_scale
+            and kw.get('inlier_ratio', 1.0) == 1.0 and kw.get('inlier_max_loss') is None
+            and (model is None or getattr(model, 'kernel_kind', None) is not None)
+            and clouds[0][0].dirs.is_cuda and all(c.inc_angles is not None for seq in clouds for c in seq))
+
+
+class PlanCloud(object):
+    """Lazy view of a fused evaluation: the DepthCloud fields callers may inspect (points, eigvals, loss, mask) are
+    produced on first access by one more forward with the per-point outputs switched on."""
+
+    def __init__(self, plan, w, exponent, poses):
+        self._plan, self._args, self._out = plan, (w, exponent, poses), None
+
+    def _materialize(self):
+        if self._out is None:
+            p = self._plan
+            w, e, poses = self._args
+            out = p.forward(w, e, poses, want_pointwise=True, want_eigvals=True)
+            self._out = dict(points=p.points(), eigvals=p.unpermute(out['eigvals']),
+                             loss=p.unpermute(out['pointwise']), mask=None if p.mask is None else p.unpermute(p.mask))
+        return self._out
+
+    def __getattr__(self, name):
+        if name in ('points', 'eigvals', 'loss', 'mask'):
+            return self._materialize()[name]
+        raise AttributeError(name)
+
+    def __len__(self):
+        return self._plan.n
+
+
+def _plan_for(seq_clouds, poses, nn, mask, model, cfg):
+    """SequencePlan cached on the neighbour tensor of the sequence (constant over the optimisation)."""
+    neighbors = nn[0]
+    kw = cfg.loss_kwargs
+    key = (tuple(id(c) for c in seq_clouds), None if mask is None else (id(mask), mask._version), neighbors._version,
+           cfg.loss, bool(kw.get('normalization', False)), bool(kw.get('sqrt', False)),
+           getattr(model, 'kernel_kind', None) if model is not None else None)
+    cached = getattr(neighbors, '_dc_plan', None)
+    if cached is None or cached[0] != key:
+        plan = SequencePlan(seq_clouds, poses.detach(), neighbors, None if mask is None else mask.to(neighbors.device),
+                            model_kind=key[-1] or 'ScaledPolynomial', loss=cfg.loss,
+                            normalization=key[4] and cfg.loss == 'min_eigval_loss', sqrt=key[5])
+        neighbors._dc_plan = cached = (key, plan)
+    return cached[1]
+
+
+def eval_loss_clouds(clouds, poses, pose_deltas, masks, ns, model, loss_fun, cfg: Config):
+    """Loss of all sequences for the current model / pose corrections (eval.py:85-112).
+
+    Returns (loss, loss_clouds, updated poses, feature clouds) like the reference."""
+    poses_upd = create_corrected_poses(poses, pose_deltas, cfg)
+
+    if cfg.loss == 'icp_loss':
+        if clouds[0][0].normals is None:
+            clouds = [[local_feature_cloud(c, cfg) for c in seq] for seq in clouds]
+        loss, loss_cloud = loss_fun(clouds, poses_upd, model, masks=masks)
+        return loss, loss_cloud, poses_upd, None
+
+    if fused_supported(clouds, model, cfg):
+        # masks are established once (train.py:212-215); when absent they come from one un-fused evaluation
+        if not masks or masks[0] is None:
+            masks = []
+            for c, p, nn in zip(clouds, poses_upd, ns):
+                g = compute_neighborhood_features(cloud=global_cloud(clouds=c, model=model, poses=p.detach()),
+                                                  neighborhoods=nn, cfg=cfg)
+                masks.append(global_cloud_mask(g, g.mask, cfg))
+        use_model = model is not None and getattr(model, 'kernel_kind', None) is not None
+        total, count, views = 0.0, 0.0, []
+        for c, p, nn, m in zip(clouds, poses_upd, ns, masks):
+            plan = _plan_for(c, p, nn, m, model, cfg)
+            w = model.w if use_model else None
+            e = model.exponent if use_model else None
+            s, cnt = consistency_loss(plan, w, e, p)
+            total, count = total + s, count + cnt
+            views.append(PlanCloud(plan, w, e, p))
+        loss = total / count if count > 0 else total * float('nan')        # mean over all masked points (loss.py:211)
+        return loss, views, poses_upd, views
+
+    offsets = [offset_cloud(c, model) for c in clouds] if cfg.loss_offset else None
+    global_clouds = [global_cloud(clouds=c, model=model, poses=p) for c, p in zip(clouds, poses_upd)]
+    feat_clouds = [compute_neighborhood_features(cloud=cloud, neighborhoods=nn, cfg=cfg)
+                   for cloud, nn in zip(global_clouds, ns)]
+    if (not masks or masks[0] is None) and isinstance(feat_clouds[0], DepthCloud):
+        masks = [global_cloud_mask(cloud, cloud.mask if hasattr(cloud, 'mask') else None, cfg) for cloud in feat_clouds]
+    loss, loss_cloud = loss_fun(feat_clouds, mask=masks, offset=offsets)
+    return loss, loss_cloud, poses_upd, feat_clouds

@@ -1,0 +1,156 @@
+"""Cloud filters with the reference's signatures (filters.py:24-309): boolean masks or sliced clouds.
+
+Eigenvalue / eigenvalue-ratio / valid-neighbour bounds run as HIP mask kernels (dc_mask_bounds, dc_valid_count)
+when the cloud lives on the GPU; ``within_bounds`` on arbitrary tensors is the reference's comparison in torch.
+Depth and voxel-grid pre-filters feed the path's inputs: ``filter_depth`` is a tensor comparison,
+``filter_grid`` keeps the reference's host algorithm (dict over voxel keys with a seeded shuffle) because which
+point survives per voxel is defined by numpy's generator.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from numpy.lib.recfunctions import structured_to_unstructured
+
+from . import ops
+from .depth_cloud import DepthCloud
+
+__all__ = ['filter_depth', 'filter_eigenvalue', 'filter_eigenvalue_ratio', 'filter_eigenvalue_ratios',
+           'filter_eigenvalues', 'filter_grid', 'filter_valid_neighbors', 'within_bounds']
+
+default_rng = np.random.default_rng(135)
+
+
+def _report(keep, lo, name, hi):
+    print('%.3f = %i / %i points kept (%.3g <= %s <= %.3g).'
+          % (keep.double().mean(), keep.sum(), keep.numel(), lo if lo is not None else float('nan'), name,
+             hi if hi is not None else float('nan')))
+
+
+def within_bounds(x, min=None, max=None, bounds=None, log_variable=None):
+    """Mask of min <= x <= max (inclusive); None / infinite bounds are inactive; NaN fails active bounds."""
+    x = x if isinstance(x, torch.Tensor) else torch.tensor(x)
+    if bounds:
+        assert min is None and max is None
+        min, max = bounds
+    keep = torch.ones((x.numel(),), dtype=torch.bool, device=x.device)
+    if min is not None and min > -float('inf'):
+        keep = keep & (x.flatten() >= min)
+    if max is not None and max < float('inf'):
+        keep = keep & (x.flatten() <= max)
+    if log_variable is not None:
+        _report(keep, min, log_variable, max)
+    return keep
+
+
+def _gpu_bounds(num, num_index, den, den_index, lo, hi):
+    mask = torch.ones((num.shape[0],), dtype=torch.bool, device=num.device)
+    return ops.mask_bounds(mask, num.detach().contiguous(), num_index, None if den is None else den.detach().contiguous(),
+                           den_index, lo, hi)
+
+
+def _finish(cloud, keep, only_mask):
+    return keep if only_mask else cloud[keep]
+
+
+def filter_depth(cloud, min=None, max=None, only_mask=False, log=False):
+    assert isinstance(cloud, (DepthCloud, np.ndarray))
+    if isinstance(cloud, DepthCloud):
+        depth = cloud.depth
+    else:
+        x = structured_to_unstructured(cloud[['x', 'y', 'z']]) if cloud.dtype.names else cloud
+        if cloud.dtype.names and 'vp_x' in cloud.dtype.names:
+            x = x - structured_to_unstructured(cloud[['vp_x', 'vp_y', 'vp_z']])
+        depth = torch.as_tensor(np.linalg.norm(x, axis=1))
+    keep = within_bounds(depth, min=min, max=max, log_variable='depth' if log else None)
+    if only_mask:
+        return keep
+    return cloud[keep] if isinstance(cloud, DepthCloud) else cloud[keep.numpy()]
+
+
+def filter_grid(cloud, grid_res, only_mask=False, keep='random', preserve_order=False, log=False, rng=default_rng):
+    """One point per voxel of edge ``grid_res``.  The survivor of a voxel is the LAST point of the (optionally
+    shuffled or reversed) sequence falling into it, exactly as the reference's dict construction yields."""
+    assert isinstance(cloud, (DepthCloud, np.ndarray, torch.Tensor))
+    assert isinstance(grid_res, float) and grid_res > 0.0 and keep in ('first', 'random', 'last')
+    if isinstance(cloud, DepthCloud):
+        x = cloud.get_points().detach().cpu().numpy()
+    elif isinstance(cloud, np.ndarray):
+        x = structured_to_unstructured(cloud[['x', 'y', 'z']]) if cloud.dtype.names else cloud
+    else:
+        x = cloud.detach().cpu().numpy()
+    voxels = np.floor(x / grid_res).astype(int)
+    order = np.arange(len(voxels))
+    if keep == 'first':
+        order = order[::-1]
+    elif keep == 'random':
+        order = list(range(len(voxels)))
+        rng.shuffle(order)
+        order = np.asarray(order, dtype=np.int64)
+    survivor = {}
+    for i, key in zip(order.tolist(), map(tuple, voxels[order].tolist())):
+        survivor[key] = i
+    ind = sorted(survivor.values()) if preserve_order else list(survivor.values())
+    if log:
+        print('%.3f = %i / %i points kept (grid res. %.3f m).' % (len(ind) / len(voxels), len(ind), len(voxels), grid_res))
+    return ind if only_mask else cloud[ind]
+
+
+def filter_valid_neighbors(cloud, min=None, only_mask=False, log=False):
+    assert isinstance(cloud, DepthCloud) and cloud.neighbors is not None
+    if cloud.neighbors.is_cuda:
+        cnt = ops.valid_count(cloud.graph().nbr)
+    else:
+        cnt = cloud.valid_neighbor_mask().sum(dim=-1)
+    keep = within_bounds(cnt, min=min, log_variable='valid neighbors' if log else None)
+    return _finish(cloud, keep, only_mask)
+
+
+def filter_eigenvalue(cloud, eigenvalue=0, min=None, max=None, only_mask=False, log=False):
+    with torch.no_grad():
+        ev = cloud.eigvals
+        if ev.is_cuda:
+            keep = _gpu_bounds(ev, eigenvalue, None, 0, min, max)
+            if log:
+                _report(keep, min, 'eigenvalue %i' % eigenvalue, max)
+        else:
+            keep = within_bounds(ev[:, eigenvalue], min=min, max=max, log_variable='eigenvalue %i' % eigenvalue if log else None)
+    return _finish(cloud, keep, only_mask)
+
+
+def filter_eigenvalue_ratio(cloud, eigenvalues=(0, 1), min=None, max=None, only_mask=False, log=False):
+    assert cloud.eigvals is not None and len(eigenvalues) == 2 and all(0 <= i <= 2 for i in eigenvalues)
+    i, j = eigenvalues
+    with torch.no_grad():
+        ev = cloud.eigvals
+        if ev.is_cuda:
+            keep = _gpu_bounds(ev, i, ev, j, min, max)
+            if log:
+                _report(keep, min, 'eigenvalue %i / eigenvalue %i' % tuple(eigenvalues), max)
+        else:
+            keep = within_bounds(ev[:, i] / ev[:, j], min=min, max=max,
+                                 log_variable='eigenvalue %i / eigenvalue %i' % tuple(eigenvalues) if log else None)
+    return _finish(cloud, keep, only_mask)
+
+
+def _all_of(cloud, bounds, one, what, only_mask, log):
+    mask = None
+    for b in (bounds or []):
+        m = one(b)
+        mask = m if mask is None else mask & m
+    if mask is None:
+        mask = torch.ones((cloud.size(),), dtype=torch.bool, device=cloud.device())
+    if log:
+        print('%.3f = %i / %i points kept (%s within bounds).' % (mask.double().mean(), mask.sum(), mask.numel(), what))
+    return _finish(cloud, mask, only_mask)
+
+
+def filter_eigenvalues(cloud: DepthCloud, bounds: list, only_mask: bool = False, log: bool = False):
+    return _all_of(cloud, bounds, lambda b: filter_eigenvalue(cloud, int(b[0]), min=b[1], max=b[2], only_mask=True, log=log),
+                   'eigenvalues', only_mask, log)
+
+
+def filter_eigenvalue_ratios(cloud: DepthCloud, bounds: list, only_mask: bool = False, log: bool = False):
+    return _all_of(cloud, bounds, lambda b: filter_eigenvalue_ratio(cloud, (int(b[0]), int(b[1])), min=b[2], max=b[3],
+                                                                   only_mask=True, log=log),
+                   'eigenvalue ratios', only_mask, log)

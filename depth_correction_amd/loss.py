@@ -1,0 +1,275 @@
+"""Map-consistency losses with the reference's signatures (loss.py:125-579).
+
+Two execution paths produce the same numbers:
+  * fused (eval.eval_loss_clouds, plan.SequencePlan): covariance -> eigen -> pointwise loss -> backward record in
+    the HIP kernels, never materialising per-point features;
+  * un-fused (this module on a DepthCloud whose features came from ``update_all``): the pointwise post-processing
+    of loss.py:250-289 on ``cloud.eigvals`` / ``cloud.cov`` (small ``[M]`` tensors), differentiable down to the
+    points through dc_features_bwd.  All of the reference's options are available here (mask, offset, sqrt,
+    normalisation, quantile inliers, reductions).
+``icp_loss`` with point-to-plane distances and precomputed correspondences runs as one kernel per scan pair
+(dc_p2plane_pair) including its backward to the model weights and poses.
+"""
+from __future__ import annotations
+
+import warnings
+from enum import Enum
+
+import torch
+
+from . import ops
+from .depth_cloud import DepthCloud
+from .utils import trace
+
+__all__ = ['batch_loss', 'create_loss', 'icp_loss', 'loss_by_name', 'min_eigval_loss', 'point_to_plane_dist',
+           'point_to_point_dist', 'reduce', 'Reduction', 'trace_loss', 'icp_correspondences']
+
+
+class Reduction(Enum):
+    NONE = 'none'
+    MEAN = 'mean'
+    SUM = 'sum'
+
+
+def reduce(x, reduction=Reduction.MEAN, weights=None, only_finite=False, skip_nans=False):
+    assert reduction in Reduction
+    keep = x.isfinite() if only_finite else (~x.isnan() if skip_nans else None)
+    if keep is not None:
+        weights = weights[keep] if weights is not None else None
+        x = x[keep]
+    if reduction == Reduction.MEAN:
+        return x.mean() if weights is None else (weights * x).sum() / weights.sum()
+    if reduction == Reduction.SUM:
+        return x.sum() if weights is None else (weights * x).sum()
+    return x
+
+
+def batch_loss(loss_fun, clouds, masks=None, offsets=None, reduction=Reduction.MEAN, only_finite=False,
+               skip_nans=False, **kwargs):
+    """Pointwise losses of several sequences, concatenated, then reduced once (loss.py:181-213)."""
+    assert callable(loss_fun) and isinstance(clouds, (list, tuple))
+    masks = len(clouds) * [None] if masks is None else masks
+    offsets = len(clouds) * [None] if offsets is None else offsets
+    assert len(masks) == len(clouds) == len(offsets)
+    parts, loss_clouds = [], []
+    for cloud, mask, offset in zip(clouds, masks, offsets):
+        part, loss_cloud = loss_fun(cloud, mask=mask, offset=offset, reduction=Reduction.NONE, **kwargs)
+        parts.append(part)
+        loss_clouds.append(loss_cloud)
+    return reduce(torch.cat(parts), reduction=reduction, only_finite=only_finite, skip_nans=skip_nans), loss_clouds
+
+
+def _pointwise(raw_fun, cloud, mask, offset, sqrt, reduction, inlier_max_loss, inlier_ratio, inlier_loss_mult,
+               only_finite, skip_nans):
+    """Shared tail of min_eigval_loss / trace_loss (loss.py:244-294, 324-370)."""
+    assert offset is None or isinstance(offset, (DepthCloud, torch.Tensor))
+    if mask is not None:
+        print('Using %.3f valid entries from input cloud.' % mask.float().mean())
+        cloud, mask = cloud[mask], None
+    loss = raw_fun(cloud)
+    if inlier_ratio < 1.0:
+        assert offset is None
+        q = torch.quantile(loss, inlier_ratio, dim=0)
+        if inlier_loss_mult != 1.0:
+            q = inlier_loss_mult * q
+        inlier_max_loss = q if inlier_max_loss is None else torch.min(torch.as_tensor(inlier_max_loss, dtype=q.dtype,
+                                                                                       device=q.device), q)
+    if inlier_max_loss is not None:
+        assert offset is None
+        mask = loss <= inlier_max_loss
+        print('Using %i (%.3g) inliers with loss <= %.3g.' % (mask.sum().item(), mask.float().mean().item(),
+                                                              float(inlier_max_loss)))
+        cloud, loss = cloud[mask], loss[mask]
+    if offset is not None:
+        loss = loss - (offset.loss if isinstance(offset, DepthCloud) else offset)
+    loss = torch.relu(loss)
+    if sqrt:
+        loss = torch.sqrt(loss)
+    cloud = cloud.copy()
+    cloud.loss = loss
+    return reduce(loss, reduction=reduction, only_finite=only_finite, skip_nans=skip_nans), cloud
+
+
+def min_eigval_loss(cloud, mask=None, offset=None, sqrt=False, normalization=False, reduction=Reduction.MEAN,
+                    inlier_max_loss=None, inlier_ratio=1.0, inlier_loss_mult=1.0, only_finite=False, skip_nans=False,
+                    **kwargs):
+    """Smallest neighbourhood eigenvalue (optionally over the total variance) averaged over the masked points."""
+    if isinstance(cloud, (list, tuple)):
+        return batch_loss(min_eigval_loss, cloud, masks=mask, offsets=offset, sqrt=sqrt, normalization=normalization,
+                          reduction=reduction, inlier_max_loss=inlier_max_loss, inlier_ratio=inlier_ratio,
+                          inlier_loss_mult=inlier_loss_mult, only_finite=only_finite, skip_nans=skip_nans)
+    assert isinstance(cloud, DepthCloud) and cloud.eigvals is not None
+
+    def raw(c):
+        lam = c.eigvals
+        return lam[:, 0] / lam.sum(dim=-1).clamp(min=1e-6) if normalization else lam[:, 0]
+    return _pointwise(raw, cloud, mask, offset, sqrt, reduction, inlier_max_loss, inlier_ratio, inlier_loss_mult,
+                      only_finite, skip_nans)
+
+
+def trace_loss(cloud, mask=None, offset=None, sqrt=None, reduction=Reduction.MEAN, inlier_max_loss=None,
+               inlier_ratio=1.0, inlier_loss_mult=1.0, only_finite=False, skip_nans=False, **kwargs):
+    """Trace of the neighbourhood covariance averaged over the masked points."""
+    if isinstance(cloud, (list, tuple)):
+        return batch_loss(trace_loss, cloud, masks=mask, offsets=offset, sqrt=sqrt, reduction=reduction,
+                          inlier_max_loss=inlier_max_loss, inlier_ratio=inlier_ratio, inlier_loss_mult=inlier_loss_mult,
+                          only_finite=only_finite, skip_nans=skip_nans)
+    assert isinstance(cloud, DepthCloud) and cloud.cov is not None
+    return _pointwise(lambda c: trace(c.cov), cloud, mask, offset, sqrt, reduction, inlier_max_loss, inlier_ratio,
+                      inlier_loss_mult, only_finite, skip_nans)
+
+
+# ---- ICP-style losses ---------------------------------------------------------------------------------------------
+def icp_correspondences(points1, points2, ratio):
+    """(mask1 bool [N1], idx2 int64 [M]): 1-NN of scan 1 in scan 2 on the GPU, inliers = dist <= quantile(dist, ratio)
+    (train.py:186-193, loss.py:440-452)."""
+    dist, idx = ops.knn(points2.detach().contiguous(), 1, query=points1.detach().to(points2.dtype).contiguous())
+    dist, idx = dist[:, 0], idx[:, 0].long()
+    th = torch.nanquantile(dist, ratio)
+    mask1 = dist <= th
+    return mask1, idx[mask1], dist
+
+
+def _pair_points(cloud):
+    pts = cloud.to_points() if cloud.points is None else cloud.points
+    assert not torch.all(torch.isnan(pts))
+    return torch.as_tensor(pts, dtype=torch.float)
+
+
+def _pair_matches(points1, points2, masks, i, ratio):
+    if masks is not None:
+        m1, m2 = masks[i]
+        return torch.as_tensor(m1, device=points1.device), torch.as_tensor(m2, device=points1.device), torch.tensor(-1.0)
+    mask1, idx2, dist = icp_correspondences(points1, points2, ratio)
+    return mask1, idx2, dist[mask1].mean()
+
+
+def point_to_plane_dist(clouds: list, icp_inlier_ratio=0.5, masks=None, differentiable=True, verbose=False, **kwargs):
+    """Mean symmetric point-to-plane distance over consecutive scan pairs (loss.py:406-488), un-fused form."""
+    assert 0.0 <= icp_inlier_ratio <= 1.0
+    assert masks is None or len(clouds) == len(masks) + 1
+    total, n_pairs = 0.0, len(clouds) - 1
+    for i in range(n_pairs):
+        c1, c2 = clouds[i], clouds[i + 1]
+        assert c1.normals is not None, 'Cloud must have normals computed to estimate point to plane distance'
+        p1, p2 = _pair_points(c1), _pair_points(c2)
+        mask1, mask2, inl_err = _pair_matches(p1, p2, masks, i, icp_inlier_ratio)
+        a, b = p1[mask1], p2[mask2]
+        assert len(a) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
+        n1, n2 = c1.normals[mask1], c2.normals[mask2]
+        d12 = torch.linalg.norm((n1 * (b - a)).sum(dim=-1, keepdims=True) * n1, dim=-1).mean()
+        d21 = torch.linalg.norm((n2 * (a - b)).sum(dim=-1, keepdims=True) * n2, dim=-1).mean()
+        total = total + 0.5 * (d12 + d21)
+        if inl_err > 0.3:
+            warnings.warn('ICP inliers error is too big: %.3f (> 0.3) [m] for pairs (%i, %i)' % (inl_err, i, i + 1))
+        if verbose:
+            print('Mean point to plane distance: %.3f [m] for scans: (%i, %i), inliers error: %.6f'
+                  % (float(total), i, i + 1, float(inl_err)))
+    return torch.as_tensor(total / n_pairs)
+
+
+def point_to_point_dist(clouds: list, icp_inlier_ratio=0.5, masks=None, differentiable=True, verbose=False, **kwargs):
+    """Mean point-to-point distance over consecutive scan pairs (loss.py:491-565)."""
+    assert 0.0 <= icp_inlier_ratio <= 1.0
+    assert masks is None or len(clouds) == len(masks) + 1
+    total, n_pairs = 0.0, len(clouds) - 1
+    for i in range(n_pairs):
+        c1, c2 = clouds[i], clouds[i + 1]
+        p1 = _pair_points(c1) if isinstance(c1, DepthCloud) else torch.as_tensor(c1, dtype=torch.float)
+        p2 = _pair_points(c2) if isinstance(c2, DepthCloud) else torch.as_tensor(c2, dtype=torch.float)
+        mask1, mask2, inl_err = _pair_matches(p1, p2, masks, i, icp_inlier_ratio)
+        a, b = p1[mask1], p2[mask2]
+        assert len(a) > 0 and len(b) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
+        total = total + torch.linalg.norm(b - a, dim=1).mean()
+        if inl_err > 0.3:
+            warnings.warn('ICP inliers error is too big: %.3f (> 0.3) [m] for pairs (%i, %i)' % (inl_err, i, i + 1))
+    return torch.as_tensor(total / n_pairs)
+
+
+class _P2PlanePair(torch.autograd.Function):
+    """sum12 + sum21 of one scan pair (dc_p2plane_pair): forward and backward come out of the same launch."""
+
+    @staticmethod
+    def forward(ctx, w, exponent, pose_a, pose_b, psa, na, psb, nb, idx_a, idx_b, kind):
+        P = lambda T: T.detach().to(torch.float64)[:3, :].reshape(12).contiguous()
+        wv = None if w is None else w.detach().reshape(-1).to(torch.float64).contiguous()
+        ev = None if exponent is None else exponent.detach().reshape(-1).to(torch.float64).contiguous()
+        sums, dw, de, dTa, dTb = ops.p2plane_pair(psa, na, psb, nb, P(pose_a), P(pose_b), idx_a, idx_b, kind, wv, ev)
+        ctx.save_for_backward(dw, de, dTa, dTb)
+        ctx.meta = (None if w is None else (w.shape, w.dtype), pose_a.dtype,
+                    exponent.shape if isinstance(exponent, torch.Tensor) else None)
+        return sums.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        dw, de, dTa, dTb = ctx.saved_tensors
+        wmeta, pdt, eshape = ctx.meta
+        pad = lambda d: torch.cat([g * d, torch.zeros((1, 4), dtype=d.dtype, device=d.device)]).to(pdt)
+        gw = (g * dw).reshape(wmeta[0]).to(wmeta[1]) if (wmeta is not None and ctx.needs_input_grad[0]) else None
+        ge = (g * de).reshape(eshape) if (eshape is not None and ctx.needs_input_grad[1]) else None
+        return (gw, ge, pad(dTa) if ctx.needs_input_grad[2] else None, pad(dTb) if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None, None)
+
+
+def _fused_icp_sequence(seq_clouds, seq_poses, model, seq_masks):
+    """Point-to-plane loss of one sequence through dc_p2plane_pair (clouds in the sensor frame + poses + model)."""
+    kind = getattr(model, 'kernel_kind', None) if model is not None else None
+    w = model.w if kind else None
+    e = model.exponent if kind else None
+    sets = []
+    for c in seq_clouds:
+        n = len(c)
+        cont = lambda t: t.detach().expand(n, t.shape[-1]).contiguous() if t.dim() == 2 else t.detach().contiguous()
+        sets.append((ops.PointSet(cont(c.vps), cont(c.dirs), cont(c.depth), None if c.inc_angles is None else cont(c.inc_angles),
+                                  c.mask), cont(c.normals.to(c.dirs.dtype))))
+    total = 0.0
+    n_pairs = len(seq_clouds) - 1
+    for i in range(n_pairs):
+        m1, m2 = seq_masks[i]
+        m1 = torch.as_tensor(m1, device=sets[i][1].device)
+        ia = (torch.nonzero(m1).reshape(-1) if m1.dtype == torch.bool else m1).to(torch.int32).contiguous()
+        ib = torch.as_tensor(m2, device=ia.device).to(torch.int32).contiguous()
+        assert len(ia) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
+        s = _P2PlanePair.apply(w, e, seq_poses[i], seq_poses[i + 1], sets[i][0], sets[i][1], sets[i + 1][0],
+                               sets[i + 1][1], ia, ib, kind)
+        total = total + 0.5 * s / len(ia)
+    return total / n_pairs
+
+
+def icp_loss(clouds, poses=None, model=None, masks=None, **kwargs):
+    """ICP-like loss over lists of sequences of scans (loss.py:373-403)."""
+    p2plane = kwargs['icp_point_to_plane']
+    fused = (p2plane and masks is not None and poses is not None and clouds and clouds[0][0].dirs.is_cuda
+             and all(c.normals is not None for seq in clouds for c in seq)
+             and (model is None or getattr(model, 'kernel_kind', None)))
+    loss, loss_cloud = 0., []
+    for i, seq in enumerate(clouds):
+        if fused:
+            loss_seq = _fused_icp_sequence(seq, poses[i], model, masks[i])
+            moved = seq
+        else:
+            moved = [model(c) for c in seq] if model is not None else seq
+            if poses is not None:
+                moved = [c.transform(p) for c, p in zip(moved, poses[i])]
+            fun = point_to_plane_dist if p2plane else point_to_point_dist
+            loss_seq = fun(moved, masks=None if masks is None else masks[i], **kwargs)
+        loss = loss + loss_seq
+        cloud = DepthCloud.concatenate(moved)
+        cloud.loss = loss
+        loss_cloud.append(cloud)
+    return loss / len(clouds), loss_cloud
+
+
+def loss_by_name(name):
+    assert name in ('min_eigval_loss', 'trace_loss', 'icp_loss')
+    return globals()[name]
+
+
+def create_loss(cfg):
+    loss = loss_by_name(cfg.loss)
+
+    def loss_fun(*args, **kwargs):
+        return loss(*args, **kwargs, **cfg.loss_kwargs)
+    loss_fun.name = cfg.loss
+    loss_fun.kwargs = cfg.loss_kwargs
+    return loss_fun

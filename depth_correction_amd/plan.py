@@ -244,17 +244,20 @@ class KernelTimer:
 class SequenceTrainer:
     """The per-iteration body of train.py:220-312 for ball neighbourhoods and the min-eigenvalue / trace loss,
     without Python in the loop: dc_sequence_eval (fwd + bwd) and dc_adam_step (torch.optim.Adam semantics) on
-    device-resident fp64 parameters.  Sequences are independent: with torch.distributed initialised,
-    one all-reduce of [sum loss, count, dL/dw] per step joins the ranks."""
+    device-resident fp64 parameters.  Sequences are independent: every rank evaluates the sequences it
+    owns and one all-reduce of [sum loss, count, dL/dw] per step joins the ranks; all ranks then take the same
+    Adam step.  ``evaluate`` / ``adam`` are injectable so the sharding logic can be exercised without a GPU."""
 
     def __init__(self, plans, w, exponent, poses, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 process_group=None, distributed=False):
+                 process_group=None, distributed=False, evaluate=None, adam=None, device=None):
         self.plans = list(plans)
-        dev = self.plans[0].device
+        dev = device if device is not None else self.plans[0].device
         self.w = torch.as_tensor(w, dtype=torch.float64).reshape(-1).to(dev).contiguous()
         self.exponent = torch.as_tensor(exponent, dtype=torch.float64).reshape(-1).to(dev).contiguous()
         self.nt = self.w.numel()
-        self.poses12 = [p.poses12(T) for p, T in zip(self.plans, poses)]
+        self.evaluate = evaluate or (lambda plan, w_, e_, P, out: plan.eval_native(w_, e_, P, out))
+        self.adam = adam or self._adam_native
+        self.poses12 = [p.poses12(T) if hasattr(p, 'poses12') else T for p, T in zip(self.plans, poses)]
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(self.w)
         self.exp_avg_sq = torch.zeros_like(self.w)
@@ -262,28 +265,31 @@ class SequenceTrainer:
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
         self.acc = torch.zeros((2 + self.nt,), dtype=torch.float64, device=dev)       # [sum loss, count, dL/dw]
         self.distributed, self.group = distributed, process_group
-        self.count = sum(p.count for p in self.plans)
+        self.count = float(sum(p.count for p in self.plans))
         if distributed:
-            import torch.distributed as dist
-            c = torch.tensor([self.count], dtype=torch.float64, device=dev)
-            dist.all_reduce(c, group=process_group)
-            self.count = float(c.item())
+            from .distributed import all_reduce_sum
+            self.count = float(all_reduce_sum(torch.tensor([self.count], dtype=torch.float64, device=dev), process_group).item())
+
+    def _adam_native(self, grad_sum):
+        check(lib().dc_adam_step(ptr(self.w), ctypes.c_void_p(grad_sum.data_ptr()), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                 self.nt, self.t, 1.0 / self.count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                 self.weight_decay, stream_ptr()), 'dc_adam_step')
 
     def step(self):
         """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
         (mean loss = acc[0] / acc[1]).  No host synchronisation."""
         for plan, P, out in zip(self.plans, self.poses12, self.outs):
-            plan.eval_native(self.w, self.exponent, P, out)
-        if len(self.outs) == 1:
+            self.evaluate(plan, self.w, self.exponent, P, out)
+        if len(self.outs) == 1 and not self.distributed:
             acc = self.outs[0][:2 + self.nt]
         else:
             acc = self.acc
-            torch.stack([o[:2 + self.nt] for o in self.outs]).sum(0, out=acc)
+            acc.zero_()
+            for o in self.outs:
+                acc += o[:2 + self.nt]
         if self.distributed:
-            import torch.distributed as dist
-            dist.all_reduce(acc, group=self.group)
+            from .distributed import all_reduce_sum
+            all_reduce_sum(acc, self.group)
         self.t += 1
-        check(lib().dc_adam_step(ptr(self.w), ctypes.c_void_p(acc.data_ptr() + 16), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                 self.nt, self.t, 1.0 / self.count, self.lr, self.betas[0], self.betas[1], self.eps,
-                                 self.weight_decay, stream_ptr()), 'dc_adam_step')
+        self.adam(acc[2:2 + self.nt])
         return acc

@@ -263,9 +263,9 @@ def within_bounds(x, lo=None, hi=None):
 def _eig_masks(eigvals, eigenvalue_bounds, eigenvalue_ratio_bounds):
     mask = torch.ones((eigvals.shape[0],), dtype=torch.bool)
     for e, lo, hi in (eigenvalue_bounds or []):                  # filters.py:196-221
-        mask = mask & within_bounds(eigvals[:, e], lo, hi)
+        mask = mask & within_bounds(eigvals[:, int(e)], lo, hi)
     for i, j, lo, hi in (eigenvalue_ratio_bounds or []):         # filters.py:224-254
-        mask = mask & within_bounds(eigvals[:, i] / eigvals[:, j], lo, hi)
+        mask = mask & within_bounds(eigvals[:, int(i)] / eigvals[:, int(j)], lo, hi)
     return mask
 
 

@@ -1,0 +1,253 @@
+"""GPU parity through the reference-API layer (DepthCloud / preproc / eval / loss / train), written the way the
+reference's own callers drive it (train.py:94-215 set-up, eval.py:85-112 iteration), against the goldens."""
+import numpy as np
+import pytest
+import torch
+from numpy.lib.recfunctions import unstructured_to_structured
+
+import dc_oracle as O
+from helpers import t, npy, scans_from_golden, assert_eigvals_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(g, **kw):
+    from depth_correction_amd.config import Config
+    cfg = Config(nn_k=int(g['cfg_nn_k']), nn_r=None, min_depth=0.0, max_depth=float('inf'), grid_res=0.0,
+                 min_valid_neighbors=int(g['cfg_min_valid_neighbors']),
+                 eigenvalue_ratio_bounds=g['eigenvalue_ratio_bounds'].tolist(),
+                 vp_dispersion_bounds=g['vp_dispersion_bounds'].tolist(), device='cuda:0')
+    return cfg.from_dict(kw)
+
+
+def _scan_arrays(g):
+    return [unstructured_to_structured(np.ascontiguousarray(g['scan%d_xyz' % s]), names=['x', 'y', 'z'])
+            for s in range(int(g['n_scans']))]
+
+
+def _setup(g, cfg):
+    """train.py:94-215 for one sequence."""
+    from depth_correction_amd.preproc import (establish_neighborhoods, global_cloud, global_cloud_mask, local_feature_cloud)
+    clouds = [local_feature_cloud(a, cfg) for a in _scan_arrays(g)]
+    poses = torch.as_tensor(g['poses'], device=cfg.device)
+    g0 = global_cloud(clouds=clouds, poses=poses)
+    ns = establish_neighborhoods(cloud=g0, cfg=cfg)
+    mask = global_cloud_mask(g0, g0.mask, cfg)
+    return clouds, poses, g0, ns, mask
+
+
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+def test_setup_phase_golden(golden, name):
+    g = golden(name)
+    cfg = _cfg(g)
+    clouds, poses, g0, ns, mask = _setup(g, cfg)
+    for s, c in enumerate(clouds):
+        assert c.neighbors.dtype == torch.int64 and np.array_equal(npy(c.neighbors), g['scan%d_neighbors' % s])
+        assert_eigvals_close(npy(c.eigvals), g['scan%d_eigvals' % s], 1e-9)
+        np.testing.assert_allclose(npy(c.inc_angles), g['scan%d_inc_angles' % s], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(npy(c.dirs), g['scan%d_dirs' % s], rtol=1e-14, atol=1e-15)
+        assert np.array_equal(npy(c.mask), g['scan%d_mask' % s])
+        assert c.weights.shape == (len(c), int(g['cfg_nn_k']), 1)
+    np.testing.assert_allclose(npy(g0.points), g['g0_points'], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(npy(ns[0]), g['g_neighbors']) and ns[1].shape == ns[0].shape + (1,)
+    assert_eigvals_close(npy(g0.eigvals), g['g0_eigvals'], 1e-9)
+    assert np.array_equal(npy(mask), g['g_mask'])
+    np.testing.assert_allclose(npy(g0.vp_dispersion()), g['g0_vp_dispersion'], rtol=1e-9, atol=1e-12)
+
+
+VARIANTS = [('mineig_norm', 'min_eigval_loss', True, False), ('mineig_raw', 'min_eigval_loss', False, False),
+            ('mineig_norm_sqrt', 'min_eigval_loss', True, True), ('trace', 'trace_loss', False, False),
+            ('trace_sqrt', 'trace_loss', False, True)]
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_iteration_golden(golden, fused):
+    """eval_loss_clouds + backward for every loss variant, fused kernels and un-fused DepthCloud operators."""
+    from depth_correction_amd.eval import eval_loss_clouds
+    from depth_correction_amd.loss import create_loss
+    from depth_correction_amd.model import ScaledPolynomial
+    g = golden('room_k10')
+    cfg = _cfg(g, fused=fused)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    for tag, loss_name, norm, sqrt in VARIANTS:
+        cfg.loss = loss_name
+        cfg.loss_kwargs.update(normalization=norm, sqrt=sqrt)
+        model = ScaledPolynomial(w=g['w'].tolist(), exponent=g['exponent'].tolist(), device=cfg.device)
+        loss, loss_clouds, poses_upd, feat = eval_loss_clouds([clouds], [poses], [None], [mask], [ns], model,
+                                                              create_loss(cfg), cfg)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[tag + '_loss'], rtol=1e-9)
+        np.testing.assert_allclose(npy(model.w.grad), g[tag + '_grad_w'], rtol=1e-7)
+        np.testing.assert_allclose(npy(loss_clouds[0].loss)[g['g_mask']] if fused else npy(loss_clouds[0].loss),
+                                   g[tag + '_pointwise'], rtol=1e-7, atol=1e-15)
+        if tag == 'mineig_norm':
+            assert_eigvals_close(npy(feat[0].eigvals), g['g_eigvals'], 1e-9)
+            np.testing.assert_allclose(npy(feat[0].points), g['g_points'], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_pose_corrections_golden(golden, fused):
+    from depth_correction_amd.config import PoseCorrection
+    from depth_correction_amd.eval import eval_loss_clouds
+    from depth_correction_amd.loss import create_loss
+    from depth_correction_amd.model import ScaledPolynomial
+    g = golden('room_k10')
+    cfg = _cfg(g, fused=fused, pose_correction=PoseCorrection.pose)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    for tag, loss_name in (('poses_mineig_norm', 'min_eigval_loss'), ('poses_trace', 'trace_loss')):
+        cfg.loss = loss_name
+        model = ScaledPolynomial(w=g['poses_w'].tolist(), exponent=g['poses_exponent'].tolist(), device=cfg.device)
+        pd = torch.tensor(g['poses_pose_deltas'], device=cfg.device, requires_grad=True)
+        loss, _, poses_upd, _ = eval_loss_clouds([clouds], [poses], [pd], [mask], [ns], model, create_loss(cfg), cfg)
+        loss.backward()
+        np.testing.assert_allclose(npy(poses_upd[0]), g['poses_poses_upd'], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(loss.item(), g[tag + '_loss'], rtol=1e-9)
+        np.testing.assert_allclose(npy(model.w.grad), g[tag + '_grad_w'], rtol=1e-7)
+        ref = g[tag + '_grad_pose_deltas']
+        np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+
+
+def test_polynomial_and_two_sequences(golden):
+    """A list of sequences: pointwise losses are pooled before the mean (batch_loss, loss.py:205-213)."""
+    from depth_correction_amd.eval import eval_loss_clouds
+    from depth_correction_amd.loss import create_loss
+    from depth_correction_amd.model import Polynomial, ScaledPolynomial
+    g = golden('room_k10')
+    cfg = _cfg(g)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    model = Polynomial(w=g['poly_w'].tolist(), exponent=g['poly_exponent'].tolist(), device=cfg.device)
+    loss, *_ = eval_loss_clouds([clouds], [poses], [None], [mask], [ns], model, create_loss(cfg), cfg)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['poly_mineig_norm_loss'], rtol=1e-9)
+    np.testing.assert_allclose(npy(model.w.grad), g['poly_mineig_norm_grad_w'], rtol=1e-7)
+    # second "sequence": the same scans with another mask
+    mask2 = mask & (torch.arange(len(mask), device=mask.device) % 3 == 0)
+    ns2 = (ns[0].clone(), ns[1])
+    m = ScaledPolynomial(w=g['w'].tolist(), exponent=g['exponent'].tolist(), device=cfg.device)
+    outs = {}
+    for fused in (True, False):
+        cfg.fused = fused
+        m.zero_grad()
+        loss, *_ = eval_loss_clouds([clouds, clouds], [poses, poses], [None, None], [mask, mask2], [ns, ns2], m,
+                                    create_loss(cfg), cfg)
+        loss.backward()
+        outs[fused] = (loss.item(), npy(m.w.grad).copy())
+    pw = g['mineig_norm_pointwise']
+    sel = npy(mask2)[g['g_mask']]
+    np.testing.assert_allclose(outs[True][0], np.concatenate([pw, pw[sel]]).mean(), rtol=1e-9)
+    np.testing.assert_allclose(outs[True][0], outs[False][0], rtol=1e-10)
+    np.testing.assert_allclose(outs[True][1], outs[False][1], rtol=1e-7)
+
+
+def test_train_matches_oracle_adam_loop(golden, tmp_path):
+    """train() for a few iterations against the same loop driven by the oracle + torch.optim.Adam on the CPU."""
+    from depth_correction_amd.train import train
+    g = golden('room_k10')
+    cfg = _cfg(g, n_opt_iters=4, lr=5e-3, log_dir=str(tmp_path),
+               model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()})
+    ds = list(zip(_scan_arrays(g), g['poses']))
+    seen = []
+
+    class CB:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+        def train_loss(self, it, model, clouds, pose_deltas, poses, masks, loss):
+            seen.append((loss.item(), npy(model.w).copy()))
+    best = train(cfg, callbacks=CB(), train_datasets=[ds], val_datasets=[ds])
+    scans = scans_from_golden(g)
+    w = torch.nn.Parameter(torch.tensor(g['w'].reshape(1, -1)))
+    opt = torch.optim.Adam([w], lr=5e-3)
+    for it in range(4):
+        opt.zero_grad()
+        loss, _ = O.eval_sequence(scans, t(g['poses']), w, t(g['exponent'].reshape(1, -1)), t(g['g_neighbors']).long(),
+                                  t(g['g_mask']), reduction='mean')
+        np.testing.assert_allclose(seen[it][0], loss.item(), rtol=1e-8)
+        np.testing.assert_allclose(seen[it][1], npy(w), rtol=1e-8)
+        loss.backward()
+        opt.step()
+    assert best is not None and best.model_state_dict.endswith('_state_dict.pth')
+    sd = torch.load(best.model_state_dict)
+    assert list(sd) == ['w'] and sd['w'].shape == (1, 2)
+
+
+def test_native_trainer_equals_autograd_adam(golden):
+    """dc_sequence_eval + dc_adam_step (no Python in the loop) vs autograd Function + torch.optim.Adam."""
+    from depth_correction_amd.plan import SequencePlan, SequenceTrainer, consistency_loss
+    g = golden('room_k10')
+    cfg = _cfg(g)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    plan = SequencePlan(clouds, poses, ns[0], mask)
+    tr = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2)
+    w = torch.nn.Parameter(torch.tensor(g['w'].reshape(1, -1), device='cuda:0'))
+    e = torch.tensor(g['exponent'].reshape(1, -1), device='cuda:0')
+    opt = torch.optim.Adam([w], lr=1e-2)
+    for it in range(5):
+        opt.zero_grad()
+        s, cnt = consistency_loss(plan, w, e, poses)
+        (s / cnt).backward()
+        acc = tr.step()
+        np.testing.assert_allclose(npy(acc)[0], s.item(), rtol=1e-13)
+        np.testing.assert_allclose(npy(acc)[2:] / cnt, npy(w.grad).ravel(), rtol=1e-12)
+        opt.step()
+        np.testing.assert_allclose(npy(tr.w), npy(w).ravel(), rtol=1e-12)
+    assert abs(npy(tr.w)[0] - g['w'][0]) > 1e-3
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_icp_loss_golden(golden, fused):
+    from depth_correction_amd.depth_cloud import DepthCloud
+    from depth_correction_amd.loss import icp_loss
+    from depth_correction_amd.model import ScaledPolynomial
+    from depth_correction_amd.transform import xyz_axis_angle_to_matrix
+    g = golden('icp_pairs')
+    dev = 'cuda:0'
+    ns = int(g['n_scans'])
+    clouds = []
+    for s in range(ns):
+        c = DepthCloud(t(g['scan%d_vps' % s], dev), t(g['scan%d_dirs' % s], dev), t(g['scan%d_depth' % s], dev),
+                       inc_angles=t(g['scan%d_inc_angles' % s], dev), mask=t(g['scan%d_mask' % s], dev),
+                       normals=t(g['scan%d_normals' % s], dev))
+        clouds.append(c)
+    masks = [(t(g['pair%d_mask1' % j], dev), t(g['pair%d_idx2' % j], dev)) for j in range(ns - 1)]
+    model = ScaledPolynomial(w=g['w'].reshape(-1).tolist(), exponent=g['exponent'].reshape(-1).tolist(), device=dev)
+    if not fused:
+        model.kernel_kind = None            # forces the reference-style tensor path of icp_loss
+    pd = torch.tensor(g['pose_deltas'], device=dev, requires_grad=True)
+    poses = torch.matmul(t(g['poses'], dev), xyz_axis_angle_to_matrix(pd))
+    loss, _ = icp_loss([clouds], [poses], model, masks=[masks], icp_point_to_plane=True, icp_inlier_ratio=float(g['ratio']))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-6)
+    np.testing.assert_allclose(npy(model.w.grad), g['grad_w'], rtol=1e-5)
+    ref = g['grad_pose_deltas']
+    np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
+
+
+def test_icp_correspondences_vs_ckdtree(golden):
+    from depth_correction_amd.loss import icp_correspondences
+    g = golden('room_k10')
+    a, b = g['scan0_xyz'] + g['poses'][0, :3, 3], g['scan1_xyz'] + g['poses'][1, :3, 3]
+    m1, i2, _ = icp_correspondences(t(a, 'cuda:0'), t(b, 'cuda:0'), 0.3)
+    rm1, ri2, _ = O.nn1_correspondences(a, b, 0.3)
+    assert np.array_equal(npy(m1), rm1) and np.array_equal(npy(i2), ri2)
+
+
+def test_nearest_neighbors_api(golden):
+    from depth_correction_amd.nearest_neighbors import nearest_neighbors
+    g = golden('knn')
+    p = t(g['points'], 'cuda:0')
+    d, i = nearest_neighbors(p, p, k=10)
+    assert i.dtype == torch.int64 and d.dtype == torch.float64 and i.device == p.device
+    assert np.array_equal(npy(i), g['k10_ind']) and np.array_equal(npy(d), g['k10_dist'])
+    d, i = nearest_neighbors(p, p, k=8, r=0.15)
+    assert np.array_equal(npy(i), g['k8_r015_ind'])
+    d, i = nearest_neighbors(p, p, r=0.12)
+    assert d is None and np.array_equal(npy(i), g['r012_ind'])
+    dc_r = t(g['points'][:500], 'cuda:0')
+    from depth_correction_amd.depth_cloud import DepthCloud
+    cloud = DepthCloud.from_points(dc_r)
+    cloud.update_all(r=0.25)                                   # radius neighbourhoods: -1 padded, weights 0 there
+    f = O.features(cloud.points.cpu(), cloud.neighbors.cpu(), cloud.dirs.cpu())
+    keep = npy((cloud.neighbors >= 0).sum(1) >= 3)
+    assert_eigvals_close(npy(cloud.eigvals)[keep], npy(f['eigvals'])[keep], 1e-9)
+    assert torch.equal(cloud.weights[..., 0] > 0, cloud.neighbors >= 0)

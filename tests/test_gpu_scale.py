@@ -1,0 +1,120 @@
+"""BASELINE.json's full sizes (200 000-point scans, 2 M-point global cloud) through size-independent properties,
+plus direct cKDTree / oracle checks where the CPU side finishes in seconds."""
+import numpy as np
+import pytest
+import torch
+
+import dc_oracle as O
+from helpers import npy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def room():
+    from depth_correction_amd.dataset import RoomBoxDataset
+    ds = RoomBoxDataset(n_pts=200_000, n_poses=10, dtype=np.float32)
+    scans = [np.stack([c[f] for f in 'xyz'], 1) for c, _ in ds]
+    poses = np.stack([p for _, p in ds])
+    return scans, poses
+
+
+def test_knn_200k_scan_bit_exact_vs_ckdtree(room):
+    """Config 1 shape: one 200k-point scan, nn_k = 10 -- every index equal to cKDTree's, distances equal in fp64."""
+    from depth_correction_amd import ops
+    x = torch.as_tensor(room[0][0], device='cuda:0')
+    dist, idx = ops.knn(x, 10)
+    dref, iref = O.knn_ckdtree(room[0][0], 10)
+    assert np.array_equal(npy(idx), iref)
+    assert np.array_equal(npy(dist), dref)
+
+
+def test_knn_2m_properties(room):
+    """2 M-point global cloud: self first, ascending distances, distances recomputable, agreement with cKDTree on a
+    random sample of 20 000 query rows."""
+    from depth_correction_amd import ops
+    scans, poses = room
+    xyz = np.concatenate([s.astype(np.float64) + p[:3, 3] for s, p in zip(scans, poses)]).astype(np.float32)
+    x = torch.as_tensor(xyz, device='cuda:0')
+    dist, idx = ops.knn(x, 10)
+    n = len(xyz)
+    assert torch.equal(idx[:, 0].long(), torch.arange(n, device='cuda:0')) and bool((dist[:, 0] == 0).all())
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()) and bool((idx >= 0).all()) and bool((idx < n).all())
+    d = (x.double()[idx.long()] - x.double()[:, None, :])
+    d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+    assert torch.allclose(torch.sqrt(d2), dist, rtol=1e-14, atol=0)
+    from scipy.spatial import cKDTree
+    rows = np.random.default_rng(0).choice(n, 20_000, replace=False)
+    dref, iref = cKDTree(xyz.astype(np.float64)).query(xyz[rows].astype(np.float64), 10, workers=-1)
+    assert np.array_equal(npy(idx)[rows], iref) and np.array_equal(npy(dist)[rows], dref)
+    ptr_, src = ops.knn_transpose(idx)
+    assert int(ptr_[-1]) == n * 10 and bool((ptr_[1:] >= ptr_[:-1]).all())
+    j = np.random.default_rng(1).integers(0, n, 1000)
+    p, s, nb = npy(ptr_), npy(src), npy(idx)
+    for jj in j:                                            # every listed centre really has jj as a neighbour
+        assert all(jj in nb[i] for i in s[p[jj]:p[jj + 1]])
+
+
+def test_fused_loss_2m_properties(room):
+    """Config 2 shape.  Layout independence (Morton-sorted vs scan-major, q32 vs fp32 points), rigid-motion
+    invariance, and the hand-derived dL/dw against central differences of the loss, all on the 2 M-point cloud."""
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import SequencePlan
+    scans, poses = room
+    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    dev = plan.device
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    T = info['poses']
+
+    def run(p, ww=w, TT=T):
+        out = torch.zeros(2 + 4 + 12 * p.n_scans, dtype=torch.float64, device=dev)
+        p.eval_native(ww, e, p.poses12(TT), out, want_pose=True)
+        return npy(out)
+    base = run(plan)
+    assert base[1] == plan.count and 0.3 * plan.n < base[1] < plan.n
+    flat = SequencePlan(info['clouds'], T, info['neighbors'], info['mask'], spatial_sort=False)
+    np.testing.assert_allclose(run(flat)[:4], base[:4], rtol=1e-11)               # same numbers in any point order
+    f32 = SequencePlan(info['clouds'], T, info['neighbors'], info['mask'], point_format='float')
+    np.testing.assert_allclose(run(f32)[:2], base[:2], rtol=1e-5)                  # fp32 points: the 1e-5 bar
+    # rigid motion of the whole map leaves the loss and dL/dw unchanged
+    a = 0.3
+    G = torch.tensor([[np.cos(a), -np.sin(a), 0, 5.0], [np.sin(a), np.cos(a), 0, -3.0], [0, 0, 1, 2.0], [0, 0, 0, 1]],
+                     dtype=torch.float64, device=dev)
+    moved = run(plan, TT=G @ T)
+    np.testing.assert_allclose(moved[0], base[0], rtol=2e-6)       # q32 grid is not rotation invariant: 3e-8 m steps
+    np.testing.assert_allclose(moved[2:4], base[2:4], rtol=2e-4, atol=1e-3 * np.abs(base[2:4]).max())
+    # dL/dw vs central differences (loss is smooth in w; fp64 accumulation)
+    for k in range(2):
+        h = 1e-4
+        dw = torch.zeros(2, dtype=torch.float64, device=dev)
+        dw[k] = h
+        num = (run(plan, ww=w + dw)[0] - run(plan, ww=w - dw)[0]) / (2 * h)
+        np.testing.assert_allclose(base[2 + k], num, rtol=2e-4)
+    # translation gradient of all poses sums to ~0 (loss invariant to a common shift)
+    gT = base[6:].reshape(plan.n_scans, 3, 4)
+    assert np.abs(gT[:, :, 3].sum(0)).max() <= 1e-6 * np.abs(gT[:, :, 3]).sum()
+
+
+def test_oracle_on_200k_sample(room):
+    """One 200k-point scan pair region: the fused loss / gradient against the oracle (fp64) on a 2-scan sequence."""
+    from depth_correction_amd.pipeline import build_sequence
+    scans, poses = room
+    sub = [s[:60_000] for s in scans[:2]]
+    plan, info = build_sequence(sub, poses[:2], k=10, dtype=torch.float32)
+    dev = plan.device
+    out = torch.zeros(2 + 4 + 24, dtype=torch.float64, device=dev)
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    plan.eval_native(w, e, plan.poses12(info['poses']), out)
+    oc = [dict(vps=c['vps'].double().cpu(), dirs=c['dirs'].double().cpu(), depth=c['depth'].double().cpu(),
+               inc=c['inc_angles'].double().cpu(), mask=c['mask'].cpu()) for c in info['clouds']]
+    wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)
+    _, ind = O.knn_ckdtree(info['points0'].double().cpu().numpy(), 10)
+    assert np.array_equal(ind, npy(info['neighbors']))
+    lo, _ = O.eval_sequence(oc, info['poses'].cpu(), wo, e.cpu().reshape(1, -1), torch.as_tensor(ind), info['mask'].cpu(),
+                            reduction='sum')
+    lo.backward()
+    o = npy(out)
+    np.testing.assert_allclose(o[0], lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(o[2:4], npy(wo.grad).ravel(), rtol=1e-5, atol=1e-6 * np.abs(npy(wo.grad)).max())

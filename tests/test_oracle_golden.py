@@ -1,0 +1,120 @@
+"""The oracle (oracle/dc_oracle.py) against the golden vectors generated from the live reference
+(oracle/gen_golden.py).  Runs on the CPU; this is what pins the checker every GPU parity test relies on."""
+import numpy as np
+import pytest
+import torch
+
+import dc_oracle as O
+from helpers import t, npy, scans_from_golden
+
+TIGHT = dict(rtol=1e-9, atol=1e-13)
+
+
+def test_knn_contract(golden):
+    g = golden('knn')
+    for fun in (O.knn_ckdtree, O.knn_bruteforce):
+        d, i = fun(g['points'], 10)
+        assert np.array_equal(i, g['k10_ind']) and np.array_equal(d, g['k10_dist'])
+        d, i = fun(g['points'], 8, r=0.15)
+        assert np.array_equal(i, g['k8_r015_ind']) and np.array_equal(d, g['k8_r015_dist'])
+    assert np.array_equal(O.radius_ckdtree(g['points'], 0.12), g['r012_ind'])
+    assert np.array_equal(O.radius_bruteforce(g['points'], 0.12), g['r012_ind'])
+
+
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+def test_local_and_global_features(golden, name):
+    g = golden(name)
+    k = int(g['cfg_nn_k'])
+    for s in range(int(g['n_scans'])):
+        x = t(g['scan%d_xyz' % s])
+        _, ind = O.knn_ckdtree(g['scan%d_xyz' % s], k)
+        assert np.array_equal(ind, g['scan%d_neighbors' % s])
+        f = O.features(x, torch.as_tensor(ind), t(g['scan%d_dirs' % s]))
+        np.testing.assert_allclose(npy(f['eigvals']), g['scan%d_eigvals' % s], **TIGHT)
+        np.testing.assert_allclose(npy(f['inc_angles']), g['scan%d_inc_angles' % s], rtol=0, atol=1e-9)
+        m = O.local_mask(f['eigvals'], None, g['eigenvalue_ratio_bounds'].tolist())
+        assert np.array_equal(npy(m), g['scan%d_mask' % s])
+    _, ind = O.knn_bruteforce(g['g0_points'], k)
+    assert np.array_equal(ind, g['g_neighbors'])
+
+
+@pytest.mark.parametrize('name', ['c0_plane', 'room_k10'])
+def test_iteration_all_variants(golden, name):
+    g = golden(name)
+    variants = [(k[:-5], ) for k in g if k.endswith('_loss') and not k.startswith(('poses_', 'poly_'))]
+    scans = scans_from_golden(g)
+    nbr, mask = t(g['g_neighbors']).long(), t(g['g_mask'])
+    for (tag,) in variants:
+        kind = 'trace_loss' if tag.startswith('trace') else 'min_eigval_loss'
+        w = torch.tensor(g['w'].reshape(1, -1), requires_grad=True)
+        loss, f = O.eval_sequence(scans, t(g['poses']), w, t(g['exponent'].reshape(1, -1)), nbr, mask, kind=kind,
+                                  normalization='norm' in tag, sqrt=tag.endswith('sqrt'), reduction='mean')
+        f['points'].retain_grad()
+        loss.backward()
+        np.testing.assert_allclose(npy(loss), g[tag + '_loss'], rtol=1e-10)
+        np.testing.assert_allclose(npy(w.grad), g[tag + '_grad_w'], rtol=1e-8)
+        if tag + '_grad_points' in g:
+            np.testing.assert_allclose(npy(f['points'].grad), g[tag + '_grad_points'], rtol=1e-8, atol=1e-14)
+            cf = O.closed_form_backward(g['g_points'], g['g_neighbors'], g['g_mask'], kind=kind, normalization='norm' in tag,
+                                        sqrt=tag.endswith('sqrt'))
+            ref = g[tag + '_grad_points']
+            np.testing.assert_allclose(cf['grad_points'], ref, rtol=1e-6, atol=1e-10 * np.abs(ref).max())
+            np.testing.assert_allclose(cf['loss'], g[tag + '_loss'], rtol=1e-10)
+
+
+def test_masks_and_dispersion(golden):
+    for name in ('c0_plane', 'room_k10'):
+        g = golden(name)
+        scans = scans_from_golden(g)
+        vps, dirs = [], []
+        for s, T in zip(scans, t(g['poses'])):
+            v, d = O.transform_cloud(s['vps'], s['dirs'], T)
+            vps.append(v), dirs.append(d)
+        vps, dirs = torch.cat(vps), torch.cat(dirs)
+        nbr = t(g['g_neighbors']).long()
+        wts = (nbr >= 0).double()[..., None]
+        np.testing.assert_allclose(npy(O.dispersion(vps, nbr, wts)), g['g0_vp_dispersion'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(npy(O.dispersion(dirs, nbr, wts)), g['g0_dir_dispersion'], rtol=1e-9, atol=1e-15)
+        m = O.global_mask(torch.cat([s['mask'] for s in scans]), nbr, t(g['g0_eigvals']), vps=vps, dirs=dirs, weights=wts,
+                          min_valid_neighbors=int(g['cfg_min_valid_neighbors']),
+                          eigenvalue_ratio_bounds=g['eigenvalue_ratio_bounds'].tolist(),
+                          vp_dispersion_bounds=g['vp_dispersion_bounds'].tolist() or None)
+        assert np.array_equal(npy(m), g['g_mask'])
+
+
+def test_pose_corrections_and_polynomial(golden):
+    g = golden('room_k10')
+    scans = scans_from_golden(g)
+    nbr, mask = t(g['g_neighbors']).long(), t(g['g_mask'])
+    pd = torch.tensor(g['poses_pose_deltas'], requires_grad=True)
+    w = torch.tensor(g['poses_w'].reshape(1, -1), requires_grad=True)
+    loss, _ = O.eval_sequence(scans, t(g['poses']), w, t(g['poses_exponent'].reshape(1, -1)), nbr, mask,
+                              pose_deltas=pd, reduction='mean')
+    loss.backward()
+    np.testing.assert_allclose(npy(loss), g['poses_mineig_norm_loss'], rtol=1e-10)
+    np.testing.assert_allclose(npy(pd.grad), g['poses_mineig_norm_grad_pose_deltas'], rtol=1e-8, atol=1e-14)
+    w = torch.tensor(g['poly_w'].reshape(1, -1), requires_grad=True)
+    loss, _ = O.eval_sequence(scans, t(g['poses']), w, t(g['poly_exponent'].reshape(1, -1)), nbr, mask,
+                              model='Polynomial', reduction='mean')
+    loss.backward()
+    np.testing.assert_allclose(npy(loss), g['poly_mineig_norm_loss'], rtol=1e-10)
+    np.testing.assert_allclose(npy(w.grad), g['poly_mineig_norm_grad_w'], rtol=1e-8)
+
+
+def test_point_to_plane(golden):
+    g = golden('icp_pairs')
+    ns = int(g['n_scans'])
+    w = torch.tensor(g['w'], requires_grad=True)
+    pd = torch.tensor(g['pose_deltas'], requires_grad=True)
+    T = torch.matmul(t(g['poses']), O.xyz_axis_angle_to_matrix(pd))
+    pts, nrm = [], []
+    for s in range(ns):
+        d = O.model_apply(t(g['scan%d_depth' % s]), t(g['scan%d_inc_angles' % s]), t(g['scan%d_mask' % s]), w, t(g['exponent']))
+        v, r, n = O.transform_cloud(t(g['scan%d_vps' % s]), t(g['scan%d_dirs' % s]), T[s], normals=t(g['scan%d_normals' % s]))
+        pts.append(O.points_from(v, r, d)), nrm.append(n)
+    masks = [(t(g['pair%d_mask1' % j]), t(g['pair%d_idx2' % j])) for j in range(ns - 1)]
+    loss = O.point_to_plane(pts, nrm, masks)
+    loss.backward()
+    np.testing.assert_allclose(npy(loss), g['loss'], rtol=1e-9)
+    np.testing.assert_allclose(npy(w.grad), g['grad_w'], rtol=1e-6)
+    np.testing.assert_allclose(npy(pd.grad), g['grad_pose_deltas'], rtol=1e-6, atol=1e-12)
