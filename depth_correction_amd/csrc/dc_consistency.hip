@@ -72,7 +72,7 @@ __device__ __forceinline__ void gather_neighbourhood(const PT* __restrict__ x, c
 // Hot-path forward: neighbourhood covariance -> smallest eigenpair -> pointwise loss + backward
 // record; block partial sums of (masked loss, mask count).
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename PT, int STRIDE>
+template <typename T, typename PT, int STRIDE, bool FULL_EIG>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
     const PT* __restrict__ x, const int32_t* __restrict__ nbr, int64_t n, int k, const uint8_t* __restrict__ mask,
     const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec, T* __restrict__ pointwise,
@@ -84,26 +84,50 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
   if (blk >= 0) {
     const int64_t i = blk * kBlock + threadIdx.x;
     if (i < n) {
-      double xi[3];
-      Row3<PT, STRIDE>::load(x, i, xi, qp);
+      const typename Pt<PT>::Raw ci = Pt<PT>::template load<STRIDE>(x, i, qp);
       CovAcc acc;
-      gather_neighbourhood<T, PT, STRIDE>(x, nbr, (const T*)nullptr, i, k, xi, qp, acc);
+      cov_init(acc);
+      const int32_t* row = nbr + i * k;
+      for (int q0 = 0; q0 < k; q0 += 4) {
+        // four independent gathers in flight per trip (a missing neighbour re-reads the centre row: always valid)
+        int32_t j[4];
+        typename Pt<PT>::Raw cj[4];
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) j[u_] = (q0 + u_ < k) ? row[q0 + u_] : -1;
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) cj[u_] = Pt<PT>::template load<STRIDE>(x, j[u_] >= 0 ? (int64_t)j[u_] : i, qp);
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) {
+          if (j[u_] >= 0) {
+            double d[3];
+            Pt<PT>::delta(cj[u_], ci, d);
+            cov_add(acc, d[0], d[1], d[2], 1.0);
+          }
+        }
+      }
+      // moments are in raw units (q32: multiples of the resolution); scale once
+      const double u = Pt<PT>::unit(qp), u2 = u * u;
       double moff[3], cm[3], C[6], D, omega;
       cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
-      double lam[3], V[3][3];
-      eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) C[q] *= u2;
       const bool m = mask ? mask[i] != 0 : true;
       const double off = offset ? (double)offset[i] : 0.0;
-      const double tr = lam[0] + lam[1] + lam[2];
-      double c1, c2;
-      const double l = loss_and_coeffs(lp, lam[0], tr, D, off, m, &c1, &c2);
-      if (m) { acc2[0] = l; acc2[1] = 1.0; }
-      if (rec) {
-        const double mabs[3] = {xi[0] + cm[0], xi[1] + cm[1], xi[2] + cm[2]};
-        Rec8<PT>::store(rec, i, mabs, c1, V[0], c2, qp);
+      double lam0, v0[3], tr, c1, c2, l;
+      if (FULL_EIG) {
+        double lam[3], V[3][3];
+        eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
+        lam0 = lam[0]; v0[0] = V[0][0]; v0[1] = V[0][1]; v0[2] = V[0][2];
+        tr = lam[0] + lam[1] + lam[2];
+        eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2];
+      } else {
+        eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
       }
+      l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2);
+      if (m) { acc2[0] = l; acc2[1] = 1.0; }
+      // record: covariance mean in the point format; coefficients act on differences in metres
+      if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
       if (pointwise) pointwise[i] = (T)l;
-      if (eigvals) { eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2]; }
     }
   }
   block_sum<2>(acc2, lds);
@@ -218,7 +242,7 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
 }
 
 // Block-reduce the parameter gradients of one block into its partial row:
-//   [0,P) w, [P,2P) exponent, [2P, 2P + 12 S) poses.
+//   [0,P) w, [P,2P) exponent, [2P, 2P + 12 S) poses.  Only the slots in use are reduced.
 template <typename T>
 __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool active, bool want_e, bool want_pose,
                                                    double* gw, double* ge, double* gT, int scan, double* lds,
@@ -226,8 +250,13 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
   const int P = in.n_terms;
   double v[2 * DC_MAX_MODEL_TERMS];
 #pragma unroll
-  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) { v[k] = gw[k]; v[DC_MAX_MODEL_TERMS + k] = want_e ? ge[k] : 0.0; }
-  block_sum<2 * DC_MAX_MODEL_TERMS>(v, lds);
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) { v[k] = gw[k]; v[DC_MAX_MODEL_TERMS + k] = 0.0; }
+  block_sum_used<DC_MAX_MODEL_TERMS>(v, P, lds);
+  if (want_e) {
+#pragma unroll
+    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) v[DC_MAX_MODEL_TERMS + k] = ge[k];
+    block_sum_used<DC_MAX_MODEL_TERMS>(v + DC_MAX_MODEL_TERMS, P, lds);
+  }
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k)
@@ -274,18 +303,32 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
     const int64_t j = blk * kBlock + threadIdx.x;
     if (j < n) {
       active = true;
-      double xj[3], g[3] = {0.0, 0.0, 0.0};
-      Row3<PT, STRIDE>::load(x, j, xj, qp);
+      double g[3] = {0.0, 0.0, 0.0};
+      const typename Pt<PT>::Raw cj = Pt<PT>::template load<STRIDE>(x, j, qp);
+      const double u = Pt<PT>::unit(qp);
       const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
-      for (int32_t e = beg; e < end; ++e) {
-        double m[3], v[3], c1, c2;
-        Rec8<PT>::load(rec, csr_src[e], m, &c1, v, &c2, qp);
-        const double d0 = xj[0] - m[0], d1 = xj[1] - m[1], d2 = xj[2] - m[2];
-        const double t = c1 * (v[0] * d0 + v[1] * d1 + v[2] * d2);
-        g[0] += t * v[0] - c2 * d0;
-        g[1] += t * v[1] - c2 * d1;
-        g[2] += t * v[2] - c2 * d2;
+      for (int32_t e0 = beg; e0 < end; e0 += 4) {
+        // four edges per trip: indices first, then all record loads, then the arithmetic (loads overlap)
+        int32_t src[4];
+        typename Pt<PT>::Raw m[4];
+        double v[4][3], c1[4], c2[4];
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) src[u_] = (e0 + u_ < end) ? csr_src[e0 + u_] : -1;
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) RecRaw<PT>::load(rec, src[u_] >= 0 ? (int64_t)src[u_] : j, m[u_], &c1[u_], v[u_], &c2[u_]);
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) {
+          if (src[u_] >= 0) {
+            double d[3];
+            Pt<PT>::delta(cj, m[u_], d);
+            const double t = c1[u_] * (v[u_][0] * d[0] + v[u_][1] * d[1] + v[u_][2] * d[2]);
+            g[0] += t * v[u_][0] - c2[u_] * d[0];
+            g[1] += t * v[u_][1] - c2[u_] * d[1];
+            g[2] += t * v[u_][2] - c2[u_] * d[2];
+          }
+        }
       }
+      g[0] *= u; g[1] *= u; g[2] *= u;
       if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
       if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
     }
@@ -379,16 +422,30 @@ __global__ __launch_bounds__(kBlock) void features_grec_kernel(const T* __restri
   for (int q = 0; q < 3; ++q) r[9 + q] = g_mean ? (T)((double)g_mean[i * 3 + q] / w) : (T)0;
 }
 
-// Sum block partial rows [n_rows, n_acc] in a fixed order into out[n_acc].
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n_rows,
-                                                                 int n_acc, double* __restrict__ out) {
-  __shared__ double lds[kBlock / kWave];
+// Sum block partial rows [n_rows, n_acc] in a fixed order into out[n_acc]: one 1024-lane block per accumulator.
+constexpr int kRedBlock = 1024;
+__global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n_rows,
+                                                                    int n_acc, double* __restrict__ out) {
+  __shared__ double lds[kRedBlock / kWave];
   const int a = blockIdx.x;
-  double s = 0.0;
-  for (int64_t r = threadIdx.x; r < n_rows; r += kBlock) s += partials[r * n_acc + a];
-  double v[1] = {s};
-  block_sum<1>(v, lds);
-  if (threadIdx.x == 0) out[a] = v[0];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int64_t r = threadIdx.x;
+  for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {        // four independent loads in flight
+    s0 += partials[r * n_acc + a];
+    s1 += partials[(r + kRedBlock) * n_acc + a];
+    s2 += partials[(r + 2 * kRedBlock) * n_acc + a];
+    s3 += partials[(r + 3 * kRedBlock) * n_acc + a];
+  }
+  for (; r < n_rows; r += kRedBlock) s0 += partials[r * n_acc + a];
+  double s = wave_sum((s0 + s1) + (s2 + s3));
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) lds[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv];
+    out[a] = t;
+  }
 }
 
 // torch.optim.Adam (single-tensor path, no amsgrad) on a small fp64 parameter vector; grad is scaled first.
@@ -536,12 +593,16 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
 #define LAUNCH(T, PT, S) \
-  hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, nbr, n, k, mask, \
-                     (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws)
+  do { \
+    if (eigvals) hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, (const PT*)points, nbr, n, k, \
+                                    mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws); \
+    else hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, (const PT*)points, nbr, n, k, \
+                            mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws); \
+  } while (0)
   { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), block, 0, stream, partials_ws, rows, 2, sums_out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, 2, sums_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -583,7 +644,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   if (params && n_acc > 0) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), block, 0, stream, partials_ws, rows, n_acc, grads_out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), dim3(kRedBlock), 0, stream, partials_ws, rows, n_acc, grads_out);
     DC_CHECK_LAUNCH();
   }
   return DC_OK;
@@ -618,7 +679,7 @@ int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, con
   else return DC_ERR_DTYPE;
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), block, 0, stream, partials_ws, rows, n_acc, grads_out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), dim3(kRedBlock), 0, stream, partials_ws, rows, n_acc, grads_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

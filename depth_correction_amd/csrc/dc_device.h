@@ -127,6 +127,77 @@ template <> struct Rec8<q32> {
   }
 };
 
+// ---- point-format policy for the hot kernels: raw rows, exact differences, quantised means ---------------
+// Differences between a neighbour and its centre are formed on the RAW representation: for q32 an int32
+// subtraction (exact) in units of `scale`, for float / double a subtraction of the widened values (exact for
+// nearby fp32 points).  Moments are accumulated in those units and scaled once per point.
+template <typename PT> struct Pt;
+template <typename F> struct PtFloat {
+  struct Raw { double v[3]; };
+  template <int STRIDE> static __device__ __forceinline__ Raw load(const F* p, int64_t i, const QParams& qp) {
+    Raw r; Row3<F, STRIDE>::load(p, i, r.v, qp); return r;
+  }
+  static __device__ __forceinline__ void delta(const Raw& a, const Raw& c, double* d) {
+    d[0] = a.v[0] - c.v[0]; d[1] = a.v[1] - c.v[1]; d[2] = a.v[2] - c.v[2];
+  }
+  static __device__ __forceinline__ double unit(const QParams&) { return 1.0; }
+  // centre + offset (offset in units) as a raw value
+  static __device__ __forceinline__ Raw offset(const Raw& c, const double* off) {
+    Raw r; r.v[0] = c.v[0] + off[0]; r.v[1] = c.v[1] + off[1]; r.v[2] = c.v[2] + off[2]; return r;
+  }
+};
+template <> struct Pt<float> : PtFloat<float> {};
+template <> struct Pt<double> : PtFloat<double> {};
+template <> struct Pt<q32> {
+  struct Raw { int32_t v[3]; };
+  template <int STRIDE> static __device__ __forceinline__ Raw load(const q32* p, int64_t i, const QParams&) {
+    const int4 q = reinterpret_cast<const int4*>(p)[i];
+    Raw r; r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; return r;
+  }
+  static __device__ __forceinline__ void delta(const Raw& a, const Raw& c, double* d) {
+    d[0] = (double)(a.v[0] - c.v[0]); d[1] = (double)(a.v[1] - c.v[1]); d[2] = (double)(a.v[2] - c.v[2]);
+  }
+  static __device__ __forceinline__ double unit(const QParams& qp) { return qp.scale; }
+  static __device__ __forceinline__ Raw offset(const Raw& c, const double* off) {
+    Raw r;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double q = (double)c.v[a] + rint(off[a]);
+      q = q > 2147483520.0 ? 2147483520.0 : (q < -2147483520.0 ? -2147483520.0 : q);
+      r.v[a] = (q == q) ? (int32_t)q : (int32_t)0x80000000;
+    }
+    return r;
+  }
+};
+
+// rec rows from / to raw means
+template <typename PT> struct RecRaw;
+template <typename F> struct RecRawFloat {
+  static __device__ __forceinline__ void store(F* rec, int64_t i, const typename Pt<F>::Raw& m, double c1, const double* v,
+                                               double c2) {
+    Rec8<F>::store(rec, i, m.v, c1, v, c2, QParams{});
+  }
+  static __device__ __forceinline__ void load(const F* rec, int64_t i, typename Pt<F>::Raw& m, double* c1, double* v, double* c2) {
+    Rec8<F>::load(rec, i, m.v, c1, v, c2, QParams{});
+  }
+};
+template <> struct RecRaw<float> : RecRawFloat<float> {};
+template <> struct RecRaw<double> : RecRawFloat<double> {};
+template <> struct RecRaw<q32> {
+  static __device__ __forceinline__ void store(q32* rec, int64_t i, const Pt<q32>::Raw& m, double c1, const double* v, double c2) {
+    int4* r = reinterpret_cast<int4*>(rec) + 2 * i;
+    r[0] = make_int4(m.v[0], m.v[1], m.v[2], __float_as_int((float)c1));
+    reinterpret_cast<float4*>(r)[1] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)c2);
+  }
+  static __device__ __forceinline__ void load(const q32* rec, int64_t i, Pt<q32>::Raw& m, double* c1, double* v, double* c2) {
+    const int4* r = reinterpret_cast<const int4*>(rec) + 2 * i;
+    const int4 a = r[0];
+    const float4 b = reinterpret_cast<const float4*>(r)[1];
+    m.v[0] = a.x; m.v[1] = a.y; m.v[2] = a.z; *c1 = (double)__int_as_float(a.w);
+    v[0] = b.x; v[1] = b.y; v[2] = b.z; *c2 = b.w;
+  }
+};
+
 // ---- reductions ---------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -151,6 +222,31 @@ __device__ __forceinline__ void block_sum(double* v, double* lds) {
       double s = 0.0;
       for (int wv = 0; wv < kBlock / kWave; ++wv) s += lds[wv * NV + q];
       v[q] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// Same, for the first `n_used` (block-uniform) of NV values only: skips the shuffles of unused slots.
+template <int NV>
+__device__ __forceinline__ void block_sum_used(double* v, int n_used, double* lds) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    if (q < n_used) {
+      double s = wave_sum(v[q]);
+      if (lane == 0) lds[wave * NV + q] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      if (q < n_used) {
+        double s = 0.0;
+        for (int wv = 0; wv < kBlock / kWave; ++wv) s += lds[wv * NV + q];
+        v[q] = s;
+      }
     }
   }
   __syncthreads();

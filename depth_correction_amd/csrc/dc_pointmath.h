@@ -96,7 +96,8 @@ DC_HD void cov_add(CovAcc& a, double dx, double dy, double dz, double wm) {
 DC_HD void cov_finish(const CovAcc& a, double scale, double* mean_off, double* cmean_off, double* C, double* D_out,
                       double* omega_out) {
   // 0/0 -> NaN exactly like the reference when a neighbourhood has no valid member.
-  for (int i = 0; i < 3; ++i) mean_off[i] = a.sm[i] / a.Wm;
+  const double invWm = 1.0 / a.Wm;
+  for (int i = 0; i < 3; ++i) mean_off[i] = a.Wm > 0.0 ? a.sm[i] * invWm : a.sm[i] / a.Wm;
   double omega = 1.0;
   if (scale > 0.0) {
     // dist = |x_i - mean_i| and x_i is the anchor
@@ -106,7 +107,7 @@ DC_HD void cov_finish(const CovAcc& a, double scale, double* mean_off, double* c
   const double Wc = omega * a.W;
   double D = Wc - 1.0;
   D = D < 1e-6 ? 1e-6 : D;
-  const double invW = 1.0 / a.W;
+  const double invW = (a.W == a.Wm) ? invWm : 1.0 / a.W;
   const double c0 = a.s[0] * invW, c1 = a.s[1] * invW, c2 = a.s[2] * invW;
   cmean_off[0] = c0; cmean_off[1] = c1; cmean_off[2] = c2;
   const double f = omega / D;
@@ -146,10 +147,11 @@ DC_HD double loss_and_coeffs(const LossParams& lp, double lam0, double tr, doubl
   double raw, g_vv = 0.0, g_eye = 0.0;    // G = g_vv * v0 v0^T + g_eye * I
   if (lp.kind == DC_LOSS_MIN_EIGVAL) {
     if (lp.normalization) {
-      double tc = tr < 1e-6 ? 1e-6 : tr;
-      raw = lam0 / tc;
-      g_vv = 1.0 / tc;
-      g_eye = (tr > 1e-6) ? -lam0 / (tc * tc) : 0.0;
+      const double tc = tr < 1e-6 ? 1e-6 : tr;
+      const double inv = 1.0 / tc;
+      raw = lam0 * inv;
+      g_vv = inv;
+      g_eye = (tr > 1e-6) ? -raw * inv : 0.0;
     } else {
       raw = lam0;
       g_vv = 1.0;
@@ -166,7 +168,7 @@ DC_HD double loss_and_coeffs(const LossParams& lp, double lam0, double tr, doubl
     a = (l > 0.0) ? a * 0.5 / s : 0.0;
     l = s;
   }
-  const double f = 2.0 * a / D;
+  const double f = (D == 9.0) ? a * (2.0 / 9.0) : 2.0 * a / D;     // K = 10 valid neighbours: no division
   *c1 = f * g_vv;
   *c2 = -f * g_eye;
   return l;
