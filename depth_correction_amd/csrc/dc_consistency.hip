@@ -101,10 +101,11 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
           if (j[u_] >= 0) {
             double d[3];
             Pt<PT>::delta(cj[u_], ci, d);
-            cov_add(acc, d[0], d[1], d[2], 1.0);
+            cov_add1(acc, d[0], d[1], d[2]);
           }
         }
       }
+      cov_same_weights(acc);
       // moments are in raw units (q32: multiples of the resolution); scale once
       const double u = Pt<PT>::unit(qp), u2 = u * u;
       double moff[3], cm[3], C[6], D, omega;
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
     }
   }
   block_sum<2>(acc2, lds);
-  if (threadIdx.x == 0) {
-    partials[(int64_t)blockIdx.x * 2] = acc2[0];
-    partials[(int64_t)blockIdx.x * 2 + 1] = acc2[1];
+  if (threadIdx.x == 0) {                       // partials are [accumulator][block]: the reduction reads rows
+    partials[blockIdx.x] = acc2[0];
+    partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
   }
 }
 
@@ -246,7 +247,9 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
 template <typename T>
 __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool active, bool want_e, bool want_pose,
                                                    double* gw, double* ge, double* gT, int scan, double* lds,
-                                                   double* __restrict__ prow) {
+                                                   double* __restrict__ pcol) {
+  // pcol = partials + blockIdx.x; slot a lives at pcol[a * gridDim.x]
+  const int64_t rs = gridDim.x;
   const int P = in.n_terms;
   double v[2 * DC_MAX_MODEL_TERMS];
 #pragma unroll
@@ -260,7 +263,7 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k)
-      if (k < P) { prow[k] = v[k]; prow[P + k] = v[DC_MAX_MODEL_TERMS + k]; }
+      if (k < P) { pcol[k * rs] = v[k]; pcol[(P + k) * rs] = v[DC_MAX_MODEL_TERMS + k]; }
   }
   if (want_pose) {
     // scans are interleaved after spatial sorting: reduce per scan id present in the block
@@ -272,7 +275,7 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
       block_sum<12>(t, lds);
       if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) prow[2 * P + s * 12 + q] = t[q];
+        for (int q = 0; q < 12; ++q) pcol[(2 * P + s * 12 + q) * rs] = t[q];
       }
     }
   }
@@ -285,8 +288,8 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
 template <typename T, typename PT, int STRIDE>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
     const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
-    const int32_t* __restrict__ csr_src, int64_t n, PointInputs in, QParams qp, int want_e, int want_pose,
-    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+    const int32_t* __restrict__ csr_src, const uint8_t* __restrict__ lane_perm, int64_t n, PointInputs in, QParams qp,
+    int want_e, int want_pose, T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
@@ -300,7 +303,9 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
   int scan = -1;
   bool active = false;
   if (blk >= 0) {
-    const int64_t j = blk * kBlock + threadIdx.x;
+    // lane_perm orders the 256 points of a block by in-degree, so the lanes of a wavefront run similar trip counts
+    const int64_t base = blk * kBlock;
+    const int64_t j = base + (lane_perm ? (int64_t)lane_perm[base + threadIdx.x] : (int64_t)threadIdx.x);
     if (j < n) {
       active = true;
       double g[3] = {0.0, 0.0, 0.0};
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
       if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
     }
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + (int64_t)blockIdx.x * n_acc);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
 }
 
 // Stand-alone point epilogue for the un-fused API path (grad of points given).
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
     Row3<T, STRIDE>::load(grad_x, j, g, QParams{});
     points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
-  reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + (int64_t)blockIdx.x * n_acc);
+  reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
 }
 
 // Generic neighbourhood-features backward for the un-fused API path:
@@ -422,21 +427,19 @@ __global__ __launch_bounds__(kBlock) void features_grec_kernel(const T* __restri
   for (int q = 0; q < 3; ++q) r[9 + q] = g_mean ? (T)((double)g_mean[i * 3 + q] / w) : (T)0;
 }
 
-// Sum block partial rows [n_rows, n_acc] in a fixed order into out[n_acc]: one 1024-lane block per accumulator.
+// Sum the block partials [n_acc][n_rows] in a fixed order into out[n_acc]: one 1024-lane block per accumulator,
+// contiguous (coalesced) reads.
 constexpr int kRedBlock = 1024;
 __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n_rows,
-                                                                    int n_acc, double* __restrict__ out) {
+                                                                    double* __restrict__ out) {
   __shared__ double lds[kRedBlock / kWave];
-  const int a = blockIdx.x;
+  const double* p = partials + (int64_t)blockIdx.x * n_rows;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int64_t r = threadIdx.x;
-  for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {        // four independent loads in flight
-    s0 += partials[r * n_acc + a];
-    s1 += partials[(r + kRedBlock) * n_acc + a];
-    s2 += partials[(r + 2 * kRedBlock) * n_acc + a];
-    s3 += partials[(r + 3 * kRedBlock) * n_acc + a];
+  for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {
+    s0 += p[r]; s1 += p[r + kRedBlock]; s2 += p[r + 2 * kRedBlock]; s3 += p[r + 3 * kRedBlock];
   }
-  for (; r < n_rows; r += kRedBlock) s0 += partials[r * n_acc + a];
+  for (; r < n_rows; r += kRedBlock) s0 += p[r];
   double s = wave_sum((s0 + s1) + (s2 + s3));
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) lds[wave] = s;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv];
-    out[a] = t;
+    out[blockIdx.x] = t;
   }
 }
 
@@ -602,13 +605,14 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
   { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, 2, sums_out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, sums_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
 
 int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
-                       const int32_t* csr_ptr, const int32_t* csr_src, int64_t n, const void* vps, const void* dirs,
+                       const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
+                       const void* vps, const void* dirs,
                        const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
                        const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
                        int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
@@ -632,19 +636,19 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
-  if (params && !want_pose_grad && n_scans > 0) {
-    // pose slots are not produced: keep them zero
-    hipError_t err = hipMemsetAsync(partials_ws, 0, (size_t)rows * n_acc * sizeof(double), stream);
+  const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
+  if (params && n_red < n_acc) {
+    hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
 #define LAUNCH(T, PT, S) \
   hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, (const PT*)rec, csr_ptr, \
-                     csr_src, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc)
+                     csr_src, lane_perm, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc)
   { ProfScope prof(2, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  if (params && n_acc > 0) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), dim3(kRedBlock), 0, stream, partials_ws, rows, n_acc, grads_out);
+  if (params && n_red > 0) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
     DC_CHECK_LAUNCH();
   }
   return DC_OK;
@@ -667,10 +671,12 @@ int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, con
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
   const int64_t rows = n_blocks(n);
   dim3 grid((unsigned)rows), block(kBlock);
-  if (!want_pose_grad && n_scans > 0) {
-    hipError_t err = hipMemsetAsync(partials_ws, 0, (size_t)rows * n_acc * sizeof(double), stream);
+  const int n_red = want_pose_grad ? n_acc : 2 * n_terms;
+  if (n_red < n_acc) {
+    hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
+  if (n_red == 0) return DC_OK;
 #define LAUNCH(T, S) \
   hipLaunchKernelGGL((points_bwd_kernel<T, S>), grid, block, 0, stream, (const T*)grad_points, n, in, \
                      want_exponent_grad, want_pose_grad, partials_ws, n_acc)
@@ -679,7 +685,7 @@ int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, con
   else return DC_ERR_DTYPE;
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_acc), dim3(kRedBlock), 0, stream, partials_ws, rows, n_acc, grads_out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -782,7 +788,8 @@ int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, 
   rc = dc_consistency_fwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->n, d->k, d->mask, nullptr,
                           d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, d->partials, out, stream);
   if (rc || !want_grad) return rc;
-  return dc_consistency_bwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->n,
+  return dc_consistency_bwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
+                            d->n,
                             d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                             d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, d->partials, out + 2, stream);
 }

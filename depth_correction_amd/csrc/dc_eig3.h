@@ -162,17 +162,18 @@ DC_HD void eig3_sym(R a00, R a01, R a02, R a11, R a12, R a22, R* lam, R (*V)[3])
 // instructions of the full solver; accuracy identical (checked against LAPACK in tests/test_hostcheck.py).
 DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22, double* lam0,
                          double* v0, double* tr_out) {
-  double m = fmax(fmax(fabs(a00), fabs(a11)), fabs(a22));
-  m = fmax(m, fmax(fabs(a01), fmax(fabs(a02), fabs(a12))));
-  *tr_out = a00 + a11 + a22;
+  // covariance matrices are positive semi-definite: the trace bounds every entry, one add instead of a max tree
+  const double m = a00 + a11 + a22;
+  *tr_out = m;
   if (!(m > 0.0) || !(m < (double)INFINITY)) {
-    *lam0 = (m == 0.0) ? 0.0 : (double)NAN;
+    const bool zero = (m == 0.0) && a01 == 0.0 && a02 == 0.0 && a12 == 0.0;
+    *lam0 = zero ? 0.0 : (double)NAN;
     v0[0] = 1.0; v0[1] = 0.0; v0[2] = 0.0;
     return;
   }
   const double inv_m = 1.0 / m;
   a00 *= inv_m; a01 *= inv_m; a02 *= inv_m; a11 *= inv_m; a12 *= inv_m; a22 *= inv_m;
-  const double q = (a00 + a11 + a22) * (1.0 / 3.0);
+  const double q = 1.0 / 3.0;             // trace of the scaled matrix is 1
   const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
   const double off = a01 * a01 + a02 * a02 + a12 * a12;
   const double p2 = (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * off) * (1.0 / 6.0);

@@ -80,6 +80,18 @@ DC_HD void cov_init(CovAcc& a) {
   for (int i = 0; i < 6; ++i) a.S[i] = 0.0;
 }
 
+// validity weights only (the hot path): mean weights == validity, filled in by cov_same_weights()
+DC_HD void cov_add1(CovAcc& a, double dx, double dy, double dz) {
+  a.W += 1.0;
+  a.s[0] += dx; a.s[1] += dy; a.s[2] += dz;
+  a.S[0] += dx * dx; a.S[1] += dx * dy; a.S[2] += dx * dz;
+  a.S[3] += dy * dy; a.S[4] += dy * dz; a.S[5] += dz * dz;
+}
+DC_HD void cov_same_weights(CovAcc& a) {
+  a.Wm = a.W;
+  a.sm[0] = a.s[0]; a.sm[1] = a.s[1]; a.sm[2] = a.s[2];
+}
+
 DC_HD void cov_add(CovAcc& a, double dx, double dy, double dz, double wm) {
   a.W += 1.0;
   a.Wm += wm;

@@ -312,8 +312,18 @@ def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss',
     return dict(sums=sums, rec=rec, pointwise=pw, eigvals=ev)
 
 
+def degree_lane_perm(csr_ptr, block=256):
+    """u8 [block * ceil(n / block)]: per block of consecutive points the lane -> point map by ascending in-degree."""
+    n = csr_ptr.shape[0] - 1
+    nb = (n + block - 1) // block
+    deg = torch.full((nb * block,), 2 ** 30, dtype=torch.int32, device=csr_ptr.device)
+    deg[:n] = csr_ptr[1:] - csr_ptr[:-1]
+    return torch.argsort(deg.reshape(nb, block), dim=1, stable=True).to(torch.uint8).reshape(-1).contiguous()
+
+
 def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_kind=None, w=None, e=None,
-                    want_exponent=False, want_pose=False, want_grad_points=False, partials=None, grads=None, qfmt=None):
+                    want_exponent=False, want_pose=False, want_grad_points=False, partials=None, grads=None, qfmt=None,
+                    lane_perm=None):
     _check_points(points, qfmt)
     n, stride = points.shape
     dev = points.device
@@ -324,10 +334,12 @@ def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_ki
     need(csr_ptr, (n + 1,), dtype=torch.int32, name='csr_ptr', device=dev)
     need(csr_src, (None,), dtype=torch.int32, name='csr_src', device=dev)
     gp = torch.empty((n, stride), dtype=dt, device=dev) if want_grad_points else None
+    if lane_perm is not None:
+        need(lane_perm, (((n + 255) // 256) * 256,), dtype=torch.uint8, name='lane_perm', device=dev)
     if ps is None:
         assert want_grad_points
-        check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src), n,
-                                       None, None, None, None, None, None, None, 0, 0, 0, None, None, 0, 0, ptr(gp), None,
+        check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src),
+                                       ptr(lane_perm), n, None, None, None, None, None, None, None, 0, 0, 0, None, None, 0, 0, ptr(gp), None,
                                        None, stream_ptr()), 'dc_consistency_bwd')
         return gp, None
     assert ps.n == n and ps.dtype == dt and ps.device == dev
@@ -341,8 +353,8 @@ def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_ki
         assert partials.numel() >= rows * nacc
     if grads is None:
         grads = torch.zeros((max(nacc, 1),), dtype=torch.float64, device=dev)
-    check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src), n,
-                                   ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
+    check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src),
+                                   ptr(lane_perm), n, ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
                                    ptr(poses), ns, kind, nt, ptr(w), ptr(e), int(want_exponent), int(want_pose), ptr(gp),
                                    ptr(partials), ptr(grads), stream_ptr()), 'dc_consistency_bwd')
     return gp, _grads_split(grads, nt, ns)

@@ -32,7 +32,7 @@ __all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer']
 
 class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
-                 normalization=True, sqrt=False, spatial_sort=True, point_format='auto'):
+                 normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -67,6 +67,17 @@ class SequencePlan:
         x0 = ops.points_fwd(ps0, P0)
         if spatial_sort and self.n > 1:
             order = ops.spatial_order(x0).long()
+            if degree_sort:
+                # inside every block of 256 Morton-consecutive points, order by in-degree: the lanes of a wavefront of
+                # the backward then walk incoming-edge lists of similar length (same cache lines per block as before)
+                valid = nbr[nbr >= 0].long()
+                deg = torch.bincount(valid, minlength=self.n)[order]
+                nb = (self.n + 255) // 256
+                pad = torch.full((nb * 256,), 2 ** 40, dtype=torch.int64, device=dev)
+                pad[:self.n] = deg
+                local = torch.argsort(pad.reshape(nb, 256), dim=1, stable=True)
+                pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
+                order = order[pos[pos < self.n]]
             rank = torch.empty_like(order)
             rank[order] = torch.arange(self.n, device=dev)
             nbr_l = nbr.long()[order]
@@ -82,6 +93,7 @@ class SequencePlan:
         self.ps = ops.PointSet(vps, dirs, depth, inc, lmask, scan_id)
         self.nbr, self.mask = nbr, mask
         self.csr_ptr, self.csr_src = ops.knn_transpose(nbr)
+        self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
         self.count = float(self.n if mask is None else int(mask.sum().item()))
 
         # ---- internal point format -------------------------------------------------------------------
@@ -115,6 +127,7 @@ class SequencePlan:
             ps = self.ps
             d.vps, d.dirs, d.depth, d.inc, d.lmask, d.scan_id = p(ps.vps), p(ps.dirs), p(ps.depth), p(ps.inc), p(ps.lmask), p(ps.scan_id)
             d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(self.csr_ptr), p(self.csr_src), p(self.mask)
+            d.lane_perm = p(self.lane_perm)
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
@@ -163,7 +176,7 @@ class SequencePlan:
         kind = self.model_kind if self.w is not None else None
         _, grads = ops.consistency_bwd(self.x, self.rec, self.csr_ptr, self.csr_src, self.ps, self.P, kind, self.w, self.e,
                                        want_exponent=want_exponent, want_pose=want_pose, partials=self.partials,
-                                       qfmt=self.qfmt)
+                                       qfmt=self.qfmt, lane_perm=self.lane_perm)
         return grads
 
     def unpermute(self, t):

@@ -127,9 +127,13 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
 
 /* Backward of sum-over-mask of l: dL/dx_j gathered over incoming edges, chained in the same kernel to
  * dL/dw, dL/dexponent, dL/d[R|t] (grads_out as in dc_points_bwd; pass dirs == NULL to get only grad_points).
- * grad_points [n, stride] optional.  partials_ws: fp64 [dc_partial_rows(n) * dc_param_grad_count()]. */
+ * grad_points [n, stride] optional.  partials_ws: fp64 [dc_partial_rows(n) * dc_param_grad_count()].
+ * lane_perm u8 [256 * ceil(n / 256)] or NULL: for every block of 256 consecutive points a permutation of 0..255
+ * (ascending in-degree) telling which point each lane handles -- lanes of a wavefront then walk edge lists of
+ * similar length; results do not depend on it. */
 int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
-                       const int32_t* csr_ptr, const int32_t* csr_src, int64_t n, const void* vps, const void* dirs,
+                       const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
+                       const void* vps, const void* dirs,
                        const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
                        const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
                        int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
@@ -174,6 +178,7 @@ typedef struct dcSequenceDesc {
   const int32_t* scan_id;
   const int32_t *nbr, *csr_ptr, *csr_src;
   const uint8_t* mask;
+  const uint8_t* lane_perm;
   void *x, *rec;
   double* partials;
   int32_t model_kind, n_terms, loss_kind, normalization, sqrt_, reserved;
