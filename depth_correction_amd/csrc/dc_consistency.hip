@@ -98,11 +98,11 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
         for (int u_ = 0; u_ < 4; ++u_) cj[u_] = Pt<PT>::template load<STRIDE>(x, j[u_] >= 0 ? (int64_t)j[u_] : i, qp);
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) {
-          if (j[u_] >= 0) {
-            double d[3];
-            Pt<PT>::delta(cj[u_], ci, d);
-            cov_add1(acc, d[0], d[1], d[2]);
-          }
+          // a missing neighbour re-read the centre row: its difference is exactly zero, only the count is masked
+          double d[3];
+          Pt<PT>::delta(cj[u_], ci, d);
+          cov_add1(acc, d[0], d[1], d[2]);
+          acc.W -= (j[u_] >= 0) ? 0.0 : 1.0;
         }
       }
       cov_same_weights(acc);
@@ -285,11 +285,12 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
 // Hot-path backward: dL/dx_j = sum over incoming edges (i -> j) of c1_i (v0_i . d) v0_i - c2_i d,
 // d = x_j - cmean_i, gathered through the transposed neighbour list; fused with the point epilogue.
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename PT, int STRIDE>
+template <typename T, typename PT, int STRIDE, bool WANT_E, bool WANT_POSE>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
     const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
     const int32_t* __restrict__ csr_src, const uint8_t* __restrict__ lane_perm, int64_t n, PointInputs in, QParams qp,
-    int want_e, int want_pose, T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+  constexpr int want_e = WANT_E, want_pose = WANT_POSE;
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
@@ -312,15 +313,190 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
       const typename Pt<PT>::Raw cj = Pt<PT>::template load<STRIDE>(x, j, qp);
       const double u = Pt<PT>::unit(qp);
       const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
+      // four edges per trip; the indices of the NEXT trip are requested before the records of this one are used,
+      // so each trip exposes one memory latency instead of two
+      int32_t nxt[4];
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (beg + u_ < end) ? csr_src[beg + u_] : -1;
       for (int32_t e0 = beg; e0 < end; e0 += 4) {
-        // four edges per trip: indices first, then all record loads, then the arithmetic (loads overlap)
+        int32_t src[4];
+        typename Pt<PT>::Raw m[4];
+        double v[4][3], c1[4], c2[4];
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) src[u_] = nxt[u_];
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) RecRaw<PT>::load(rec, src[u_] >= 0 ? (int64_t)src[u_] : j, m[u_], &c1[u_], v[u_], &c2[u_]);
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (e0 + 4 + u_ < end) ? csr_src[e0 + 4 + u_] : -1;
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) {
+          // empty slots re-read the point's own record with zeroed coefficients: no exec-mask churn
+          const double k1 = src[u_] >= 0 ? c1[u_] : 0.0, k2 = src[u_] >= 0 ? c2[u_] : 0.0;
+          double d[3];
+          Pt<PT>::delta(cj, m[u_], d);
+          const double t = k1 * (v[u_][0] * d[0] + v[u_][1] * d[1] + v[u_][2] * d[2]);
+          g[0] += t * v[u_][0] - k2 * d[0];
+          g[1] += t * v[u_][1] - k2 * d[1];
+          g[2] += t * v[u_][2] - k2 * d[2];
+        }
+      }
+      g[0] *= u; g[1] *= u; g[2] *= u;
+      if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
+      if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+    }
+  }
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged neighbour tiles.  In Morton order ~95 % of a block's neighbours (forward) / incoming-edge sources
+// (backward) lie within +-512 positions of the block, so every block of 256 points first copies a window of
+// kTileRows rows into LDS with fully coalesced 16-B loads and then gathers from LDS (ds_read_b128); the few edges
+// that leave the window read global memory as before.  This replaces ~20 M random 16/32-B global gathers per launch
+// (bounded by the per-CU address/L1 rate, not by HBM) with ~0.25 GB of streaming reads.
+// ------------------------------------------------------------------------------------------------
+template <typename PT> struct TileRows { static constexpr int value = 1024; };
+template <> struct TileRows<double> { static constexpr int value = 512; };
+
+// first row of the window of block `blk` (clamped into [0, n - rows] when the array is long enough)
+__device__ __forceinline__ int64_t tile_origin(int64_t blk, int64_t n, int rows) {
+  int64_t lo = blk * kBlock - (rows - kBlock) / 2;
+  if (lo + rows > n) lo = n - rows;
+  return lo < 0 ? 0 : lo;
+}
+
+template <int ROW16>
+__device__ __forceinline__ void stage_tile(const int4* __restrict__ src, int64_t lo, int64_t n, int rows, int4* tile) {
+  const int64_t avail = (n - lo < rows ? n - lo : (int64_t)rows) * ROW16;
+  const int4* base = src + lo * ROW16;
+  for (int t = threadIdx.x; t < rows * ROW16; t += kBlock)
+    if (t < avail) tile[t] = base[t];
+}
+
+template <typename T, typename PT, bool FULL_EIG>
+__global__ __launch_bounds__(kBlock) void consistency_fwd_tiled_kernel(
+    const PT* __restrict__ x, const int32_t* __restrict__ nbr, int64_t n, int k, const uint8_t* __restrict__ mask,
+    const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec, T* __restrict__ pointwise,
+    T* __restrict__ eigvals, double* __restrict__ partials) {
+  constexpr int kRows = TileRows<PT>::value, XR = Pt<PT>::kRow16;
+  __shared__ int4 tile[kRows * XR];
+  __shared__ double lds[(kBlock / kWave) * 2];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0};
+  const int4* xg = reinterpret_cast<const int4*>(x);
+  int64_t lo = 0;
+  if (blk >= 0) {
+    lo = tile_origin(blk, n, kRows);
+    stage_tile<XR>(xg, lo, n, kRows, tile);
+  }
+  __syncthreads();
+  if (blk >= 0) {
+    const int64_t i = blk * kBlock + threadIdx.x;
+    if (i < n) {
+      const typename Pt<PT>::Raw ci = Pt<PT>::from_row(tile + (i - lo) * XR);
+      CovAcc acc;
+      cov_init(acc);
+      const int32_t* row = nbr + i * k;
+      for (int q0 = 0; q0 < k; q0 += 4) {
+        int32_t j[4];
+        typename Pt<PT>::Raw cj[4];
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) j[u_] = (q0 + u_ < k) ? row[q0 + u_] : -1;
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) {
+          const int64_t jj = j[u_] >= 0 ? (int64_t)j[u_] : i;
+          const uint64_t off = (uint64_t)(jj - lo);
+          if (off < (uint64_t)kRows) cj[u_] = Pt<PT>::from_row(tile + off * XR);
+          else cj[u_] = Pt<PT>::from_row(xg + jj * XR);
+        }
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) {
+          if (j[u_] >= 0) {
+            double d[3];
+            Pt<PT>::delta(cj[u_], ci, d);
+            cov_add1(acc, d[0], d[1], d[2]);
+          }
+        }
+      }
+      cov_same_weights(acc);
+      const double u = Pt<PT>::unit(qp), u2 = u * u;
+      double moff[3], cm[3], C[6], D, omega;
+      cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) C[q] *= u2;
+      const bool m = mask ? mask[i] != 0 : true;
+      const double off = offset ? (double)offset[i] : 0.0;
+      double lam0, v0[3], tr, c1, c2, l;
+      if (FULL_EIG) {
+        double lam[3], V[3][3];
+        eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
+        lam0 = lam[0]; v0[0] = V[0][0]; v0[1] = V[0][1]; v0[2] = V[0][2];
+        tr = lam[0] + lam[1] + lam[2];
+        eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2];
+      } else {
+        eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
+      }
+      l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2);
+      if (m) { acc2[0] = l; acc2[1] = 1.0; }
+      if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
+      if (pointwise) pointwise[i] = (T)l;
+    }
+  }
+  block_sum<2>(acc2, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = acc2[0];
+    partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
+  }
+}
+
+template <typename T, typename PT>
+__global__ __launch_bounds__(kBlock) void consistency_bwd_tiled_kernel(
+    const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
+    const int32_t* __restrict__ csr_src, int64_t n, PointInputs in, QParams qp, int want_e, int want_pose,
+    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+  constexpr int kRows = TileRows<PT>::value, RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
+  __shared__ int4 tile[kRows * RR];
+  __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  const int4* rg = reinterpret_cast<const int4*>(rec);
+  int64_t lo = 0;
+  if (blk >= 0) {
+    lo = tile_origin(blk, n, kRows);
+    stage_tile<RR>(rg, lo, n, kRows, tile);
+  }
+  __syncthreads();
+  ModelParams mp;
+  load_model(in, mp);
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gT[k] = 0.0;
+  int scan = -1;
+  bool active = false;
+  if (blk >= 0) {
+    const int64_t j = blk * kBlock + threadIdx.x;
+    if (j < n) {
+      active = true;
+      double g[3] = {0.0, 0.0, 0.0};
+      const typename Pt<PT>::Raw cj = Pt<PT>::from_row(reinterpret_cast<const int4*>(x) + j * XR);
+      const double u = Pt<PT>::unit(qp);
+      const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
+      for (int32_t e0 = beg; e0 < end; e0 += 4) {
         int32_t src[4];
         typename Pt<PT>::Raw m[4];
         double v[4][3], c1[4], c2[4];
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) src[u_] = (e0 + u_ < end) ? csr_src[e0 + u_] : -1;
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) RecRaw<PT>::load(rec, src[u_] >= 0 ? (int64_t)src[u_] : j, m[u_], &c1[u_], v[u_], &c2[u_]);
+        for (int u_ = 0; u_ < 4; ++u_) {
+          const int64_t ii = src[u_] >= 0 ? (int64_t)src[u_] : j;
+          const uint64_t off = (uint64_t)(ii - lo);
+          if (off < (uint64_t)kRows) RecRaw<PT>::from_row(tile + off * RR, m[u_], &c1[u_], v[u_], &c2[u_]);
+          else RecRaw<PT>::from_row(rg + ii * RR, m[u_], &c1[u_], v[u_], &c2[u_]);
+        }
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) {
           if (src[u_] >= 0) {
@@ -334,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
         }
       }
       g[0] *= u; g[1] *= u; g[2] *= u;
-      if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
+      if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
       if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
     }
   }
@@ -480,6 +656,7 @@ using namespace dc;
   } while (0)
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
+static bool g_no_tiles = true;           // LDS-tiled variants are opt-in (dc_set_option(0, 0)): measured slower, see DESIGN.md
 
 // ---- in-library kernel timer: HIP events recorded on the launch stream right around the main kernels ------
 namespace {
@@ -595,12 +772,16 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
   LossParams lp{loss_kind, normalization, sqrt_};
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
+#define FWD_ARGS(T, PT) (const PT*)points, nbr, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
 #define LAUNCH(T, PT, S) \
   do { \
-    if (eigvals) hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, (const PT*)points, nbr, n, k, \
-                                    mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws); \
-    else hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, (const PT*)points, nbr, n, k, \
-                            mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws); \
+    if (S == 4 && !g_no_tiles) { /* padded rows: LDS-staged neighbour tiles */ \
+      if (eigvals) hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+      else hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+    } else { \
+      if (eigvals) hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+      else hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+    } \
   } while (0)
   { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
@@ -641,9 +822,19 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
     hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
+#define BWD_ARGS(T, PT) (const PT*)points, (const PT*)rec, csr_ptr, csr_src, lane_perm, n, in, qp, (T*)grad_points, partials_ws, n_acc
 #define LAUNCH(T, PT, S) \
-  hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S>), grid, block, 0, stream, (const PT*)points, (const PT*)rec, csr_ptr, \
-                     csr_src, lane_perm, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc)
+  do { \
+    if (S == 4 && !lane_perm && !g_no_tiles) \
+      hipLaunchKernelGGL((consistency_bwd_tiled_kernel<T, PT>), grid, block, 0, stream, (const PT*)points, (const PT*)rec, \
+                         csr_ptr, csr_src, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc); \
+    else \
+    { \
+      if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      else if (want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      else hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, false, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+    } \
+  } while (0)
   { ProfScope prof(2, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
@@ -733,6 +924,12 @@ int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* cs
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   return DC_OK;
+}
+
+// option 0: 1 = disable the LDS-tiled kernels (ablation / A-B measurements), 0 = default.
+int dc_set_option(int option, int value) {
+  if (option == 0) { g_no_tiles = value != 0; return DC_OK; }
+  return DC_ERR_ARG;
 }
 
 // ---- profiler control ---------------------------------------------------------------------------------------

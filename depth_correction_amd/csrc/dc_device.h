@@ -146,10 +146,30 @@ template <typename F> struct PtFloat {
     Raw r; r.v[0] = c.v[0] + off[0]; r.v[1] = c.v[1] + off[1]; r.v[2] = c.v[2] + off[2]; return r;
   }
 };
-template <> struct Pt<float> : PtFloat<float> {};
-template <> struct Pt<double> : PtFloat<double> {};
+template <> struct Pt<float> : PtFloat<float> {
+  static constexpr int kRow16 = 1;                       // 16-B units per padded point row
+  static __device__ __forceinline__ Raw from_row(const int4* row) {
+    const int4 b = row[0];
+    Raw r; r.v[0] = (double)__int_as_float(b.x); r.v[1] = (double)__int_as_float(b.y); r.v[2] = (double)__int_as_float(b.z);
+    return r;
+  }
+};
+template <> struct Pt<double> : PtFloat<double> {
+  static constexpr int kRow16 = 2;
+  static __device__ __forceinline__ Raw from_row(const int4* row) {
+    const int4 a = row[0], b = row[1];
+    Raw r;
+    r.v[0] = __hiloint2double(a.y, a.x); r.v[1] = __hiloint2double(a.w, a.z); r.v[2] = __hiloint2double(b.y, b.x);
+    return r;
+  }
+};
 template <> struct Pt<q32> {
   struct Raw { int32_t v[3]; };
+  static constexpr int kRow16 = 1;
+  static __device__ __forceinline__ Raw from_row(const int4* row) {
+    const int4 q = row[0];
+    Raw r; r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; return r;
+  }
   template <int STRIDE> static __device__ __forceinline__ Raw load(const q32* p, int64_t i, const QParams&) {
     const int4 q = reinterpret_cast<const int4*>(p)[i];
     Raw r; r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; return r;
@@ -181,9 +201,34 @@ template <typename F> struct RecRawFloat {
     Rec8<F>::load(rec, i, m.v, c1, v, c2, QParams{});
   }
 };
-template <> struct RecRaw<float> : RecRawFloat<float> {};
-template <> struct RecRaw<double> : RecRawFloat<double> {};
+template <> struct RecRaw<float> : RecRawFloat<float> {
+  static constexpr int kRow16 = 2;                       // 16-B units per record row
+  static __device__ __forceinline__ void from_row(const int4* row, Pt<float>::Raw& m, double* c1, double* v, double* c2) {
+    const int4 a = row[0], b = row[1];
+    m.v[0] = (double)__int_as_float(a.x); m.v[1] = (double)__int_as_float(a.y); m.v[2] = (double)__int_as_float(a.z);
+    *c1 = (double)__int_as_float(a.w);
+    v[0] = (double)__int_as_float(b.x); v[1] = (double)__int_as_float(b.y); v[2] = (double)__int_as_float(b.z);
+    *c2 = (double)__int_as_float(b.w);
+  }
+};
+template <> struct RecRaw<double> : RecRawFloat<double> {
+  static constexpr int kRow16 = 4;
+  static __device__ __forceinline__ void from_row(const int4* row, Pt<double>::Raw& m, double* c1, double* v, double* c2) {
+    const int4 a = row[0], b = row[1], c = row[2], d = row[3];
+    m.v[0] = __hiloint2double(a.y, a.x); m.v[1] = __hiloint2double(a.w, a.z); m.v[2] = __hiloint2double(b.y, b.x);
+    *c1 = __hiloint2double(b.w, b.z);
+    v[0] = __hiloint2double(c.y, c.x); v[1] = __hiloint2double(c.w, c.z); v[2] = __hiloint2double(d.y, d.x);
+    *c2 = __hiloint2double(d.w, d.z);
+  }
+};
 template <> struct RecRaw<q32> {
+  static constexpr int kRow16 = 2;
+  static __device__ __forceinline__ void from_row(const int4* row, Pt<q32>::Raw& m, double* c1, double* v, double* c2) {
+    const int4 a = row[0], b = row[1];
+    m.v[0] = a.x; m.v[1] = a.y; m.v[2] = a.z; *c1 = (double)__int_as_float(a.w);
+    v[0] = (double)__int_as_float(b.x); v[1] = (double)__int_as_float(b.y); v[2] = (double)__int_as_float(b.z);
+    *c2 = (double)__int_as_float(b.w);
+  }
   static __device__ __forceinline__ void store(q32* rec, int64_t i, const Pt<q32>::Raw& m, double c1, const double* v, double c2) {
     int4* r = reinterpret_cast<int4*>(rec) + 2 * i;
     r[0] = make_int4(m.v[0], m.v[1], m.v[2], __float_as_int((float)c1));

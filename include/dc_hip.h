@@ -195,6 +195,10 @@ int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp
                  double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
                  dcStream_t stream);
 
+/* Tuning / ablation switches.  option 0: value 1 disables the LDS-staged neighbour tiles of the fused kernels
+ * (results are identical either way). */
+int dc_set_option(int option, int value);
+
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
  * bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them. */
 int dc_profiler_enable(int on);

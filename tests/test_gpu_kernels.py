@@ -351,3 +351,22 @@ def test_p2plane_golden(golden, dev):
     T.backward(gT)
     ref = g['grad_pose_deltas']
     np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
+
+
+def test_lds_tiles_do_not_change_results(golden, dev):
+    """The LDS-staged neighbour tiles are a pure data-movement optimisation: bitwise identical sums with and without,
+    for a cloud longer than one window (so both the in-window LDS path and the global fallback run)."""
+    from depth_correction_amd import _native as nv
+    g = golden('room_k10')
+    outs = []
+    for off in (0, 1):
+        nv.check(nv.lib().dc_set_option(0, off), 'dc_set_option')
+        try:
+            r32 = _run_sequence(g, dev, torch.float32, stride=4, q32=True)
+            r64 = _run_sequence(g, dev, torch.float64, stride=4)
+        finally:
+            nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
+        outs.append([npy(r['fw']['sums']) for r in (r32, r64)] + [npy(r['gw']) for r in (r32, r64)]
+                    + [npy(r['gp']) for r in (r32, r64)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
