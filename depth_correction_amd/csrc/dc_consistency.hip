@@ -627,6 +627,34 @@ __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double
   }
 }
 
+// One launch for a whole evaluation: out[0..2) <- forward partials, out[2..2+n_red) <- backward partials,
+// out[2+n_red..2+n_acc) <- 0 (gradient slots that were not requested).
+__global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __restrict__ p_fwd, const double* __restrict__ p_bwd,
+                                                                int64_t n_rows, int n_red, double* __restrict__ out) {
+  __shared__ double lds[kRedBlock / kWave];
+  const int a = blockIdx.x;
+  if (a >= 2 + n_red) {
+    if (threadIdx.x == 0) out[a] = 0.0;
+    return;
+  }
+  const double* p = (a < 2 ? p_fwd + (int64_t)a * n_rows : p_bwd + (int64_t)(a - 2) * n_rows);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int64_t r = threadIdx.x;
+  for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {
+    s0 += p[r]; s1 += p[r + kRedBlock]; s2 += p[r + 2 * kRedBlock]; s3 += p[r + 3 * kRedBlock];
+  }
+  for (; r < n_rows; r += kRedBlock) s0 += p[r];
+  double s = wave_sum((s0 + s1) + (s2 + s3));
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) lds[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv];
+    out[a] = t;
+  }
+}
+
 // torch.optim.Adam (single-tensor path, no amsgrad) on a small fp64 parameter vector; grad is scaled first.
 __global__ void adam_kernel(double* __restrict__ p, const double* __restrict__ grad, double* __restrict__ m,
                             double* __restrict__ v, int64_t n, double grad_scale, double lr, double b1, double b2,
@@ -656,6 +684,7 @@ using namespace dc;
   } while (0)
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
+static bool g_defer_reduce = false;      // set by dc_sequence_eval: it reduces forward and backward partials in one launch
 static bool g_no_tiles = true;           // LDS-tiled variants are opt-in (dc_set_option(0, 0)): measured slower, see DESIGN.md
 
 // ---- in-library kernel timer: HIP events recorded on the launch stream right around the main kernels ------
@@ -786,6 +815,7 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
   { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
+  if (g_defer_reduce) return DC_OK;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, sums_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
@@ -818,7 +848,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
-  if (params && n_red < n_acc) {
+  if (params && n_red < n_acc && !g_defer_reduce) {
     hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
@@ -838,7 +868,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
   { ProfScope prof(2, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  if (params && n_red > 0) {
+  if (params && n_red > 0 && !g_defer_reduce) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
     DC_CHECK_LAUNCH();
   }
@@ -976,19 +1006,32 @@ int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp
 // (+ two fixed-order reductions).  out fp64 [2 + 2 P + 12 S] = {sum loss over mask, mask count, grads of the sum}.
 int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
                      int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream) {
-  if (!d || !out || !poses) return DC_ERR_ARG;
+  if (!d || !out || !poses || !d->partials) return DC_ERR_ARG;
   const int stride = 4;
   int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                          d->n_terms, w, e, d->n, d->dtype, d->point_fmt, d->qparams, stride, d->x, nullptr, nullptr,
                          nullptr, stream);
   if (rc) return rc;
+  const int n_terms = d->model_kind == DC_MODEL_NONE ? 0 : d->n_terms;
+  const int n_acc = 2 * n_terms + 12 * d->n_scans;
+  if (d->n == 0) return (int)hipMemsetAsync(out, 0, (size_t)(2 + n_acc) * sizeof(double), stream);
+  // forward partials live in the first 2 * rows doubles of the workspace, backward partials behind them; ONE reduction
+  const int64_t rows = xcd_grid(n_blocks(d->n));
+  double* p_fwd = d->partials;
+  double* p_bwd = d->partials + 2 * rows;
+  const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
+  g_defer_reduce = true;
   rc = dc_consistency_fwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->n, d->k, d->mask, nullptr,
-                          d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, d->partials, out, stream);
-  if (rc || !want_grad) return rc;
-  return dc_consistency_bwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
-                            d->n,
-                            d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
-                            d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, d->partials, out + 2, stream);
+                          d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream);
+  if (!rc && want_grad)
+    rc = dc_consistency_bwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
+                            d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
+                            d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream);
+  g_defer_reduce = false;
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows, n_red, out);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
 }
 
 }  // extern "C"

@@ -108,7 +108,7 @@ class SequencePlan:
         self.rec = torch.empty((self.n, 8), dtype=pdt, device=dev)
         rows = ops.lib().dc_partial_rows(self.n)
         nacc = 2 * ops.nv.MAX_MODEL_TERMS + 12 * self.n_scans
-        self.partials = torch.empty((rows * max(nacc, 2),), dtype=torch.float64, device=dev)
+        self.partials = torch.empty((rows * (nacc + 2),), dtype=torch.float64, device=dev)
         self.version = 0
         self._desc = None
 

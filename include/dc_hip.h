@@ -168,7 +168,7 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
 /* ---- whole-sequence evaluation + optimiser step (train.py:220-312 per-iteration body for one sequence) ----------
  * The caller fills a descriptor with the device arrays of one sequence (SequencePlan in Python) once; every
  * iteration is then ONE host call that launches dc_points_fwd, dc_consistency_fwd and dc_consistency_bwd.
- * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_partial_rows(n) * max(2, 2 P + 12 S)] are scratch. */
+ * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_partial_rows(n) * (2 + 2 P + 12 S)] are scratch. */
 typedef struct dcSequenceDesc {
   int64_t n;
   int32_t k, n_scans, dtype, point_fmt;
