@@ -769,6 +769,7 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
                   const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
                   const double* w, const double* e, int64_t n, int dtype, int point_fmt, const double* qparams,
                   int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (n < 0 || !vps || !dirs || !depth || !points_out || (out_stride != 3 && out_stride != 4)) return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
   int rc = check_model(model_kind, n_terms, inc, w, e);
@@ -792,6 +793,7 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
                        const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
                        int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
                        double* sums_out, hipStream_t stream) {
+  if (n == 0 && sums_out) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
   if (n < 0 || k < 1 || !points || !nbr || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   if (loss_kind != DC_LOSS_MIN_EIGVAL && loss_kind != DC_LOSS_TRACE) return DC_ERR_ARG;
   QParams qp;
@@ -915,9 +917,9 @@ int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nb
                     const void* mean_weights, double scale, const void* dirs, void* mean, void* cov, void* eigvals,
                     void* eigvecs, void* normals, void* inc_angles, int32_t* nvalid, void* weights_out,
                     void* cmean_out, void* invd_out, hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (n < 0 || k < 1 || !points || !nbr || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   if ((normals || inc_angles) && !dirs) return DC_ERR_ARG;
-  if (n == 0) return DC_OK;
   dim3 grid((unsigned)xcd_grid(n_blocks(n))), block(kBlock);
 #define LAUNCH(T, S) \
   hipLaunchKernelGGL((features_fwd_kernel<T, S>), grid, block, 0, stream, (const T*)points, nbr, (const T*)mean_weights, \
@@ -935,6 +937,7 @@ int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* cs
                     int64_t n, const void* cmean, const void* invd, const int32_t* nvalid, const void* eigvecs,
                     const void* grad_mean, const void* grad_cov, const void* grad_eigvals, void* grec_ws,
                     void* grad_points, hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (n < 0 || !points || !csr_ptr || !csr_src || !cmean || !invd || !nvalid || !grec_ws || !grad_points) return DC_ERR_ARG;
   if (stride != 3 && stride != 4) return DC_ERR_ARG;
   if (grad_eigvals && !eigvecs) return DC_ERR_ARG;

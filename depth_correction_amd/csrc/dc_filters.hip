@@ -72,6 +72,7 @@ extern "C" {
 
 int dc_mask_bounds(const void* num, int num_stride, int num_index, const void* den, int den_stride, int den_index,
                    int dtype, int64_t n, double lo, double hi, uint8_t* mask, hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (!num || !mask || n < 0 || num_stride < 1 || num_index < 0 || num_index >= num_stride) return DC_ERR_ARG;
   if (den && (den_stride < 1 || den_index < 0 || den_index >= den_stride)) return DC_ERR_ARG;
   if (n == 0) return DC_OK;
@@ -88,6 +89,7 @@ int dc_mask_bounds(const void* num, int num_stride, int num_index, const void* d
 }
 
 int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (!nbr || !count_out || n < 0 || k < 1) return DC_ERR_ARG;
   if (n == 0) return DC_OK;
   hipLaunchKernelGGL(valid_count_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, nbr, n, k, count_out);
@@ -97,6 +99,7 @@ int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, hip
 
 int dc_dispersion(const void* vec, int dtype, const int32_t* nbr, const void* weights, int64_t n, int k, void* out,
                   hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (!vec || !nbr || !out || n < 0 || k < 1) return DC_ERR_ARG;
   if (n == 0) return DC_OK;
   const dim3 grid((unsigned)xcd_grid((n + kBlock - 1) / kBlock)), block(kBlock);

@@ -512,6 +512,7 @@ size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
 int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride, int64_t n_query,
                  int k, double r, double cell_hint, int32_t* idx_out, double* dist_out, void* ws, size_t ws_bytes,
                  hipStream_t stream) {
+  if (n == 0 && !query) return DC_OK;
   if (!points || n < 0 || k < 1 || k > 64 || !idx_out || !ws || stride < 3) return DC_ERR_ARG;
   if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
   if (query && (n_query < 0 || q_stride < 3)) return DC_ERR_ARG;
@@ -589,6 +590,7 @@ size_t dc_knn_transpose_workspace_bytes(int64_t n, int k) {
 // csr_ptr[N+1], csr_src[N*K]: for every point j the ascending list of centres i whose neighbourhood contains j.
 int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int32_t* csr_ptr, int32_t* csr_src, void* ws, size_t ws_bytes,
                      hipStream_t stream) {
+  if (n == 0 && csr_ptr) return (int)hipMemsetAsync(csr_ptr, 0, sizeof(int32_t), stream);
   if (!nbr || n < 0 || k < 1 || !csr_ptr || !csr_src || !ws) return DC_ERR_ARG;
   const int64_t ne = n * k;
   if (ne >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
@@ -626,6 +628,7 @@ size_t dc_spatial_order_workspace_bytes(int64_t n) {
 // order_out[p] = index of the point at position p of the Morton (Z-curve) order over the bounding box.
 int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32_t* order_out, void* ws, size_t ws_bytes,
                      hipStream_t stream) {
+  if (n == 0) return DC_OK;
   if (!points || n < 0 || !order_out || !ws || stride < 3) return DC_ERR_ARG;
   if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
   if (ws_bytes < dc_spatial_order_workspace_bytes(n)) return DC_ERR_WORKSPACE;

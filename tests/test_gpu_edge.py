@@ -1,0 +1,171 @@
+"""Edge cases of the domain on the GPU: empty and tiny clouds, k larger than the cloud, ragged radius neighbourhoods,
+neighbourhoods with one / zero valid members, duplicate points, non-finite coordinates, sizes around the block and
+window boundaries, the widest k the builder supports."""
+import numpy as np
+import pytest
+import torch
+
+import dc_oracle as O
+from helpers import t, npy, assert_eigvals_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _cloud(n, seed=0, flat=0.02):
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-2, 2, size=(n, 3)) * [1, 1, flat]).astype(np.float32).astype(np.float64)
+
+
+def test_empty_inputs():
+    from depth_correction_amd import ops
+    x = torch.zeros((0, 3), dtype=torch.float64, device=DEV)
+    d, i = ops.knn(x, 4)
+    assert d.shape == (0, 4) and i.shape == (0, 4)
+    nbr = torch.zeros((0, 4), dtype=torch.int32, device=DEV)
+    f = ops.features_fwd(x, nbr, want=('mean', 'cov', 'eigvals'))
+    assert f['eigvals'].shape == (0, 3)
+    out = ops.consistency_fwd(x, nbr)
+    assert npy(out['sums']).tolist() == [0.0, 0.0]
+    p, s = ops.knn_transpose(nbr)
+    assert npy(p).tolist() == [0]
+    assert ops.radius_neighbors(x, 0.5).shape[0] == 0
+    assert ops.spatial_order(x).numel() == 0
+
+
+@pytest.mark.parametrize('n,k', [(1, 1), (1, 4), (3, 5), (7, 7), (40, 64)])
+def test_k_larger_than_cloud(n, k):
+    """cKDTree pads with index n (-> -1) and inf when fewer than k points exist (nearest_neighbors.py:48-49)."""
+    from depth_correction_amd import ops
+    pts = _cloud(n, seed=n)
+    d, i = ops.knn(t(pts, DEV), k)
+    dref, iref = O.knn_ckdtree(pts, k)
+    if k == 1:
+        dref, iref = dref.reshape(-1, 1), iref.reshape(-1, 1)          # cKDTree squeezes k = 1
+    assert np.array_equal(npy(i), iref) and np.array_equal(npy(d), dref)
+
+
+@pytest.mark.parametrize('n', [255, 256, 257, 1023, 1025, 5000])
+def test_sizes_around_block_and_window_edges(n):
+    from depth_correction_amd import ops
+    pts = _cloud(n, seed=n)
+    x = t(pts, DEV)
+    _, idx = ops.knn(x, 6)
+    assert np.array_equal(npy(idx), O.knn_ckdtree(pts, 6)[1])
+    ref = O.closed_form_backward(pts, npy(idx).astype(np.int64), None, normalization=True, reduction='sum')
+    for q32 in (False, True):
+        if q32:
+            qf = ops.QFormat.for_extent(pts.min(0), pts.max(0))
+            xq = torch.round((x - torch.tensor(qf.origin, device=DEV)) / qf.scale).to(torch.int32)
+            xs = torch.cat([xq, torch.zeros((n, 1), dtype=torch.int32, device=DEV)], 1).contiguous()
+        else:
+            qf, xs = None, torch.cat([x, torch.zeros((n, 1), dtype=x.dtype, device=DEV)], 1).contiguous()
+        fw = ops.consistency_fwd(xs, idx, qfmt=qf, want_pointwise=True)
+        cp, cs = ops.knn_transpose(idx)
+        gp, _ = ops.consistency_bwd(xs, fw['rec'], cp, cs, want_grad_points=True, qfmt=qf)
+        tol = 1e-9 if not q32 else 1e-4
+        np.testing.assert_allclose(npy(fw['sums'])[0], ref['loss'], rtol=tol)
+        np.testing.assert_allclose(npy(gp)[:, :3], ref['grad_points'], rtol=10 * tol, atol=tol * np.abs(ref['grad_points']).max())
+
+
+def test_ragged_radius_neighbourhoods():
+    """Radius search: variable neighbour counts, -1 padding, isolated points keep only themselves; features use
+    weight 0 for the padding exactly like the reference (depth_cloud.py:213,291-295)."""
+    from depth_correction_amd import ops
+    pts = np.concatenate([_cloud(600, 1), np.array([[50.0, 50.0, 50.0], [-40.0, 0.0, 9.0]])])
+    x = t(pts, DEV)
+    idx = ops.radius_neighbors(x, 0.3)
+    ref = O.radius_ckdtree(pts, 0.3)
+    assert np.array_equal(npy(idx), ref)
+    assert npy(idx)[-1].tolist()[:2] == [len(pts) - 1, -1] and (ref[-2] >= 0).sum() == 1
+    f = ops.features_fwd(x, idx, want=('mean', 'cov', 'eigvals'), want_saved=True)
+    fo = O.features(t(pts), t(ref), torch.zeros((len(pts), 3), dtype=torch.float64))
+    many = (ref >= 0).sum(1) >= 3
+    np.testing.assert_allclose(npy(f['mean']), npy(fo['mean']), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(npy(f['cov']), npy(fo['cov']), rtol=1e-9, atol=1e-16)
+    assert_eigvals_close(npy(f['eigvals'])[many], npy(fo['eigvals'])[many], 1e-9)
+    assert np.array_equal(npy(f['nvalid']), (ref >= 0).sum(1))
+    # one valid neighbour: W - 1 = 0 is clamped to 1e-6, the covariance is exactly zero (utils.py:145-147)
+    assert np.all(npy(f['cov'])[-1] == 0) and np.all(npy(f['eigvals'])[-1] == 0)
+
+
+def test_neighbourhood_without_valid_members_is_nan_like_the_reference():
+    from depth_correction_amd import ops
+    pts = _cloud(50, 3)
+    nbr = O.knn_ckdtree(pts, 4)[1]
+    nbr[7] = -1                                                      # W = 0 -> 0/0 (depth_cloud.py:292-293)
+    x = t(pts, DEV)
+    f = ops.features_fwd(x, t(nbr, DEV).int(), want=('mean', 'eigvals'))
+    valid = nbr.copy()
+    valid[7] = 7                       # the reference itself cannot finish here: LAPACK rejects the NaN covariance
+    fo = O.features(t(pts), t(valid), torch.zeros((50, 3), dtype=torch.float64))
+    assert np.isnan(npy(f['mean'])[7]).all() and np.isnan(npy(f['eigvals'])[7]).all()
+    ok = np.arange(50) != 7
+    np.testing.assert_allclose(npy(f['mean'])[ok], npy(fo['mean'])[ok], rtol=1e-12, atol=1e-13)
+    mask = torch.ones(50, dtype=torch.bool, device=DEV)
+    mask[7] = False
+    xs = torch.cat([x, torch.zeros((50, 1), dtype=x.dtype, device=DEV)], 1).contiguous()
+    out = ops.consistency_fwd(xs, t(nbr, DEV).int(), mask=mask)
+    assert np.isfinite(npy(out['sums'])).all() and npy(out['sums'])[1] == 49
+
+
+def test_duplicate_points_are_deterministic_and_valid():
+    """Exact ties are outside the cKDTree contract (tree-traversal order); here they resolve by index."""
+    from depth_correction_amd import ops
+    base = _cloud(300, 5)
+    pts = np.concatenate([base, base[:100], base[:50]])
+    x = t(pts, DEV)
+    d1, i1 = ops.knn(x, 8)
+    d2, i2 = ops.knn(x, 8)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    dref, _ = O.knn_ckdtree(pts, 8)
+    assert np.array_equal(npy(d1), dref)                              # the distance multiset is still the exact k-NN
+    dd = np.linalg.norm(pts[npy(i1)] - pts[:, None, :], axis=-1)
+    np.testing.assert_allclose(dd, npy(d1), rtol=1e-14, atol=0)
+    i = npy(i1)
+    tie = npy(d1)[:, 1:] == npy(d1)[:, :-1]
+    assert np.all(i[:, 1:][tie] > i[:, :-1][tie])                     # ties ordered by ascending index
+
+
+def test_non_finite_points_do_not_poison_the_rest():
+    from depth_correction_amd import ops
+    pts = _cloud(400, 9)
+    pts[13] = np.nan
+    pts[77, 1] = np.inf
+    x = t(pts, DEV)
+    d, i = ops.knn(x, 5)
+    good = np.isfinite(pts).all(1)
+    sub = pts[good]
+    remap = np.flatnonzero(good)
+    dref, iref = O.knn_ckdtree(sub, 5)
+    rows = npy(i)[good]
+    assert np.array_equal(rows, remap[iref]) and np.array_equal(npy(d)[good], dref)
+
+
+@pytest.mark.parametrize('k', [2, 16, 17, 33, 64])
+def test_wide_and_narrow_k(k):
+    from depth_correction_amd import ops
+    pts = _cloud(3000, k)
+    d, i = ops.knn(t(pts, DEV), k)
+    dref, iref = O.knn_ckdtree(pts, k)
+    assert np.array_equal(npy(i), iref) and np.array_equal(npy(d), dref)
+    x4 = torch.cat([t(pts, DEV), torch.zeros((3000, 1), dtype=torch.float64, device=DEV)], 1).contiguous()
+    kind = 'trace_loss' if k == 2 else 'min_eigval_loss'        # two points: lambda0 is pure round-off
+    fw = ops.consistency_fwd(x4, i, loss=kind, normalization=False)
+    ref = O.closed_form_backward(pts, iref, None, kind=kind, normalization=False, reduction='sum')
+    np.testing.assert_allclose(npy(fw['sums'])[0], ref['loss'], rtol=1e-9)
+    with pytest.raises(ValueError):
+        ops.knn(t(pts, DEV), 65)
+
+
+def test_operand_checks_refuse_bad_shapes():
+    from depth_correction_amd import ops
+    x = t(_cloud(10), DEV)
+    with pytest.raises(ValueError):
+        ops.features_fwd(x, torch.zeros((9, 3), dtype=torch.int32, device=DEV))
+    with pytest.raises(TypeError):
+        ops.features_fwd(x, torch.zeros((10, 3), dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.knn(x.cpu(), 3)
+    with pytest.raises(RuntimeError):
+        ops.knn(x.t().contiguous().t(), 3)                             # non-contiguous view
