@@ -293,8 +293,8 @@ class SequenceTrainer:
         (mean loss = acc[0] / acc[1]).  No host synchronisation."""
         for plan, P, out in zip(self.plans, self.poses12, self.outs):
             self.evaluate(plan, self.w, self.exponent, P, out)
-        if len(self.outs) == 1 and not self.distributed:
-            acc = self.outs[0][:2 + self.nt]
+        if len(self.outs) == 1:
+            acc = self.outs[0][:2 + self.nt]          # reduced in place across ranks below
         else:
             acc = self.acc
             acc.zero_()

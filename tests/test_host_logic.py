@@ -203,3 +203,20 @@ def test_synthetic_generators():
     k = KittiLikeDataset(n_poses=2, n_rings=8, n_azimuth=64)
     c, p = k[1]
     assert 0 < len(c) <= 8 * 64 and np.isclose(p[0, 3], 1.0)
+
+
+def test_install_as_reference_package():
+    """Unmodified reference callers import `depth_correction.*`; the alias hands them this package."""
+    import sys
+    import depth_correction_amd
+    assert 'depth_correction' not in sys.modules
+    depth_correction_amd.install_as('depth_correction')
+    try:
+        from depth_correction.depth_cloud import DepthCloud as DC
+        from depth_correction.loss import min_eigval_loss as f
+        from depth_correction.preproc import local_feature_cloud, global_cloud, establish_neighborhoods  # noqa: F401
+        from depth_correction.model import ScaledPolynomial as SP
+        assert DC is DepthCloud and f is min_eigval_loss and SP is ScaledPolynomial
+    finally:
+        for k in [k for k in sys.modules if k == 'depth_correction' or k.startswith('depth_correction.')]:
+            del sys.modules[k]
