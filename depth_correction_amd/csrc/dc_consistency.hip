@@ -31,7 +31,8 @@ __global__ __launch_bounds__(kBlock) void points_fwd_kernel(PointInputs in, int6
   ModelParams mp;
   load_model(in, mp);
   double vp[3], dr[3], T12[12];
-  Row3<T, 3>::load((const T*)in.vps, i, vp, qp);
+  if (in.vps) Row3<T, 3>::load((const T*)in.vps, i, vp, qp);           // NULL: viewpoints at the sensor origin
+  else { vp[0] = vp[1] = vp[2] = 0.0; }
   Row3<T, 3>::load((const T*)in.dirs, i, dr, qp);
   const double d = (double)((const T*)in.depth)[i];
   const bool lm = in.lmask ? in.lmask[i] != 0 : true;
@@ -205,7 +206,8 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
                                                  bool want_pose, int* scan) {
   double vp[3], dr[3], T12[12];
   const QParams qp0{};
-  Row3<T, 3>::load((const T*)in.vps, j, vp, qp0);
+  if (in.vps) Row3<T, 3>::load((const T*)in.vps, j, vp, qp0);
+  else { vp[0] = vp[1] = vp[2] = 0.0; }
   Row3<T, 3>::load((const T*)in.dirs, j, dr, qp0);
   const double d = (double)((const T*)in.depth)[j];
   const bool lm = in.lmask ? in.lmask[j] != 0 : true;
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_tiled_kernel(
     const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
     const int32_t* __restrict__ csr_src, int64_t n, PointInputs in, QParams qp, int want_e, int want_pose,
     T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+#pragma clang fp contract(off)
   constexpr int kRows = TileRows<PT>::value, RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
   __shared__ int4 tile[kRows * RR];
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
@@ -773,7 +776,7 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
                   const double* w, const double* e, int64_t n, int dtype, int point_fmt, const double* qparams,
                   int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, hipStream_t stream) {
   if (n == 0) return DC_OK;
-  if (n < 0 || !vps || !dirs || !depth || !points_out || (out_stride != 3 && out_stride != 4)) return DC_ERR_ARG;
+  if (n < 0 || !dirs || !depth || !points_out || (out_stride != 3 && out_stride != 4)) return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
   int rc = check_model(model_kind, n_terms, inc, w, e);
   if (rc) return rc;
@@ -837,7 +840,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
   const bool params = dirs != nullptr;
   if (!params && !grad_points) return DC_ERR_ARG;
   if (params) {
-    if (!vps || !depth || !partials_ws || !grads_out) return DC_ERR_ARG;
+    if (!depth || !partials_ws || !grads_out) return DC_ERR_ARG;
     if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
     if (want_pose_grad && n_scans < 1) return DC_ERR_ARG;
     int rc = check_model(model_kind, n_terms, inc, w, e);
@@ -885,7 +888,7 @@ int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, con
                   const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
                   int want_exponent_grad, int want_pose_grad, double* partials_ws, double* grads_out,
                   hipStream_t stream) {
-  if (n < 0 || !grad_points || !vps || !dirs || !depth || !partials_ws || !grads_out || (stride != 3 && stride != 4))
+  if (n < 0 || !grad_points || !dirs || !depth || !partials_ws || !grads_out || (stride != 3 && stride != 4))
     return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
   int rc = check_model(model_kind, n_terms, inc, w, e);

@@ -25,7 +25,8 @@ template <typename T>
 __device__ __forceinline__ void load_scan_point(const ScanView& s, const ModelParams& mp, const double* T12, int64_t i,
                                                 ScanPoint<T>& p) {
   double vp[3];
-  Row3<T, 3>::load((const T*)s.vps, i, vp, QParams{});
+  if (s.vps) Row3<T, 3>::load((const T*)s.vps, i, vp, QParams{});
+  else { vp[0] = vp[1] = vp[2] = 0.0; }
   Row3<T, 3>::load((const T*)s.dirs, i, p.dr, QParams{});
   Row3<T, 3>::load((const T*)s.normals, i, p.nl, QParams{});
   p.d = (double)((const T*)s.depth)[i];
@@ -165,7 +166,7 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
                     const int32_t* idxB, int64_t m, int want_exponent_grad, int want_pose_grad, double* partials_ws,
                     double* out, hipStream_t stream) {
   (void)want_exponent_grad; (void)want_pose_grad;      // always produced: the kernel is tiny next to the k-NN set-up
-  if (!vpsA || !dirsA || !depthA || !normalsA || !vpsB || !dirsB || !depthB || !normalsB) return DC_ERR_ARG;
+  if (!dirsA || !depthA || !normalsA || !dirsB || !depthB || !normalsB) return DC_ERR_ARG;
   if (!poseA || !poseB || !idxA || !idxB || m < 0 || !partials_ws || !out) return DC_ERR_ARG;
   if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
   if (model_kind != DC_MODEL_NONE && (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !incA || !incB || !w || !e)) return DC_ERR_ARG;

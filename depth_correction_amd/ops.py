@@ -108,7 +108,8 @@ class PointSet:
         need(dirs, (None, 3), name='dirs')
         n = dirs.shape[0]
         dev, dt = dirs.device, dirs.dtype
-        need(vps, (n, 3), dtype=dt, name='vps', device=dev)
+        if vps is not None:                  # None: every viewpoint is the sensor origin
+            need(vps, (n, 3), dtype=dt, name='vps', device=dev)
         depth = depth.reshape(-1)
         need(depth, (n,), dtype=dt, name='depth', device=dev)
         if inc is not None:
@@ -190,7 +191,7 @@ def points_fwd(ps, poses=None, model_kind=None, w=None, e=None, stride=3, want_p
     _check_points(x, qfmt, 'points_out')
     assert x.shape == (ps.n, stride) and x.device == ps.device
     fmt, qptr = _fmt_args(ps.dtype, qfmt)
-    parts = (torch.empty_like(ps.vps), torch.empty_like(ps.dirs), torch.empty_like(ps.depth)) if want_parts \
+    parts = (torch.empty_like(ps.dirs), torch.empty_like(ps.dirs), torch.empty_like(ps.depth)) if want_parts \
         else (None, None, None)
     check(lib().dc_points_fwd(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
                               ptr(poses), ns, kind, nt, ptr(w), ptr(e), ps.n, dtype_code(ps.dirs), fmt, qptr, stride,

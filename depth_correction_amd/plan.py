@@ -90,6 +90,8 @@ class SequencePlan:
             self.order, self.rank = order, rank
         else:
             self.order = self.rank = None
+        if not bool(vps.any()):
+            vps = None                      # sensor-frame scans: viewpoints are the origin, nothing to stream
         self.ps = ops.PointSet(vps, dirs, depth, inc, lmask, scan_id)
         self.nbr, self.mask = nbr, mask
         self.csr_ptr, self.csr_src = ops.knn_transpose(nbr)

@@ -75,7 +75,8 @@ int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32
 /* ---- corrected points: model.py:243-261 (ScaledPolynomial), :181-199 (Polynomial), BaseModel.forward :76-78,
  *      DepthCloud.transform depth_cloud.py:135-152, to_points :122-124, preproc.global_cloud :80-119 ---------
  * d' = model(depth, inc) on points with lmask != 0 (NULL = all), scan s = scan_id[i] (NULL = 0) is moved by
- * poses[s] (fp64 [n_scans, 12] row-major [R|t], NULL = identity), x = vps' + d' dirs'.
+ * poses[s] (fp64 [n_scans, 12] row-major [R|t], NULL = identity), x = vps' + d' dirs'.  vps == NULL means all
+ * viewpoints sit at the sensor origin (the usual case for scans in their own frame): 12 B/point less to read.
  * w, e: fp64 device arrays [n_terms] (model weights / exponents).  out_stride 3 or 4 (4 = padded rows).
  * point_fmt: format of points_out -- `dtype` itself, or DC_Q32 (dtype DC_F32, stride 4) with qparams = HOST
  * fp64 [4] {origin.xyz, scale}: fixed-point rows with uniform resolution `scale` (fp32 traffic, ~2^8 finer
