@@ -38,8 +38,8 @@ def parse():
     ap.add_argument('--points', type=int, default=200_000, help='points per scan')
     ap.add_argument('--k', type=int, default=10)
     ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
-    ap.add_argument('--cpu-scans', type=int, default=2, help='scans in the CPU-baseline sample (0 = skip)')
-    ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--cpu-scans', type=int, default=4, help='scans in the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-iters', type=int, default=5)
     ap.add_argument('--no-sort', action='store_true', help='keep the scan-major point order (ablation)')
     ap.add_argument('--point-format', default='auto', choices=['auto', 'q32', 'float'])
     ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')

@@ -690,7 +690,6 @@ using namespace dc;
   } while (0)
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
-static bool g_defer_reduce = false;      // set by dc_sequence_eval: it reduces forward and backward partials in one launch
 static bool g_no_tiles = true;           // LDS-tiled variants are opt-in (dc_set_option(0, 0)): measured slower, see DESIGN.md
 
 // ---- in-library kernel timer: HIP events recorded on the launch stream right around the main kernels ------
@@ -795,10 +794,11 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
   return DC_OK;
 }
 
-int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
-                       const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
-                       int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
-                       double* sums_out, hipStream_t stream) {
+// `reduce` = false leaves the block partials in partials_ws for a later combined reduction (dc_sequence_eval).
+static int consistency_fwd_impl(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
+                                const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
+                                int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
+                                double* sums_out, hipStream_t stream, bool reduce) {
   if (n == 0 && sums_out) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
   if (n < 0 || k < 1 || !points || !nbr || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   if (loss_kind != DC_LOSS_MIN_EIGVAL && loss_kind != DC_LOSS_TRACE) return DC_ERR_ARG;
@@ -823,19 +823,26 @@ int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt,
   { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  if (g_defer_reduce) return DC_OK;
+  if (!reduce) return DC_OK;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, sums_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
 
-int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
-                       const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
-                       const void* vps, const void* dirs,
-                       const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
-                       const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
-                       int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
-                       double* grads_out, hipStream_t stream) {
+int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
+                       const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
+                       int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
+                       double* sums_out, hipStream_t stream) {
+  return consistency_fwd_impl(points, stride, dtype, point_fmt, qparams, nbr, n, k, mask, offset, loss_kind, normalization,
+                              sqrt_, rec, pointwise, eigvals, partials_ws, sums_out, stream, true);
+}
+
+static int consistency_bwd_impl(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
+                                const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
+                                const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                                const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
+                                const double* w, const double* e, int want_exponent_grad, int want_pose_grad,
+                                void* grad_points, double* partials_ws, double* grads_out, hipStream_t stream, bool reduce) {
   if (n < 0 || !points || !rec || !csr_ptr || !csr_src || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   const bool params = dirs != nullptr;
   if (!params && !grad_points) return DC_ERR_ARG;
@@ -856,7 +863,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
-  if (params && n_red < n_acc && !g_defer_reduce) {
+  if (params && n_red < n_acc && reduce) {
     hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
@@ -876,11 +883,22 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
   { ProfScope prof(2, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  if (params && n_red > 0 && !g_defer_reduce) {
+  if (params && n_red > 0 && reduce) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
     DC_CHECK_LAUNCH();
   }
   return DC_OK;
+}
+
+int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
+                       const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
+                       const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                       const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* w,
+                       const double* e, int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
+                       double* grads_out, hipStream_t stream) {
+  return consistency_bwd_impl(points, stride, dtype, point_fmt, qparams, rec, csr_ptr, csr_src, lane_perm, n, vps, dirs, depth,
+                              inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e, want_exponent_grad,
+                              want_pose_grad, grad_points, partials_ws, grads_out, stream, true);
 }
 
 int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, const void* vps, const void* dirs,
@@ -1029,14 +1047,12 @@ int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, 
   double* p_fwd = d->partials;
   double* p_bwd = d->partials + 2 * rows;
   const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
-  g_defer_reduce = true;
-  rc = dc_consistency_fwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->n, d->k, d->mask, nullptr,
-                          d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream);
+  rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->n, d->k, d->mask, nullptr,
+                            d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream, false);
   if (!rc && want_grad)
-    rc = dc_consistency_bwd(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
-                            d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
-                            d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream);
-  g_defer_reduce = false;
+    rc = consistency_bwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
+                              d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
+                              d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false);
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows, n_red, out);
   DC_CHECK_LAUNCH();
