@@ -16,7 +16,7 @@ from . import ops
 from .depth_cloud import DepthCloud
 
 __all__ = ['filter_depth', 'filter_eigenvalue', 'filter_eigenvalue_ratio', 'filter_eigenvalue_ratios',
-           'filter_eigenvalues', 'filter_grid', 'filter_valid_neighbors', 'within_bounds']
+           'filter_eigenvalues', 'filter_grid', 'filter_shadow_points', 'filter_valid_neighbors', 'within_bounds']
 
 default_rng = np.random.default_rng(135)
 
@@ -154,3 +154,22 @@ def filter_eigenvalue_ratios(cloud: DepthCloud, bounds: list, only_mask: bool = 
     return _all_of(cloud, bounds, lambda b: filter_eigenvalue_ratio(cloud, (int(b[0]), int(b[1])), min=b[2], max=b[3],
                                                                    only_mask=True, log=log),
                    'eigenvalue ratios', only_mask, log)
+
+
+def filter_shadow_points(cloud: DepthCloud, angle_bounds: list, only_mask: bool = False, log: bool = False):
+    """Scan-shadow filter (filters.py:257-309): keep a point when the angles between the ray back to its viewpoint
+    and the vectors to its direction-neighbours all lie within ``angle_bounds``.  Needs ``update_dir_neighbors``
+    (radius search on the unit directions, on the GPU).  ``only_mask=True`` returns the mask (the reference returns
+    the flag itself there, an obvious slip)."""
+    assert cloud.vps is not None and cloud.dir_neighbors is not None
+    lo = 0.0 if (angle_bounds[0] is None or not (angle_bounds[0] >= 0.0)) else float(angle_bounds[0])
+    hi = torch.pi if (angle_bounds[1] is None or not (angle_bounds[1] <= torch.pi)) else float(angle_bounds[1])
+    x = cloud.get_points()
+    to_vp = (cloud.vps.expand_as(x) - x).unsqueeze(dim=1)
+    to_nb = x[cloud.dir_neighbors] - x.unsqueeze(dim=1)
+    ang = torch.acos(torch.nn.functional.cosine_similarity(to_vp, to_nb, dim=-1))
+    ang = torch.where(cloud.dir_neighbor_weights != 1.0, torch.full_like(ang, 0.5 * (lo + hi)), ang)
+    mask = (ang.amin(dim=-1) >= lo) & (ang.amax(dim=-1) <= hi)
+    if log:
+        print('%.3f = %i / %i points kept (shadow points removed).' % (mask.double().mean(), mask.sum(), mask.numel()))
+    return mask if only_mask else cloud[mask]

@@ -9,8 +9,8 @@ import torch
 
 from .config import Config, NeighborhoodType
 from .depth_cloud import DepthCloud
-from .filters import (filter_depth, filter_eigenvalue_ratios, filter_eigenvalues, filter_grid, filter_valid_neighbors,
-                      within_bounds)
+from .filters import (filter_depth, filter_eigenvalue_ratios, filter_eigenvalues, filter_grid, filter_shadow_points,
+                      filter_valid_neighbors, within_bounds)
 from .transform import xyz_axis_angle_to_matrix
 
 __all__ = ['compute_neighborhood_features', 'establish_neighborhoods', 'filtered_cloud', 'global_cloud',
@@ -44,8 +44,9 @@ def local_feature_cloud(cloud, cfg: Config):
         make = DepthCloud.from_structured_array if cloud.dtype.names else DepthCloud.from_points
         cloud = make(cloud, dtype=cfg.numpy_float_type(), device=cfg.device)
     assert isinstance(cloud, DepthCloud)
-    if cfg.shadow_angle_bounds:
-        raise NotImplementedError('shadow-point filtering is a next-row item (SURVEY 8f-2)')
+    if cfg.shadow_angle_bounds:                      # preproc.py:44-47
+        cloud.update_dir_neighbors(angle=cfg.shadow_neighborhood_angle)
+        cloud = filter_shadow_points(cloud, cfg.shadow_angle_bounds, log=cfg.log_filters)
     cloud.update_all(k=cfg.nn_k, r=cfg.nn_r)
     if cfg.eigenvalue_bounds:
         _and_mask(cloud, filter_eigenvalues(cloud, cfg.eigenvalue_bounds, only_mask=True, log=cfg.log_filters))

@@ -251,3 +251,54 @@ def test_nearest_neighbors_api(golden):
     keep = npy((cloud.neighbors >= 0).sum(1) >= 3)
     assert_eigvals_close(npy(cloud.eigvals)[keep], npy(f['eigvals'])[keep], 1e-9)
     assert torch.equal(cloud.weights[..., 0] > 0, cloud.neighbors >= 0)
+
+
+def test_chamfer_metric_vs_ckdtree(golden):
+    """metrics.chamfer_distance (map accuracy, scripts/model_poses_learning:142-146) on the GPU 1-NN builder."""
+    from scipy.spatial import cKDTree
+    from depth_correction_amd.metrics import chamfer_distance
+    g = golden('room_k10')
+    a, b = g['scan0_xyz'] + g['poses'][0, :3, 3], g['scan2_xyz'] + g['poses'][2, :3, 3]
+    ref = cKDTree(b).query(a, k=1)[0]
+    got = chamfer_distance(t(a, 'cuda:0'), t(b, 'cuda:0'))
+    np.testing.assert_allclose(got.item(), ref.mean(), rtol=1e-14)
+    per = chamfer_distance(t(a, 'cuda:0'), t(b, 'cuda:0'), apply_point_reduction=False)
+    assert np.array_equal(npy(per), ref)
+    batch = chamfer_distance([t(a, 'cuda:0'), t(b, 'cuda:0')], [t(b, 'cuda:0'), t(a, 'cuda:0')], batch_reduction='sum')
+    np.testing.assert_allclose(batch.item(), ref.mean() + cKDTree(a).query(b, k=1)[0].mean(), rtol=1e-13)
+
+
+def test_shadow_filter_and_dir_neighbors(golden):
+    """update_dir_neighbors (radius search on unit directions) + filter_shadow_points against a plain tensor
+    restatement of filters.py:257-309 with cKDTree neighbours."""
+    from scipy.spatial import cKDTree
+    from depth_correction_amd.depth_cloud import DepthCloud
+    from depth_correction_amd.filters import filter_shadow_points
+    from depth_correction_amd.nearest_neighbors import ball_angle_to_distance
+    g = golden('room_k10')
+    xyz = g['scan1_xyz'][:1500]
+    cloud = DepthCloud.from_points(t(xyz, 'cuda:0'))
+    angle = 0.06
+    cloud.update_dir_neighbors(angle=angle)
+    dirs = npy(cloud.dirs)
+    r = float(ball_angle_to_distance(torch.as_tensor(angle)))
+    lists = cKDTree(dirs).query_ball_point(dirs, r)
+    kmax = max(map(len, lists))
+    ref = np.full((len(dirs), kmax), -1)
+    for i, l in enumerate(lists):
+        ref[i, :len(l)] = sorted(l)
+    assert np.array_equal(npy(cloud.dir_neighbors), ref)
+    bounds = [0.3, float('inf')]
+    mask = npy(filter_shadow_points(cloud, list(bounds), only_mask=True))
+    x = xyz
+    nb = np.where(ref >= 0, ref, 0)
+    ox, nx = (0 - x)[:, None, :], x[nb] - x[:, None, :]
+    cos = (ox * nx).sum(-1) / np.maximum(np.linalg.norm(ox, axis=-1) * np.linalg.norm(nx, axis=-1), 1e-8)
+    with np.errstate(invalid='ignore'):
+        a = np.arccos(cos)
+    a[ref < 0] = 0.5 * (0.3 + np.pi)
+    want = (np.nanmin(a, -1) >= 0.3) & (np.nanmax(a, -1) <= np.pi)
+    nan_rows = np.isnan(a).any(-1)
+    assert np.array_equal(mask[~nan_rows], want[~nan_rows]) and 0 < mask.sum() < len(mask)
+    kept = filter_shadow_points(cloud, list(bounds))
+    assert len(kept) == int(mask.sum())
