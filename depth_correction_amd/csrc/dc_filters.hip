@@ -2,9 +2,13 @@
 // (within_bounds), :184-193 (valid neighbours), :196-254 (eigenvalue / ratio bounds),
 // depth_cloud.py:314-326 (dir / vp dispersion), preproc.py:122-164 (global_cloud_mask).
 // HBM-bound elementwise passes; one lane per point, coalesced.
+#include <cstring>
+#include <cstdlib>
 #include "dc_common.h"
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 namespace dc {
 
@@ -64,6 +68,73 @@ __global__ __launch_bounds__(kBlock) void dispersion_kernel(const T* __restrict_
   out[i] = (T)((S - (s0 * s0 + s1 * s1 + s2 * s2) / W) / D);
 }
 
+
+// ---- voxel-grid filter: one survivor per voxel, the reference's dict semantics (filters.py:24-82) --------------------
+// The reference feeds points to a dict {voxel -> index} in a processing sequence (identity, reversed, or a seeded
+// shuffle): the LAST point of the sequence falling into a voxel survives, and voxels are listed in order of FIRST
+// appearance.  On the GPU: voxel keys in sequence order -> stable radix sort (key, t) -> runs; the head of a run gives
+// the first appearance, its tail the survivor; runs are finally ordered by first appearance (or survivors by index).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void voxel_coords_kernel(const T* __restrict__ xyz, int stride, int64_t n, double res,
+                                                              int32_t* __restrict__ vox, int32_t* __restrict__ vmin,
+                                                              int32_t* __restrict__ vmax, int32_t* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const T r = (T)res;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const T f = floor(xyz[i * stride + a] / r);              // in the cloud's precision, like numpy does
+    int32_t v = 0;
+    if (f >= (T)-1073741824.0 && f <= (T)1073741824.0) v = (int32_t)f; else atomicOr(bad, 1);
+    vox[i * 3 + a] = v;
+    atomicMin(vmin + a, v);
+    atomicMax(vmax + a, v);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const int32_t* __restrict__ vox, const int32_t* __restrict__ seq,
+                                                            int64_t n, const int32_t* __restrict__ vmin,
+                                                            const int32_t* __restrict__ vmax, int32_t* __restrict__ bad,
+                                                            uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n) return;
+  const int64_t i = seq ? seq[t] : t;
+  uint64_t key = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int64_t range = (int64_t)vmax[a] - vmin[a];
+    if (range >= (1 << 21)) atomicOr(bad, 2);
+    key |= (uint64_t)((int64_t)vox[i * 3 + a] - vmin[a]) << (21 * a);
+  }
+  keys[t] = key;
+  vals[t] = (int32_t)t;
+}
+
+__global__ __launch_bounds__(kBlock) void run_heads_kernel(const uint64_t* __restrict__ skeys, int64_t n, int32_t* __restrict__ head) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  head[p] = (p == 0 || skeys[p] != skeys[p - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void run_emit_kernel(const uint64_t* __restrict__ skeys, const int32_t* __restrict__ svals,
+                                                          const int32_t* __restrict__ run_id, const int32_t* __restrict__ seq,
+                                                          int64_t n, int preserve_order, int32_t* __restrict__ sort_key,
+                                                          int32_t* __restrict__ surv, int32_t* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const int32_t r = run_id[p] - 1;
+  const bool head = p == 0 || skeys[p] != skeys[p - 1];
+  const bool tail = p == n - 1 || skeys[p] != skeys[p + 1];
+  if (tail) {
+    const int32_t t = svals[p];
+    const int32_t s = seq ? seq[t] : t;
+    surv[r] = s;
+    if (preserve_order) sort_key[r] = s;
+    if (p == n - 1) *count = r + 1;
+  }
+  if (head && !preserve_order) sort_key[r] = svals[p];        // first appearance in the processing sequence
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -110,6 +181,73 @@ int dc_dispersion(const void* vec, int dtype, const int32_t* nbr, const void* we
   else return DC_ERR_DTYPE;
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DC_OK : (int)e;
+}
+
+static size_t voxel_ws(void* base, int64_t n, int32_t** vox, int32_t** box, uint64_t** keys, uint64_t** skeys, int32_t** vals,
+                       int32_t** svals, int32_t** head, int32_t** run_id, int32_t** skey, int32_t** surv, int32_t** skey2,
+                       void** tmp, size_t* tmp_bytes) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; void* p = base ? (char*)base + off : nullptr; off += bytes; return p; };
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  *vox = (int32_t*)take(3 * m * 4); *box = (int32_t*)take(8 * 4);
+  *keys = (uint64_t*)take(m * 8); *skeys = (uint64_t*)take(m * 8);
+  *vals = (int32_t*)take(m * 4); *svals = (int32_t*)take(m * 4);
+  *head = (int32_t*)take(m * 4); *run_id = (int32_t*)take(m * 4);
+  *skey = (int32_t*)take(m * 4); *surv = (int32_t*)take(m * 4); *skey2 = (int32_t*)take(m * 4);
+  size_t a = 0, b = 0, c = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 63, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 32, (hipStream_t)0);
+  (void)rocprim::inclusive_scan(nullptr, c, (int32_t*)nullptr, (int32_t*)nullptr, m, rocprim::plus<int32_t>(), (hipStream_t)0);
+  *tmp_bytes = a > b ? (a > c ? a : c) : (b > c ? b : c);
+  *tmp = take(*tmp_bytes);
+  return off + 256;
+}
+
+size_t dc_voxel_filter_workspace_bytes(int64_t n) {
+  int32_t *a, *b, *e, *f, *g, *h, *i, *j, *k; uint64_t *c, *d; void* t; size_t tb;
+  return n < 0 ? 0 : voxel_ws(nullptr, n, &a, &b, &c, &d, &e, &f, &g, &h, &i, &j, &k, &t, &tb);
+}
+
+// seq int32 [n] or NULL: processing sequence (seq[t] = index of the t-th point offered to the dict).  out_idx int32 [n]
+// (first *count_out entries valid), count_out device int32; status_out device int32: 0 ok, != 0 voxel range too large
+// for the 3 x 21-bit key (use the host filter then).
+int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double grid_res, const int32_t* seq,
+                    int preserve_order, int32_t* out_idx, int32_t* count_out, int32_t* status_out, void* ws, size_t ws_bytes,
+                    hipStream_t stream) {
+  if (n == 0 && count_out && status_out) {
+    hipError_t e0 = hipMemsetAsync(count_out, 0, 4, stream);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(status_out, 0, 4, stream);
+    return (int)e0;
+  }
+  if (!points || n < 0 || stride < 3 || !(grid_res > 0.0) || !out_idx || !count_out || !status_out || !ws) return DC_ERR_ARG;
+  if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  int32_t *vox, *box, *vals, *svals, *head, *run_id, *skey, *surv, *skey2; uint64_t *keys, *skeys; void* tmp; size_t tmp_bytes;
+  if (ws_bytes < voxel_ws(ws, n, &vox, &box, &keys, &skeys, &vals, &svals, &head, &run_id, &skey, &surv, &skey2, &tmp, &tmp_bytes))
+    return DC_ERR_WORKSPACE;
+  const int32_t init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0, (int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000, 0};
+  hipError_t err = hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, stream);
+  if (err != hipSuccess) return (int)err;
+  err = hipMemsetAsync(status_out, 0, 4, stream);
+  if (err != hipSuccess) return (int)err;
+  err = hipMemsetAsync(skey, 0x7f, (size_t)n * 4, stream);               // 0x7f7f7f7f: unused slots sort last
+  if (err != hipSuccess) return (int)err;
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((voxel_coords_kernel<float>), grid, block, 0, stream, (const float*)points, stride, n, grid_res, vox, box, box + 4, status_out);
+  else if (dtype == DC_F64)
+    hipLaunchKernelGGL((voxel_coords_kernel<double>), grid, block, 0, stream, (const double*)points, stride, n, grid_res, vox, box, box + 4, status_out);
+  else return DC_ERR_DTYPE;
+  hipLaunchKernelGGL(voxel_keys_kernel, grid, block, 0, stream, vox, seq, n, box, box + 4, status_out, keys, vals);
+  err = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, svals, (size_t)n, 0, 63, stream);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(run_heads_kernel, grid, block, 0, stream, skeys, n, head);
+  err = rocprim::inclusive_scan(tmp, tmp_bytes, head, run_id, (size_t)n, rocprim::plus<int32_t>(), stream);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(run_emit_kernel, grid, block, 0, stream, skeys, svals, run_id, seq, n, preserve_order, skey, surv, count_out);
+  err = rocprim::radix_sort_pairs(tmp, tmp_bytes, skey, skey2, surv, out_idx, (size_t)n, 0, 32, stream);
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
 }
 
 }  // extern "C"

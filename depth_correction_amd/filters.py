@@ -73,6 +73,25 @@ def filter_grid(cloud, grid_res, only_mask=False, keep='random', preserve_order=
     shuffled or reversed) sequence falling into it, exactly as the reference's dict construction yields."""
     assert isinstance(cloud, (DepthCloud, np.ndarray, torch.Tensor))
     assert isinstance(grid_res, float) and grid_res > 0.0 and keep in ('first', 'random', 'last')
+    pts = cloud.get_points() if isinstance(cloud, DepthCloud) else cloud
+    if isinstance(pts, torch.Tensor) and pts.is_cuda and pts.dim() == 2 and pts.shape[1] == 3:
+        # GPU path (dc_voxel_filter): only the processing sequence is made on the host, because numpy's generator
+        # defines which point of a voxel survives a 'random' filter
+        n = pts.shape[0]
+        seq = None
+        if keep == 'first':
+            seq = torch.arange(n - 1, -1, -1, dtype=torch.int32, device=pts.device)
+        elif keep == 'random':
+            perm = np.arange(n)
+            rng.shuffle(perm)                       # same permutation as shuffling the reference's index list
+            seq = torch.as_tensor(perm.astype(np.int32), device=pts.device)
+        ind = ops.voxel_filter(pts.detach().contiguous(), grid_res, seq, preserve_order)
+        if ind is not None:
+            if log:
+                print('%.3f = %i / %i points kept (grid res. %.3f m).' % (len(ind) / max(n, 1), len(ind), n, grid_res))
+            return ind.tolist() if only_mask else cloud[ind]
+        if keep == 'random':
+            raise RuntimeError('voxel range too large for the GPU key and the generator was already advanced')
     if isinstance(cloud, DepthCloud):
         x = cloud.get_points().detach().cpu().numpy()
     elif isinstance(cloud, np.ndarray):

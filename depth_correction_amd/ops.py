@@ -408,6 +408,25 @@ def dispersion(vec, nbr, weights=None):
     return out
 
 
+def voxel_filter(points, grid_res, seq=None, preserve_order=False):
+    """Indices (int64, device) of one survivor per voxel with filter_grid's dict semantics; None if the voxel range
+    does not fit the 63-bit key (caller falls back to the host algorithm)."""
+    need(points, (None, 3), name='points')
+    n = points.shape[0]
+    dev = points.device
+    if seq is not None:
+        need(seq, (n,), dtype=torch.int32, name='seq', device=dev)
+    out = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    meta = torch.zeros((2,), dtype=torch.int32, device=dev)
+    nbytes = lib().dc_voxel_filter_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    check(lib().dc_voxel_filter(ptr(points), 3, dtype_code(points), n, float(grid_res), ptr(seq), int(bool(preserve_order)),
+                                ptr(out), ctypes.c_void_p(meta.data_ptr()), ctypes.c_void_p(meta.data_ptr() + 4), ptr(ws),
+                                nbytes, stream_ptr()), 'dc_voxel_filter')
+    count, status = meta.tolist()
+    return None if status else out[:count].long()
+
+
 # ------------------------------------------------------------------------------------------------
 # point-to-plane ICP pair
 # ------------------------------------------------------------------------------------------------

@@ -196,6 +196,17 @@ int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp
                  double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
                  dcStream_t stream);
 
+/* ---- voxel-grid pre-filter (next row): filters.filter_grid filters.py:24-82 -------------------------------
+ * One survivor per voxel of edge grid_res with the reference's dict semantics: points are offered in the sequence
+ * seq (int32 [n], NULL = 0..n-1; reversed for keep='first', numpy's seeded shuffle for keep='random'), the LAST one
+ * offered to a voxel survives; survivors come out in order of their voxel's FIRST appearance (preserve_order: by index).
+ * out_idx int32 [n] (first *count_out valid), count_out / status_out device int32 (status != 0: voxel range exceeds
+ * the 3 x 21-bit key, fall back to the host).  ws: dc_voxel_filter_workspace_bytes(n). */
+size_t dc_voxel_filter_workspace_bytes(int64_t n);
+int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double grid_res, const int32_t* seq,
+                    int preserve_order, int32_t* out_idx, int32_t* count_out, int32_t* status_out, void* ws, size_t ws_bytes,
+                    dcStream_t stream);
+
 /* Tuning / ablation switches.  option 0: value 1 disables the LDS-staged neighbour tiles of the fused kernels
  * (results are identical either way). */
 int dc_set_option(int option, int value);

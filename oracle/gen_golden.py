@@ -9,7 +9,7 @@ oracle's restatement of the published algorithm (recorded in each fixture's ``me
 Before a fixture is written, the oracle restatement (oracle/dc_oracle.py) is run on the same inputs
 and asserted equal to the reference's outputs, so a committed fixture certifies both.
 
-Usage:  python oracle/gen_golden.py            (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn}.npz, about 5 MB)
+Usage:  python oracle/gen_golden.py            (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid}.npz, about 9 MB)
 """
 import os
 import sys
@@ -299,6 +299,21 @@ def gen_icp():
     np.savez_compressed(os.path.join(GOLD, 'icp_pairs.npz'), **out)
 
 
+def gen_grid():
+    """filters.filter_grid (filters.py:24-82) for the three keep modes and a seeded generator."""
+    from depth_correction.filters import filter_grid
+    rng = np.random.default_rng(21)
+    pts = np.concatenate([rng.uniform(-3, 3, size=(4000, 3)) * [1, 1, 0.1], rng.normal(size=(1000, 3))])
+    pts = pts.astype(np.float32).astype(np.float64)
+    out = dict(meta=np.array(META), points=pts, grid_res=0.25)
+    for keep in ('first', 'last', 'random'):
+        for po in (False, True):
+            ind = filter_grid(pts, 0.25, only_mask=True, keep=keep, preserve_order=po, rng=np.random.default_rng(135))
+            out['%s_%d' % (keep, po)] = np.asarray(ind, dtype=np.int32)
+    print('grid: %d points -> %d voxels' % (len(pts), len(out['last_0'])))
+    np.savez_compressed(os.path.join(GOLD, 'grid.npz'), **out)
+
+
 def gen_knn():
     """nearest_neighbors() itself: k, k within r, r only (nearest_neighbors.py:22-80)."""
     rng = np.random.default_rng(3)
@@ -327,7 +342,9 @@ def gen_knn():
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['knn', 'c0', 'room', 'icp']
+    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp']
+    if 'grid' in which:
+        gen_grid()
     if 'knn' in which:
         gen_knn()
     if 'c0' in which:

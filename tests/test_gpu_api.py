@@ -302,3 +302,21 @@ def test_shadow_filter_and_dir_neighbors(golden):
     assert np.array_equal(mask[~nan_rows], want[~nan_rows]) and 0 < mask.sum() < len(mask)
     kept = filter_shadow_points(cloud, list(bounds))
     assert len(kept) == int(mask.sum())
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_voxel_grid_filter_gpu_golden(golden, dtype):
+    """dc_voxel_filter against the reference's filter_grid output: same survivors in the same order for every keep mode."""
+    from depth_correction_amd.depth_cloud import DepthCloud
+    from depth_correction_amd.filters import filter_grid
+    g = golden('grid')
+    pts = t(g['points'], 'cuda:0', dtype)               # fixture points are fp32-representable
+    for keep in ('first', 'last', 'random'):
+        for po in (False, True):
+            ind = filter_grid(pts, float(g['grid_res']), only_mask=True, keep=keep, preserve_order=po,
+                              rng=np.random.default_rng(135))
+            assert np.array_equal(np.asarray(ind), g['%s_%d' % (keep, po)]), (keep, po)
+    cloud = DepthCloud.from_points(pts)
+    kept = filter_grid(cloud, float(g['grid_res']), keep='random', rng=np.random.default_rng(135))
+    assert len(kept) == len(g['random_0'])
+    np.testing.assert_allclose(npy(kept.to_points()), g['points'][g['random_0']], rtol=1e-6, atol=1e-6)

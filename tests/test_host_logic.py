@@ -220,3 +220,12 @@ def test_install_as_reference_package():
     finally:
         for k in [k for k in sys.modules if k == 'depth_correction' or k.startswith('depth_correction.')]:
             del sys.modules[k]
+
+
+def test_filter_grid_host_matches_reference_golden(golden):
+    g = golden('grid')
+    for keep in ('first', 'last', 'random'):
+        for po in (False, True):
+            ind = filter_grid(g['points'], float(g['grid_res']), only_mask=True, keep=keep, preserve_order=po,
+                              rng=np.random.default_rng(135))
+            assert np.array_equal(np.asarray(ind), g['%s_%d' % (keep, po)]), (keep, po)
