@@ -196,36 +196,45 @@ class SequencePlan:
 
 
 class _ConsistencyLoss(torch.autograd.Function):
-    """sum over the mask of the pointwise loss of one sequence, differentiable w.r.t. w, exponent, poses."""
+    """sum over the mask of the pointwise loss of one sequence, differentiable w.r.t. w, exponent, poses.
+
+    Forward and backward kernels are issued together by ONE dc_sequence_eval call whenever a gradient will be needed
+    (the gradients of the sum are a handful of numbers); ``backward`` only scales them by the upstream gradient."""
 
     @staticmethod
     def forward(ctx, plan, w, exponent, poses):
-        out = plan.forward(w, exponent, poses)
-        ctx.plan, ctx.version = plan, plan.version
-        ctx.w_shape = None if w is None else w.shape
-        ctx.w_dtype = None if w is None else w.dtype
-        ctx.e_info = (exponent.shape, exponent.dtype, exponent.device) if isinstance(exponent, torch.Tensor) else None
-        ctx.p_info = (poses.dtype, poses.device)
-        return out['sums'][0].clone()
+        need_w = isinstance(w, torch.Tensor) and w.requires_grad
+        need_e = isinstance(exponent, torch.Tensor) and exponent.requires_grad
+        need_p = isinstance(poses, torch.Tensor) and poses.requires_grad
+        dev = plan.device
+        wv = None if w is None else w.detach().reshape(-1).to(device=dev, dtype=torch.float64).contiguous()
+        ev = None if w is None else exponent.detach().reshape(-1).to(device=dev, dtype=torch.float64).contiguous()
+        nt = 0 if wv is None else wv.numel()
+        P = plan.poses12(poses)
+        out = torch.empty((2 + 2 * nt + 12 * plan.n_scans,), dtype=torch.float64, device=dev)
+        plan.eval_native(wv, ev, P, out, want_grad=need_w or need_e or need_p, want_exponent=need_e, want_pose=need_p)
+        plan.w, plan.e, plan.P = wv, ev, P              # for PlanCloud / plan.backward() users
+        ctx.save_for_backward(out)
+        ctx.meta = (nt, plan.n_scans, None if w is None else (w.shape, w.dtype, w.device),
+                    (exponent.shape, exponent.dtype, exponent.device) if isinstance(exponent, torch.Tensor) else None,
+                    (poses.dtype, poses.device) if isinstance(poses, torch.Tensor) else None)
+        return out[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        plan = ctx.plan
-        if plan.version != ctx.version:
-            raise RuntimeError('SequencePlan was evaluated again before backward(); its buffers were overwritten')
-        need_w, need_e, need_p = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        gw, ge, gT = plan.backward(want_exponent=need_e, want_pose=need_p)
-        out_w = (grad_out * gw).reshape(ctx.w_shape).to(ctx.w_dtype) if need_w else None
-        out_e = None
-        if need_e:
-            shp, dt, dv = ctx.e_info
-            out_e = (grad_out * ge).reshape(shp).to(device=dv, dtype=dt)
-        out_p = None
-        if need_p:
-            g = torch.zeros((plan.n_scans, 4, 4), dtype=torch.float64, device=plan.device)
-            g[:, :3, :] = grad_out * gT
-            out_p = g.to(device=ctx.p_info[1], dtype=ctx.p_info[0])
-        return None, out_w, out_e, out_p
+        (out,) = ctx.saved_tensors
+        nt, ns, wmeta, emeta, pmeta = ctx.meta
+        g = grad_out.to(out.dtype) * out[2:]
+        gw = ge = gp = None
+        if ctx.needs_input_grad[1] and wmeta is not None:
+            gw = g[:nt].reshape(wmeta[0]).to(device=wmeta[2], dtype=wmeta[1])
+        if ctx.needs_input_grad[2] and emeta is not None:
+            ge = g[nt:2 * nt].reshape(emeta[0]).to(device=emeta[2], dtype=emeta[1])
+        if ctx.needs_input_grad[3] and pmeta is not None:
+            gp = torch.zeros((ns, 4, 4), dtype=torch.float64, device=out.device)
+            gp[:, :3, :] = g[2 * nt:].reshape(ns, 3, 4)
+            gp = gp.to(device=pmeta[1], dtype=pmeta[0])
+        return None, gw, ge, gp
 
 
 def consistency_loss(plan, w, exponent, poses):
