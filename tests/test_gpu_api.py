@@ -320,3 +320,105 @@ def test_voxel_grid_filter_gpu_golden(golden, dtype):
     kept = filter_grid(cloud, float(g['grid_res']), keep='random', rng=np.random.default_rng(135))
     assert len(kept) == len(g['random_0'])
     np.testing.assert_allclose(npy(kept.to_points()), g['points'][g['random_0']], rtol=1e-6, atol=1e-6)
+
+
+def test_unfused_options_match_oracle(golden):
+    """Options outside the fused kernels: distance-scaled neighbour weights (nn_scale, depth_cloud.py:356-364), loss
+    offsets and quantile inliers (loss.py:256-281) -- forward values through the un-fused operators vs the oracle."""
+    from depth_correction_amd.depth_cloud import DepthCloud
+    from depth_correction_amd.loss import min_eigval_loss, trace_loss
+    g = golden('room_k10')
+    x = t(g['g0_points'], 'cuda:0')
+    cloud = DepthCloud.from_points(x)
+    cloud.update_all(k=int(g['cfg_nn_k']), scale=0.05)
+    f = O.features(t(g['g0_points']), t(g['g_neighbors']).long(), cloud.dirs.cpu(), scale=0.05)
+    np.testing.assert_allclose(npy(cloud.weights), npy(f['weights']), rtol=1e-12)
+    np.testing.assert_allclose(npy(cloud.mean), npy(f['mean']), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(npy(cloud.cov), npy(f['cov']), rtol=1e-9, atol=1e-16)
+    assert_eigvals_close(npy(cloud.eigvals), npy(f['eigvals']), 1e-9)
+    # quantile inliers + offsets on the GPU tensors
+    ev = f['eigvals']
+    loss, lc = min_eigval_loss(cloud, normalization=True, inlier_ratio=0.7)
+    raw = ev[:, 0] / ev.sum(-1).clamp(min=1e-6)
+    keep = raw <= torch.quantile(raw, 0.7)
+    np.testing.assert_allclose(loss.item(), raw[keep].mean().item(), rtol=1e-9)
+    assert len(lc) == int(keep.sum())
+    off = torch.full((len(cloud),), 1e-4, dtype=torch.float64, device='cuda:0')
+    loss, _ = trace_loss(cloud, offset=off)
+    np.testing.assert_allclose(loss.item(), torch.relu(O.trace(f['cov']) - 1e-4).mean().item(), rtol=1e-9)
+    # and the fused path refuses nothing silently: eval_loss_clouds routes nn_scale configs to the un-fused operators
+    from depth_correction_amd.config import Config
+    from depth_correction_amd.eval import fused_supported
+    from depth_correction_amd.model import ScaledPolynomial
+    cloud.inc_angles = cloud.inc_angles
+    cfg = Config(nn_k=10, nn_r=None, nn_scale=0.05)
+    assert not fused_supported([[cloud]], ScaledPolynomial(w=[0.0, 0.0], exponent=[2.0, 4.0]), cfg)
+    cfg = Config(nn_k=10, nn_r=None)
+    assert fused_supported([[cloud]], ScaledPolynomial(w=[0.0, 0.0], exponent=[2.0, 4.0]), cfg)
+    cfg.loss_kwargs['inlier_ratio'] = 0.5
+    assert not fused_supported([[cloud]], None, cfg)
+
+
+def test_icp_training_matches_oracle_loop(tmp_path):
+    """BASELINE config 4 shape, reduced: KITTI-like ring scans, depth + voxel-grid pre-filter, radius neighbourhoods
+    (nn_r = 0.4), point-to-plane ICP loss, model weights AND per-pose corrections optimised by train(); every iteration's
+    loss and parameters against the same loop on the CPU oracle (cKDTree, fp64, torch.optim.Adam)."""
+    from depth_correction_amd.config import Config, Loss, PoseCorrection
+    from depth_correction_amd.dataset import KittiLikeDataset
+    from depth_correction_amd.preproc import filtered_cloud
+    from depth_correction_amd.train import train
+    cfg = Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2, min_depth=5.0,
+                 max_depth=12.0, vp_dispersion_bounds=[], n_opt_iters=3, lr=2e-3, log_dir=str(tmp_path),
+                 model_kwargs={'w': [1e-3, -1e-3], 'exponent': [2.0, 4.0]})
+    # 96 rings: every 0.4 m neighbourhood spans several rings, so no neighbourhood is collinear (for a collinear one
+    # lambda0 = lambda1 and the normal is whatever vector of that eigenspace LAPACK happens to return)
+    ds = KittiLikeDataset(n_poses=3, n_rings=96, n_azimuth=384)
+    seq = [(filtered_cloud(cloud, cfg), pose) for cloud, pose in ds]
+    assert all(5000 < len(c) < 96 * 384 for c, _ in seq)
+    seen = []
+
+    class CB:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+        def train_loss(self, it, model, clouds, pose_deltas, poses, masks, loss):
+            seen.append((loss.item(), npy(model.w).copy(), npy(pose_deltas[0]).copy()))
+    train(cfg, callbacks=CB(), train_datasets=[seq], val_datasets=[])
+
+    # ---- the same on the oracle ----
+    scans, poses = [], torch.as_tensor(np.stack([p for _, p in seq]))
+    for cloud, _ in seq:
+        pts = torch.as_tensor(np.stack([cloud[f] for f in 'xyz'], 1).astype(np.float64))
+        depth = pts.norm(dim=-1, keepdim=True)
+        dirs = pts / depth
+        nbr = torch.as_tensor(O.radius_ckdtree(pts.numpy(), 0.4))
+        f = O.features(pts, nbr, dirs)
+        ev = f['eigvals']
+        assert bool(((ev[:, 1] - ev[:, 0]) > 1e-6 * ev[:, 2]).all())                 # well-defined normals everywhere
+        scans.append(dict(vps=torch.zeros_like(pts), dirs=dirs, depth=depth, inc=f['inc_angles'], normals=f['normals'],
+                          mask=O.local_mask(f['eigvals'], None, cfg.eigenvalue_ratio_bounds)))
+    masks = []
+    for j in range(len(scans) - 1):
+        pj = [O.points_from(*O.transform_cloud(s['vps'], s['dirs'], T), s['depth']) for s, T in ((scans[j], poses[j]), (scans[j + 1], poses[j + 1]))]
+        m1, i2, _ = O.nn1_correspondences(pj[0].numpy(), pj[1].numpy(), 0.3)
+        masks.append((torch.as_tensor(m1), torch.as_tensor(i2)))
+    w = torch.nn.Parameter(torch.tensor([[1e-3, -1e-3]], dtype=torch.float64))
+    e = torch.tensor([[2.0, 4.0]], dtype=torch.float64)
+    pd = torch.nn.Parameter(torch.zeros((3, 6), dtype=torch.float64))
+    opt = torch.optim.Adam([{'params': [w], 'lr': 2e-3}, {'params': [pd], 'lr': 2e-3}])
+    for it in range(3):
+        opt.zero_grad()
+        T = torch.matmul(poses, O.xyz_axis_angle_to_matrix(pd))
+        pts, nrm = [], []
+        for s, Ts in zip(scans, T):
+            d = O.model_apply(s['depth'], s['inc'], s['mask'], w, e)
+            v, r, n = O.transform_cloud(s['vps'], s['dirs'], Ts, normals=s['normals'])
+            pts.append(O.points_from(v, r, d)), nrm.append(n)
+        loss = O.point_to_plane(pts, nrm, masks)
+        np.testing.assert_allclose(seen[it][0], loss.item(), rtol=1e-5)
+        np.testing.assert_allclose(seen[it][1], npy(w), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(seen[it][2], npy(pd), rtol=1e-4, atol=1e-8)
+        loss.backward()
+        pd.grad[0].zero_()
+        opt.step()
+    assert np.abs(seen[-1][2][1:]).max() > 1e-3 and np.all(seen[-1][2][0] == 0)     # poses moved, the first stays fixed
