@@ -42,15 +42,18 @@ def parse():
     ap.add_argument('--cpu-iters', type=int, default=5)
     ap.add_argument('--no-sort', action='store_true', help='keep the scan-major point order (ablation)')
     ap.add_argument('--point-format', default='auto', choices=['auto', 'q32', 'float'])
+    ap.add_argument('--active-only', action='store_true',
+                    help='evaluate only masked points as neighbourhood centres (identical loss / gradients, see DESIGN.md)')
     ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')
     return ap.parse_args()
 
 
-def algorithmic_bytes(k):
-    """SURVEY 8d accounting (fp32 data, int32 indices), bytes per point and launch."""
-    fwd = 72 + 16 * k            # whole forward incl. the raw point inputs
-    bwd = 72 + 28 * k
-    return dict(points_fwd=32 + 12, consistency_fwd=fwd - 32 + 12, consistency_bwd=bwd, path=fwd + bwd)
+def algorithmic_bytes(k, active=1.0):
+    """SURVEY 8d accounting (fp32 data, int32 indices), bytes per point and launch.  `active` = fraction of the points
+    that are neighbourhood centres (1 unless --active-only drops the masked-out centres and their edges)."""
+    fwd = 32 + active * (40 + 16 * k)            # raw point inputs + per-centre (outputs, indices, gathers)
+    bwd = 72 + active * 28 * k                   # per-point epilogue / saved tensors + per-edge gather and scatter
+    return dict(points_fwd=32 + 12, consistency_fwd=fwd - 32 + active * 12, consistency_bwd=bwd, path=fwd + bwd)
 
 
 def host_cores():
@@ -147,7 +150,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, spatial_sort=not args.no_sort,
-                                point_format=args.point_format)
+                                point_format=args.point_format, active_only=args.active_only)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     # the k-NN build alone, on the global cloud (reported separately)
@@ -219,7 +222,7 @@ def main():
 
     if rank == 0:
         ms = {name: v[0] for name, v in kernel_ms.items()}
-        ab = algorithmic_bytes(args.k)
+        ab = algorithmic_bytes(args.k, (plan.count / n_local) if args.active_only else 1.0)
         dom = max(('consistency_fwd', 'consistency_bwd'), key=lambda n_: ms.get(n_, 0.0))
         achieved = ab[dom] * n_local / (ms[dom] * 1e-3) / 1e9
         traffic = None
@@ -241,7 +244,7 @@ def main():
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
                        'loop': 'autograd+torch.optim.Adam' if args.autograd else 'native (dc_sequence_eval + dc_adam_step)',
-                       'masked_points': total_count, 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
+                       'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3), 'setup_s': setup_s},
             'roofline': {'bound': 'hbm', 'kernel': 'dc_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,

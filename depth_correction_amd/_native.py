@@ -29,7 +29,7 @@ _SIGNATURES = {
     'dc_radius_count': (_i32, [_vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_fill': (_i32, [_i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     'dc_knn_transpose_workspace_bytes': (_sz, [_i64, _i32]),
-    'dc_knn_transpose': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'dc_knn_transpose': (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     'dc_spatial_order_workspace_bytes': (_sz, [_i64]),
     'dc_spatial_order': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
     'dc_points_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
@@ -41,7 +41,7 @@ _SIGNATURES = {
     'dc_features_fwd': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
     'dc_features_bwd': (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
+    'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
     'dc_consistency_bwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -67,7 +67,8 @@ class SequenceDesc(ctypes.Structure):
     _fields_ = [('n', ctypes.c_int64), ('k', ctypes.c_int32), ('n_scans', ctypes.c_int32), ('dtype', ctypes.c_int32),
                 ('point_fmt', ctypes.c_int32), ('qparams', ctypes.c_double * 4),
                 ('vps', _vp), ('dirs', _vp), ('depth', _vp), ('inc', _vp), ('lmask', _vp), ('scan_id', _vp),
-                ('nbr', _vp), ('csr_ptr', _vp), ('csr_src', _vp), ('mask', _vp), ('lane_perm', _vp), ('x', _vp), ('rec', _vp),
+                ('nbr', _vp), ('csr_ptr', _vp), ('csr_src', _vp), ('mask', _vp), ('lane_perm', _vp), ('centre_idx', _vp),
+                ('n_centres', ctypes.c_int64), ('x', _vp), ('rec', _vp),
                 ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
                 ('reserved', ctypes.c_int32)]

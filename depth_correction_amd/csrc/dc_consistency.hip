@@ -75,7 +75,8 @@ __device__ __forceinline__ void gather_neighbourhood(const PT* __restrict__ x, c
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename PT, int STRIDE, bool FULL_EIG>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
-    const PT* __restrict__ x, const int32_t* __restrict__ nbr, int64_t n, int k, const uint8_t* __restrict__ mask,
+    const PT* __restrict__ x, const int32_t* __restrict__ nbr, const int32_t* __restrict__ centre_idx, int64_t n, int k,
+    const uint8_t* __restrict__ mask,
     const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec, T* __restrict__ pointwise,
     T* __restrict__ eigvals, double* __restrict__ partials) {
   __shared__ double lds[(kBlock / kWave) * 2];
@@ -83,9 +84,11 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
   const int64_t blk = xcd_block(nblocks);
   double acc2[2] = {0.0, 0.0};
   if (blk >= 0) {
-    const int64_t i = blk * kBlock + threadIdx.x;
+    const int64_t i = blk * kBlock + threadIdx.x;          // row of nbr / rec / pointwise
     if (i < n) {
-      const typename Pt<PT>::Raw ci = Pt<PT>::template load<STRIDE>(x, i, qp);
+      // with a centre list only the listed points are centres (e.g. the masked ones); rows stay compact
+      const int64_t ip = centre_idx ? (int64_t)centre_idx[i] : i;
+      const typename Pt<PT>::Raw ci = Pt<PT>::template load<STRIDE>(x, ip, qp);
       CovAcc acc;
       cov_init(acc);
       const int32_t* row = nbr + i * k;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) j[u_] = (q0 + u_ < k) ? row[q0 + u_] : -1;
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) cj[u_] = Pt<PT>::template load<STRIDE>(x, j[u_] >= 0 ? (int64_t)j[u_] : i, qp);
+        for (int u_ = 0; u_ < 4; ++u_) cj[u_] = Pt<PT>::template load<STRIDE>(x, j[u_] >= 0 ? (int64_t)j[u_] : ip, qp);
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) {
           // a missing neighbour re-read the centre row: its difference is exactly zero, only the count is masked
@@ -636,14 +639,16 @@ __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double
 // One launch for a whole evaluation: out[0..2) <- forward partials, out[2..2+n_red) <- backward partials,
 // out[2+n_red..2+n_acc) <- 0 (gradient slots that were not requested).
 __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __restrict__ p_fwd, const double* __restrict__ p_bwd,
-                                                                int64_t n_rows, int n_red, double* __restrict__ out) {
+                                                                int64_t rows_fwd, int64_t rows_bwd, int n_red,
+                                                                double* __restrict__ out) {
   __shared__ double lds[kRedBlock / kWave];
   const int a = blockIdx.x;
   if (a >= 2 + n_red) {
     if (threadIdx.x == 0) out[a] = 0.0;
     return;
   }
-  const double* p = (a < 2 ? p_fwd + (int64_t)a * n_rows : p_bwd + (int64_t)(a - 2) * n_rows);
+  const int64_t n_rows = a < 2 ? rows_fwd : rows_bwd;
+  const double* p = (a < 2 ? p_fwd + (int64_t)a * rows_fwd : p_bwd + (int64_t)(a - 2) * rows_bwd);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int64_t r = threadIdx.x;
   for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {
@@ -796,7 +801,8 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
 
 // `reduce` = false leaves the block partials in partials_ws for a later combined reduction (dc_sequence_eval).
 static int consistency_fwd_impl(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
-                                const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
+                                const int32_t* nbr, const int32_t* centre_idx, int64_t n, int k, const uint8_t* mask,
+                                const void* offset, int loss_kind,
                                 int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
                                 double* sums_out, hipStream_t stream, bool reduce) {
   if (n == 0 && sums_out) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
@@ -809,12 +815,13 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   LossParams lp{loss_kind, normalization, sqrt_};
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
-#define FWD_ARGS(T, PT) (const PT*)points, nbr, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
+#define FWD_ARGS(T, PT) (const PT*)points, nbr, centre_idx, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
+#define FWD_TILED_ARGS(T, PT) (const PT*)points, nbr, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
 #define LAUNCH(T, PT, S) \
   do { \
-    if (S == 4 && !g_no_tiles) { /* padded rows: LDS-staged neighbour tiles */ \
-      if (eigvals) hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
-      else hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+    if (S == 4 && !g_no_tiles && !centre_idx) { /* padded rows: LDS-staged neighbour tiles */ \
+      if (eigvals) hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, true>), grid, block, 0, stream, FWD_TILED_ARGS(T, PT)); \
+      else hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, false>), grid, block, 0, stream, FWD_TILED_ARGS(T, PT)); \
     } else { \
       if (eigvals) hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
       else hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
@@ -830,10 +837,10 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
 }
 
 int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
-                       const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
-                       int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
-                       double* sums_out, hipStream_t stream) {
-  return consistency_fwd_impl(points, stride, dtype, point_fmt, qparams, nbr, n, k, mask, offset, loss_kind, normalization,
+                       const int32_t* nbr, const int32_t* centre_idx, int64_t n, int k, const uint8_t* mask, const void* offset,
+                       int loss_kind, int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals,
+                       double* partials_ws, double* sums_out, hipStream_t stream) {
+  return consistency_fwd_impl(points, stride, dtype, point_fmt, qparams, nbr, centre_idx, n, k, mask, offset, loss_kind, normalization,
                               sqrt_, rec, pointwise, eigvals, partials_ws, sums_out, stream, true);
 }
 
@@ -1043,18 +1050,22 @@ int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, 
   const int n_acc = 2 * n_terms + 12 * d->n_scans;
   if (d->n == 0) return (int)hipMemsetAsync(out, 0, (size_t)(2 + n_acc) * sizeof(double), stream);
   // forward partials live in the first 2 * rows doubles of the workspace, backward partials behind them; ONE reduction
+  const int64_t n_rows = d->centre_idx ? d->n_centres : d->n;      // forward rows (centres); the backward runs over all points
+  if (d->centre_idx && (d->n_centres < 0 || d->n_centres > d->n)) return DC_ERR_ARG;
   const int64_t rows = xcd_grid(n_blocks(d->n));
   double* p_fwd = d->partials;
   double* p_bwd = d->partials + 2 * rows;
   const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
-  rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->n, d->k, d->mask, nullptr,
-                            d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream, false);
+  rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->centre_idx, n_rows, d->k, d->mask,
+                            nullptr, d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream,
+                            false);
   if (!rc && want_grad)
     rc = consistency_bwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
                               d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                               d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false);
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows, n_red, out);
+  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)), rows,
+                     n_red, out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

@@ -588,14 +588,16 @@ size_t dc_knn_transpose_workspace_bytes(int64_t n, int k) {
 }
 
 // csr_ptr[N+1], csr_src[N*K]: for every point j the ascending list of centres i whose neighbourhood contains j.
-int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int32_t* csr_ptr, int32_t* csr_src, void* ws, size_t ws_bytes,
-                     hipStream_t stream) {
-  if (n == 0 && csr_ptr) return (int)hipMemsetAsync(csr_ptr, 0, sizeof(int32_t), stream);
+int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int64_t n_dst, int32_t* csr_ptr, int32_t* csr_src, void* ws,
+                     size_t ws_bytes, hipStream_t stream) {
+  // n rows of k neighbour indices into [0, n_dst); n_dst <= 0 means n_dst = n (the square self-neighbourhood case)
+  if (n_dst <= 0) n_dst = n;
+  if (n == 0 && csr_ptr) return (int)hipMemsetAsync(csr_ptr, 0, (size_t)(n_dst + 1) * sizeof(int32_t), stream);
   if (!nbr || n < 0 || k < 1 || !csr_ptr || !csr_src || !ws) return DC_ERR_ARG;
   const int64_t ne = n * k;
   if (ne >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
   if (ws_bytes < dc_knn_transpose_workspace_bytes(n, k)) return DC_ERR_WORKSPACE;
-  if (n == 0) return (int)hipMemsetAsync(csr_ptr, 0, sizeof(int32_t), stream);
+  if (n_dst >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
   Carver c(ws);
   uint32_t* keys = c.take<uint32_t>(ne);
   uint32_t* skeys = c.take<uint32_t>(ne);
@@ -605,11 +607,11 @@ int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int32_t* csr_ptr, int
                             (size_t)ne, 0, 32, (hipStream_t)0);
   void* tmp = c.take<char>(sb);
   int bits = 1;
-  while (((int64_t)1 << bits) <= n) ++bits;
+  while (((int64_t)1 << bits) <= n_dst) ++bits;
   const dim3 block(kBlock);
-  hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)((ne + kBlock - 1) / kBlock)), block, 0, stream, nbr, ne, k, (int32_t)n, keys, src);
+  hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)((ne + kBlock - 1) / kBlock)), block, 0, stream, nbr, ne, k, (int32_t)n_dst, keys, src);
   DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, src, csr_src, (size_t)ne, 0, (unsigned)bits, stream));
-  hipLaunchKernelGGL(csr_ptr_kernel, dim3((unsigned)((n + 1 + kBlock - 1) / kBlock)), block, 0, stream, skeys, ne, (int32_t)n, csr_ptr);
+  hipLaunchKernelGGL(csr_ptr_kernel, dim3((unsigned)((n_dst + 1 + kBlock - 1) / kBlock)), block, 0, stream, skeys, ne, (int32_t)n_dst, csr_ptr);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

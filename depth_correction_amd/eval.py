@@ -70,7 +70,8 @@ class PlanCloud(object):
             w, e, poses = self._args
             out = p.forward(w, e, poses, want_pointwise=True, want_eigvals=True)
             self._out = dict(points=p.points(), eigvals=p.unpermute(out['eigvals']),
-                             loss=p.unpermute(out['pointwise']), mask=None if p.mask is None else p.unpermute(p.mask))
+                             loss=p.unpermute(out['pointwise']),
+                             mask=None if p.mask_full is None else p.unpermute(p.mask_full))
         return self._out
 
     def __getattr__(self, name):

@@ -74,15 +74,17 @@ def radius_neighbors(points, r):
     return idx
 
 
-def knn_transpose(nbr):
-    """(csr_ptr i32 [N+1], csr_src i32 [N*K]) -- incoming edges of every point."""
+def knn_transpose(nbr, n_dst=None):
+    """(csr_ptr i32 [n_dst+1], csr_src i32 [rows*K]) -- for every point the rows whose neighbourhood contains it.
+    ``n_dst`` (default: the number of rows) is the number of points the indices refer to."""
     need(nbr, (None, None), dtype=torch.int32, name='neighbors')
     n, k = nbr.shape
-    csr_ptr = torch.empty((n + 1,), dtype=torch.int32, device=nbr.device)
+    n_dst = n if n_dst is None else int(n_dst)
+    csr_ptr = torch.empty((n_dst + 1,), dtype=torch.int32, device=nbr.device)
     csr_src = torch.empty((max(n * k, 1),), dtype=torch.int32, device=nbr.device)
     nbytes = lib().dc_knn_transpose_workspace_bytes(n, k)
     ws = _ws(nbytes, nbr.device)
-    check(lib().dc_knn_transpose(ptr(nbr), n, k, ptr(csr_ptr), ptr(csr_src), ptr(ws), nbytes, stream_ptr()),
+    check(lib().dc_knn_transpose(ptr(nbr), n, k, n_dst, ptr(csr_ptr), ptr(csr_src), ptr(ws), nbytes, stream_ptr()),
           'dc_knn_transpose')
     return csr_ptr, csr_src
 
@@ -281,11 +283,18 @@ def features_bwd(points, csr_ptr, csr_src, cmean, invd, nvalid, eigvecs=None, gr
 # fused consistency loss
 # ------------------------------------------------------------------------------------------------
 def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss', normalization=True, sqrt=False,
-                    rec=None, want_pointwise=False, want_eigvals=False, partials=None, sums=None, qfmt=None):
+                    rec=None, want_pointwise=False, want_eigvals=False, partials=None, sums=None, qfmt=None,
+                    centre_idx=None):
     _check_points(points, qfmt)
-    n, stride = points.shape
+    n_points, stride = points.shape
     dev = points.device
     dt = torch.float32 if qfmt is not None else points.dtype
+    if centre_idx is not None:               # compact centre list: rows of nbr / rec / outputs follow it
+        need(centre_idx, (None,), dtype=torch.int32, name='centre_idx', device=dev)
+        n = centre_idx.shape[0]
+        assert n == 0 or (int(centre_idx.min()) >= 0 and int(centre_idx.max()) < n_points)
+    else:
+        n = n_points
     need(nbr, (n, None), dtype=torch.int32, name='neighbors', device=dev)
     k = nbr.shape[1]
     if mask is not None:
@@ -307,7 +316,8 @@ def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss',
         assert partials.numel() >= rows * 2
     if sums is None:
         sums = torch.empty((2,), dtype=torch.float64, device=dev)
-    check(lib().dc_consistency_fwd(ptr(points), stride, fmt if qfmt is None else nv.DC_F32, fmt, qptr, ptr(nbr), n, k,
+    check(lib().dc_consistency_fwd(ptr(points), stride, fmt if qfmt is None else nv.DC_F32, fmt, qptr, ptr(nbr),
+                                   ptr(centre_idx), n, k,
                                    ptr(mask), ptr(offset), nv.LOSS_KINDS[loss], int(bool(normalization)), int(bool(sqrt)), ptr(rec), ptr(pw),
                                    ptr(ev), ptr(partials), ptr(sums), stream_ptr()), 'dc_consistency_fwd')
     return dict(sums=sums, rec=rec, pointwise=pw, eigvals=ev)
@@ -331,7 +341,7 @@ def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_ki
     dt = torch.float32 if qfmt is not None else points.dtype
     fmt, qptr = _fmt_args(dt, qfmt)
     dcode = nv.DC_F32 if qfmt is not None else fmt
-    need(rec, (n, 8), dtype=points.dtype, name='rec', device=dev)
+    need(rec, (None, 8), dtype=points.dtype, name='rec', device=dev)        # one row per centre (<= n with a centre list)
     need(csr_ptr, (n + 1,), dtype=torch.int32, name='csr_ptr', device=dev)
     need(csr_src, (None,), dtype=torch.int32, name='csr_src', device=dev)
     gp = torch.empty((n, stride), dtype=dt, device=dev) if want_grad_points else None

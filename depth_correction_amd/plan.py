@@ -32,13 +32,16 @@ __all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer']
 
 class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
-                 normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False):
+                 normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
+                 active_only=False):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
         :param poses: [S,4,4] initial scan poses (used for the layout only; every evaluation takes its own).
         :param neighbors: [N,K] int neighbour indices of the global cloud (scan-major order, -1 = missing).
         :param mask: [N] bool global mask (None = all points).
+        :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
+                            the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
         get = (lambda c, f: c[f]) if isinstance(clouds[0], dict) else getattr
         vps = torch.cat([get(c, 'vps') for c in clouds]).contiguous()
@@ -93,10 +96,16 @@ class SequencePlan:
         if not bool(vps.any()):
             vps = None                      # sensor-frame scans: viewpoints are the origin, nothing to stream
         self.ps = ops.PointSet(vps, dirs, depth, inc, lmask, scan_id)
+        self.nbr_full, self.mask_full = nbr, mask
+        self.centre_idx = None
+        if active_only and mask is not None:
+            self.centre_idx = torch.nonzero(mask).reshape(-1).to(torch.int32).contiguous()
+            nbr = nbr[self.centre_idx.long()].contiguous()
+            mask = None
         self.nbr, self.mask = nbr, mask
-        self.csr_ptr, self.csr_src = ops.knn_transpose(nbr)
+        self.csr_ptr, self.csr_src = ops.knn_transpose(nbr, n_dst=self.n)
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
-        self.count = float(self.n if mask is None else int(mask.sum().item()))
+        self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
         # ---- internal point format -------------------------------------------------------------------
         if point_format == 'auto':
@@ -107,7 +116,7 @@ class SequencePlan:
             self.qfmt = ops.QFormat.for_extent(lo, hi)
         pdt = torch.int32 if self.qfmt is not None else self.dtype
         self.x = torch.empty((self.n, 4), dtype=pdt, device=dev)
-        self.rec = torch.empty((self.n, 8), dtype=pdt, device=dev)
+        self.rec = torch.empty((nbr.shape[0], 8), dtype=pdt, device=dev)
         rows = ops.lib().dc_partial_rows(self.n)
         nacc = 2 * ops.nv.MAX_MODEL_TERMS + 12 * self.n_scans
         self.partials = torch.empty((rows * (nacc + 2),), dtype=torch.float64, device=dev)
@@ -130,6 +139,7 @@ class SequencePlan:
             d.vps, d.dirs, d.depth, d.inc, d.lmask, d.scan_id = p(ps.vps), p(ps.dirs), p(ps.depth), p(ps.inc), p(ps.lmask), p(ps.scan_id)
             d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(self.csr_ptr), p(self.csr_src), p(self.mask)
             d.lane_perm = p(self.lane_perm)
+            d.centre_idx, d.n_centres = p(self.centre_idx), (0 if self.centre_idx is None else self.centre_idx.shape[0])
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
@@ -167,9 +177,17 @@ class SequencePlan:
         self.e = None if exponent is None else exponent.detach().reshape(-1).to(device=self.device, dtype=torch.float64).contiguous()
         kind = self.model_kind if self.w is not None else None
         ops.points_fwd(self.ps, self.P, kind, self.w, self.e, stride=4, qfmt=self.qfmt, out=self.x)
+        if self.centre_idx is not None and (want_pointwise or want_eigvals):
+            # per-point outputs for ALL points: the complete neighbour table, records into a scratch buffer
+            out = ops.consistency_fwd(self.x, self.nbr_full, mask=self.mask_full, loss=self.loss,
+                                      normalization=self.normalization, sqrt=self.sqrt, want_pointwise=want_pointwise,
+                                      want_eigvals=want_eigvals, qfmt=self.qfmt)
+            out['rec'] = None
+            return out
         out = ops.consistency_fwd(self.x, self.nbr, mask=self.mask, loss=self.loss, normalization=self.normalization,
                                   sqrt=self.sqrt, rec=self.rec, want_pointwise=want_pointwise,
-                                  want_eigvals=want_eigvals, partials=self.partials, qfmt=self.qfmt)
+                                  want_eigvals=want_eigvals, partials=self.partials, qfmt=self.qfmt,
+                                  centre_idx=self.centre_idx)
         self.version += 1
         return out
 

@@ -61,9 +61,10 @@ int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double
 int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, size_t ws_bytes, dcStream_t stream);
 
 /* Transposed neighbour list for the backward (replaces autograd's index_put scatter of depth_cloud.py:303-304):
- * csr_ptr int32 [n+1], csr_src int32 [n*k] (first csr_ptr[n] entries valid, ascending centre index). */
+ * nbr int32 [n,k] with values in [0, n_dst) (n_dst <= 0: n_dst = n); csr_ptr int32 [n_dst+1], csr_src int32 [n*k]
+ * (first csr_ptr[n_dst] entries valid, ascending row index). */
 size_t dc_knn_transpose_workspace_bytes(int64_t n, int k);
-int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int32_t* csr_ptr, int32_t* csr_src, void* ws,
+int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int64_t n_dst, int32_t* csr_ptr, int32_t* csr_src, void* ws,
                      size_t ws_bytes, dcStream_t stream);
 
 /* Morton (Z-curve) order of the points over their bounding box: order_out[p] = index of the p-th point.
@@ -120,11 +121,13 @@ int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* cs
  *   l = relu(lam0 [/ clamp(sum lam, 1e-6)] - offset) [sqrt], and the 8-element backward record rec [n,8]
  *   (same format as the points: point_fmt / qparams as in dc_points_fwd).
  * sums_out fp64 [2] = {sum of l over mask, number of masked points}; mask u8 [n] or NULL; offset [n] or NULL;
- * pointwise [n], eigvals [n,3] optional.  partials_ws: fp64 [dc_partial_rows(n) * 2]. */
+ * pointwise [n], eigvals [n,3] optional.  partials_ws: fp64 [dc_partial_rows(n) * 2].
+ * centre_idx int32 [n] or NULL: when given, row r of nbr / rec / pointwise / mask belongs to point centre_idx[r]
+ * (a compact list of centres, e.g. only the masked points -- the others contribute nothing to loss or gradient). */
 int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
-                       const int32_t* nbr, int64_t n, int k, const uint8_t* mask, const void* offset, int loss_kind,
-                       int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
-                       double* sums_out, dcStream_t stream);
+                       const int32_t* nbr, const int32_t* centre_idx, int64_t n, int k, const uint8_t* mask, const void* offset,
+                       int loss_kind, int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals,
+                       double* partials_ws, double* sums_out, dcStream_t stream);
 
 /* Backward of sum-over-mask of l: dL/dx_j gathered over incoming edges, chained in the same kernel to
  * dL/dw, dL/dexponent, dL/d[R|t] (grads_out as in dc_points_bwd; pass dirs == NULL to get only grad_points).
@@ -180,6 +183,8 @@ typedef struct dcSequenceDesc {
   const int32_t *nbr, *csr_ptr, *csr_src;
   const uint8_t* mask;
   const uint8_t* lane_perm;
+  const int32_t* centre_idx; /* optional compact centre list (see dc_consistency_fwd); nbr / rec / mask then have n_centres rows */
+  int64_t n_centres;
   void *x, *rec;
   double* partials;
   int32_t model_kind, n_terms, loss_kind, normalization, sqrt_, reserved;

@@ -422,3 +422,28 @@ def test_icp_training_matches_oracle_loop(tmp_path):
         pd.grad[0].zero_()
         opt.step()
     assert np.abs(seen[-1][2][1:]).max() > 1e-3 and np.all(seen[-1][2][0] == 0)     # poses moved, the first stays fixed
+
+
+def test_active_only_plan_is_exact(golden):
+    """Evaluating only the masked points as centres changes nothing in the loss, the count or any gradient."""
+    from depth_correction_amd.plan import SequencePlan
+    g = golden('room_k10')
+    cfg = _cfg(g)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    dev = poses.device
+    w = torch.tensor(g['w'].reshape(-1), device=dev)
+    e = torch.tensor(g['exponent'].reshape(-1), device=dev)
+    outs = []
+    for active in (False, True):
+        plan = SequencePlan(clouds, poses, ns[0], mask, active_only=active)
+        out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+        plan.eval_native(w, e, plan.poses12(poses), out, want_exponent=True, want_pose=True)
+        outs.append(npy(out))
+        assert plan.count == int(g['g_mask'].sum())
+        full = plan.forward(w, e, poses, want_pointwise=True, want_eigvals=True)
+        assert_eigvals_close(npy(plan.unpermute(full['eigvals'])), g['g_eigvals'], 1e-9)
+    np.testing.assert_allclose(outs[1][:2], outs[0][:2], rtol=1e-13)
+    np.testing.assert_allclose(outs[1][2:], outs[0][2:], rtol=1e-10, atol=1e-12 * np.abs(outs[0][2:]).max())
+    M = g['g_mask'].sum()
+    np.testing.assert_allclose(outs[1][0] / M, g['mineig_norm_loss'], rtol=1e-9)
+    np.testing.assert_allclose(outs[1][2:4] / M, g['mineig_norm_grad_w'].reshape(-1), rtol=1e-7)
