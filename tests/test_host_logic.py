@@ -229,3 +229,35 @@ def test_filter_grid_host_matches_reference_golden(golden):
             ind = filter_grid(g['points'], float(g['grid_res']), only_mask=True, keep=keep, preserve_order=po,
                               rng=np.random.default_rng(135))
             assert np.array_equal(np.asarray(ind), g['%s_%d' % (keep, po)]), (keep, po)
+
+
+def test_scan_file_formats_roundtrip(tmp_path):
+    from depth_correction_amd.scan_io import (ScanFolderDataset, read_kitti_bin, read_points_csv, read_points_npz,
+                                              read_poses_csv, write_poses_csv)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-5, 5, size=(200, 4)).astype(np.float32)
+    pts[:10, :2] = rng.uniform(-0.9, 0.9, size=(10, 2))                  # inside the ego box
+    d = tmp_path / 'velodyne'
+    d.mkdir()
+    pts.tofile(str(d / ('%010d.bin' % 7)))
+    cloud = read_kitti_bin(str(d / ('%010d.bin' % 7)))
+    keep = (np.abs(pts[:, 0]) > 1.0) | (np.abs(pts[:, 1]) > 1.0)
+    assert cloud.dtype.names == ('x', 'y', 'z', 'i') and len(cloud) == keep.sum() and np.array_equal(cloud['x'], pts[keep, 0])
+    assert len(read_kitti_bin(str(d / ('%010d.bin' % 7)), filter_ego_pts_depth=None)) == 200
+    csv = tmp_path / 'scan.csv'
+    np.savetxt(str(csv), np.concatenate([np.arange(5)[:, None], pts[:5, :3].astype(np.float64), np.ones((5, 2))], 1),
+               delimiter=',', header='id,x,y,z,a,b')
+    np.testing.assert_allclose(read_points_csv(str(csv)), pts[:5, :3], rtol=1e-12)
+    np.savez(str(tmp_path / 'a.npz'), pts[:, :3])
+    np.savez(str(tmp_path / 'b.npz'), cloud=pts[:, :3])
+    assert np.array_equal(read_points_npz(str(tmp_path / 'a.npz')), pts[:, :3])
+    assert np.array_equal(read_points_npz(str(tmp_path / 'b.npz')), pts[:, :3])
+    poses = [np.eye(4), np.eye(4)]
+    poses[1][:3, 3] = [1.5, -2.0, 0.25]
+    write_poses_csv([7, 9], poses, str(tmp_path / 'poses.csv'))
+    ids, back = read_poses_csv(str(tmp_path / 'poses.csv'))
+    assert ids == [7, 9] and np.allclose(back[1], poses[1])
+    ds = ScanFolderDataset(str(d), str(tmp_path / 'poses.csv'))
+    assert len(ds) == 1 and ds.ids == [7]                               # scan 9 has no cloud file
+    c, p = ds[0]
+    assert len(c) == keep.sum() and np.allclose(p, np.eye(4))
