@@ -161,6 +161,24 @@ def main():
     torch.cuda.synchronize()
     knn_ms = ev0.elapsed_time(ev1)
 
+    # BASELINE config 1 (one 200k-point scan, nn_k = 10, covariance + eig forward only, all DepthCloud features written),
+    # reported next to the headline: 284 B/point by the SURVEY accounting
+    c0 = info['clouds'][0]
+    x1, n1 = c0['points'], c0['points'].shape[0]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(21):
+        if it == 1:
+            evs[0].record()
+        ops.features_fwd(x1, c0['neighbors'], dirs=c0['dirs'])
+    evs[1].record()
+    torch.cuda.synchronize()
+    c1_ms = evs[0].elapsed_time(evs[1]) / 20
+    evs[0].record()
+    ops.knn(x1, args.k, want_dist=False)
+    evs[1].record()
+    torch.cuda.synchronize()
+    c1_knn_ms = evs[0].elapsed_time(evs[1])
+
     n_local = plan.n
     from depth_correction_amd.plan import SequenceTrainer, KernelTimer
     w0, e0 = [1e-3, 2e-3], [2.0, 4.0]
@@ -245,7 +263,9 @@ def main():
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
                        'loop': 'autograd+torch.optim.Adam' if args.autograd else 'native (dc_sequence_eval + dc_adam_step)',
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
-                       'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3), 'setup_s': setup_s},
+                       'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3), 'setup_s': setup_s,
+                       'c1_forward_only': {'points': n1, 'features_fwd_ms': c1_ms, 'points_per_s': n1 / (c1_ms * 1e-3),
+                                           'algorithmic_GBps': 284 * n1 / (c1_ms * 1e-3) / 1e9, 'knn_build_ms': c1_knn_ms}},
             'roofline': {'bound': 'hbm', 'kernel': 'dc_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_point': ab[dom], 'kernel_ms': ms,

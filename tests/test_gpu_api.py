@@ -447,3 +447,24 @@ def test_active_only_plan_is_exact(golden):
     M = g['g_mask'].sum()
     np.testing.assert_allclose(outs[1][0] / M, g['mineig_norm_loss'], rtol=1e-9)
     np.testing.assert_allclose(outs[1][2:4] / M, g['mineig_norm_grad_w'].reshape(-1), rtol=1e-7)
+
+
+def test_trainer_with_two_sequences_on_one_gpu(golden):
+    """Config 3 shape on one device: two sequences per rank, accumulated before the (here trivial) rank reduction."""
+    from depth_correction_amd.plan import SequencePlan, SequenceTrainer
+    g = golden('room_k10')
+    cfg = _cfg(g)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    mask2 = mask & (torch.arange(len(mask), device=mask.device) % 2 == 0)
+    plans = [SequencePlan(clouds, poses, ns[0], mask), SequencePlan(clouds, poses, ns[0].clone(), mask2, active_only=True)]
+    tr = SequenceTrainer(plans, g['w'], g['exponent'], [poses, poses], lr=1e-2)
+    acc = npy(tr.step())
+    singles = []
+    for p in plans:
+        out = torch.zeros(2 + 4 + 12 * p.n_scans, dtype=torch.float64, device=poses.device)
+        p.eval_native(torch.tensor(g['w'].reshape(-1), device=poses.device), torch.tensor(g['exponent'].reshape(-1), device=poses.device),
+                      p.poses12(poses), out)
+        singles.append(npy(out))
+    np.testing.assert_allclose(acc[:4], singles[0][:4] + singles[1][:4], rtol=1e-13)
+    assert tr.count == float(mask.sum() + mask2.sum()) and acc[1] == tr.count
+    assert not np.allclose(npy(tr.w), g['w'].reshape(-1))
