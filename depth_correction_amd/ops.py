@@ -69,6 +69,9 @@ def radius_neighbors(points, r):
     check(lib().dc_radius_count(ptr(points), 3, dtype_code(points), n, float(r), ptr(count), ptr(kmax), ptr(ws), nbytes,
                                 stream_ptr()), 'dc_radius_count')
     km = int(kmax.item())            # set-up phase: the padded width is needed on the host
+    if n * max(km, 1) * 4 > (16 << 30):
+        raise MemoryError('radius neighbourhoods too dense: %d points x %d neighbours do not fit a padded [N, Kmax] table; '
+                          'voxel-filter the cloud first (cfg.grid_res) as the reference pipeline does' % (n, km))
     idx = torch.empty((n, max(km, 1)), dtype=torch.int32, device=points.device)
     check(lib().dc_radius_fill(n, float(r), max(km, 1), ptr(idx), ptr(ws), nbytes, stream_ptr()), 'dc_radius_fill')
     return idx
