@@ -92,6 +92,11 @@ __global__ __launch_bounds__(kBlock) void voxel_coords_kernel(const T* __restric
   }
 }
 
+__global__ void voxel_box_init_kernel(int32_t* __restrict__ box) {
+  const int t = threadIdx.x;                 // box[0..3) running minima, box[4..7) running maxima
+  if (t < 8) box[t] = t < 3 ? 0x7fffffff : ((t >= 4 && t < 7) ? (int32_t)0x80000000 : 0);
+}
+
 __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const int32_t* __restrict__ vox, const int32_t* __restrict__ seq,
                                                             int64_t n, const int32_t* __restrict__ vmin,
                                                             const int32_t* __restrict__ vmax, int32_t* __restrict__ bad,
@@ -224,10 +229,8 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
   int32_t *vox, *box, *vals, *svals, *head, *run_id, *skey, *surv, *skey2; uint64_t *keys, *skeys; void* tmp; size_t tmp_bytes;
   if (ws_bytes < voxel_ws(ws, n, &vox, &box, &keys, &skeys, &vals, &svals, &head, &run_id, &skey, &surv, &skey2, &tmp, &tmp_bytes))
     return DC_ERR_WORKSPACE;
-  const int32_t init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0, (int32_t)0x80000000, (int32_t)0x80000000, (int32_t)0x80000000, 0};
-  hipError_t err = hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, stream);
-  if (err != hipSuccess) return (int)err;
-  err = hipMemsetAsync(status_out, 0, 4, stream);
+  hipLaunchKernelGGL(voxel_box_init_kernel, dim3(1), dim3(8), 0, stream, box);       // no host buffer behind an async copy
+  hipError_t err = hipMemsetAsync(status_out, 0, 4, stream);
   if (err != hipSuccess) return (int)err;
   err = hipMemsetAsync(skey, 0x7f, (size_t)n * 4, stream);               // 0x7f7f7f7f: unused slots sort last
   if (err != hipSuccess) return (int)err;
