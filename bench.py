@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--point-format', default='auto', choices=['auto', 'q32', 'float'])
     ap.add_argument('--active-only', action='store_true',
                     help='evaluate only masked points as neighbourhood centres (identical loss / gradients, see DESIGN.md)')
+    ap.add_argument('--degree-sort', action='store_true', help='order points by in-degree inside 256-point blocks (ablation)')
     ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')
     return ap.parse_args()
 
@@ -150,7 +151,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, spatial_sort=not args.no_sort,
-                                point_format=args.point_format, active_only=args.active_only)
+                                point_format=args.point_format, active_only=args.active_only, degree_sort=args.degree_sort)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     # the k-NN build alone, on the global cloud (reported separately)

@@ -294,7 +294,7 @@ template <typename T, typename PT, int STRIDE, bool WANT_E, bool WANT_POSE>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
     const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
     const int32_t* __restrict__ csr_src, const uint8_t* __restrict__ lane_perm, int64_t n, PointInputs in, QParams qp,
-    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc, uint32_t rec_bytes) {
   // measured: the edge loop is faster with separate multiplies and adds (more independent work per trip) than with
   // the dependent FMA chains contraction produces (90 vs 98 us at N = 2 M)
 #pragma clang fp contract(off)
@@ -322,7 +322,9 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
       const double u = Pt<PT>::unit(qp);
       const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
       // four edges per trip; the indices of the NEXT trip are requested before the records of this one are used,
-      // so each trip exposes one memory latency instead of two
+      // so each trip exposes one memory latency instead of two.  Records come through a buffer resource: 32-bit
+      // offsets, and an empty slot (index -1) is out of range and reads an all-zero record (c1 = c2 = 0).
+      const BufRsrc rrec = make_rsrc(rec, rec_bytes);
       int32_t nxt[4];
 #pragma unroll
       for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (beg + u_ < end) ? csr_src[beg + u_] : -1;
@@ -333,19 +335,17 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) src[u_] = nxt[u_];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) RecRaw<PT>::load(rec, src[u_] >= 0 ? (int64_t)src[u_] : j, m[u_], &c1[u_], v[u_], &c2[u_]);
+        for (int u_ = 0; u_ < 4; ++u_) buf_record<PT>(rrec, src[u_], m[u_], &c1[u_], v[u_], &c2[u_]);
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (e0 + 4 + u_ < end) ? csr_src[e0 + 4 + u_] : -1;
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) {
-          // empty slots re-read the point's own record with zeroed coefficients: no exec-mask churn
-          const double k1 = src[u_] >= 0 ? c1[u_] : 0.0, k2 = src[u_] >= 0 ? c2[u_] : 0.0;
           double d[3];
           Pt<PT>::delta(cj, m[u_], d);
-          const double t = k1 * (v[u_][0] * d[0] + v[u_][1] * d[1] + v[u_][2] * d[2]);
-          g[0] += t * v[u_][0] - k2 * d[0];
-          g[1] += t * v[u_][1] - k2 * d[1];
-          g[2] += t * v[u_][2] - k2 * d[2];
+          const double t = c1[u_] * (v[u_][0] * d[0] + v[u_][1] * d[1] + v[u_][2] * d[2]);
+          g[0] += t * v[u_][0] - c2[u_] * d[0];
+          g[1] += t * v[u_][1] - c2[u_] * d[1];
+          g[2] += t * v[u_][2] - c2[u_] * d[2];
         }
       }
       g[0] *= u; g[1] *= u; g[2] *= u;
@@ -849,7 +849,8 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
                                 const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                                 const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
                                 const double* w, const double* e, int want_exponent_grad, int want_pose_grad,
-                                void* grad_points, double* partials_ws, double* grads_out, hipStream_t stream, bool reduce) {
+                                void* grad_points, double* partials_ws, double* grads_out, hipStream_t stream, bool reduce,
+                                int64_t rec_rows) {
   if (n < 0 || !points || !rec || !csr_ptr || !csr_src || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   const bool params = dirs != nullptr;
   if (!params && !grad_points) return DC_ERR_ARG;
@@ -869,12 +870,16 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
+  // byte size of the record array for the buffer resource (rows <= n; a compact centre list has fewer)
+  const uint64_t rec_total = (uint64_t)(rec_rows > 0 ? rec_rows : n) * (point_fmt == DC_F64 ? 64u : 32u);
+  if (rec_total >= (1ull << 32)) return DC_ERR_UNSUPPORTED;
+  const uint32_t rec_bytes = (uint32_t)rec_total;
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
   if (params && n_red < n_acc && reduce) {
     hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
-#define BWD_ARGS(T, PT) (const PT*)points, (const PT*)rec, csr_ptr, csr_src, lane_perm, n, in, qp, (T*)grad_points, partials_ws, n_acc
+#define BWD_ARGS(T, PT) (const PT*)points, (const PT*)rec, csr_ptr, csr_src, lane_perm, n, in, qp, (T*)grad_points, partials_ws, n_acc, rec_bytes
 #define LAUNCH(T, PT, S) \
   do { \
     if (S == 4 && !lane_perm && !g_no_tiles) \
@@ -905,7 +910,7 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
                        double* grads_out, hipStream_t stream) {
   return consistency_bwd_impl(points, stride, dtype, point_fmt, qparams, rec, csr_ptr, csr_src, lane_perm, n, vps, dirs, depth,
                               inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e, want_exponent_grad,
-                              want_pose_grad, grad_points, partials_ws, grads_out, stream, true);
+                              want_pose_grad, grad_points, partials_ws, grads_out, stream, true, 0);
 }
 
 int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, const void* vps, const void* dirs,
@@ -1062,7 +1067,8 @@ int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, 
   if (!rc && want_grad)
     rc = consistency_bwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
                               d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
-                              d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false);
+                              d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false,
+                              n_rows);
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)), rows,
                      n_red, out);

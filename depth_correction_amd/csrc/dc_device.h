@@ -190,6 +190,18 @@ template <> struct Pt<q32> {
   }
 };
 
+// ---- buffer-resource gathers: 32-bit byte offsets + hardware range check (an out-of-range row, e.g. index -1, reads 0)
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ int4 buf_load16(BufRsrc r, uint32_t byte_off) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]);
+}
+template <typename PT> struct RowBytes { static constexpr uint32_t x = 16, rec = 32; };
+template <> struct RowBytes<double> { static constexpr uint32_t x = 32, rec = 64; };
+
 // rec rows from / to raw means
 template <typename PT> struct RecRaw;
 template <typename F> struct RecRawFloat {
@@ -295,6 +307,22 @@ __device__ __forceinline__ void block_sum_used(double* v, int n_used, double* ld
     }
   }
   __syncthreads();
+}
+
+// point / record rows through a buffer resource (row index may be -1: all-zero row)
+template <typename PT>
+__device__ __forceinline__ typename Pt<PT>::Raw buf_point(BufRsrc r, int32_t row) {
+  int4 q[Pt<PT>::kRow16];
+#pragma unroll
+  for (int a = 0; a < Pt<PT>::kRow16; ++a) q[a] = buf_load16(r, (uint32_t)row * RowBytes<PT>::x + 16u * a);
+  return Pt<PT>::from_row(q);
+}
+template <typename PT>
+__device__ __forceinline__ void buf_record(BufRsrc r, int32_t row, typename Pt<PT>::Raw& m, double* c1, double* v, double* c2) {
+  int4 q[RecRaw<PT>::kRow16];
+#pragma unroll
+  for (int a = 0; a < RecRaw<PT>::kRow16; ++a) q[a] = buf_load16(r, (uint32_t)row * RowBytes<PT>::rec + 16u * a);
+  RecRaw<PT>::from_row(q, m, c1, v, c2);
 }
 
 }  // namespace dc
