@@ -36,7 +36,7 @@ _SIGNATURES = {
                              _vp, _vp, _vp, _vp, _vp]),
     'dc_partial_rows': (_i64, [_i64]),
     'dc_param_grad_count': (_i32, [_i32, _i32]),
-    'dc_points_bwd': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32,
+    'dc_points_bwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32,
                              _i32, _vp, _vp, _vp]),
     'dc_features_fwd': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),

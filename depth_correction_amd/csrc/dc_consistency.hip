@@ -271,8 +271,15 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
       if (k < P) { pcol[k * rs] = v[k]; pcol[(P + k) * rs] = v[DC_MAX_MODEL_TERMS + k]; }
   }
   if (want_pose) {
-    // scans are interleaved after spatial sorting: reduce per scan id present in the block
-    for (int s = 0; s < in.n_scans; ++s) {
+    // only the scans present in this block are reduced (scan-major order: one or two; Morton order: most of them);
+    // the others keep the zeros the caller put into the workspace
+    __shared__ int s_range[2];
+    if (threadIdx.x == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
+    __syncthreads();
+    if (active) { atomicMin(&s_range[0], scan); atomicMax(&s_range[1], scan); }
+    __syncthreads();
+    const int s_lo = s_range[0], s_hi = s_range[1] < in.n_scans ? s_range[1] : in.n_scans - 1;
+    for (int s = s_lo; s <= s_hi; ++s) {
       double t[12];
       const bool mine = active && scan == s;
 #pragma unroll
@@ -528,9 +535,9 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_tiled_kernel(
 
 // Stand-alone point epilogue for the un-fused API path (grad of points given).
 template <typename T, int STRIDE>
-__global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict__ grad_x, int64_t n, PointInputs in,
-                                                            int want_e, int want_pose, double* __restrict__ partials,
-                                                            int n_acc) {
+__global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict__ grad_x, const int32_t* __restrict__ perm,
+                                                            int64_t n, PointInputs in, int want_e, int want_pose,
+                                                            double* __restrict__ partials, int n_acc) {
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
   ModelParams mp;
   load_model(in, mp);
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
   const bool active = j < n;
   if (active) {
     double g[3];
-    Row3<T, STRIDE>::load(grad_x, j, g, QParams{});
+    Row3<T, STRIDE>::load(grad_x, perm ? (int64_t)perm[j] : j, g, QParams{});      // perm: grad rows live in another point order
     points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
   reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
@@ -875,6 +882,10 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   if (rec_total >= (1ull << 32)) return DC_ERR_UNSUPPORTED;
   const uint32_t rec_bytes = (uint32_t)rec_total;
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
+  if (params && want_pose_grad) {
+    hipError_t err = hipMemsetAsync(partials_ws + (size_t)rows * 2 * n_terms, 0, (size_t)rows * 12 * n_scans * sizeof(double), stream);
+    if (err != hipSuccess) return (int)err;
+  }
   if (params && n_red < n_acc && reduce) {
     hipError_t err = hipMemsetAsync(grads_out + n_red, 0, (size_t)(n_acc - n_red) * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
@@ -913,8 +924,8 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
                               want_pose_grad, grad_points, partials_ws, grads_out, stream, true, 0);
 }
 
-int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, const void* vps, const void* dirs,
-                  const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int dtype, int64_t n, const void* vps,
+                  const void* dirs, const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
                   const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
                   int want_exponent_grad, int want_pose_grad, double* partials_ws, double* grads_out,
                   hipStream_t stream) {
@@ -936,8 +947,12 @@ int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, con
     if (err != hipSuccess) return (int)err;
   }
   if (n_red == 0) return DC_OK;
+  if (want_pose_grad) {      // blocks only write the pose slots of the scans they contain
+    hipError_t err = hipMemsetAsync(partials_ws + (size_t)rows * 2 * n_terms, 0, (size_t)rows * 12 * n_scans * sizeof(double), stream);
+    if (err != hipSuccess) return (int)err;
+  }
 #define LAUNCH(T, S) \
-  hipLaunchKernelGGL((points_bwd_kernel<T, S>), grid, block, 0, stream, (const T*)grad_points, n, in, \
+  hipLaunchKernelGGL((points_bwd_kernel<T, S>), grid, block, 0, stream, (const T*)grad_points, perm, n, in, \
                      want_exponent_grad, want_pose_grad, partials_ws, n_acc)
   if (dtype == DC_F32) { if (stride == 3) LAUNCH(float, 3); else LAUNCH(float, 4); }
   else if (dtype == DC_F64) { if (stride == 3) LAUNCH(double, 3); else LAUNCH(double, 4); }

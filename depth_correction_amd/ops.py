@@ -208,19 +208,26 @@ def _grads_split(g, nt, ns):
     return g[:nt], g[nt:2 * nt], g[2 * nt:].reshape(ns, 3, 4)
 
 
-def points_bwd(grad_points, ps, poses=None, model_kind=None, w=None, e=None, want_exponent=False, want_pose=False):
-    """(dL/dw [P], dL/dexponent [P], dL/d[R|t] [S,3,4]) for a given dL/dpoints."""
+def points_bwd(grad_points, ps, poses=None, model_kind=None, w=None, e=None, want_exponent=False, want_pose=False,
+               perm=None, out=None):
+    """(dL/dw [P], dL/dexponent [P], dL/d[R|t] [S,3,4]) for a given dL/dpoints; ``perm`` int32 [N]: point i uses
+    row perm[i] of ``grad_points``."""
     kind, nt, w, e = _model_args(model_kind, w, e, ps)
     poses, ns = _pose_args(poses, ps)
     need(grad_points, (ps.n, None), dtype=ps.dtype, name='grad_points', device=ps.device)
+    if perm is not None:
+        need(perm, (ps.n,), dtype=torch.int32, name='perm', device=ps.device)
     stride = grad_points.shape[1]
     nacc = 2 * nt + 12 * ns
-    out = torch.zeros((max(nacc, 1),), dtype=torch.float64, device=ps.device)
+    if out is None:
+        out = torch.zeros((max(nacc, 1),), dtype=torch.float64, device=ps.device)
+    else:
+        need(out, (nacc,), dtype=torch.float64, name='grads_out', device=ps.device)
     if nacc == 0:
         return _grads_split(out[:0], 0, 0)
     rows = lib().dc_partial_rows(ps.n)
     part = torch.empty((rows * nacc,), dtype=torch.float64, device=ps.device)
-    check(lib().dc_points_bwd(ptr(grad_points), stride, dtype_code(grad_points), ps.n, ptr(ps.vps), ptr(ps.dirs),
+    check(lib().dc_points_bwd(ptr(grad_points), ptr(perm), stride, dtype_code(grad_points), ps.n, ptr(ps.vps), ptr(ps.dirs),
                               ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id), ptr(poses), ns, kind, nt,
                               ptr(w), ptr(e), int(want_exponent), int(want_pose), ptr(part), ptr(out), stream_ptr()),
           'dc_points_bwd')

@@ -89,11 +89,14 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
                   int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, dcStream_t stream);
 
 /* Backward of dc_points_fwd for a given dL/dpoints: grads_out fp64 [2*n_terms + 12*n_scans] =
- * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count]. */
+ * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count].
+ * perm int32 [n] or NULL: point i takes its gradient from row perm[i] of grad_points (the gradient then lives in another
+ * point order, e.g. the Morton layout of the fused kernels while the inputs here are scan-major, where a block of 256
+ * points contains one or two scans and the per-scan pose reduction is cheap). */
 int64_t dc_partial_rows(int64_t n);
 int dc_param_grad_count(int n_terms, int n_scans);
-int dc_points_bwd(const void* grad_points, int stride, int dtype, int64_t n, const void* vps, const void* dirs,
-                  const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int dtype, int64_t n, const void* vps,
+                  const void* dirs, const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
                   const double* poses, int n_scans, int model_kind, int n_terms, const double* w, const double* e,
                   int want_exponent_grad, int want_pose_grad, double* partials_ws, double* grads_out,
                   dcStream_t stream);
