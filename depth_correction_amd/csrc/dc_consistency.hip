@@ -241,9 +241,77 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
   if (want_pose) {
     // x = R xl + t, xl = vps + d' dirs:  dL/dR = g xl^T, dL/dt = g
     const double xl0 = vp[0] + dcorr * dr[0], xl1 = vp[1] + dcorr * dr[1], xl2 = vp[2] + dcorr * dr[2];
-    gT[0] = g[0] * xl0; gT[1] = g[0] * xl1; gT[2] = g[0] * xl2; gT[3] = g[0];
-    gT[4] = g[1] * xl0; gT[5] = g[1] * xl1; gT[6] = g[1] * xl2; gT[7] = g[1];
-    gT[8] = g[2] * xl0; gT[9] = g[2] * xl1; gT[10] = g[2] * xl2; gT[11] = g[2];
+    // kept factored (6 values, not 12) until the block reduction: gT = [g, xl], dL/d[R|t]_{a,b} = g_a * [xl, 1]_b
+    gT[0] = g[0]; gT[1] = g[1]; gT[2] = g[2]; gT[3] = xl0; gT[4] = xl1; gT[5] = xl2;
+  }
+}
+
+// Per-scan sums of the 12 pose-gradient values g_a * [xl, 1]_b of the 256 points of a block (gx = [g, xl] of this
+// lane; pcol0 = first pose slot of this block's partial column).  The lanes are counting-sorted by scan id (wave ballots + a tiny prefix), staged in LDS in that
+// order and every (scan, value) pair is summed by one thread over its contiguous segment: ~25 additions per pair
+// instead of a 256-lane tree per scan, and a fixed order (wave, lane) => bitwise reproducible.  Scans absent from the
+// block keep the zeros the caller put into the workspace.
+constexpr int kPoseRow = 13;             // doubles per staged point: 12 + 1 pad (conflict-free 8-B LDS stores)
+constexpr int kMaxBlockScans = 64;       // more distinct scans in one block: per-scan tree reduction instead
+
+__device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool active, const double* gx, int scan,
+                                                  double* lds, double* __restrict__ pcol0) {
+  constexpr int NW = kBlock / kWave;
+  __shared__ double s_val[kBlock * kPoseRow];
+  __shared__ int s_cnt[NW][kMaxBlockScans];
+  __shared__ int s_start[kMaxBlockScans + 1];
+  __shared__ int s_range[2];
+  const int64_t rs = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  if (tid == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
+  __syncthreads();
+  const bool ok = active && scan >= 0 && scan < in.n_scans;
+  if (ok) { atomicMin(&s_range[0], scan); atomicMax(&s_range[1], scan); }
+  __syncthreads();
+  const int s_lo = s_range[0], s_hi = s_range[1];
+  if (s_hi < s_lo) return;                                  // block-uniform: nothing to add
+  const int ns = s_hi - s_lo + 1;
+  if (ns > kMaxBlockScans) {
+    for (int s = s_lo; s <= s_hi; ++s) {
+      double t[12];
+      const bool mine = ok && scan == s;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) t[q] = mine ? gx[q >> 2] * ((q & 3) == 3 ? 1.0 : gx[3 + (q & 3)]) : 0.0;
+      block_sum<12>(t, lds);
+      if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) pcol0[(s * 12 + q) * rs] = t[q];
+      }
+    }
+    return;
+  }
+  const int r = ok ? scan - s_lo : -1;
+  int rank_in_wave = 0;
+  for (int q = 0; q < ns; ++q) {
+    const unsigned long long m = __ballot(r == q);
+    if (lane == 0) s_cnt[wave][q] = __popcll(m);
+    if (r == q) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (tid <= ns) {                                          // s_start[ns] = number of contributing lanes
+    int start = 0;
+    for (int q = 0; q < tid; ++q)
+      for (int w = 0; w < NW; ++w) start += s_cnt[w][q];
+    s_start[tid] = start;
+  }
+  __syncthreads();
+  if (ok) {
+    int pos = s_start[r] + rank_in_wave;
+    for (int w = 0; w < wave; ++w) pos += s_cnt[w][r];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) s_val[pos * kPoseRow + q] = gx[q >> 2] * ((q & 3) == 3 ? 1.0 : gx[3 + (q & 3)]);
+  }
+  __syncthreads();
+  for (int item = tid; item < ns * 12; item += kBlock) {
+    const int rr = item / 12, q = item - rr * 12;
+    double acc = 0.0;
+    for (int p = s_start[rr]; p < s_start[rr + 1]; ++p) acc += s_val[p * kPoseRow + q];
+    pcol0[((s_lo + rr) * 12 + q) * rs] = acc;
   }
 }
 
@@ -270,27 +338,7 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
     for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k)
       if (k < P) { pcol[k * rs] = v[k]; pcol[(P + k) * rs] = v[DC_MAX_MODEL_TERMS + k]; }
   }
-  if (want_pose) {
-    // only the scans present in this block are reduced (scan-major order: one or two; Morton order: most of them);
-    // the others keep the zeros the caller put into the workspace
-    __shared__ int s_range[2];
-    if (threadIdx.x == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
-    __syncthreads();
-    if (active) { atomicMin(&s_range[0], scan); atomicMax(&s_range[1], scan); }
-    __syncthreads();
-    const int s_lo = s_range[0], s_hi = s_range[1] < in.n_scans ? s_range[1] : in.n_scans - 1;
-    for (int s = s_lo; s <= s_hi; ++s) {
-      double t[12];
-      const bool mine = active && scan == s;
-#pragma unroll
-      for (int q = 0; q < 12; ++q) t[q] = mine ? gT[q] : 0.0;
-      block_sum<12>(t, lds);
-      if (threadIdx.x == 0) {
-#pragma unroll
-        for (int q = 0; q < 12; ++q) pcol[(2 * P + s * 12 + q) * rs] = t[q];
-      }
-    }
-  }
+  if (want_pose) reduce_pose_grads(in, active, gT, scan, lds, pcol + 2 * P * rs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,11 +359,11 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
   const int64_t blk = xcd_block(nblocks);
   ModelParams mp;
   load_model(in, mp);
-  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[6];
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) gT[k] = 0.0;
+  for (int k = 0; k < 6; ++k) gT[k] = 0.0;
   int scan = -1;
   bool active = false;
   if (blk >= 0) {
@@ -485,11 +533,11 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_tiled_kernel(
   __syncthreads();
   ModelParams mp;
   load_model(in, mp);
-  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[6];
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) gT[k] = 0.0;
+  for (int k = 0; k < 6; ++k) gT[k] = 0.0;
   int scan = -1;
   bool active = false;
   if (blk >= 0) {
@@ -541,11 +589,11 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
   ModelParams mp;
   load_model(in, mp);
-  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[12];
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[6];
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) gT[k] = 0.0;
+  for (int k = 0; k < 6; ++k) gT[k] = 0.0;
   int scan = -1;
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool active = j < n;
@@ -898,7 +946,8 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
                          csr_ptr, csr_src, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc); \
     else \
     { \
-      if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      if (want_pose_grad && want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      else if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, false, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
       else if (want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
       else hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, false, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
     } \

@@ -66,10 +66,8 @@ class SequencePlan:
 
         # ---- layout: Morton order of the initial global cloud ----------------------------------
         ps0 = ops.PointSet(vps if bool(vps.any()) else None, dirs, depth, inc, lmask, scan_id)
-        self.ps_scan_major = ps0           # pose gradients are reduced in scan-major order (one or two scans per block)
         P0 = self.poses12(poses)
         x0 = ops.points_fwd(ps0, P0)
-        self.rank32 = None
         if spatial_sort and self.n > 1:
             order = ops.spatial_order(x0).long()
             if degree_sort:
@@ -93,7 +91,6 @@ class SequencePlan:
             scan_id = scan_id[order].contiguous()
             mask = None if mask is None else mask[order].contiguous()
             self.order, self.rank = order, rank
-            self.rank32 = rank.to(torch.int32).contiguous()
         else:
             self.order = self.rank = None
         if not bool(vps.any()):
@@ -162,16 +159,8 @@ class SequencePlan:
         if nt:
             need(w, (nt,), dtype=torch.float64, name='w', device=self.device)
             need(exponent, (nt,), dtype=torch.float64, name='exponent', device=self.device)
-        two_pass = want_grad and want_pose and self.rank32 is not None
-        check(lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad and not two_pass),
+        check(lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
                                      int(want_exponent), int(want_pose), ptr(out), stream_ptr()), 'dc_sequence_eval')
-        if two_pass:
-            # pose gradients: the fused kernel only gathers dL/dx (Morton order); the per-scan sums are then formed by
-            # dc_points_bwd over the scan-major inputs, where a block of 256 points sees one or two scans
-            kind = self.model_kind if nt else None
-            g, _ = ops.consistency_bwd(self.x, self.rec, self.csr_ptr, self.csr_src, want_grad_points=True, qfmt=self.qfmt)
-            ops.points_bwd(g, self.ps_scan_major, poses12, kind, w, exponent, want_exponent=want_exponent, want_pose=True,
-                           perm=self.rank32, out=out[2:])
         self.version += 1
         return out
 
@@ -205,10 +194,6 @@ class SequencePlan:
     def backward(self, want_exponent=False, want_pose=False):
         """Gradients of the *sum* of the pointwise loss over the mask w.r.t. (w [P], exponent [P], [R|t] [S,3,4])."""
         kind = self.model_kind if self.w is not None else None
-        if want_pose and self.rank32 is not None:
-            g, _ = ops.consistency_bwd(self.x, self.rec, self.csr_ptr, self.csr_src, want_grad_points=True, qfmt=self.qfmt)
-            return ops.points_bwd(g, self.ps_scan_major, self.P, kind, self.w, self.e, want_exponent=want_exponent,
-                                  want_pose=True, perm=self.rank32)
         _, grads = ops.consistency_bwd(self.x, self.rec, self.csr_ptr, self.csr_src, self.ps, self.P, kind, self.w, self.e,
                                        want_exponent=want_exponent, want_pose=want_pose, partials=self.partials,
                                        qfmt=self.qfmt, lane_perm=self.lane_perm)

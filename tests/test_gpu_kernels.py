@@ -277,6 +277,49 @@ def test_pose_gradients_golden(golden, dev, tag, loss):
     np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
 
 
+def test_points_bwd_matches_fused_epilogue(golden, dev):
+    """dc_points_bwd (given dL/dx) == the epilogue fused into the hot backward kernel; `perm` reads the rows of
+    dL/dx through a permutation (rows kept in another point order)."""
+    from depth_correction_amd import ops
+    g = golden('room_k10')
+    r = _run_sequence(g, dev, torch.float64, prefix='poses_')
+    scans = scans_from_golden(g, torch.float64)
+    ps = concat_scans(scans, dev)
+    w, e = t(g['poses_w'].reshape(-1), dev), t(g['poses_exponent'].reshape(-1), dev)
+    P = poses12(g['poses'], dev)
+    model = str(g['poses_model'])
+    gw, ge, gT = ops.points_bwd(r['gp'], ps, P, model, w, e, want_exponent=True, want_pose=True)
+    for a, b in ((gw, r['gw']), (ge, r['ge']), (gT, r['gT'])):
+        np.testing.assert_allclose(npy(a), npy(b), rtol=1e-12, atol=1e-12 * float(b.abs().max()))
+    n = ps.n
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(3)).to(dev)
+    shuffled = torch.empty_like(r['gp'])
+    shuffled[perm] = r['gp']                                   # row perm[i] holds the gradient of point i
+    gw2, ge2, gT2 = ops.points_bwd(shuffled, ps, P, model, w, e, want_exponent=True, want_pose=True,
+                                   perm=perm.to(torch.int32))
+    assert torch.equal(gw2, gw) and torch.equal(ge2, ge) and torch.equal(gT2, gT)
+
+
+@pytest.mark.parametrize('n_scans', [1, 7, 300])
+def test_pose_gradient_per_scan_sums(dev, n_scans):
+    """Per-scan reduction of dL/d[R|t] = sum_j g_j [xl_j, 1]^T: few scans per block (sorted segments), and more than
+    64 scans inside one block (tree reduction per scan), scan ids in arbitrary order."""
+    from depth_correction_amd import ops
+    rng = np.random.default_rng(n_scans)
+    n = 1000
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    depth = rng.uniform(1, 20, size=(n, 1)); vps = rng.normal(size=(n, 3)) * 0.1
+    sid = rng.integers(0, n_scans, n).astype(np.int32)
+    gx = rng.normal(size=(n, 3))
+    ps = ops.PointSet(t(vps, dev), t(dirs, dev), t(depth, dev), None, None, t(sid, dev))
+    P = torch.eye(4, dtype=torch.float64)[:3].reshape(1, 12).repeat(n_scans, 1).contiguous().to(dev)
+    _, _, gT = ops.points_bwd(t(gx, dev), ps, P, None, None, None, want_pose=True)
+    xl1 = np.concatenate([vps + depth * dirs, np.ones((n, 1))], 1)
+    ref = np.zeros((n_scans, 3, 4))
+    np.add.at(ref, sid, gx[:, :, None] * xl1[:, None, :])
+    np.testing.assert_allclose(npy(gT).reshape(n_scans, 3, 4), ref, rtol=1e-12, atol=1e-12)
+
+
 def test_exponent_gradient_vs_oracle_autograd(golden, dev):
     g = golden('room_k10')
     r = _run_sequence(g, dev, torch.float64)
