@@ -59,7 +59,19 @@ _SIGNATURES = {
     'dc_p2plane_partial_count': (_i64, [_i64]),
     'dc_p2plane_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'dc_p2plane_sequence': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+class IcpScan(ctypes.Structure):
+    """dcIcpScan of include/dc_hip.h."""
+    _fields_ = [('vps', _vp), ('dirs', _vp), ('depth', _vp), ('inc', _vp), ('lmask', _vp), ('normals', _vp)]
+
+
+class IcpPair(ctypes.Structure):
+    """dcIcpPair of include/dc_hip.h."""
+    _fields_ = [('scan_a', ctypes.c_int32), ('scan_b', ctypes.c_int32), ('idx_a', _vp), ('idx_b', _vp),
+                ('m', ctypes.c_int64), ('weight', ctypes.c_double)]
 
 
 class SequenceDesc(ctypes.Structure):

@@ -151,6 +151,31 @@ __global__ __launch_bounds__(kBlock) void p2plane_reduce_kernel(const double* __
   if (dst >= 0) out[dst] = v[0];
 }
 
+// Sequence layout: out = { loss, dw[P], dexponent[P], d[R|t][S,12] }; every pair ADDS weight * its sums (pairs run
+// one after the other on the stream, one thread per slot => fixed order).  Block 0 folds both directed sums into the
+// loss slot; block 1 is idle.
+__global__ __launch_bounds__(kBlock) void p2plane_reduce_seq_kernel(const double* __restrict__ partials, int64_t n_rows,
+                                                                    int n_terms, double weight, int scan_a, int scan_b,
+                                                                    double* __restrict__ out) {
+  __shared__ double lds[kBlock / kWave];
+  const int a = blockIdx.x;
+  if (a == 1) return;
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < n_rows; r += kBlock)
+    s += partials[r * kIcpAcc + a] + (a == 0 ? partials[r * kIcpAcc + 1] : 0.0);
+  double v[1] = {s};
+  block_sum<1>(v, lds);
+  if (threadIdx.x != 0) return;
+  int dst = -1;
+  const int pw = 2, pe = 2 + DC_MAX_MODEL_TERMS, pa = 2 + 2 * DC_MAX_MODEL_TERMS, pb = pa + 12;
+  if (a == 0) dst = 0;
+  else if (a < pe) { if (a - pw < n_terms) dst = 1 + (a - pw); }
+  else if (a < pa) { if (a - pe < n_terms) dst = 1 + n_terms + (a - pe); }
+  else if (a < pb) dst = 1 + 2 * n_terms + 12 * scan_a + (a - pa);
+  else dst = 1 + 2 * n_terms + 12 * scan_b + (a - pb);
+  if (dst >= 0) out[dst] += weight * v[0];
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -183,6 +208,43 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
     hipLaunchKernelGGL((p2plane_pair_kernel<double>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, idxA, idxB, m, partials_ws);
   else return DC_ERR_DTYPE;
   hipLaunchKernelGGL(p2plane_reduce_kernel, dim3(kIcpAcc), dim3(kBlock), 0, stream, partials_ws, rows, n_terms, out);
+  err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                        const double* poses, int model_kind, int n_terms, const double* w, const double* e,
+                        double* partials_ws, double* out, hipStream_t stream) {
+  if (n_scans < 0 || n_pairs < 0 || (n_scans > 0 && !scans) || (n_pairs > 0 && !pairs) || !out) return DC_ERR_ARG;
+  if (dtype != DC_F32 && dtype != DC_F64) return DC_ERR_DTYPE;
+  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
+  if (model_kind != DC_MODEL_NONE && (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !w || !e)) return DC_ERR_ARG;
+  if (model_kind == DC_MODEL_NONE) n_terms = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    const dcIcpPair& q = pairs[p];
+    if (q.scan_a < 0 || q.scan_a >= n_scans || q.scan_b < 0 || q.scan_b >= n_scans || q.scan_a == q.scan_b) return DC_ERR_ARG;
+    if (q.m < 0 || (q.m > 0 && (!q.idx_a || !q.idx_b || !poses || !partials_ws))) return DC_ERR_ARG;
+    for (int side = 0; side < 2; ++side) {
+      const dcIcpScan& c = scans[side ? q.scan_b : q.scan_a];
+      if (!c.dirs || !c.depth || !c.normals || (model_kind != DC_MODEL_NONE && !c.inc)) return DC_ERR_ARG;
+    }
+  }
+  hipError_t err = hipMemsetAsync(out, 0, (size_t)(1 + 2 * n_terms + 12 * n_scans) * sizeof(double), stream);
+  if (err != hipSuccess) return (int)err;
+  for (int p = 0; p < n_pairs; ++p) {
+    const dcIcpPair& q = pairs[p];
+    if (q.m == 0) continue;
+    const dcIcpScan &a = scans[q.scan_a], &b = scans[q.scan_b];
+    ScanView A{a.vps, a.dirs, a.depth, a.inc, a.lmask, a.normals}, B{b.vps, b.dirs, b.depth, b.inc, b.lmask, b.normals};
+    const double *poseA = poses + 12 * q.scan_a, *poseB = poses + 12 * q.scan_b;
+    const int64_t rows = (q.m + kBlock - 1) / kBlock;
+    if (dtype == DC_F32)
+      hipLaunchKernelGGL((p2plane_pair_kernel<float>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, q.idx_a, q.idx_b, q.m, partials_ws);
+    else
+      hipLaunchKernelGGL((p2plane_pair_kernel<double>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, q.idx_a, q.idx_b, q.m, partials_ws);
+    hipLaunchKernelGGL(p2plane_reduce_seq_kernel, dim3(kIcpAcc), dim3(kBlock), 0, stream, partials_ws, rows, n_terms,
+                       q.weight, q.scan_a, q.scan_b, out);
+  }
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
 }

@@ -186,54 +186,78 @@ def point_to_point_dist(clouds: list, icp_inlier_ratio=0.5, masks=None, differen
     return torch.as_tensor(total / n_pairs)
 
 
-class _P2PlanePair(torch.autograd.Function):
-    """sum12 + sum21 of one scan pair (dc_p2plane_pair): forward and backward come out of the same launch."""
+class _P2PlaneSequence(torch.autograd.Function):
+    """icp_loss of one sequence (all consecutive pairs) through dc_p2plane_sequence: forward and backward come out
+    of the same host call."""
 
     @staticmethod
-    def forward(ctx, w, exponent, pose_a, pose_b, psa, na, psb, nb, idx_a, idx_b, kind):
-        P = lambda T: T.detach().to(torch.float64)[:3, :].reshape(12).contiguous()
+    def forward(ctx, w, exponent, poses, plan, kind):
+        P12 = poses.detach().to(torch.float64)[:, :3, :].reshape(-1, 12).contiguous()
         wv = None if w is None else w.detach().reshape(-1).to(torch.float64).contiguous()
         ev = None if exponent is None else exponent.detach().reshape(-1).to(torch.float64).contiguous()
-        sums, dw, de, dTa, dTb = ops.p2plane_pair(psa, na, psb, nb, P(pose_a), P(pose_b), idx_a, idx_b, kind, wv, ev)
-        ctx.save_for_backward(dw, de, dTa, dTb)
-        ctx.meta = (None if w is None else (w.shape, w.dtype), pose_a.dtype,
+        out = plan.eval(P12, kind, wv, ev)
+        ctx.save_for_backward(out)
+        ctx.meta = (None if w is None else (w.shape, w.dtype), poses.dtype, poses.shape[0],
                     exponent.shape if isinstance(exponent, torch.Tensor) else None)
-        return sums.sum()
+        return out[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        dw, de, dTa, dTb = ctx.saved_tensors
-        wmeta, pdt, eshape = ctx.meta
-        pad = lambda d: torch.cat([g * d, torch.zeros((1, 4), dtype=d.dtype, device=d.device)]).to(pdt)
-        gw = (g * dw).reshape(wmeta[0]).to(wmeta[1]) if (wmeta is not None and ctx.needs_input_grad[0]) else None
-        ge = (g * de).reshape(eshape) if (eshape is not None and ctx.needs_input_grad[1]) else None
-        return (gw, ge, pad(dTa) if ctx.needs_input_grad[2] else None, pad(dTb) if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None)
+        out, = ctx.saved_tensors
+        wmeta, pdt, ns, eshape = ctx.meta
+        nt = (out.numel() - 1 - 12 * ns) // 2
+        gw = ge = gT = None
+        if wmeta is not None and ctx.needs_input_grad[0]:
+            gw = (g * out[1:1 + nt]).reshape(wmeta[0]).to(wmeta[1])
+        if eshape is not None and ctx.needs_input_grad[1]:
+            ge = (g * out[1 + nt:1 + 2 * nt]).reshape(eshape)
+        if ctx.needs_input_grad[2]:
+            gT = torch.zeros((ns, 4, 4), dtype=torch.float64, device=out.device)
+            gT[:, :3, :] = (g * out[1 + 2 * nt:]).reshape(ns, 3, 4)
+            gT = gT.to(pdt)
+        return gw, ge, gT, None, None
 
 
-def _fused_icp_sequence(seq_clouds, seq_poses, model, seq_masks):
-    """Point-to-plane loss of one sequence through dc_p2plane_pair (clouds in the sensor frame + poses + model)."""
-    kind = getattr(model, 'kernel_kind', None) if model is not None else None
-    w = model.w if kind else None
-    e = model.exponent if kind else None
-    sets = []
+def _icp_sequence_plan(seq_clouds, seq_masks, with_model):
+    """ops.IcpSequence of (clouds, correspondences), cached on the first correspondence tensor: an optimisation loop
+    passes the same clouds and masks every iteration (train.py:212-215)."""
+    holder = seq_masks[0][0] if len(seq_masks) and isinstance(seq_masks[0][0], torch.Tensor) else None
+    key = tuple(id(t) for c in seq_clouds for t in (c.vps, c.dirs, c.depth, c.inc_angles, c.normals, c.mask)) \
+        + tuple(id(m) for pair in seq_masks for m in pair) + (bool(with_model),)
+    cached = getattr(holder, '_dc_icp_plan', None) if holder is not None else None
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    scans = []
     for c in seq_clouds:
         n = len(c)
         cont = lambda t: t.detach().expand(n, t.shape[-1]).contiguous() if t.dim() == 2 else t.detach().contiguous()
-        sets.append((ops.PointSet(cont(c.vps), cont(c.dirs), cont(c.depth), None if c.inc_angles is None else cont(c.inc_angles),
-                                  c.mask), cont(c.normals.to(c.dirs.dtype))))
-    total = 0.0
-    n_pairs = len(seq_clouds) - 1
-    for i in range(n_pairs):
-        m1, m2 = seq_masks[i]
-        m1 = torch.as_tensor(m1, device=sets[i][1].device)
+        vps = None if not bool(c.vps.any()) else cont(c.vps)
+        inc = cont(c.inc_angles) if (with_model and c.inc_angles is not None) else None
+        scans.append((ops.PointSet(vps, cont(c.dirs), cont(c.depth), inc, c.mask if with_model else None),
+                      cont(c.normals.to(c.dirs.dtype))))
+    dev = scans[0][1].device
+    pairs = []
+    for i, (m1, m2) in enumerate(seq_masks):
+        m1 = torch.as_tensor(m1, device=dev)
         ia = (torch.nonzero(m1).reshape(-1) if m1.dtype == torch.bool else m1).to(torch.int32).contiguous()
-        ib = torch.as_tensor(m2, device=ia.device).to(torch.int32).contiguous()
+        ib = torch.as_tensor(m2, device=dev).to(torch.int32).contiguous()
         assert len(ia) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
-        s = _P2PlanePair.apply(w, e, seq_poses[i], seq_poses[i + 1], sets[i][0], sets[i][1], sets[i + 1][0],
-                               sets[i + 1][1], ia, ib, kind)
-        total = total + 0.5 * s / len(ia)
-    return total / n_pairs
+        pairs.append((i, i + 1, ia, ib))
+    plan = ops.IcpSequence(scans, pairs, with_model=with_model)
+    plan._refs = (list(seq_clouds), list(seq_masks))          # the ids in `key` stay valid while the plan lives
+    if holder is not None:
+        holder._dc_icp_plan = (key, plan)
+    return plan
+
+
+def _fused_icp_sequence(seq_clouds, seq_poses, model, seq_masks):
+    """Point-to-plane loss of one sequence through dc_p2plane_sequence (clouds in the sensor frame + poses + model)."""
+    kind = getattr(model, 'kernel_kind', None) if model is not None else None
+    w = model.w if kind else None
+    e = model.exponent if kind else None
+    plan = _icp_sequence_plan(seq_clouds, seq_masks, bool(kind))
+    poses = seq_poses if isinstance(seq_poses, torch.Tensor) else torch.stack(list(seq_poses))
+    return _P2PlaneSequence.apply(w, e, poses, plan, kind)
 
 
 def icp_loss(clouds, poses=None, model=None, masks=None, **kwargs):

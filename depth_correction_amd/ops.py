@@ -14,7 +14,7 @@ from ._native import lib, check, need, ptr, stream_ptr, dtype_code
 
 __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
-    'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair',
+    'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'IcpSequence',
     'as_index32',
 ]
 
@@ -474,3 +474,55 @@ def p2plane_pair(psa, normals_a, psb, normals_b, pose_a, pose_b, idx_a, idx_b, m
           'dc_p2plane_pair')
     return out[:2], out[2:2 + nt], out[2 + nt:2 + 2 * nt], out[2 + 2 * nt:14 + 2 * nt].reshape(3, 4), \
         out[14 + 2 * nt:].reshape(3, 4)
+
+
+class IcpSequence:
+    """Descriptors of one sequence of scans and its pair correspondences for dc_p2plane_sequence, filled once;
+    ``eval`` is then one host call per evaluation.  ``scans``: list of (PointSet, normals [n,3]); ``pairs``: list of
+    (scan_a, scan_b, idx_a int32 [m], idx_b int32 [m]); pair weights follow icp_loss (loss.py:391-403):
+    0.5 / (m * n_pairs)."""
+
+    def __init__(self, scans, pairs, with_model=True):
+        ps0 = scans[0][0]
+        self.device, self.dtype, self.n_scans = ps0.device, ps0.dtype, len(scans)
+        self.with_model = bool(with_model)
+        self._keep = []
+        self.scan_desc = (nv.IcpScan * max(len(scans), 1))()
+        for d, (ps, normals) in zip(self.scan_desc, scans):
+            assert ps.device == self.device and ps.dtype == self.dtype
+            need(normals, (ps.n, 3), dtype=self.dtype, name='normals', device=self.device)
+            if with_model and ps.inc is None:
+                raise ValueError('the model needs incidence angles')
+            self._keep.append((ps, normals))
+            d.vps, d.dirs, d.depth, d.inc = ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc)
+            d.lmask, d.normals = ptr(ps.lmask), ptr(normals)
+        self.pair_desc = (nv.IcpPair * max(len(pairs), 1))()
+        self.n_pairs, max_m = len(pairs), 0
+        for d, (a, b, idx_a, idx_b) in zip(self.pair_desc, pairs):
+            need(idx_a, (None,), dtype=torch.int32, name='idx_a', device=self.device)
+            m = idx_a.shape[0]
+            need(idx_b, (m,), dtype=torch.int32, name='idx_b', device=self.device)
+            if not (0 <= a < self.n_scans and 0 <= b < self.n_scans and a != b):
+                raise ValueError('pair (%d, %d) outside the sequence' % (a, b))
+            self._keep.append((idx_a, idx_b))
+            d.scan_a, d.scan_b, d.idx_a, d.idx_b, d.m = int(a), int(b), ptr(idx_a), ptr(idx_b), m
+            d.weight = 0.5 / (max(m, 1) * len(pairs))
+            max_m = max(max_m, m)
+        self.part = torch.empty((lib().dc_p2plane_partial_count(max_m),), dtype=torch.float64, device=self.device)
+
+    def eval(self, poses12, model_kind=None, w=None, e=None, out=None):
+        """out fp64 [1 + 2P + 12 S] = {loss, dloss/dw, dloss/dexponent, dloss/d[R|t]}."""
+        kind, nt, w, e = _model_args(model_kind, w, e, self._keep[0][0]) if self.n_scans else (0, 0, None, None)
+        if kind != 0 and not self.with_model:
+            raise ValueError('sequence was built without incidence angles')
+        need(poses12, (self.n_scans, 12), dtype=torch.float64, name='poses[S,12]', device=self.device)
+        n_out = 1 + 2 * nt + 12 * self.n_scans
+        if out is None:
+            out = torch.empty((n_out,), dtype=torch.float64, device=self.device)
+        else:
+            need(out, (n_out,), dtype=torch.float64, name='out', device=self.device)
+        check(lib().dc_p2plane_sequence(ctypes.cast(self.scan_desc, ctypes.c_void_p), self.n_scans,
+                                        ctypes.cast(self.pair_desc, ctypes.c_void_p), self.n_pairs,
+                                        0 if self.dtype == torch.float32 else 1, ptr(poses12), kind, nt, ptr(w), ptr(e),
+                                        ptr(self.part), ptr(out), stream_ptr()), 'dc_p2plane_sequence')
+        return out

@@ -172,6 +172,32 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
                     const int32_t* idxB, int64_t m, int want_exponent_grad, int want_pose_grad, double* partials_ws,
                     double* out, dcStream_t stream);
 
+/* The same for a whole sequence of scans in ONE host call (icp_loss loss.py:373-403 loops over consecutive pairs,
+ * :391-399, and averages them): pair p adds weight_p * (sum12 + sum21) and its gradients, so with
+ * weight_p = 0.5 / (m_p * n_pairs) out[0] is the reference's loss of the sequence.
+ *   scans / pairs: HOST arrays of descriptors holding device pointers (idx_a / idx_b index the local points of
+ *                  scans scan_a / scan_b, scan_a != scan_b); poses fp64 [n_scans, 12] device;
+ *   out fp64 [1 + 2 P + 12 n_scans] = { loss, dloss/dw [P], /dexponent [P], /d[R|t] [n_scans, 12] };
+ *   partials_ws fp64 [dc_p2plane_partial_count(max_p m_p)] (pairs run one after the other on the stream). */
+typedef struct dcIcpScan {
+  const void* vps;            /* [n,3] or NULL (sensor at the origin) */
+  const void* dirs;           /* [n,3] */
+  const void* depth;          /* [n,1] */
+  const void* inc;            /* [n,1] incidence angles (NULL without a model) */
+  const uint8_t* lmask;       /* [n] local mask gating the model, or NULL */
+  const void* normals;        /* [n,3] local normals */
+} dcIcpScan;
+typedef struct dcIcpPair {
+  int32_t scan_a, scan_b;
+  const int32_t* idx_a;       /* [m] */
+  const int32_t* idx_b;       /* [m] */
+  int64_t m;
+  double weight;
+} dcIcpPair;
+int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                        const double* poses, int model_kind, int n_terms, const double* w, const double* e,
+                        double* partials_ws, double* out, dcStream_t stream);
+
 /* ---- whole-sequence evaluation + optimiser step (train.py:220-312 per-iteration body for one sequence) ----------
  * The caller fills a descriptor with the device arrays of one sequence (SequencePlan in Python) once; every
  * iteration is then ONE host call that launches dc_points_fwd, dc_consistency_fwd and dc_consistency_bwd.
