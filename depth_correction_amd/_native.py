@@ -41,9 +41,12 @@ _SIGNATURES = {
     'dc_features_fwd': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
     'dc_features_bwd': (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp,
-                                  _vp, _vp, _vp]),
-    'dc_consistency_bwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    'dc_block_table_slots': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    'dc_block_table_workspace_bytes': (_sz, [_i64]),
+    'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
+                                  _vp, _vp, _vp, _vp]),
+    'dc_consistency_bwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'dc_mask_bounds': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _f64, _f64, _vp, _vp]),
     'dc_valid_count': (_i32, [_vp, _i64, _i32, _vp, _vp]),
@@ -61,6 +64,12 @@ _SIGNATURES = {
                                _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     'dc_p2plane_sequence': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+class BlockTableDesc(ctypes.Structure):
+    """dcBlockTable of include/dc_hip.h."""
+    _fields_ = [('blk_ptr', _vp), ('blk_ids', _vp), ('slot_ptr', _vp), ('loc', _vp), ('max_rows', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
 
 
 class IcpScan(ctypes.Structure):
@@ -83,7 +92,7 @@ class SequenceDesc(ctypes.Structure):
                 ('n_centres', ctypes.c_int64), ('x', _vp), ('rec', _vp),
                 ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp)]
 
 
 def lib_path():

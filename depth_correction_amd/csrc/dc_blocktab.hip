@@ -1,0 +1,216 @@
+// Block-local gather tables for the hot kernels (gfx950).
+//
+// The forward kernel gathers the K neighbour rows of every point (depth_cloud.py:303-304 `points[neighbors]`), the
+// backward kernel the records of every centre whose neighbourhood contains the point (autograd's scatter of the same
+// index).  In Morton order the 256 points of a block reference only ~1.5 x 256 DISTINCT rows (375 of 2560 references
+// at K = 10), yet a per-lane gather costs one L1 tag lookup per reference, and the L1 serves one lookup per cycle --
+// that, not HBM and not the ALUs, bounded both kernels (rocprofv3: TCP_TOTAL_CACHE_ACCESSES ~ 1.06 per CU cycle).
+//
+// A block table, built once per neighbourhood set, lists for every block of 256 rows the distinct rows it
+// references (`blk_ids[blk_ptr[b] .. blk_ptr[b+1])`, ascending) and replaces every reference by a 16-bit position in
+// that list, stored slot-major (`loc[(slot_ptr[b] + s) * 256 + lane]`, 0xFFFF = empty slot) so that a wavefront reads
+// its slot s with one coalesced 128-B load.  The kernels stage the distinct rows into LDS once per block and gather
+// from LDS.
+//
+// Build: keys (block << 32 | id) of all references -> radix sort -> heads of runs -> prefix sum -> scatter.
+#include <cstring>
+#include <cstdlib>
+#include "dc_common.h"
+#include "../../include/dc_hip.h"
+#include "dc_device.h"
+#include "dc_hostutil.h"
+#include <rocprim/rocprim.hpp>
+
+namespace dc {
+
+constexpr uint64_t kNoKey = ~0ull;
+
+// slots per block: the longest reference list among the block's rows (fixed k: k)
+__global__ __launch_bounds__(kBlock) void bt_slot_count_kernel(const int32_t* __restrict__ row_ptr, int64_t n_rows, int k,
+                                                               int32_t* __restrict__ cnt) {
+  __shared__ int s_max;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int deg = 0;
+  if (r < n_rows) deg = row_ptr ? row_ptr[r + 1] - row_ptr[r] : k;
+  for (int off = kWave / 2; off > 0; off >>= 1) deg = max(deg, __shfl_down(deg, off, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(&s_max, deg);
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s_max;
+}
+
+// exclusive prefix sum of cnt[0..m) into out[0..m]; one block (m is the number of 256-row blocks)
+__global__ __launch_bounds__(1024) void bt_scan_kernel(const int32_t* __restrict__ cnt, int64_t m, int32_t* __restrict__ out) {
+  __shared__ int s_part[1024];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < m; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < m ? cnt[i] : 0;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < m) out[i] = s_carry + s_part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry += s_part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[m] = s_carry;
+}
+
+// CSR lists: the row every reference belongs to (references beyond row_ptr[n_rows] keep -1)
+__global__ __launch_bounds__(kBlock) void bt_row_of_kernel(const int32_t* __restrict__ row_ptr, int64_t n_rows,
+                                                           int32_t* __restrict__ row_of) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n_rows) return;
+  for (int32_t e = row_ptr[r]; e < row_ptr[r + 1]; ++e) row_of[e] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(kBlock) void bt_keys_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ row_of,
+                                                         int64_t n_refs, int k, uint64_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n_refs) return;
+  const int64_t row = row_of ? (int64_t)row_of[e] : e / k;
+  const int32_t id = ids[e];
+  keys[e] = (row >= 0 && id >= 0) ? (((uint64_t)(row / kBlock)) << 32) | (uint32_t)id : kNoKey;
+  vals[e] = (uint32_t)e;
+}
+
+__global__ __launch_bounds__(kBlock) void bt_heads_kernel(const uint64_t* __restrict__ skeys, int64_t n_refs,
+                                                          uint32_t* __restrict__ heads) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_refs) return;
+  const uint64_t key = skeys[p];
+  heads[p] = (key != kNoKey && (p == 0 || skeys[p - 1] != key)) ? 1u : 0u;
+}
+
+// blk_ptr[b] = number of distinct (block, id) pairs of the blocks before b
+__global__ __launch_bounds__(kBlock) void bt_blk_ptr_kernel(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ rank1,
+                                                            int64_t n_refs, int64_t n_blocks, int32_t* __restrict__ blk_ptr) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b > n_blocks) return;
+  const uint64_t want = (uint64_t)b << 32;          // first key of block b (invalid keys are larger than any block's)
+  int64_t lo = 0, hi = n_refs;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (skeys[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  blk_ptr[b] = lo == 0 ? 0 : (int32_t)rank1[lo - 1];
+}
+
+__global__ __launch_bounds__(kBlock) void bt_scatter_kernel(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                                                            const uint32_t* __restrict__ heads, const uint32_t* __restrict__ rank1,
+                                                            const int32_t* __restrict__ row_of, const int32_t* __restrict__ row_ptr,
+                                                            int64_t n_refs, int k, const int32_t* __restrict__ blk_ptr,
+                                                            const int32_t* __restrict__ slot_ptr, int32_t* __restrict__ blk_ids,
+                                                            uint16_t* __restrict__ loc, int32_t* __restrict__ info) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_refs) return;
+  const uint64_t key = skeys[p];
+  if (key == kNoKey) return;
+  const int64_t b = (int64_t)(key >> 32);
+  const int32_t r = (int32_t)rank1[p] - 1;
+  if (heads[p]) blk_ids[r] = (int32_t)(uint32_t)key;
+  const int32_t local = r - blk_ptr[b];
+  if (local >= 0xFFFF) { atomicMax(&info[2], 1); return; }
+  const int64_t e = svals[p];
+  const int64_t row = row_of ? (int64_t)row_of[e] : e / k;
+  const int64_t slot = row_ptr ? e - row_ptr[row] : e - row * k;
+  loc[((int64_t)slot_ptr[b] + slot) * kBlock + (row & (kBlock - 1))] = (uint16_t)local;
+}
+
+__global__ __launch_bounds__(kBlock) void bt_info_kernel(const int32_t* __restrict__ blk_ptr, int64_t n_blocks,
+                                                         int32_t* __restrict__ info) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b < n_blocks) atomicMax(&info[1], blk_ptr[b + 1] - blk_ptr[b]);
+  if (b == 0) info[0] = blk_ptr[n_blocks];
+}
+
+static inline int64_t blocks_of(int64_t n) { return (n + kBlock - 1) / kBlock; }
+static inline unsigned grid_of(int64_t n) { return (unsigned)(n > 0 ? (n + kBlock - 1) / kBlock : 1); }
+
+}  // namespace dc
+
+using namespace dc;
+
+extern "C" {
+
+int dc_block_table_slots(const int32_t* row_ptr, int64_t n_rows, int k, int32_t* slot_cnt_ws, int32_t* slot_ptr,
+                         hipStream_t stream) {
+  if (n_rows < 0 || !slot_ptr || (!row_ptr && k < 1) || (n_rows > 0 && !slot_cnt_ws)) return DC_ERR_ARG;
+  const int64_t nb = blocks_of(n_rows);
+  if (nb == 0) return (int)hipMemsetAsync(slot_ptr, 0, sizeof(int32_t), stream);
+  hipLaunchKernelGGL(bt_slot_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, stream, row_ptr, n_rows, k, slot_cnt_ws);
+  hipLaunchKernelGGL(bt_scan_kernel, dim3(1), dim3(1024), 0, stream, slot_cnt_ws, nb, slot_ptr);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+size_t dc_block_table_workspace_bytes(int64_t n_refs) {
+  if (n_refs < 0) return 0;
+  const size_t ne = (size_t)(n_refs > 0 ? n_refs : 1);
+  Carver c(nullptr);
+  c.take<uint64_t>(ne); c.take<uint64_t>(ne); c.take<uint32_t>(ne); c.take<uint32_t>(ne);
+  c.take<uint32_t>(ne); c.take<uint32_t>(ne); c.take<int32_t>(ne);
+  size_t sb = 0, cb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  ne, 0, 64, (hipStream_t)0);
+  (void)rocprim::inclusive_scan(nullptr, cb, (uint32_t*)nullptr, (uint32_t*)nullptr, ne, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  c.take<char>(sb > cb ? sb : cb);
+  return c.off + 256;
+}
+
+int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
+                         const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
+                         int32_t* info, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n_rows < 0 || n_refs < 0 || n_slot_rows < 0 || !blk_ptr || !info || (!row_ptr && k < 1)) return DC_ERR_ARG;
+  DC_HIP(hipMemsetAsync(info, 0, 4 * sizeof(int32_t), stream));
+  const int64_t nb = blocks_of(n_rows);
+  if (n_rows == 0 || n_refs == 0) return (int)hipMemsetAsync(blk_ptr, 0, (size_t)(nb + 1) * sizeof(int32_t), stream);
+  if (!ids || !slot_ptr || !blk_ids || !loc || !ws) return DC_ERR_ARG;
+  if (!row_ptr && n_refs != n_rows * (int64_t)k) return DC_ERR_ARG;
+  if (n_refs >= (int64_t)0x7fffffff || n_slot_rows * kBlock >= ((int64_t)1 << 40)) return DC_ERR_UNSUPPORTED;
+  if (ws_bytes < dc_block_table_workspace_bytes(n_refs)) return DC_ERR_WORKSPACE;
+  Carver c(ws);
+  uint64_t* keys = c.take<uint64_t>(n_refs);
+  uint64_t* skeys = c.take<uint64_t>(n_refs);
+  uint32_t* vals = c.take<uint32_t>(n_refs);
+  uint32_t* svals = c.take<uint32_t>(n_refs);
+  uint32_t* heads = c.take<uint32_t>(n_refs);
+  uint32_t* rank1 = c.take<uint32_t>(n_refs);
+  int32_t* row_of = c.take<int32_t>(n_refs);
+  size_t sb = 0, cb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (size_t)n_refs, 0, 64, (hipStream_t)0);
+  (void)rocprim::inclusive_scan(nullptr, cb, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_refs, rocprim::plus<uint32_t>(),
+                                (hipStream_t)0);
+  void* tmp = c.take<char>(sb > cb ? sb : cb);
+  const dim3 block(kBlock);
+  if (row_ptr) {
+    DC_HIP(hipMemsetAsync(row_of, 0xff, (size_t)n_refs * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(bt_row_of_kernel, dim3(grid_of(n_rows)), block, 0, stream, row_ptr, n_rows, row_of);
+  }
+  const int32_t* rows = row_ptr ? row_of : nullptr;
+  DC_HIP(hipMemsetAsync(loc, 0xff, (size_t)n_slot_rows * kBlock * sizeof(uint16_t), stream));
+  hipLaunchKernelGGL(bt_keys_kernel, dim3(grid_of(n_refs)), block, 0, stream, ids, rows, n_refs, k, keys, vals);
+  // all 64 key bits: invalid references carry the all-ones key and sort behind every block
+  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, vals, svals, (size_t)n_refs, 0, 64, stream));
+  hipLaunchKernelGGL(bt_heads_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, n_refs, heads);
+  DC_HIP(rocprim::inclusive_scan(tmp, cb, heads, rank1, (size_t)n_refs, rocprim::plus<uint32_t>(), stream));
+  hipLaunchKernelGGL(bt_blk_ptr_kernel, dim3(grid_of(nb + 1)), block, 0, stream, skeys, rank1, n_refs, nb, blk_ptr);
+  hipLaunchKernelGGL(bt_scatter_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, svals, heads, rank1, rows, row_ptr,
+                     n_refs, k, blk_ptr, slot_ptr, blk_ids, loc, info);
+  hipLaunchKernelGGL(bt_info_kernel, dim3(grid_of(nb)), block, 0, stream, blk_ptr, nb, info);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+}  // extern "C"

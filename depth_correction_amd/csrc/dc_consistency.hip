@@ -11,6 +11,7 @@
 // All arithmetic on chip is fp64 (differences against the centre point are exact, covariances and the
 // eigen-solve keep LAPACK-level accuracy); only storage is T.  No atomics: block partial sums are
 // written to a workspace and reduced in a fixed order, so every result is bitwise reproducible.
+#include <type_traits>
 #include "dc_common.h"
 #include "dc_device.h"
 #include "dc_pointmath.h"
@@ -69,6 +70,39 @@ __device__ __forceinline__ void gather_neighbourhood(const PT* __restrict__ x, c
   }
 }
 
+// Everything of the forward after the neighbourhood moments are gathered: covariance -> smallest eigenpair -> loss,
+// backward record, masked loss / count of this lane (acc2).  Shared by the gather and the LDS-staged kernel.
+template <typename T, typename PT, bool FULL_EIG>
+__device__ __forceinline__ void consistency_point(CovAcc& acc, const typename Pt<PT>::Raw& ci, int64_t i,
+                                                  const uint8_t* __restrict__ mask, const T* __restrict__ offset,
+                                                  const LossParams& lp, const QParams& qp, PT* __restrict__ rec,
+                                                  T* __restrict__ pointwise, T* __restrict__ eigvals, double* acc2) {
+  cov_same_weights(acc);
+  // moments are in raw units (q32: multiples of the resolution); scale once
+  const double u = Pt<PT>::unit(qp), u2 = u * u;
+  double moff[3], cm[3], C[6], D, omega;
+  cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) C[q] *= u2;
+  const bool m = mask ? mask[i] != 0 : true;
+  const double off = offset ? (double)offset[i] : 0.0;
+  double lam0, v0[3], tr, c1, c2, l;
+  if (FULL_EIG) {
+    double lam[3], V[3][3];
+    eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
+    lam0 = lam[0]; v0[0] = V[0][0]; v0[1] = V[0][1]; v0[2] = V[0][2];
+    tr = lam[0] + lam[1] + lam[2];
+    eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2];
+  } else {
+    eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
+  }
+  l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2);
+  if (m) { acc2[0] = l; acc2[1] = 1.0; }
+  // record: covariance mean in the point format; coefficients act on differences in metres
+  if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
+  if (pointwise) pointwise[i] = (T)l;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hot-path forward: neighbourhood covariance -> smallest eigenpair -> pointwise loss + backward
 // record; block partial sums of (masked loss, mask count).
@@ -109,30 +143,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
           acc.W -= (j[u_] >= 0) ? 0.0 : 1.0;
         }
       }
-      cov_same_weights(acc);
-      // moments are in raw units (q32: multiples of the resolution); scale once
-      const double u = Pt<PT>::unit(qp), u2 = u * u;
-      double moff[3], cm[3], C[6], D, omega;
-      cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
-#pragma unroll
-      for (int q = 0; q < 6; ++q) C[q] *= u2;
-      const bool m = mask ? mask[i] != 0 : true;
-      const double off = offset ? (double)offset[i] : 0.0;
-      double lam0, v0[3], tr, c1, c2, l;
-      if (FULL_EIG) {
-        double lam[3], V[3][3];
-        eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
-        lam0 = lam[0]; v0[0] = V[0][0]; v0[1] = V[0][1]; v0[2] = V[0][2];
-        tr = lam[0] + lam[1] + lam[2];
-        eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2];
-      } else {
-        eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
-      }
-      l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2);
-      if (m) { acc2[0] = l; acc2[1] = 1.0; }
-      // record: covariance mean in the point format; coefficients act on differences in metres
-      if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
-      if (pointwise) pointwise[i] = (T)l;
+      consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
     }
   }
   block_sum<2>(acc2, lds);
@@ -345,6 +356,51 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
 // Hot-path backward: dL/dx_j = sum over incoming edges (i -> j) of c1_i (v0_i . d) v0_i - c2_i d,
 // d = x_j - cmean_i, gathered through the transposed neighbour list; fused with the point epilogue.
 // ------------------------------------------------------------------------------------------------
+#ifndef DC_BWD_F32
+#define DC_BWD_F32 1
+#endif
+template <typename PT> constexpr bool kEdgeF32 = DC_BWD_F32 && std::is_same<PT, q32>::value;
+
+// g += sum over four incoming edges of c1 (v0 . d) v0 - c2 d, d = x_j - cmean_i, from the raw 16-B pieces of the four
+// records (an all-zero record contributes exactly nothing).  Shared by the gather and the LDS-staged kernel.
+//   q32: the records hold c1, v0, c2 in fp32 and the integer differences of neighbouring points are exact in fp32
+//   (< 2^24 grid steps), so the terms are formed in fp32 and the trip's partial sum is folded into the fp64
+//   accumulators (error ~1e-7 of the largest term of the trip);
+//   float / double points: fp64 throughout, separate multiplies and adds (measured faster than the dependent FMA
+//   chains contraction produces: 90 vs 98 us at N = 2 M).
+template <typename PT>
+__device__ __forceinline__ void edge_terms4(const typename Pt<PT>::Raw& cj, const int4 (*q)[RecRaw<PT>::kRow16], double* g) {
+  if constexpr (kEdgeF32<PT>) {
+#pragma clang fp contract(fast)
+    float gf[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u_ = 0; u_ < 4; ++u_) {
+      const int4 ra = q[u_][0], rb = q[u_][1];
+      const float d0 = (float)(cj.v[0] - ra.x), d1 = (float)(cj.v[1] - ra.y), d2 = (float)(cj.v[2] - ra.z);
+      const float c1 = __int_as_float(ra.w), c2 = __int_as_float(rb.w);
+      const float v0 = __int_as_float(rb.x), v1 = __int_as_float(rb.y), v2 = __int_as_float(rb.z);
+      const float t = c1 * (v0 * d0 + v1 * d1 + v2 * d2);
+      gf[0] += t * v0 - c2 * d0;
+      gf[1] += t * v1 - c2 * d1;
+      gf[2] += t * v2 - c2 * d2;
+    }
+    g[0] += (double)gf[0]; g[1] += (double)gf[1]; g[2] += (double)gf[2];
+  } else {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int u_ = 0; u_ < 4; ++u_) {
+      typename Pt<PT>::Raw m;
+      double v[3], c1, c2, d[3];
+      RecRaw<PT>::from_row(q[u_], m, &c1, v, &c2);
+      Pt<PT>::delta(cj, m, d);
+      const double t = c1 * (v[0] * d[0] + v[1] * d[1] + v[2] * d[2]);
+      g[0] += t * v[0] - c2 * d[0];
+      g[1] += t * v[1] - c2 * d[1];
+      g[2] += t * v[2] - c2 * d[2];
+    }
+  }
+}
+
 template <typename T, typename PT, int STRIDE, bool WANT_E, bool WANT_POSE>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
     const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
@@ -385,23 +441,17 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
       for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (beg + u_ < end) ? csr_src[beg + u_] : -1;
       for (int32_t e0 = beg; e0 < end; e0 += 4) {
         int32_t src[4];
-        typename Pt<PT>::Raw m[4];
-        double v[4][3], c1[4], c2[4];
+        int4 q[4][RecRaw<PT>::kRow16];
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) src[u_] = nxt[u_];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) buf_record<PT>(rrec, src[u_], m[u_], &c1[u_], v[u_], &c2[u_]);
+        for (int u_ = 0; u_ < 4; ++u_) {
+#pragma unroll
+          for (int a = 0; a < RecRaw<PT>::kRow16; ++a) q[u_][a] = buf_load16(rrec, (uint32_t)src[u_] * RowBytes<PT>::rec + 16u * a);
+        }
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (e0 + 4 + u_ < end) ? csr_src[e0 + 4 + u_] : -1;
-#pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) {
-          double d[3];
-          Pt<PT>::delta(cj, m[u_], d);
-          const double t = c1[u_] * (v[u_][0] * d[0] + v[u_][1] * d[1] + v[u_][2] * d[2]);
-          g[0] += t * v[u_][0] - c2[u_] * d[0];
-          g[1] += t * v[u_][1] - c2[u_] * d[1];
-          g[2] += t * v[u_][2] - c2[u_] * d[2];
-        }
+        edge_terms4<PT>(cj, q, g);
       }
       g[0] *= u; g[1] *= u; g[2] *= u;
       if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
@@ -412,99 +462,99 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-staged neighbour tiles.  In Morton order ~95 % of a block's neighbours (forward) / incoming-edge sources
-// (backward) lie within +-512 positions of the block, so every block of 256 points first copies a window of
-// kTileRows rows into LDS with fully coalesced 16-B loads and then gathers from LDS (ds_read_b128); the few edges
-// that leave the window read global memory as before.  This replaces ~20 M random 16/32-B global gathers per launch
-// (bounded by the per-CU address/L1 rate, not by HBM) with ~0.25 GB of streaming reads.
+// LDS-staged gathers through a block table (dc_blocktab.hip).  A per-lane gather from global memory costs one L1 tag
+// lookup per reference and the L1 serves one lookup per cycle: at K = 10 the 2560 references of a 256-point block kept
+// the L1 of its CU busy for ~2560 cycles, which bounded both hot kernels (rocprofv3 TCP_TOTAL_CACHE_ACCESSES ~ 1.06 per
+// CU cycle).  In Morton order those references hit only ~375 distinct rows, so every block first copies its distinct
+// rows into LDS (one lookup each), then gathers from LDS through 16-bit block-local positions that are stored
+// slot-major (a wavefront reads one slot with a single coalesced 128-B load).  Same arithmetic in the same order as the
+// gather kernels => bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <typename PT> struct TileRows { static constexpr int value = 1024; };
-template <> struct TileRows<double> { static constexpr int value = 512; };
+struct BlockTab {
+  const int32_t* __restrict__ blk_ptr;
+  const int32_t* __restrict__ blk_ids;
+  const int32_t* __restrict__ slot_ptr;
+  const uint16_t* __restrict__ loc;
+};
+constexpr uint32_t kNoLoc = 0xFFFFu;
 
-// first row of the window of block `blk` (clamped into [0, n - rows] when the array is long enough)
-__device__ __forceinline__ int64_t tile_origin(int64_t blk, int64_t n, int rows) {
-  int64_t lo = blk * kBlock - (rows - kBlock) / 2;
-  if (lo + rows > n) lo = n - rows;
-  return lo < 0 ? 0 : lo;
+// Copy the distinct rows of block `blk` (ROW16 16-B pieces each) into `tile`; returns their number.  Piece a of row t
+// lives at tile[a * cap + t]: a ds_read_b128 serves 16 lanes per cycle from 16 four-bank groups, and with whole rows
+// back to back (32-B records) the group would be (2 t + a) mod 16 -- only 8 of the 16 for each piece, measured as 2/3
+// of all LDS cycles lost to bank conflicts.  Piece-major, the group is t mod 16.
+template <int ROW16>
+__device__ __forceinline__ int stage_rows(const BlockTab& tab, int64_t blk, const int4* __restrict__ src, int4* tile, int cap) {
+  const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+  for (int t = threadIdx.x; t < nd; t += kBlock) {
+    const int64_t id = tab.blk_ids[base + t];
+#pragma unroll
+    for (int a = 0; a < ROW16; ++a) tile[a * cap + t] = src[id * ROW16 + a];
+  }
+  return nd;
 }
 
 template <int ROW16>
-__device__ __forceinline__ void stage_tile(const int4* __restrict__ src, int64_t lo, int64_t n, int rows, int4* tile) {
-  const int64_t avail = (n - lo < rows ? n - lo : (int64_t)rows) * ROW16;
-  const int4* base = src + lo * ROW16;
-  for (int t = threadIdx.x; t < rows * ROW16; t += kBlock)
-    if (t < avail) tile[t] = base[t];
+__device__ __forceinline__ void read_row(const int4* tile, int cap, uint32_t row, int4* q) {
+#pragma unroll
+  for (int a = 0; a < ROW16; ++a) q[a] = tile[a * cap + row];
 }
 
 template <typename T, typename PT, bool FULL_EIG>
-__global__ __launch_bounds__(kBlock) void consistency_fwd_tiled_kernel(
-    const PT* __restrict__ x, const int32_t* __restrict__ nbr, int64_t n, int k, const uint8_t* __restrict__ mask,
-    const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec, T* __restrict__ pointwise,
-    T* __restrict__ eigvals, double* __restrict__ partials) {
-  constexpr int kRows = TileRows<PT>::value, XR = Pt<PT>::kRow16;
-  __shared__ int4 tile[kRows * XR];
+__global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
+    const PT* __restrict__ x, BlockTab tab, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec,
+    T* __restrict__ pointwise, T* __restrict__ eigvals, double* __restrict__ partials) {
+  constexpr int XR = Pt<PT>::kRow16;
+  extern __shared__ int4 tile[];
   __shared__ double lds[(kBlock / kWave) * 2];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   double acc2[2] = {0.0, 0.0};
   const int4* xg = reinterpret_cast<const int4*>(x);
-  int64_t lo = 0;
+  const int64_t i = blk * kBlock + threadIdx.x;
+  const bool live = blk >= 0 && i < n;
+  typename Pt<PT>::Raw ci;
+  int32_t nslots = 0;
+  const uint16_t* lrow = tab.loc;
   if (blk >= 0) {
-    lo = tile_origin(blk, n, kRows);
-    stage_tile<XR>(xg, lo, n, kRows, tile);
+    // the lane's own requests go out before the staging loop, so their latency hides behind it
+    const int32_t s0 = tab.slot_ptr[blk];
+    nslots = tab.slot_ptr[blk + 1] - s0;
+    lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    if (live) ci = Pt<PT>::from_row(xg + (centre_idx ? (int64_t)centre_idx[i] : i) * XR);
+    stage_rows<XR>(tab, blk, xg, tile, cap);
   }
   __syncthreads();
-  if (blk >= 0) {
-    const int64_t i = blk * kBlock + threadIdx.x;
-    if (i < n) {
-      const typename Pt<PT>::Raw ci = Pt<PT>::from_row(tile + (i - lo) * XR);
-      CovAcc acc;
-      cov_init(acc);
-      const int32_t* row = nbr + i * k;
-      for (int q0 = 0; q0 < k; q0 += 4) {
-        int32_t j[4];
-        typename Pt<PT>::Raw cj[4];
+  if (live) {
+    CovAcc acc;
+    cov_init(acc);
+    uint32_t nxt[4];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) j[u_] = (q0 + u_ < k) ? row[q0 + u_] : -1;
+    for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (u_ < nslots) ? (uint32_t)lrow[u_ * kBlock] : kNoLoc;
+    for (int q0 = 0; q0 < nslots; q0 += 4) {
+      uint32_t l[4];
+      typename Pt<PT>::Raw cj[4];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) {
-          const int64_t jj = j[u_] >= 0 ? (int64_t)j[u_] : i;
-          const uint64_t off = (uint64_t)(jj - lo);
-          if (off < (uint64_t)kRows) cj[u_] = Pt<PT>::from_row(tile + off * XR);
-          else cj[u_] = Pt<PT>::from_row(xg + jj * XR);
-        }
+      for (int u_ = 0; u_ < 4; ++u_) l[u_] = nxt[u_];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) {
-          if (j[u_] >= 0) {
-            double d[3];
-            Pt<PT>::delta(cj[u_], ci, d);
-            cov_add1(acc, d[0], d[1], d[2]);
-          }
-        }
+      for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (q0 + 4 + u_ < nslots) ? (uint32_t)lrow[(q0 + 4 + u_) * kBlock] : kNoLoc;
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        int4 piece[XR];
+        read_row<XR>(tile, cap, l[u_] == kNoLoc ? 0u : l[u_], piece);
+        cj[u_] = Pt<PT>::from_row(piece);
       }
-      cov_same_weights(acc);
-      const double u = Pt<PT>::unit(qp), u2 = u * u;
-      double moff[3], cm[3], C[6], D, omega;
-      cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
 #pragma unroll
-      for (int q = 0; q < 6; ++q) C[q] *= u2;
-      const bool m = mask ? mask[i] != 0 : true;
-      const double off = offset ? (double)offset[i] : 0.0;
-      double lam0, v0[3], tr, c1, c2, l;
-      if (FULL_EIG) {
-        double lam[3], V[3][3];
-        eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
-        lam0 = lam[0]; v0[0] = V[0][0]; v0[1] = V[0][1]; v0[2] = V[0][2];
-        tr = lam[0] + lam[1] + lam[2];
-        eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2];
-      } else {
-        eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
+      for (int u_ = 0; u_ < 4; ++u_) {
+        // a missing neighbour takes the centre itself: its difference is exactly zero, only the count is masked
+        const bool have = l[u_] != kNoLoc;
+        double d[3];
+        Pt<PT>::delta(have ? cj[u_] : ci, ci, d);
+        cov_add1(acc, d[0], d[1], d[2]);
+        acc.W -= have ? 0.0 : 1.0;
       }
-      l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2);
-      if (m) { acc2[0] = l; acc2[1] = 1.0; }
-      if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
-      if (pointwise) pointwise[i] = (T)l;
     }
+    consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
   }
   block_sum<2>(acc2, lds);
   if (threadIdx.x == 0) {
@@ -513,24 +563,16 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_tiled_kernel(
   }
 }
 
-template <typename T, typename PT>
-__global__ __launch_bounds__(kBlock) void consistency_bwd_tiled_kernel(
-    const PT* __restrict__ x, const PT* __restrict__ rec, const int32_t* __restrict__ csr_ptr,
-    const int32_t* __restrict__ csr_src, int64_t n, PointInputs in, QParams qp, int want_e, int want_pose,
+template <typename T, typename PT, bool WANT_E, bool WANT_POSE>
+__global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
+    const PT* __restrict__ x, const PT* __restrict__ rec, BlockTab tab, int cap, int64_t n, PointInputs in, QParams qp,
     T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
-#pragma clang fp contract(off)
-  constexpr int kRows = TileRows<PT>::value, RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
-  __shared__ int4 tile[kRows * RR];
+  constexpr int want_e = WANT_E, want_pose = WANT_POSE;
+  constexpr int RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
+  extern __shared__ int4 tile[];
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
-  const int4* rg = reinterpret_cast<const int4*>(rec);
-  int64_t lo = 0;
-  if (blk >= 0) {
-    lo = tile_origin(blk, n, kRows);
-    stage_tile<RR>(rg, lo, n, kRows, tile);
-  }
-  __syncthreads();
   ModelParams mp;
   load_model(in, mp);
   double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[6];
@@ -539,44 +581,46 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_tiled_kernel(
 #pragma unroll
   for (int k = 0; k < 6; ++k) gT[k] = 0.0;
   int scan = -1;
-  bool active = false;
+  const int64_t j = blk * kBlock + threadIdx.x;
+  const bool active = blk >= 0 && j < n;
+  typename Pt<PT>::Raw cj;
+  int32_t nslots = 0;
+  uint32_t nd = 0;
+  const uint16_t* lrow = tab.loc;
   if (blk >= 0) {
-    const int64_t j = blk * kBlock + threadIdx.x;
-    if (j < n) {
-      active = true;
-      double g[3] = {0.0, 0.0, 0.0};
-      const typename Pt<PT>::Raw cj = Pt<PT>::from_row(reinterpret_cast<const int4*>(x) + j * XR);
-      const double u = Pt<PT>::unit(qp);
-      const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
-      for (int32_t e0 = beg; e0 < end; e0 += 4) {
-        int32_t src[4];
-        typename Pt<PT>::Raw m[4];
-        double v[4][3], c1[4], c2[4];
+    const int32_t s0 = tab.slot_ptr[blk];
+    nslots = tab.slot_ptr[blk + 1] - s0;
+    lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    if (active) cj = Pt<PT>::from_row(reinterpret_cast<const int4*>(x) + j * XR);
+    nd = (uint32_t)stage_rows<RR>(tab, blk, reinterpret_cast<const int4*>(rec), tile, cap);
+    // row nd is an all-zero record: empty slots point there and contribute exactly nothing
+    if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  if (active) {
+    double g[3] = {0.0, 0.0, 0.0};
+    const double u = Pt<PT>::unit(qp);
+    uint32_t nxt[4];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) src[u_] = (e0 + u_ < end) ? csr_src[e0 + u_] : -1;
+    for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (u_ < nslots) ? (uint32_t)lrow[u_ * kBlock] : kNoLoc;
+    for (int q0 = 0; q0 < nslots; q0 += 4) {
+      uint32_t l[4];
+      int4 q[4][RR];
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) {
-          const int64_t ii = src[u_] >= 0 ? (int64_t)src[u_] : j;
-          const uint64_t off = (uint64_t)(ii - lo);
-          if (off < (uint64_t)kRows) RecRaw<PT>::from_row(tile + off * RR, m[u_], &c1[u_], v[u_], &c2[u_]);
-          else RecRaw<PT>::from_row(rg + ii * RR, m[u_], &c1[u_], v[u_], &c2[u_]);
-        }
+      for (int u_ = 0; u_ < 4; ++u_) l[u_] = nxt[u_];
+      // a lane's slots fill from 0 upwards: once a whole trip is empty for every lane of the wavefront, so are the rest
+      if (__all((int)(l[0] == kNoLoc))) break;
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) {
-          if (src[u_] >= 0) {
-            double d[3];
-            Pt<PT>::delta(cj, m[u_], d);
-            const double t = c1[u_] * (v[u_][0] * d[0] + v[u_][1] * d[1] + v[u_][2] * d[2]);
-            g[0] += t * v[u_][0] - c2[u_] * d[0];
-            g[1] += t * v[u_][1] - c2[u_] * d[1];
-            g[2] += t * v[u_][2] - c2[u_] * d[2];
-          }
-        }
+      for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (q0 + 4 + u_ < nslots) ? (uint32_t)lrow[(q0 + 4 + u_) * kBlock] : kNoLoc;
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        read_row<RR>(tile, cap, l[u_] < nd ? l[u_] : nd, q[u_]);
       }
-      g[0] *= u; g[1] *= u; g[2] *= u;
-      if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
-      if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+      edge_terms4<PT>(cj, q, g);
     }
+    g[0] *= u; g[1] *= u; g[2] *= u;
+    if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
+    if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
   if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
 }
@@ -750,7 +794,21 @@ using namespace dc;
   } while (0)
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
-static bool g_no_tiles = true;           // LDS-tiled variants are opt-in (dc_set_option(0, 0)): measured slower, see DESIGN.md
+static bool g_no_tab = false;            // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements)
+
+// a usable table -> device view; LDS bytes of the staged rows (+ `extra_rows`) must fit `lds_limit`
+static bool use_table(const dcBlockTable* t, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit, BlockTab* out,
+                      size_t* lds_bytes, int* lds_rows) {
+  if (!t || g_no_tab || stride != 4 || !t->blk_ptr || !t->slot_ptr || !t->loc || t->max_rows < 0) return false;
+  if (t->max_rows > 0 && !t->blk_ids) return false;
+  const size_t rows = (size_t)t->max_rows + extra_rows + (t->max_rows + extra_rows == 0 ? 1 : 0);
+  const size_t need = rows * row_bytes;
+  if (need > lds_limit || t->max_rows >= 0xFFFF) return false;
+  *out = BlockTab{t->blk_ptr, t->blk_ids, t->slot_ptr, t->loc};
+  *lds_bytes = need;
+  *lds_rows = (int)rows;
+  return true;
+}
 
 // ---- in-library kernel timer: HIP events recorded on the launch stream right around the main kernels ------
 namespace {
@@ -856,13 +914,19 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
 
 // `reduce` = false leaves the block partials in partials_ws for a later combined reduction (dc_sequence_eval).
 static int consistency_fwd_impl(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
-                                const int32_t* nbr, const int32_t* centre_idx, int64_t n, int k, const uint8_t* mask,
+                                const int32_t* nbr, const int32_t* centre_idx, const dcBlockTable* table, int64_t n, int k,
+                                const uint8_t* mask,
                                 const void* offset, int loss_kind,
                                 int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals, double* partials_ws,
                                 double* sums_out, hipStream_t stream, bool reduce) {
   if (n == 0 && sums_out) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
-  if (n < 0 || k < 1 || !points || !nbr || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
+  if (n < 0 || k < 1 || !points || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   if (loss_kind != DC_LOSS_MIN_EIGVAL && loss_kind != DC_LOSS_TRACE) return DC_ERR_ARG;
+  BlockTab tab{};
+  size_t lds_bytes = 0;
+  int lds_rows = 0;
+  const bool staged = use_table(table, stride, point_fmt == DC_F64 ? 32u : 16u, 0, 60 * 1024, &tab, &lds_bytes, &lds_rows);
+  if (!staged && !nbr) return table ? DC_ERR_UNSUPPORTED : DC_ERR_ARG;
   QParams qp;
   int rc = make_qparams(point_fmt, dtype, stride, qparams, &qp);
   if (rc) return rc;
@@ -871,12 +935,12 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
 #define FWD_ARGS(T, PT) (const PT*)points, nbr, centre_idx, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
-#define FWD_TILED_ARGS(T, PT) (const PT*)points, nbr, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
+#define FWD_STAGED_ARGS(T, PT) (const PT*)points, tab, lds_rows, centre_idx, n, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
 #define LAUNCH(T, PT, S) \
   do { \
-    if (S == 4 && !g_no_tiles && !centre_idx) { /* padded rows: LDS-staged neighbour tiles */ \
-      if (eigvals) hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, true>), grid, block, 0, stream, FWD_TILED_ARGS(T, PT)); \
-      else hipLaunchKernelGGL((consistency_fwd_tiled_kernel<T, PT, false>), grid, block, 0, stream, FWD_TILED_ARGS(T, PT)); \
+    if (S == 4 && staged) { /* padded rows + block table: gathers served from LDS */ \
+      if (eigvals) hipLaunchKernelGGL((consistency_fwd_staged_kernel<T, PT, true>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
+      else hipLaunchKernelGGL((consistency_fwd_staged_kernel<T, PT, false>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
     } else { \
       if (eigvals) hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
       else hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
@@ -892,21 +956,28 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
 }
 
 int dc_consistency_fwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
-                       const int32_t* nbr, const int32_t* centre_idx, int64_t n, int k, const uint8_t* mask, const void* offset,
-                       int loss_kind, int normalization, int sqrt_, void* rec, void* pointwise, void* eigvals,
-                       double* partials_ws, double* sums_out, hipStream_t stream) {
-  return consistency_fwd_impl(points, stride, dtype, point_fmt, qparams, nbr, centre_idx, n, k, mask, offset, loss_kind, normalization,
+                       const int32_t* nbr, const int32_t* centre_idx, const dcBlockTable* table, int64_t n, int k,
+                       const uint8_t* mask, const void* offset, int loss_kind, int normalization, int sqrt_, void* rec,
+                       void* pointwise, void* eigvals, double* partials_ws, double* sums_out, hipStream_t stream) {
+  return consistency_fwd_impl(points, stride, dtype, point_fmt, qparams, nbr, centre_idx, table, n, k, mask, offset, loss_kind, normalization,
                               sqrt_, rec, pointwise, eigvals, partials_ws, sums_out, stream, true);
 }
 
 static int consistency_bwd_impl(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
-                                const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
+                                const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm,
+                                const dcBlockTable* table, int64_t n,
                                 const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                                 const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
                                 const double* w, const double* e, int want_exponent_grad, int want_pose_grad,
                                 void* grad_points, double* partials_ws, double* grads_out, hipStream_t stream, bool reduce,
                                 int64_t rec_rows) {
-  if (n < 0 || !points || !rec || !csr_ptr || !csr_src || (stride != 3 && stride != 4)) return DC_ERR_ARG;
+  if (n < 0 || !points || !rec || (stride != 3 && stride != 4)) return DC_ERR_ARG;
+  BlockTab tab{};
+  size_t lds_bytes = 0;
+  int lds_rows = 0;
+  // the pose variants hold 28 KB of static LDS for the per-scan sums: keep the staged records within 32 KB
+  const bool staged = !lane_perm && use_table(table, stride, point_fmt == DC_F64 ? 64u : 32u, 1, 32 * 1024, &tab, &lds_bytes, &lds_rows);
+  if (!staged && (!csr_ptr || !csr_src)) return table ? DC_ERR_UNSUPPORTED : DC_ERR_ARG;
   const bool params = dirs != nullptr;
   if (!params && !grad_points) return DC_ERR_ARG;
   if (params) {
@@ -939,12 +1010,15 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
     if (err != hipSuccess) return (int)err;
   }
 #define BWD_ARGS(T, PT) (const PT*)points, (const PT*)rec, csr_ptr, csr_src, lane_perm, n, in, qp, (T*)grad_points, partials_ws, n_acc, rec_bytes
+#define BWD_STAGED_ARGS(T, PT) (const PT*)points, (const PT*)rec, tab, lds_rows, n, in, qp, (T*)grad_points, partials_ws, n_acc
 #define LAUNCH(T, PT, S) \
   do { \
-    if (S == 4 && !lane_perm && !g_no_tiles) \
-      hipLaunchKernelGGL((consistency_bwd_tiled_kernel<T, PT>), grid, block, 0, stream, (const PT*)points, (const PT*)rec, \
-                         csr_ptr, csr_src, n, in, qp, want_exponent_grad, want_pose_grad, (T*)grad_points, partials_ws, n_acc); \
-    else \
+    if (S == 4 && staged) { \
+      if (want_pose_grad && want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, true, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      else if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, false, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      else if (want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, true, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      else hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, false, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+    } else \
     { \
       if (want_pose_grad && want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
       else if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, false, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
@@ -963,12 +1037,12 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
 }
 
 int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt, const double* qparams, const void* rec,
-                       const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, int64_t n,
-                       const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                       const int32_t* csr_ptr, const int32_t* csr_src, const uint8_t* lane_perm, const dcBlockTable* table,
+                       int64_t n, const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                        const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* w,
                        const double* e, int want_exponent_grad, int want_pose_grad, void* grad_points, double* partials_ws,
                        double* grads_out, hipStream_t stream) {
-  return consistency_bwd_impl(points, stride, dtype, point_fmt, qparams, rec, csr_ptr, csr_src, lane_perm, n, vps, dirs, depth,
+  return consistency_bwd_impl(points, stride, dtype, point_fmt, qparams, rec, csr_ptr, csr_src, lane_perm, table, n, vps, dirs, depth,
                               inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e, want_exponent_grad,
                               want_pose_grad, grad_points, partials_ws, grads_out, stream, true, 0);
 }
@@ -1059,9 +1133,9 @@ int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* cs
   return DC_OK;
 }
 
-// option 0: 1 = disable the LDS-tiled kernels (ablation / A-B measurements), 0 = default.
+// option 0: 1 = ignore block tables and gather from global memory (ablation / A-B measurements), 0 = default.
 int dc_set_option(int option, int value) {
-  if (option == 0) { g_no_tiles = value != 0; return DC_OK; }
+  if (option == 0) { g_no_tab = value != 0; return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -1125,12 +1199,12 @@ int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, 
   double* p_fwd = d->partials;
   double* p_bwd = d->partials + 2 * rows;
   const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
-  rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->centre_idx, n_rows, d->k, d->mask,
+  rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->centre_idx, d->fwd_table, n_rows, d->k, d->mask,
                             nullptr, d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream,
                             false);
   if (!rc && want_grad)
     rc = consistency_bwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
-                              d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
+                              d->bwd_table, d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                               d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false,
                               n_rows);
   if (rc) return rc;

@@ -19,6 +19,7 @@
 #include "dc_common.h"
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
+#include "dc_hostutil.h"
 #include <rocprim/rocprim.hpp>
 
 namespace dc {
@@ -420,19 +421,6 @@ __global__ __launch_bounds__(kBlock) void max_i32_kernel(const int32_t* __restri
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// ---- workspace carving -------------------------------------------------------------------------------
-struct Carver {
-  char* base;
-  size_t off;
-  explicit Carver(void* b) : base((char*)b), off(0) {}
-  template <typename U> U* take(size_t count) {
-    off = (off + 255) & ~(size_t)255;
-    U* p = base ? (U*)(base + off) : nullptr;
-    off += count * sizeof(U);
-    return p;
-  }
-};
-
 constexpr int kBoxBlocks = 256;
 
 static uint32_t table_size(int64_t n) {
@@ -470,7 +458,6 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   return g;
 }
 
-#define DC_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
 
 template <typename T>
 static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hint, GridWs& w, hipStream_t st) {

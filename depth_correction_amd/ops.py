@@ -13,7 +13,7 @@ from . import _native as nv
 from ._native import lib, check, need, ptr, stream_ptr, dtype_code
 
 __all__ = [
-    'knn', 'radius_neighbors', 'knn_transpose', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
+    'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'IcpSequence',
     'as_index32',
 ]
@@ -90,6 +90,61 @@ def knn_transpose(nbr, n_dst=None):
     check(lib().dc_knn_transpose(ptr(nbr), n, k, n_dst, ptr(csr_ptr), ptr(csr_src), ptr(ws), nbytes, stream_ptr()),
           'dc_knn_transpose')
     return csr_ptr, csr_src
+
+
+class BlockTable:
+    """Block table of a reference list (dcBlockTable): per block of 256 rows the distinct rows it references and the
+    slot-major 16-bit positions of every reference in that list; lets the fused kernels gather from LDS."""
+
+    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows):
+        self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc = blk_ptr, blk_ids, slot_ptr, loc
+        self.max_rows, self.n_rows = int(max_rows), int(n_rows)
+        self.desc = nv.BlockTableDesc(ptr(blk_ptr), ptr(blk_ids), ptr(slot_ptr), ptr(loc), self.max_rows, 0)
+
+    def ref(self):
+        return ctypes.cast(ctypes.pointer(self.desc), ctypes.c_void_p)
+
+    @property
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in (self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc))
+
+
+def _table_ref(table, n_rows):
+    if table is None:
+        return None
+    assert isinstance(table, BlockTable) and table.n_rows == n_rows, 'block table built for another row count'
+    return table.ref()
+
+
+def block_table(nbr=None, csr=None):
+    """BlockTable of a neighbour table ``nbr`` int32 [rows, K] (forward) or of CSR lists ``csr`` = (ptr, ids)
+    (backward: knn_transpose's output).  Returns None when a block references 65535 or more distinct rows."""
+    if nbr is not None:
+        need(nbr, (None, None), dtype=torch.int32, name='neighbors')
+        n_rows, k = nbr.shape
+        row_ptr, ids, n_refs, dev = None, nbr, n_rows * k, nbr.device
+    else:
+        row_ptr, ids = csr
+        need(row_ptr, (None,), dtype=torch.int32, name='csr_ptr')
+        need(ids, (None,), dtype=torch.int32, name='csr_src', device=row_ptr.device)
+        n_rows, k, n_refs, dev = row_ptr.shape[0] - 1, 0, ids.shape[0], row_ptr.device
+    nb = (n_rows + 255) // 256
+    slot_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
+    check(lib().dc_block_table_slots(ptr(row_ptr), n_rows, k, ptr(cnt), ptr(slot_ptr), stream_ptr()), 'dc_block_table_slots')
+    n_slot_rows = int(slot_ptr[-1])                                  # one synchronisation, at set-up time
+    blk_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
+    blk_ids = torch.empty((max(n_refs, 1),), dtype=torch.int32, device=dev)
+    loc = torch.empty((max(n_slot_rows, 1) * 256,), dtype=torch.uint16, device=dev)
+    info = torch.empty((4,), dtype=torch.int32, device=dev)
+    nbytes = lib().dc_block_table_workspace_bytes(n_refs)
+    ws = _ws(nbytes, dev)
+    check(lib().dc_block_table_build(ptr(row_ptr), ptr(ids), n_rows, k, n_refs, ptr(slot_ptr), n_slot_rows, ptr(blk_ptr),
+                                     ptr(blk_ids), ptr(loc), ptr(info), ptr(ws), nbytes, stream_ptr()), 'dc_block_table_build')
+    total, max_rows, overflow, _ = info.tolist()
+    if overflow:
+        return None
+    return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows)
 
 
 def spatial_order(points):
@@ -294,7 +349,7 @@ def features_bwd(points, csr_ptr, csr_src, cmean, invd, nvalid, eigvecs=None, gr
 # ------------------------------------------------------------------------------------------------
 def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss', normalization=True, sqrt=False,
                     rec=None, want_pointwise=False, want_eigvals=False, partials=None, sums=None, qfmt=None,
-                    centre_idx=None):
+                    centre_idx=None, table=None):
     _check_points(points, qfmt)
     n_points, stride = points.shape
     dev = points.device
@@ -327,7 +382,7 @@ def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss',
     if sums is None:
         sums = torch.empty((2,), dtype=torch.float64, device=dev)
     check(lib().dc_consistency_fwd(ptr(points), stride, fmt if qfmt is None else nv.DC_F32, fmt, qptr, ptr(nbr),
-                                   ptr(centre_idx), n, k,
+                                   ptr(centre_idx), _table_ref(table, n), n, k,
                                    ptr(mask), ptr(offset), nv.LOSS_KINDS[loss], int(bool(normalization)), int(bool(sqrt)), ptr(rec), ptr(pw),
                                    ptr(ev), ptr(partials), ptr(sums), stream_ptr()), 'dc_consistency_fwd')
     return dict(sums=sums, rec=rec, pointwise=pw, eigvals=ev)
@@ -344,7 +399,7 @@ def degree_lane_perm(csr_ptr, block=256):
 
 def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_kind=None, w=None, e=None,
                     want_exponent=False, want_pose=False, want_grad_points=False, partials=None, grads=None, qfmt=None,
-                    lane_perm=None):
+                    lane_perm=None, table=None):
     _check_points(points, qfmt)
     n, stride = points.shape
     dev = points.device
@@ -360,7 +415,8 @@ def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_ki
     if ps is None:
         assert want_grad_points
         check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src),
-                                       ptr(lane_perm), n, None, None, None, None, None, None, None, 0, 0, 0, None, None, 0, 0, ptr(gp), None,
+                                       ptr(lane_perm), _table_ref(table, n), n, None, None, None, None, None, None, None, 0, 0, 0,
+                                       None, None, 0, 0, ptr(gp), None,
                                        None, stream_ptr()), 'dc_consistency_bwd')
         return gp, None
     assert ps.n == n and ps.dtype == dt and ps.device == dev
@@ -375,7 +431,7 @@ def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_ki
     if grads is None:
         grads = torch.zeros((max(nacc, 1),), dtype=torch.float64, device=dev)
     check(lib().dc_consistency_bwd(ptr(points), stride, dcode, fmt, qptr, ptr(rec), ptr(csr_ptr), ptr(csr_src),
-                                   ptr(lane_perm), n, ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
+                                   ptr(lane_perm), _table_ref(table, n), n, ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
                                    ptr(poses), ns, kind, nt, ptr(w), ptr(e), int(want_exponent), int(want_pose), ptr(gp),
                                    ptr(partials), ptr(grads), stream_ptr()), 'dc_consistency_bwd')
     return gp, _grads_split(grads, nt, ns)

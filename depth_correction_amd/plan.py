@@ -33,13 +33,14 @@ __all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer']
 class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
-                 active_only=False):
+                 active_only=False, block_tables=True):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
         :param poses: [S,4,4] initial scan poses (used for the layout only; every evaluation takes its own).
         :param neighbors: [N,K] int neighbour indices of the global cloud (scan-major order, -1 = missing).
         :param mask: [N] bool global mask (None = all points).
+        :param block_tables: build the block tables that let both hot kernels gather from LDS (ops.block_table).
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
                             the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
@@ -105,6 +106,9 @@ class SequencePlan:
         self.nbr, self.mask = nbr, mask
         self.csr_ptr, self.csr_src = ops.knn_transpose(nbr, n_dst=self.n)
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
+        # block tables: distinct rows per 256-point block + 16-bit block-local positions (gathers served from LDS)
+        self.fwd_table = ops.block_table(nbr=nbr) if block_tables else None
+        self.bwd_table = ops.block_table(csr=(self.csr_ptr, self.csr_src)) if block_tables else None
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
         # ---- internal point format -------------------------------------------------------------------
@@ -139,6 +143,8 @@ class SequencePlan:
             d.vps, d.dirs, d.depth, d.inc, d.lmask, d.scan_id = p(ps.vps), p(ps.dirs), p(ps.depth), p(ps.inc), p(ps.lmask), p(ps.scan_id)
             d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(self.csr_ptr), p(self.csr_src), p(self.mask)
             d.lane_perm = p(self.lane_perm)
+            d.fwd_table = None if self.fwd_table is None else self.fwd_table.ref()
+            d.bwd_table = None if self.bwd_table is None else self.bwd_table.ref()
             d.centre_idx, d.n_centres = p(self.centre_idx), (0 if self.centre_idx is None else self.centre_idx.shape[0])
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
@@ -187,7 +193,7 @@ class SequencePlan:
         out = ops.consistency_fwd(self.x, self.nbr, mask=self.mask, loss=self.loss, normalization=self.normalization,
                                   sqrt=self.sqrt, rec=self.rec, want_pointwise=want_pointwise,
                                   want_eigvals=want_eigvals, partials=self.partials, qfmt=self.qfmt,
-                                  centre_idx=self.centre_idx)
+                                  centre_idx=self.centre_idx, table=self.fwd_table)
         self.version += 1
         return out
 
@@ -196,7 +202,7 @@ class SequencePlan:
         kind = self.model_kind if self.w is not None else None
         _, grads = ops.consistency_bwd(self.x, self.rec, self.csr_ptr, self.csr_src, self.ps, self.P, kind, self.w, self.e,
                                        want_exponent=want_exponent, want_pose=want_pose, partials=self.partials,
-                                       qfmt=self.qfmt, lane_perm=self.lane_perm)
+                                       qfmt=self.qfmt, lane_perm=self.lane_perm, table=self.bwd_table)
         return grads
 
     def unpermute(self, t):

@@ -141,7 +141,7 @@ VARIANTS = [('mineig_norm', 'min_eigval_loss', True, False), ('mineig_raw', 'min
 
 
 def _run_sequence(g, dev, dtype, prefix='', loss='min_eigval_loss', normalization=True, sqrt=False, poses=None,
-                  stride=3, q32=False):
+                  stride=3, q32=False, tables=False):
     from depth_correction_amd import ops
     qfmt = None
     if q32:
@@ -156,11 +156,13 @@ def _run_sequence(g, dev, dtype, prefix='', loss='min_eigval_loss', normalizatio
     x = ops.points_fwd(ps, P, model, w, e, stride=stride, qfmt=qfmt)
     nbr = t(g['g_neighbors'], dev)
     mask = t(g['g_mask'], dev)
-    fw = ops.consistency_fwd(x, nbr, mask=mask, loss=loss, normalization=normalization, sqrt=sqrt, want_pointwise=True,
-                             want_eigvals=True, qfmt=qfmt)
     cp, cs = ops.knn_transpose(nbr)
+    ft = ops.block_table(nbr=nbr) if tables else None
+    bt = ops.block_table(csr=(cp, cs)) if tables else None
+    fw = ops.consistency_fwd(x, nbr, mask=mask, loss=loss, normalization=normalization, sqrt=sqrt, want_pointwise=True,
+                             want_eigvals=True, qfmt=qfmt, table=ft)
     gp, (gw, ge, gT) = ops.consistency_bwd(x, fw['rec'], cp, cs, ps, P, model, w, e, want_exponent=True, want_pose=True,
-                                           want_grad_points=True, qfmt=qfmt)
+                                           want_grad_points=True, qfmt=qfmt, table=bt)
     if q32:
         x = torch.as_tensor(qfmt.origin, dtype=torch.float64, device=dev) + x[:, :3].double() * qfmt.scale
     return dict(x=x, fw=fw, gp=gp, gw=gw, ge=ge, gT=gT, mask=mask, qfmt=qfmt)
@@ -396,20 +398,52 @@ def test_p2plane_golden(golden, dev):
     np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
 
 
-def test_lds_tiles_do_not_change_results(golden, dev):
-    """The LDS-staged neighbour tiles are a pure data-movement optimisation: bitwise identical sums with and without,
-    for a cloud longer than one window (so both the in-window LDS path and the global fallback run)."""
-    from depth_correction_amd import _native as nv
+def test_block_table_structure(golden, dev):
+    """dc_block_table_build against a direct numpy construction: per block of 256 rows the sorted distinct references,
+    every reference's position in that list (slot-major), 0xFFFF in empty slots; for a table (forward) and for CSR
+    lists (backward)."""
+    from depth_correction_amd import ops
+    g = golden('room_k10')
+    nbr = t(g['g_neighbors'], dev).clone()
+    nbr[5, 3:] = -1                                                  # a ragged row
+    nbr[300:600, 9] = -1
+    n, k = nbr.shape
+    nb = (n + 255) // 256
+    cp, cs = ops.knn_transpose(nbr)
+    for table, lists in ((ops.block_table(nbr=nbr), [r[r >= 0] for r in npy(nbr)]),
+                         (ops.block_table(csr=(cp, cs)), np.split(npy(cs)[:int(cp[-1])], npy(cp)[1:-1]))):
+        bp, ids, sp, loc = npy(table.blk_ptr), npy(table.blk_ids), npy(table.slot_ptr), npy(table.loc).reshape(-1, 256)
+        assert len(bp) == nb + 1 and len(sp) == nb + 1 and bp[0] == 0 and sp[0] == 0
+        assert table.max_rows == int(np.diff(bp).max())
+        for b in range(nb):
+            rows = lists[b * 256:(b + 1) * 256]
+            want = np.unique(np.concatenate(rows)) if len(rows) else np.zeros(0, np.int64)
+            assert np.array_equal(ids[bp[b]:bp[b + 1]], want)
+            assert sp[b + 1] - sp[b] == max(len(r) for r in rows)
+            blk = loc[sp[b]:sp[b + 1]]
+            for lane, r in enumerate(rows):
+                assert np.array_equal(want[blk[:len(r), lane]], r) and np.all(blk[len(r):, lane] == 0xFFFF)
+            assert np.all(blk[:, len(rows):] == 0xFFFF)
+
+
+def test_block_tables_do_not_change_results(golden, dev):
+    """Gathering through block tables (LDS-staged distinct rows) is a pure data-movement change: bitwise identical
+    sums, gradients and per-point outputs with and without, for every point format."""
     g = golden('room_k10')
     outs = []
-    for off in (0, 1):
-        nv.check(nv.lib().dc_set_option(0, off), 'dc_set_option')
-        try:
-            r32 = _run_sequence(g, dev, torch.float32, stride=4, q32=True)
-            r64 = _run_sequence(g, dev, torch.float64, stride=4)
-        finally:
-            nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
-        outs.append([npy(r['fw']['sums']) for r in (r32, r64)] + [npy(r['gw']) for r in (r32, r64)]
-                    + [npy(r['gp']) for r in (r32, r64)])
+    for tables in (False, True):
+        runs = [_run_sequence(g, dev, torch.float32, stride=4, q32=True, tables=tables),
+                _run_sequence(g, dev, torch.float32, stride=4, tables=tables),
+                _run_sequence(g, dev, torch.float64, stride=4, tables=tables)]
+        outs.append([npy(r[f]) for r in runs for f in ('gw', 'ge', 'gT', 'gp')]
+                    + [npy(r['fw'][f]) for r in runs for f in ('sums', 'pointwise', 'eigvals', 'rec')])
     for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+        assert np.array_equal(a, b, equal_nan=True)
+    # the ablation switch routes a call with tables through the gather kernels again
+    from depth_correction_amd import _native as nv
+    nv.check(nv.lib().dc_set_option(0, 1), 'dc_set_option')
+    try:
+        r = _run_sequence(g, dev, torch.float32, stride=4, q32=True, tables=True)
+    finally:
+        nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
+    assert np.array_equal(npy(r['gw']), outs[0][0])
