@@ -46,6 +46,9 @@ def parse():
                     help='evaluate only masked points as neighbourhood centres (identical loss / gradients, see DESIGN.md)')
     ap.add_argument('--degree-sort', action='store_true', help='order points by in-degree inside 256-point blocks (ablation)')
     ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')
+    ap.add_argument('--timer-every', type=int, default=8,
+                    help='HIP-event timing of every N-th launch of the hot kernels inside the timed region (0 = off)')
+    ap.add_argument('--no-block-tables', action='store_true', help='gather from global memory instead of LDS (ablation)')
     return ap.parse_args()
 
 
@@ -151,7 +154,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, spatial_sort=not args.no_sort,
-                                point_format=args.point_format, active_only=args.active_only, degree_sort=args.degree_sort)
+                                point_format=args.point_format, active_only=args.active_only, degree_sort=args.degree_sort,
+                                block_tables=not args.no_block_tables)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     # the k-NN build alone, on the global cloud (reported separately)
@@ -223,7 +227,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    with KernelTimer() as timer:
+    with KernelTimer(every=args.timer_every) as timer:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
@@ -242,17 +246,25 @@ def main():
     if rank == 0:
         ms = {name: v[0] for name, v in kernel_ms.items()}
         ab = algorithmic_bytes(args.k, (plan.count / n_local) if args.active_only else 1.0)
-        dom = max(('consistency_fwd', 'consistency_bwd'), key=lambda n_: ms.get(n_, 0.0))
-        achieved = ab[dom] * n_local / (ms[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            key = '%s/N%d/K%d/%s' % (dom, n_local, args.k, args.dtype)
-            traffic = tj.get(key)
-        gpu_ms = sum(ms.values())
         value = n_local * world * args.steps / elapsed
+        roofline = None
+        if 'consistency_fwd' in ms and 'consistency_bwd' in ms:
+            dom = max(('consistency_fwd', 'consistency_bwd'), key=lambda n_: ms[n_])
+            achieved = ab[dom] * n_local / (ms[dom] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic = tj.get('%s/N%d/K%d/%s' % (dom, n_local, args.k, args.dtype))
+            roofline = {'bound': 'hbm', 'kernel': 'dc_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                        'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                        'algorithmic_bytes_per_point': ab[dom], 'kernel_ms': ms,
+                        'timed_launches': {name: v[1] for name, v in kernel_ms.items()},
+                        'timing': 'HIP events around every %d-th launch inside the timed region' % args.timer_every,
+                        'path_achieved': ab['path'] * value / world / 1e9,
+                        'path_frac': ab['path'] * value / world / 1e9 / HBM_PEAK_GBPS,
+                        'gpu_kernel_ms_per_step': sum(ms.values())}
         out = {
             'metric': 'points/sec through min_eigval_loss fwd+bwd (200k pts, k=10); HBM GB/s vs peak',
             'value': value, 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -267,12 +279,7 @@ def main():
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3), 'setup_s': setup_s,
                        'c1_forward_only': {'points': n1, 'features_fwd_ms': c1_ms, 'points_per_s': n1 / (c1_ms * 1e-3),
                                            'algorithmic_GBps': 284 * n1 / (c1_ms * 1e-3) / 1e9, 'knn_build_ms': c1_knn_ms}},
-            'roofline': {'bound': 'hbm', 'kernel': 'dc_' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'algorithmic_bytes_per_point': ab[dom], 'kernel_ms': ms,
-                         'path_achieved': ab['path'] * value / world / 1e9,
-                         'path_frac': ab['path'] * value / world / 1e9 / HBM_PEAK_GBPS,
-                         'gpu_kernel_ms_per_step': gpu_ms},
+            'roofline': roofline,
         }
         if world == 1 and args.cpu_scans > 0:
             torch.cuda.empty_cache()

@@ -12,6 +12,7 @@
 // eigen-solve keep LAPACK-level accuracy); only storage is T.  No atomics: block partial sums are
 // written to a workspace and reduced in a fixed order, so every result is bitwise reproducible.
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include "dc_common.h"
 #include "dc_device.h"
 #include "dc_pointmath.h"
@@ -815,31 +816,34 @@ namespace {
 constexpr int kProfKinds = 3;            // 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd
 constexpr int kProfCap = 4096;
 struct ProfState {
-  bool on = false;
+  int every = 0;                           // 0 = off, N = time every N-th launch of each kind
+  int64_t seen[kProfKinds] = {0, 0, 0};
   int count[kProfKinds] = {0, 0, 0};
   hipEvent_t start[kProfKinds][kProfCap];
   hipEvent_t stop[kProfKinds][kProfCap];
   int created[kProfKinds] = {0, 0, 0};
 } g_prof;
 
+// One timed launch: the kernel is launched through hipExtLaunchKernelGGL, which stamps the two events with the
+// dispatch's own start / end times (what rocprofv3 reports) instead of bracketing it with event packets.
 struct ProfScope {
   int kind, slot;
-  hipStream_t stream;
-  ProfScope(int kind_, hipStream_t s) : kind(kind_), slot(-1), stream(s) {
-    if (!g_prof.on || g_prof.count[kind] >= kProfCap) return;
+  explicit ProfScope(int kind_) : kind(kind_), slot(-1) {
+    if (g_prof.every <= 0 || g_prof.count[kind] >= kProfCap) return;
+    if ((g_prof.seen[kind]++ % g_prof.every) != 0) return;
     slot = g_prof.count[kind];
     if (slot >= g_prof.created[kind]) {
       if (hipEventCreate(&g_prof.start[kind][slot]) != hipSuccess || hipEventCreate(&g_prof.stop[kind][slot]) != hipSuccess) { slot = -1; return; }
       g_prof.created[kind] = slot + 1;
     }
-    (void)hipEventRecord(g_prof.start[kind][slot], stream);
   }
-  ~ProfScope() {
-    if (slot < 0) return;
-    (void)hipEventRecord(g_prof.stop[kind][slot], stream);
-    g_prof.count[kind] = slot + 1;
-  }
+  hipEvent_t start() const { return slot < 0 ? nullptr : g_prof.start[kind][slot]; }
+  hipEvent_t stop() const { return slot < 0 ? nullptr : g_prof.stop[kind][slot]; }
+  ~ProfScope() { if (slot >= 0) g_prof.count[kind] = slot + 1; }
 };
+// launch of a hot kernel inside a `ProfScope prof` block
+#define DC_TIMED_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, prof.start(), prof.stop(), 0, __VA_ARGS__)
 }  // namespace
 
 extern "C" {
@@ -905,8 +909,8 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
   dim3 grid((unsigned)n_blocks(n)), block(kBlock);
 #define LAUNCH(T, PT, S) \
-  hipLaunchKernelGGL((points_fwd_kernel<T, PT, S>), grid, block, 0, stream, in, n, qp, (PT*)points_out, (T*)vps_out, (T*)dirs_out, (T*)depth_out)
-  { ProfScope prof(0, stream); DC_DISPATCH_FMT(dtype, point_fmt, out_stride, LAUNCH); }
+  DC_TIMED_LAUNCH((points_fwd_kernel<T, PT, S>), grid, block, 0, stream, in, n, qp, (PT*)points_out, (T*)vps_out, (T*)dirs_out, (T*)depth_out)
+  { ProfScope prof(0); DC_DISPATCH_FMT(dtype, point_fmt, out_stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   return DC_OK;
@@ -939,14 +943,14 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
 #define LAUNCH(T, PT, S) \
   do { \
     if (S == 4 && staged) { /* padded rows + block table: gathers served from LDS */ \
-      if (eigvals) hipLaunchKernelGGL((consistency_fwd_staged_kernel<T, PT, true>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
-      else hipLaunchKernelGGL((consistency_fwd_staged_kernel<T, PT, false>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
+      if (eigvals) DC_TIMED_LAUNCH((consistency_fwd_staged_kernel<T, PT, true>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
+      else DC_TIMED_LAUNCH((consistency_fwd_staged_kernel<T, PT, false>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
     } else { \
-      if (eigvals) hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
-      else hipLaunchKernelGGL((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+      if (eigvals) DC_TIMED_LAUNCH((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
+      else DC_TIMED_LAUNCH((consistency_fwd_kernel<T, PT, S, false>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
     } \
   } while (0)
-  { ProfScope prof(1, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
+  { ProfScope prof(1); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   if (!reduce) return DC_OK;
@@ -1014,19 +1018,19 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
 #define LAUNCH(T, PT, S) \
   do { \
     if (S == 4 && staged) { \
-      if (want_pose_grad && want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, true, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
-      else if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, false, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
-      else if (want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, true, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
-      else hipLaunchKernelGGL((consistency_bwd_staged_kernel<T, PT, false, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      if (want_pose_grad && want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, true, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      else if (want_pose_grad) DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, false, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      else if (want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, true, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
+      else DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, false, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
     } else \
     { \
-      if (want_pose_grad && want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
-      else if (want_pose_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, false, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
-      else if (want_exponent_grad) hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, true, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
-      else hipLaunchKernelGGL((consistency_bwd_kernel<T, PT, S, false, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      if (want_pose_grad && want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_kernel<T, PT, S, true, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      else if (want_pose_grad) DC_TIMED_LAUNCH((consistency_bwd_kernel<T, PT, S, false, true>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      else if (want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_kernel<T, PT, S, true, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
+      else DC_TIMED_LAUNCH((consistency_bwd_kernel<T, PT, S, false, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
     } \
   } while (0)
-  { ProfScope prof(2, stream); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
+  { ProfScope prof(2); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   if (params && n_red > 0 && reduce) {
@@ -1140,12 +1144,12 @@ int dc_set_option(int option, int value) {
 }
 
 // ---- profiler control ---------------------------------------------------------------------------------------
-int dc_profiler_enable(int on) {
-  g_prof.on = on != 0;
+int dc_profiler_enable(int every) {
+  g_prof.every = every < 0 ? 0 : every;
   return DC_OK;
 }
 int dc_profiler_reset(void) {
-  for (int k = 0; k < kProfKinds; ++k) g_prof.count[k] = 0;
+  for (int k = 0; k < kProfKinds; ++k) { g_prof.count[k] = 0; g_prof.seen[k] = 0; }
   return DC_OK;
 }
 // kind: 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd.  Waits for the recorded launches to finish.

@@ -270,9 +270,13 @@ class KernelTimer:
     """HIP-event timing of the three hot kernels, recorded inside the library on the launch stream."""
     KINDS = ('points_fwd', 'consistency_fwd', 'consistency_bwd')
 
+    def __init__(self, every=1):
+        """every: time every N-th launch of each kernel (an event pair idles the GPU for a few microseconds)."""
+        self.every = int(every)
+
     def __enter__(self):
         check(lib().dc_profiler_reset(), 'dc_profiler_reset')
-        check(lib().dc_profiler_enable(1), 'dc_profiler_enable')
+        check(lib().dc_profiler_enable(self.every), 'dc_profiler_enable')
         return self
 
     def __exit__(self, *exc):

@@ -283,8 +283,10 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
- * bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them. */
-int dc_profiler_enable(int on);
+ * bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them.
+ * every: 0 = off, N >= 1 = time every N-th launch of each kind (an event pair costs a few microseconds of idle GPU
+ * around the kernel, so a timed production loop samples); `launches` counts the timed launches. */
+int dc_profiler_enable(int every);
 int dc_profiler_reset(void);
 int dc_profiler_read(int kind, double* total_ms, int64_t* launches);
 
