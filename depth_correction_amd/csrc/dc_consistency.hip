@@ -500,6 +500,63 @@ __device__ __forceinline__ void read_row(const int4* tile, int cap, uint32_t row
   for (int a = 0; a < ROW16; ++a) q[a] = tile[a * cap + row];
 }
 
+constexpr int kPreSlots = 16;
+
+// second moments of one neighbour about the centre (W is set from the count afterwards)
+__device__ __forceinline__ void cov_add_d(CovAcc& a, double dx, double dy, double dz) {
+  a.s[0] += dx; a.s[1] += dy; a.s[2] += dz;
+  a.S[0] += dx * dx; a.S[1] += dx * dy; a.S[2] += dx * dz;
+  a.S[3] += dy * dy; a.S[4] += dy * dz; a.S[5] += dz * dz;
+}
+
+// one slot from LDS; returns 1 if it held a neighbour.  MISS = false: the caller knows the slot is filled.
+template <typename PT, bool MISS>
+__device__ __forceinline__ int slot_add(const int4* tile, int cap, const typename Pt<PT>::Raw& ci, uint32_t l, CovAcc& acc) {
+  constexpr int XR = Pt<PT>::kRow16;
+  const bool have = !MISS || l != kNoLoc;
+  int4 piece[XR];
+  read_row<XR>(tile, cap, have ? l : 0u, piece);
+  const typename Pt<PT>::Raw cj = Pt<PT>::from_row(piece);
+  double d[3];
+  Pt<PT>::delta(have ? cj : ci, ci, d);
+  cov_add_d(acc, d[0], d[1], d[2]);
+  return have ? 1 : 0;
+}
+
+// the first min(nslots, 16) slots from registers: whole trips of four with the LDS reads batched, then the remainder
+template <typename PT, bool MISS>
+__device__ __forceinline__ int gather_slots(const int4* tile, int cap, const typename Pt<PT>::Raw& ci, const uint32_t* pre,
+                                            int nslots, CovAcc& acc) {
+  constexpr int XR = Pt<PT>::kRow16;
+  int n_have = 0;
+#pragma unroll
+  for (int t = 0; t < kPreSlots / 4; ++t) {
+    if (4 * t + 4 <= nslots) {
+      typename Pt<PT>::Raw cj[4];
+      bool have[4];
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        have[u_] = !MISS || pre[4 * t + u_] != kNoLoc;
+        int4 piece[XR];
+        read_row<XR>(tile, cap, have[u_] ? pre[4 * t + u_] : 0u, piece);
+        cj[u_] = Pt<PT>::from_row(piece);
+      }
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        double d[3];
+        Pt<PT>::delta(have[u_] ? cj[u_] : ci, ci, d);
+        cov_add_d(acc, d[0], d[1], d[2]);
+        n_have += have[u_] ? 1 : 0;
+      }
+    } else {
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_)
+        if (4 * t + u_ < nslots) n_have += slot_add<PT, MISS>(tile, cap, ci, pre[4 * t + u_], acc);
+    }
+  }
+  return n_have;
+}
+
 template <typename T, typename PT, bool FULL_EIG>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
     const PT* __restrict__ x, BlockTab tab, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
@@ -517,44 +574,34 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
   typename Pt<PT>::Raw ci;
   int32_t nslots = 0;
   const uint16_t* lrow = tab.loc;
+  uint32_t pre[kPreSlots];                 // the lane's first 16 block-local positions
   if (blk >= 0) {
     // the lane's own requests go out before the staging loop, so their latency hides behind it
     const int32_t s0 = tab.slot_ptr[blk];
     nslots = tab.slot_ptr[blk + 1] - s0;
     lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
     if (live) ci = Pt<PT>::from_row(xg + (centre_idx ? (int64_t)centre_idx[i] : i) * XR);
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q) pre[q] = (live && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
     stage_rows<XR>(tab, blk, xg, tile, cap);
   }
   __syncthreads();
   if (live) {
     CovAcc acc;
     cov_init(acc);
-    uint32_t nxt[4];
+    // a missing neighbour (empty slot) contributes a zero difference and is not counted; only wavefronts that hold one
+    // pay for the selects
+    bool miss = false;
 #pragma unroll
-    for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (u_ < nslots) ? (uint32_t)lrow[u_ * kBlock] : kNoLoc;
-    for (int q0 = 0; q0 < nslots; q0 += 4) {
-      uint32_t l[4];
-      typename Pt<PT>::Raw cj[4];
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) l[u_] = nxt[u_];
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (q0 + 4 + u_ < nslots) ? (uint32_t)lrow[(q0 + 4 + u_) * kBlock] : kNoLoc;
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) {
-        int4 piece[XR];
-        read_row<XR>(tile, cap, l[u_] == kNoLoc ? 0u : l[u_], piece);
-        cj[u_] = Pt<PT>::from_row(piece);
-      }
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) {
-        // a missing neighbour takes the centre itself: its difference is exactly zero, only the count is masked
-        const bool have = l[u_] != kNoLoc;
-        double d[3];
-        Pt<PT>::delta(have ? cj[u_] : ci, ci, d);
-        cov_add1(acc, d[0], d[1], d[2]);
-        acc.W -= have ? 0.0 : 1.0;
-      }
+    for (int q = 0; q < kPreSlots; ++q) miss |= (q < nslots) && pre[q] == kNoLoc;
+    int n_have = 0;
+    if (__any((int)miss)) n_have = gather_slots<PT, true>(tile, cap, ci, pre, nslots, acc);
+    else n_have = gather_slots<PT, false>(tile, cap, ci, pre, nslots, acc);
+    for (int q = kPreSlots; q < nslots; ++q) {             // K > 16: one slot at a time
+      const uint32_t l = lrow[q * kBlock];
+      n_have += slot_add<PT, true>(tile, cap, ci, l, acc);
     }
+    acc.W = (double)n_have;
     consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
   }
   block_sum<2>(acc2, lds);
@@ -736,11 +783,29 @@ __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double
   }
 }
 
+// torch.optim.Adam (single-tensor path, no amsgrad) for one fp64 parameter; grad is scaled first.
+struct AdamArgs {
+  double* p; double* m; double* v;     // parameters, exp_avg, exp_avg_sq (p == nullptr: no update)
+  int n;
+  double grad_scale, lr, b1, b2, eps, weight_decay, bias1, bias2_sqrt;
+};
+__device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double grad) {
+  double g = grad * a.grad_scale;
+  if (a.weight_decay != 0.0) g += a.weight_decay * a.p[i];
+  const double mi = a.m[i] + (g - a.m[i]) * (1.0 - a.b1);          // exp_avg.lerp_(grad, 1 - beta1)
+  const double vi = a.v[i] * a.b2 + (1.0 - a.b2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  a.m[i] = mi; a.v[i] = vi;
+  const double denom = sqrt(vi) / a.bias2_sqrt + a.eps;
+  a.p[i] = a.p[i] + (-(a.lr / a.bias1)) * (mi / denom);
+}
+
 // One launch for a whole evaluation: out[0..2) <- forward partials, out[2..2+n_red) <- backward partials,
-// out[2+n_red..2+n_acc) <- 0 (gradient slots that were not requested).
+// out[2+n_red..2+n_acc) <- 0 (gradient slots that were not requested).  With `adam.p` the block that finishes
+// dL/dw_i also takes the Adam step of w_i (dc_sequence_step: the kernels of the next evaluation come after it on
+// the stream).
 __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __restrict__ p_fwd, const double* __restrict__ p_bwd,
                                                                 int64_t rows_fwd, int64_t rows_bwd, int n_red,
-                                                                double* __restrict__ out) {
+                                                                double* __restrict__ out, AdamArgs adam) {
   __shared__ double lds[kRedBlock / kWave];
   const int a = blockIdx.x;
   if (a >= 2 + n_red) {
@@ -763,22 +828,13 @@ __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __
     double t = 0.0;
     for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv];
     out[a] = t;
+    if (adam.p && a >= 2 && a - 2 < adam.n) adam_update(adam, a - 2, t);
   }
 }
 
-// torch.optim.Adam (single-tensor path, no amsgrad) on a small fp64 parameter vector; grad is scaled first.
-__global__ void adam_kernel(double* __restrict__ p, const double* __restrict__ grad, double* __restrict__ m,
-                            double* __restrict__ v, int64_t n, double grad_scale, double lr, double b1, double b2,
-                            double eps, double weight_decay, double bias1, double bias2_sqrt) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double g = grad[i] * grad_scale;
-  if (weight_decay != 0.0) g += weight_decay * p[i];
-  const double mi = m[i] + (g - m[i]) * (1.0 - b1);          // exp_avg.lerp_(grad, 1 - beta1)
-  const double vi = v[i] * b2 + (1.0 - b2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-  m[i] = mi; v[i] = vi;
-  const double denom = sqrt(vi) / bias2_sqrt + eps;
-  p[i] = p[i] + (-(lr / bias1)) * (mi / denom);
+__global__ void adam_kernel(const double* __restrict__ grad, AdamArgs adam) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < adam.n) adam_update(adam, i, grad[i]);
 }
 
 }  // namespace dc
@@ -1170,23 +1226,31 @@ int dc_profiler_read(int kind, double* total_ms, int64_t* launches) {
   return DC_OK;
 }
 
+static int make_adam(double* param, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t step, double grad_scale, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, AdamArgs* a) {
+  if (!param || !exp_avg || !exp_avg_sq || n < 0 || n > 0x7fffffff || step < 1) return DC_ERR_ARG;
+  *a = AdamArgs{param, exp_avg, exp_avg_sq, (int)n, grad_scale, lr, beta1, beta2, eps, weight_decay,
+                1.0 - pow(beta1, (double)step), sqrt(1.0 - pow(beta2, (double)step))};
+  return DC_OK;
+}
+
 int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t step,
                  double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
                  hipStream_t stream) {
-  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return DC_ERR_ARG;
+  AdamArgs a;
+  int rc = make_adam(param, exp_avg, exp_avg_sq, n, step, grad_scale, lr, beta1, beta2, eps, weight_decay, &a);
+  if (rc || !grad) return rc ? rc : DC_ERR_ARG;
   if (n == 0) return DC_OK;
-  const double bias1 = 1.0 - pow(beta1, (double)step);
-  const double bias2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
-                     grad_scale, lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, grad, a);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
 
 // One evaluation of a whole sequence (eval.py:85-112 + backward) from a caller-filled descriptor: three kernels
 // (+ two fixed-order reductions).  out fp64 [2 + 2 P + 12 S] = {sum loss over mask, mask count, grads of the sum}.
-int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
-                     int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream) {
+static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
+                              int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream,
+                              const AdamArgs& adam) {
   if (!d || !out || !poses || !d->partials) return DC_ERR_ARG;
   const int stride = 4;
   int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
@@ -1213,9 +1277,26 @@ int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, 
                               n_rows);
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)), rows,
-                     n_red, out);
+                     n_red, out, adam);
   DC_CHECK_LAUNCH();
   return DC_OK;
+}
+
+int dc_sequence_eval(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
+                     int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream) {
+  return sequence_eval_impl(d, w, e, poses, want_grad, want_exponent_grad, want_pose_grad, out, stream, AdamArgs{});
+}
+
+// Evaluation + optimiser step of the model weights in one host call (train.py:220-312 for a single sequence on this
+// rank): the block of the final reduction that finishes dL/dw_i also applies torch.optim.Adam's update to w_i.
+int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                     double* exp_avg_sq, int64_t step, double grad_scale, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, double* out, hipStream_t stream) {
+  if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0) return DC_ERR_ARG;
+  AdamArgs a;
+  int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step, grad_scale, lr, beta1, beta2, eps, weight_decay, &a);
+  if (rc) return rc;
+  return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out, stream, a);
 }
 
 }  // extern "C"

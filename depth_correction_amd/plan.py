@@ -170,6 +170,20 @@ class SequencePlan:
         self.version += 1
         return out
 
+    def step_native(self, w, exponent, poses12, out, exp_avg, exp_avg_sq, t, grad_scale, lr, betas, eps, weight_decay):
+        """Evaluation + Adam step of ``w`` (in place) in one host call (dc_sequence_step); out as in eval_native."""
+        nt = w.numel()
+        d = self.desc(nt)
+        need(poses12, (self.n_scans, 12), dtype=torch.float64, name='poses12', device=self.device)
+        need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
+            need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
+        check(lib().dc_sequence_step(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
+                                     int(t), float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                     float(weight_decay), ptr(out), stream_ptr()), 'dc_sequence_step')
+        self.version += 1
+        return out
+
     # ------------------------------------------------------------------------------------------------
     def poses12(self, poses):
         poses = torch.as_tensor(poses, device=self.device) if not isinstance(poses, torch.Tensor) else poses
@@ -307,6 +321,8 @@ class SequenceTrainer:
         self.w = torch.as_tensor(w, dtype=torch.float64).reshape(-1).to(dev).contiguous()
         self.exponent = torch.as_tensor(exponent, dtype=torch.float64).reshape(-1).to(dev).contiguous()
         self.nt = self.w.numel()
+        # a single local sequence with the native evaluation and optimiser: one host call, Adam inside the last kernel
+        self.fused_step = evaluate is None and adam is None and len(self.plans) == 1 and not distributed and self.nt > 0
         self.evaluate = evaluate or (lambda plan, w_, e_, P, out: plan.eval_native(w_, e_, P, out))
         self.adam = adam or self._adam_native
         self.poses12 = [p.poses12(T) if hasattr(p, 'poses12') else T for p, T in zip(self.plans, poses)]
@@ -330,6 +346,12 @@ class SequenceTrainer:
     def step(self):
         """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
         (mean loss = acc[0] / acc[1]).  No host synchronisation."""
+        if self.fused_step:
+            self.t += 1
+            out = self.plans[0].step_native(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg,
+                                            self.exp_avg_sq, self.t, 1.0 / self.count, self.lr, self.betas, self.eps,
+                                            self.weight_decay)
+            return out[:2 + self.nt]
         for plan, P, out in zip(self.plans, self.poses12, self.outs):
             self.evaluate(plan, self.w, self.exponent, P, out)
         if len(self.outs) == 1:
