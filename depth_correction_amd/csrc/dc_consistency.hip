@@ -215,18 +215,37 @@ __global__ __launch_bounds__(kBlock) void features_fwd_kernel(
 // Backward epilogue per point: dL/dx_j -> dL/dw, dL/dexponent, dL/d[R|t] of the point's scan.
 // acc layout: [0,P) grad w, [P,2P) grad exponent, then 12 per-scan slots handled by the caller.
 // ------------------------------------------------------------------------------------------------
+// the per-point inputs of the epilogue in their storage type, so they can be requested early (before a gather loop)
 template <typename T>
-__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j,
+struct PointRaw {
+  T dr[3], d, inc;
+  bool lm;
+  int s;
+};
+template <typename T>
+__device__ __forceinline__ PointRaw<T> load_point_raw(const PointInputs& in, const ModelParams& mp, int64_t j) {
+  PointRaw<T> r;
+  const T* dirs = (const T*)in.dirs;
+  r.dr[0] = dirs[j * 3]; r.dr[1] = dirs[j * 3 + 1]; r.dr[2] = dirs[j * 3 + 2];
+  r.d = ((const T*)in.depth)[j];
+  r.lm = in.lmask ? in.lmask[j] != 0 : true;
+  r.s = in.scan_id ? in.scan_id[j] : 0;
+  r.inc = (mp.kind != DC_MODEL_NONE) ? ((const T*)in.inc)[j] : (T)0;
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j, const PointRaw<T>& raw,
                                                  const double* g, double* gw, double* ge, double* gT, bool want_e,
                                                  bool want_pose, int* scan) {
   double vp[3], dr[3], T12[12];
   const QParams qp0{};
   if (in.vps) Row3<T, 3>::load((const T*)in.vps, j, vp, qp0);
   else { vp[0] = vp[1] = vp[2] = 0.0; }
-  Row3<T, 3>::load((const T*)in.dirs, j, dr, qp0);
-  const double d = (double)((const T*)in.depth)[j];
-  const bool lm = in.lmask ? in.lmask[j] != 0 : true;
-  const int s = in.scan_id ? in.scan_id[j] : 0;
+  dr[0] = (double)raw.dr[0]; dr[1] = (double)raw.dr[1]; dr[2] = (double)raw.dr[2];
+  const double d = (double)raw.d;
+  const bool lm = raw.lm;
+  const int s = raw.s;
   *scan = s;
   load_pose(in, s, T12);
   // dL/dd' = (R dir) . g = dir . (R^T g)
@@ -236,7 +255,7 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
   const double gd = dr[0] * rg0 + dr[1] * rg1 + dr[2] * rg2;
   double dcorr = d;
   if (mp.kind != DC_MODEL_NONE && lm) {
-    const double inc = (double)((const T*)in.inc)[j];
+    const double inc = (double)raw.inc;
     const double base = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d * gd : -gd;
     double bias = 0.0;
 #pragma unroll
@@ -256,6 +275,13 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
     // kept factored (6 values, not 12) until the block reduction: gT = [g, xl], dL/d[R|t]_{a,b} = g_a * [xl, 1]_b
     gT[0] = g[0]; gT[1] = g[1]; gT[2] = g[2]; gT[3] = xl0; gT[4] = xl1; gT[5] = xl2;
   }
+}
+
+template <typename T>
+__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j,
+                                                 const double* g, double* gw, double* ge, double* gT, bool want_e,
+                                                 bool want_pose, int* scan) {
+  points_bwd_point<T>(in, mp, j, load_point_raw<T>(in, mp, j), g, gw, ge, gT, want_e, want_pose, scan);
 }
 
 // Per-scan sums of the 12 pose-gradient values g_a * [xl, 1]_b of the 256 points of a block (gx = [g, xl] of this
@@ -632,6 +658,8 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
   const int64_t j = blk * kBlock + threadIdx.x;
   const bool active = blk >= 0 && j < n;
   typename Pt<PT>::Raw cj;
+  PointRaw<T> raw;
+  uint32_t pre[kPreSlots];
   int32_t nslots = 0;
   uint32_t nd = 0;
   const uint16_t* lrow = tab.loc;
@@ -639,7 +667,13 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
     const int32_t s0 = tab.slot_ptr[blk];
     nslots = tab.slot_ptr[blk + 1] - s0;
     lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
-    if (active) cj = Pt<PT>::from_row(reinterpret_cast<const int4*>(x) + j * XR);
+    if (active) {
+      // everything this lane needs later is requested before the staging loop: its latency hides behind it
+      cj = Pt<PT>::from_row(reinterpret_cast<const int4*>(x) + j * XR);
+      if (in.dirs) raw = load_point_raw<T>(in, mp, j);
+    }
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q) pre[q] = (active && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
     nd = (uint32_t)stage_rows<RR>(tab, blk, reinterpret_cast<const int4*>(rec), tile, cap);
     // row nd is an all-zero record: empty slots point there and contribute exactly nothing
     if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
@@ -648,27 +682,41 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
   if (active) {
     double g[3] = {0.0, 0.0, 0.0};
     const double u = Pt<PT>::unit(qp);
-    uint32_t nxt[4];
+    // a lane's slots fill from 0 upwards: once a whole trip is empty for every lane of the wavefront, so are the rest
+    bool more = true;
 #pragma unroll
-    for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (u_ < nslots) ? (uint32_t)lrow[u_ * kBlock] : kNoLoc;
-    for (int q0 = 0; q0 < nslots; q0 += 4) {
-      uint32_t l[4];
-      int4 q[4][RR];
+    for (int t = 0; t < kPreSlots / 4; ++t) {
+      if (more && 4 * t < nslots) {
+        if (__all((int)(pre[4 * t] == kNoLoc))) {
+          more = false;
+        } else {
+          int4 q[4][RR];
 #pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) l[u_] = nxt[u_];
-      // a lane's slots fill from 0 upwards: once a whole trip is empty for every lane of the wavefront, so are the rest
-      if (__all((int)(l[0] == kNoLoc))) break;
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (q0 + 4 + u_ < nslots) ? (uint32_t)lrow[(q0 + 4 + u_) * kBlock] : kNoLoc;
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) {
-        read_row<RR>(tile, cap, l[u_] < nd ? l[u_] : nd, q[u_]);
+          for (int u_ = 0; u_ < 4; ++u_) read_row<RR>(tile, cap, pre[4 * t + u_] < nd ? pre[4 * t + u_] : nd, q[u_]);
+          edge_terms4<PT>(cj, q, g);
+        }
       }
-      edge_terms4<PT>(cj, q, g);
+    }
+    if (more && nslots > kPreSlots) {                       // in-degrees above 16: positions fetched trip by trip
+      uint32_t nxt[4];
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (kPreSlots + u_ < nslots) ? (uint32_t)lrow[(kPreSlots + u_) * kBlock] : kNoLoc;
+      for (int q0 = kPreSlots; q0 < nslots; q0 += 4) {
+        uint32_t l[4];
+        int4 q[4][RR];
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) l[u_] = nxt[u_];
+        if (__all((int)(l[0] == kNoLoc))) break;
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (q0 + 4 + u_ < nslots) ? (uint32_t)lrow[(q0 + 4 + u_) * kBlock] : kNoLoc;
+#pragma unroll
+        for (int u_ = 0; u_ < 4; ++u_) read_row<RR>(tile, cap, l[u_] < nd ? l[u_] : nd, q[u_]);
+        edge_terms4<PT>(cj, q, g);
+      }
     }
     g[0] *= u; g[1] *= u; g[2] *= u;
     if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
-    if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+    if (in.dirs) points_bwd_point<T>(in, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
   if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
 }
