@@ -19,8 +19,16 @@ namespace dc {
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 template <typename R> DC_HD R rsqrt_(R x) { return (R)rsqrt((double)x); }       // v_rsq_f64 + refinement, no division
+// 1 / x for a normal, finite, non-zero x (counts, traces, clamped denominators): v_rcp_f64 (~2^-26) and two
+// Newton steps instead of the IEEE division sequence (div_scale x2, rcp, fma x5, div_fmas, div_fixup); <= 1 ulp.
+DC_HD double recip_(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
 #else
 template <typename R> DC_HD R rsqrt_(R x) { return R(1) / sqrt(x); }
+DC_HD double recip_(double x) { return 1.0 / x; }
 #endif
 
 template <typename R>
@@ -171,7 +179,7 @@ DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double 
     v0[0] = 1.0; v0[1] = 0.0; v0[2] = 0.0;
     return;
   }
-  const double inv_m = 1.0 / m;
+  const double inv_m = recip_(m);       // 0 < m < inf
   a00 *= inv_m; a01 *= inv_m; a02 *= inv_m; a11 *= inv_m; a12 *= inv_m; a22 *= inv_m;
   const double q = 1.0 / 3.0;             // trace of the scaled matrix is 1
   const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
@@ -198,7 +206,7 @@ DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double 
     const double m0 = d1 * d2 - a12 * a12, m1 = d0 * d2 - a02 * a02, m2 = d0 * d1 - a01 * a01;
     const double f = d0 * m0 - a01 * (a01 * d2 - a12 * a02) + a02 * (a01 * a12 - d1 * a02);
     const double fp = -(m0 + m1 + m2);
-    if (fp != 0.0) l -= f / fp;
+    if (fabs(fp) > 1e-200) l -= f * recip_(fp);
   }
   double iso[3];
   eigvec_isolated(a00, a01, a02, a11, a12, a22, l, iso);

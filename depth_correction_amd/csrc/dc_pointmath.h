@@ -108,7 +108,7 @@ DC_HD void cov_add(CovAcc& a, double dx, double dy, double dz, double wm) {
 DC_HD void cov_finish(const CovAcc& a, double scale, double* mean_off, double* cmean_off, double* C, double* D_out,
                       double* omega_out) {
   // 0/0 -> NaN exactly like the reference when a neighbourhood has no valid member.
-  const double invWm = 1.0 / a.Wm;
+  const double invWm = recip_(a.Wm);        // Wm = 0 -> NaN either way (0 * inf), like the reference's 0/0
   for (int i = 0; i < 3; ++i) mean_off[i] = a.Wm > 0.0 ? a.sm[i] * invWm : a.sm[i] / a.Wm;
   double omega = 1.0;
   if (scale > 0.0) {
@@ -119,10 +119,10 @@ DC_HD void cov_finish(const CovAcc& a, double scale, double* mean_off, double* c
   const double Wc = omega * a.W;
   double D = Wc - 1.0;
   D = D < 1e-6 ? 1e-6 : D;
-  const double invW = (a.W == a.Wm) ? invWm : 1.0 / a.W;
+  const double invW = (a.W == a.Wm) ? invWm : recip_(a.W);
   const double c0 = a.s[0] * invW, c1 = a.s[1] * invW, c2 = a.s[2] * invW;
   cmean_off[0] = c0; cmean_off[1] = c1; cmean_off[2] = c2;
-  const double f = omega / D;
+  const double f = omega * recip_(D);       // D >= 1e-6
   C[0] = (a.S[0] - a.s[0] * c0) * f;
   C[1] = (a.S[1] - a.s[0] * c1) * f;
   C[2] = (a.S[2] - a.s[0] * c2) * f;
@@ -160,7 +160,7 @@ DC_HD double loss_and_coeffs(const LossParams& lp, double lam0, double tr, doubl
   if (lp.kind == DC_LOSS_MIN_EIGVAL) {
     if (lp.normalization) {
       const double tc = tr < 1e-6 ? 1e-6 : tr;
-      const double inv = 1.0 / tc;
+      const double inv = recip_(tc);          // tc >= 1e-6
       raw = lam0 * inv;
       g_vv = inv;
       g_eye = (tr > 1e-6) ? -raw * inv : 0.0;
@@ -180,7 +180,7 @@ DC_HD double loss_and_coeffs(const LossParams& lp, double lam0, double tr, doubl
     a = (l > 0.0) ? a * 0.5 / s : 0.0;
     l = s;
   }
-  const double f = (D == 9.0) ? a * (2.0 / 9.0) : 2.0 * a / D;     // K = 10 valid neighbours: no division
+  const double f = (D == 9.0) ? a * (2.0 / 9.0) : 2.0 * a * recip_(D);     // K = 10 valid neighbours: a constant
   *c1 = f * g_vv;
   *c2 = -f * g_eye;
   return l;
