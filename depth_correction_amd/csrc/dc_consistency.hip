@@ -528,13 +528,6 @@ __device__ __forceinline__ void read_row(const int4* tile, int cap, uint32_t row
 
 constexpr int kPreSlots = 16;
 
-// second moments of one neighbour about the centre (W is set from the count afterwards)
-__device__ __forceinline__ void cov_add_d(CovAcc& a, double dx, double dy, double dz) {
-  a.s[0] += dx; a.s[1] += dy; a.s[2] += dz;
-  a.S[0] += dx * dx; a.S[1] += dx * dy; a.S[2] += dx * dz;
-  a.S[3] += dy * dy; a.S[4] += dy * dz; a.S[5] += dz * dz;
-}
-
 // one slot from LDS; returns 1 if it held a neighbour.  MISS = false: the caller knows the slot is filled.
 template <typename PT, bool MISS>
 __device__ __forceinline__ int slot_add(const int4* tile, int cap, const typename Pt<PT>::Raw& ci, uint32_t l, CovAcc& acc) {

@@ -81,11 +81,15 @@ DC_HD void cov_init(CovAcc& a) {
 }
 
 // validity weights only (the hot path): mean weights == validity, filled in by cov_same_weights()
+// (explicit fma: the same rounding wherever this is inlined -- the gather and the LDS-staged kernels must agree bit for bit)
+DC_HD void cov_add_d(CovAcc& a, double dx, double dy, double dz) {
+  a.s[0] += dx; a.s[1] += dy; a.s[2] += dz;
+  a.S[0] = fma(dx, dx, a.S[0]); a.S[1] = fma(dx, dy, a.S[1]); a.S[2] = fma(dx, dz, a.S[2]);
+  a.S[3] = fma(dy, dy, a.S[3]); a.S[4] = fma(dy, dz, a.S[4]); a.S[5] = fma(dz, dz, a.S[5]);
+}
 DC_HD void cov_add1(CovAcc& a, double dx, double dy, double dz) {
   a.W += 1.0;
-  a.s[0] += dx; a.s[1] += dy; a.s[2] += dz;
-  a.S[0] += dx * dx; a.S[1] += dx * dy; a.S[2] += dx * dz;
-  a.S[3] += dy * dy; a.S[4] += dy * dz; a.S[5] += dz * dz;
+  cov_add_d(a, dx, dy, dz);
 }
 DC_HD void cov_same_weights(CovAcc& a) {
   a.Wm = a.W;

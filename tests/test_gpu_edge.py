@@ -169,3 +169,64 @@ def test_operand_checks_refuse_bad_shapes():
         ops.knn(x.cpu(), 3)
     with pytest.raises(RuntimeError):
         ops.knn(x.t().contiguous().t(), 3)                             # non-contiguous view
+
+
+def _staged_vs_gather(x4, nbr, qf=None, mask=None):
+    """Forward + backward through block tables (LDS-staged) and without: everything must agree bit for bit."""
+    from depth_correction_amd import ops
+    cp, cs = ops.knn_transpose(nbr, n_dst=x4.shape[0])
+    ft, bt = ops.block_table(nbr=nbr), ops.block_table(csr=(cp, cs))
+    assert ft is not None and bt is not None
+    outs = []
+    for tabs in ((None, None), (ft, bt)):
+        fw = ops.consistency_fwd(x4, nbr, mask=mask, want_pointwise=True, want_eigvals=True, qfmt=qf, table=tabs[0])
+        gp, _ = ops.consistency_bwd(x4, fw['rec'], cp, cs, want_grad_points=True, qfmt=qf, table=tabs[1])
+        outs.append([npy(fw[f]) for f in ('sums', 'pointwise', 'eigvals', 'rec')] + [npy(gp)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    return outs[1]
+
+
+@pytest.mark.parametrize('n,k', [(1, 1), (2, 2), (255, 6), (256, 6), (257, 6), (1025, 10), (3000, 16), (3000, 17),
+                                 (3000, 33), (2000, 64)])
+def test_block_tables_sizes_and_wide_k(n, k):
+    """Block boundaries, a single point, and neighbour lists longer than the 16 positions the staged kernels keep in
+    registers (k = 17, 33, 64; in-degrees above 16 in the backward)."""
+    from depth_correction_amd import ops
+    pts = _cloud(n, seed=n + k)
+    x = t(pts, DEV)
+    _, idx = ops.knn(x, k)
+    for q32 in (False, True):
+        if q32:
+            qf = ops.QFormat.for_extent(pts.min(0), pts.max(0))
+            xq = torch.round((x - torch.tensor(qf.origin, device=DEV)) / qf.scale).to(torch.int32)
+            xs = torch.cat([xq, torch.zeros((n, 1), dtype=torch.int32, device=DEV)], 1).contiguous()
+        else:
+            qf, xs = None, torch.cat([x, torch.zeros((n, 1), dtype=x.dtype, device=DEV)], 1).contiguous()
+        _staged_vs_gather(xs, idx, qf)
+
+
+def test_block_tables_ragged_lists_and_hubs():
+    """Radius neighbourhoods (empty slots, isolated points, rows without any valid member) and a hub point that sits in
+    hundreds of neighbourhoods (an in-degree far above the block's other points)."""
+    from depth_correction_amd import ops
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([_cloud(1500, 2), np.array([[50.0, 50.0, 50.0], [-40.0, 0.0, 9.0]])])
+    x = t(pts, DEV)
+    idx = ops.radius_neighbors(x, 0.25)
+    idx[7] = -1                                                      # a centre without any valid neighbour
+    hub = rng.choice(len(pts), 400, replace=False)
+    idx[hub, idx.shape[1] - 1] = 3                                   # point 3 gains ~400 incoming edges
+    xs = torch.cat([x, torch.zeros((len(pts), 1), dtype=x.dtype, device=DEV)], 1).contiguous()
+    mask = t(rng.random(len(pts)) < 0.7, DEV)
+    out = _staged_vs_gather(xs, idx.contiguous(), mask=mask)
+    assert np.isfinite(out[4][3]).all() and np.abs(out[4][3]).max() > 0
+
+
+def test_block_table_of_empty_cloud():
+    from depth_correction_amd import ops
+    nbr = torch.zeros((0, 4), dtype=torch.int32, device=DEV)
+    tab = ops.block_table(nbr=nbr)
+    assert tab.max_rows == 0 and npy(tab.blk_ptr).tolist() == [0] and npy(tab.slot_ptr).tolist() == [0]
+    x = torch.zeros((0, 4), dtype=torch.float64, device=DEV)
+    assert npy(ops.consistency_fwd(x, nbr, table=tab)['sums']).tolist() == [0.0, 0.0]
