@@ -36,6 +36,44 @@ def test_binding_covers_header(built):
     assert set(built._SIGNATURES) == set(_declared())
 
 
+def _prototypes():
+    """{name: (return type, [parameter declarations])} of every function include/dc_hip.h declares."""
+    text = open(os.path.join(ROOT, 'include', 'dc_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b([A-Za-z_][A-Za-z0-9_]*(?:\s*\*)?)\s+(dc_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', text, flags=re.S):
+        params = [p.strip() for p in m.group(3).replace('\n', ' ').split(',')]
+        out[m.group(2)] = (m.group(1).strip(), [] if params in (['void'], ['']) else params)
+    return out
+
+
+def _ctype_of(decl):
+    """ctypes type a C parameter declaration must be bound with."""
+    if '*' in decl or 'dcStream_t' in decl:
+        return ctypes.c_void_p
+    if decl.startswith('int64_t'):
+        return ctypes.c_int64
+    if decl.startswith('size_t'):
+        return ctypes.c_size_t
+    if decl.startswith('double'):
+        return ctypes.c_double
+    if decl.startswith('int ') or decl.startswith('int32_t'):
+        return ctypes.c_int
+    raise AssertionError('unhandled parameter type: %r' % decl)
+
+
+def test_binding_signatures_match_header(built):
+    """Every ctypes signature has the header's parameter list: same length, same kind per position, same return."""
+    protos = _prototypes()
+    assert set(protos) == set(built._SIGNATURES)
+    for name, (ret, params) in protos.items():
+        res, args = built._SIGNATURES[name]
+        assert len(args) == len(params), (name, len(args), len(params))
+        for pos, (a, decl) in enumerate(zip(args, params)):
+            assert a is _ctype_of(decl), (name, pos, decl, a)
+        assert res is _ctype_of(ret + ' '), (name, ret, res)
+
+
 def test_code_object_is_gfx950(built):
     blob = open(built.lib_path(), 'rb').read()
     targets = set(re.findall(rb'hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)', blob))
