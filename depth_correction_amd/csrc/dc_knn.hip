@@ -478,7 +478,9 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, const double
                       const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, hipStream_t st) {
   const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
 #define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist)
-  if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
+  // the sorted insertion costs ~12 instructions per slot and runs for a whole wavefront whenever one lane accepts a
+  // candidate, so the slot count follows k closely (10 = the reference's default nn_k)
+  if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 10) LK(10); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
 #undef LK
   DC_HIP(hipGetLastError());
   return DC_OK;
