@@ -52,25 +52,6 @@ __global__ __launch_bounds__(kBlock) void points_fwd_kernel(PointInputs in, int6
   if (depth_out) depth_out[i] = (T)dc_;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Gather one neighbourhood and accumulate mean / second moments about the centre point.
-// ------------------------------------------------------------------------------------------------
-template <typename T, typename PT, int STRIDE>
-__device__ __forceinline__ void gather_neighbourhood(const PT* __restrict__ x, const int32_t* __restrict__ nbr,
-                                                     const T* __restrict__ wmean, int64_t i, int k, const double* xi,
-                                                     const QParams& qp, CovAcc& acc) {
-  cov_init(acc);
-  const int32_t* row = nbr + i * k;
-  for (int q = 0; q < k; ++q) {
-    const int32_t j = row[q];
-    if (j < 0) continue;
-    double xj[3];
-    Row3<PT, STRIDE>::load(x, j, xj, qp);
-    const double wm = wmean ? (double)wmean[i * k + q] : 1.0;
-    cov_add(acc, xj[0] - xi[0], xj[1] - xi[1], xj[2] - xi[2], wm);
-  }
-}
-
 // Everything of the forward after the neighbourhood moments are gathered: covariance -> smallest eigenpair -> loss,
 // backward record, masked loss / count of this lane (acc2).  Shared by the gather and the LDS-staged kernel.
 template <typename T, typename PT, bool FULL_EIG>
@@ -151,63 +132,6 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
   if (threadIdx.x == 0) {                       // partials are [accumulator][block]: the reduction reads rows
     partials[blockIdx.x] = acc2[0];
     partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Full neighbourhood features (DepthCloud.update_features): mean, cov, eigvals, eigvecs, normals,
-// incidence angles, valid-neighbour count, weights.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int STRIDE>
-__global__ __launch_bounds__(kBlock) void features_fwd_kernel(
-    const T* __restrict__ x, const int32_t* __restrict__ nbr, const T* __restrict__ wmean, const T* __restrict__ dirs,
-    int64_t n, int k, double scale, T* __restrict__ mean, T* __restrict__ cov, T* __restrict__ eigvals,
-    T* __restrict__ eigvecs, T* __restrict__ normals, T* __restrict__ inc, int32_t* __restrict__ nvalid,
-    T* __restrict__ weights_out, T* __restrict__ cmean_out, T* __restrict__ invd_out) {
-  const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block(nblocks);
-  if (blk < 0) return;
-  const int64_t i = blk * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const QParams qp{};
-  double xi[3];
-  Row3<T, STRIDE>::load(x, i, xi, qp);
-  CovAcc acc;
-  gather_neighbourhood<T, T, STRIDE>(x, nbr, wmean, i, k, xi, qp, acc);
-  double moff[3], cm[3], C[6], D, omega;
-  cov_finish(acc, scale, moff, cm, C, &D, &omega);
-  if (mean) { mean[i * 3] = (T)(xi[0] + moff[0]); mean[i * 3 + 1] = (T)(xi[1] + moff[1]); mean[i * 3 + 2] = (T)(xi[2] + moff[2]); }
-  if (cmean_out) { cmean_out[i * 3] = (T)(xi[0] + cm[0]); cmean_out[i * 3 + 1] = (T)(xi[1] + cm[1]); cmean_out[i * 3 + 2] = (T)(xi[2] + cm[2]); }
-  if (invd_out) invd_out[i] = (T)(omega / D);
-  if (cov) {
-    T* c = cov + i * 9;
-    c[0] = (T)C[0]; c[1] = (T)C[1]; c[2] = (T)C[2];
-    c[3] = (T)C[1]; c[4] = (T)C[3]; c[5] = (T)C[4];
-    c[6] = (T)C[2]; c[7] = (T)C[4]; c[8] = (T)C[5];
-  }
-  if (nvalid) nvalid[i] = (int32_t)acc.W;
-  if (weights_out) {
-    const int32_t* row = nbr + i * k;
-    for (int q = 0; q < k; ++q) weights_out[i * k + q] = row[q] >= 0 ? (T)omega : (T)0;
-  }
-  if (eigvals || eigvecs || normals || inc) {
-    double lam[3], V[3][3];
-    eig3_sym<double>(C[0], C[1], C[2], C[3], C[4], C[5], lam, V);
-    if (eigvals) { eigvals[i * 3] = (T)lam[0]; eigvals[i * 3 + 1] = (T)lam[1]; eigvals[i * 3 + 2] = (T)lam[2]; }
-    if (eigvecs) {   // torch layout: eigvecs[i, :, k] = k-th eigenvector
-      T* e = eigvecs + i * 9;
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) e[r * 3 + c] = (T)V[c][r];
-    }
-    if (normals || inc) {
-      double dr[3], nrm[3], a;
-      Row3<T, 3>::load(dirs, i, dr, qp);
-      normal_and_incidence(dr, V[0], nrm, &a);
-      if (normals) Row3<T, 3>::store(normals, i, nrm, qp);
-      if (inc) inc[i] = (T)a;
-    }
   }
 }
 
@@ -738,68 +662,6 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
   reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
 }
 
-// Generic neighbourhood-features backward for the un-fused API path:
-//   dL/dx_j = sum_{i -> j} [ Gs_i (x_j - cmean_i) + gm_i ],  grec[N,12] = {cmean.xyz, Gs(xx xy xz yy yz zz), gm.xyz}
-template <typename T, int STRIDE>
-__global__ __launch_bounds__(kBlock) void features_bwd_kernel(const T* __restrict__ x, const T* __restrict__ grec,
-                                                              const int32_t* __restrict__ csr_ptr,
-                                                              const int32_t* __restrict__ csr_src, int64_t n,
-                                                              T* __restrict__ grad_points) {
-  const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block(nblocks);
-  if (blk < 0) return;
-  const int64_t j = blk * kBlock + threadIdx.x;
-  if (j >= n) return;
-  double xj[3], g[3] = {0.0, 0.0, 0.0};
-  Row3<T, STRIDE>::load(x, j, xj, QParams{});
-  const int32_t beg = csr_ptr[j], end = csr_ptr[j + 1];
-  for (int32_t e = beg; e < end; ++e) {
-    const T* r = grec + (int64_t)csr_src[e] * 12;
-    const double d0 = xj[0] - (double)r[0], d1 = xj[1] - (double)r[1], d2 = xj[2] - (double)r[2];
-    const double xx = r[3], xy = r[4], xz = r[5], yy = r[6], yz = r[7], zz = r[8];
-    g[0] += xx * d0 + xy * d1 + xz * d2 + (double)r[9];
-    g[1] += xy * d0 + yy * d1 + yz * d2 + (double)r[10];
-    g[2] += xz * d0 + yz * d1 + zz * d2 + (double)r[11];
-  }
-  Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
-}
-
-// Build the generic backward record from upstream gradients of (mean, cov, eigvals):
-//   G = V diag(ge) V^T + sym(gcov);  Gs = 2 (omega / D) G;  gm = gmean / W.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void features_grec_kernel(const T* __restrict__ cmean, const T* __restrict__ invd,
-                                                               const int32_t* __restrict__ nvalid,
-                                                               const T* __restrict__ eigvecs, const T* __restrict__ g_mean,
-                                                               const T* __restrict__ g_cov, const T* __restrict__ g_eig,
-                                                               int64_t n, T* __restrict__ grec) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  double G[6] = {0, 0, 0, 0, 0, 0};
-  if (g_eig) {
-    const T* e = eigvecs + i * 9;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double ge = (double)g_eig[i * 3 + k];
-      const double v0 = e[0 * 3 + k], v1 = e[1 * 3 + k], v2 = e[2 * 3 + k];
-      G[0] += ge * v0 * v0; G[1] += ge * v0 * v1; G[2] += ge * v0 * v2;
-      G[3] += ge * v1 * v1; G[4] += ge * v1 * v2; G[5] += ge * v2 * v2;
-    }
-  }
-  if (g_cov) {
-    const T* c = g_cov + i * 9;
-    G[0] += (double)c[0]; G[1] += 0.5 * ((double)c[1] + (double)c[3]); G[2] += 0.5 * ((double)c[2] + (double)c[6]);
-    G[3] += (double)c[4]; G[4] += 0.5 * ((double)c[5] + (double)c[7]); G[5] += (double)c[8];
-  }
-  const double f = 2.0 * (double)invd[i];
-  T* r = grec + i * 12;
-  r[0] = cmean[i * 3]; r[1] = cmean[i * 3 + 1]; r[2] = cmean[i * 3 + 2];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) r[3 + q] = (T)(f * G[q]);
-  const double w = (double)nvalid[i];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) r[9 + q] = g_mean ? (T)((double)g_mean[i * 3 + q] / w) : (T)0;
-}
-
 // Sum the block partials [n_acc][n_rows] in a fixed order into out[n_acc]: one 1024-lane block per accumulator,
 // contiguous (coalesced) reads.
 constexpr int kRedBlock = 1024;
@@ -1184,52 +1046,6 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
-  DC_CHECK_LAUNCH();
-  return DC_OK;
-}
-
-int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nbr, int64_t n, int k,
-                    const void* mean_weights, double scale, const void* dirs, void* mean, void* cov, void* eigvals,
-                    void* eigvecs, void* normals, void* inc_angles, int32_t* nvalid, void* weights_out,
-                    void* cmean_out, void* invd_out, hipStream_t stream) {
-  if (n == 0) return DC_OK;
-  if (n < 0 || k < 1 || !points || !nbr || (stride != 3 && stride != 4)) return DC_ERR_ARG;
-  if ((normals || inc_angles) && !dirs) return DC_ERR_ARG;
-  dim3 grid((unsigned)xcd_grid(n_blocks(n))), block(kBlock);
-#define LAUNCH(T, S) \
-  hipLaunchKernelGGL((features_fwd_kernel<T, S>), grid, block, 0, stream, (const T*)points, nbr, (const T*)mean_weights, \
-                     (const T*)dirs, n, k, scale, (T*)mean, (T*)cov, (T*)eigvals, (T*)eigvecs, (T*)normals, \
-                     (T*)inc_angles, nvalid, (T*)weights_out, (T*)cmean_out, (T*)invd_out)
-  if (dtype == DC_F32) { if (stride == 3) LAUNCH(float, 3); else LAUNCH(float, 4); }
-  else if (dtype == DC_F64) { if (stride == 3) LAUNCH(double, 3); else LAUNCH(double, 4); }
-  else return DC_ERR_DTYPE;
-#undef LAUNCH
-  DC_CHECK_LAUNCH();
-  return DC_OK;
-}
-
-int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* csr_ptr, const int32_t* csr_src,
-                    int64_t n, const void* cmean, const void* invd, const int32_t* nvalid, const void* eigvecs,
-                    const void* grad_mean, const void* grad_cov, const void* grad_eigvals, void* grec_ws,
-                    void* grad_points, hipStream_t stream) {
-  if (n == 0) return DC_OK;
-  if (n < 0 || !points || !csr_ptr || !csr_src || !cmean || !invd || !nvalid || !grec_ws || !grad_points) return DC_ERR_ARG;
-  if (stride != 3 && stride != 4) return DC_ERR_ARG;
-  if (grad_eigvals && !eigvecs) return DC_ERR_ARG;
-  if (n == 0) return DC_OK;
-  dim3 block(kBlock);
-#define LAUNCH(T, S) \
-  do { \
-    hipLaunchKernelGGL((features_grec_kernel<T>), dim3((unsigned)n_blocks(n)), block, 0, stream, (const T*)cmean, \
-                       (const T*)invd, nvalid, (const T*)eigvecs, (const T*)grad_mean, (const T*)grad_cov, \
-                       (const T*)grad_eigvals, n, (T*)grec_ws); \
-    hipLaunchKernelGGL((features_bwd_kernel<T, S>), dim3((unsigned)xcd_grid(n_blocks(n))), block, 0, stream, \
-                       (const T*)points, (const T*)grec_ws, csr_ptr, csr_src, n, (T*)grad_points); \
-  } while (0)
-  if (dtype == DC_F32) { if (stride == 3) LAUNCH(float, 3); else LAUNCH(float, 4); }
-  else if (dtype == DC_F64) { if (stride == 3) LAUNCH(double, 3); else LAUNCH(double, 4); }
-  else return DC_ERR_DTYPE;
-#undef LAUNCH
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
