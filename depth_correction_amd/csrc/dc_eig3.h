@@ -26,9 +26,13 @@ DC_HD double recip_(double x) {
   r = fma(fma(-x, r, 1.0), r, r);
   return fma(fma(-x, r, 1.0), r, r);
 }
+// cos for the root estimate (argument in [0, pi], result only seeds a Newton step): the hardware cosine.  cosf() would
+// drag in the large-argument range reduction (~250 instructions, computed for every lane because it is select-based).
+DC_HD float cos_est_(float x) { return __cosf(x); }
 #else
 template <typename R> DC_HD R rsqrt_(R x) { return R(1) / sqrt(x); }
 DC_HD double recip_(double x) { return 1.0 / x; }
+DC_HD float cos_est_(float x) { return cosf(x); }
 #endif
 
 template <typename R>
@@ -198,7 +202,7 @@ DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double 
   half = fminf(fmaxf(half, -1.0f), 1.0f);
   const bool iso_is_max = half >= 0.0f;
   const float ang = acosf(half) * (1.0f / 3.0f);
-  const float beta = iso_is_max ? 2.0f * cosf(ang) : 2.0f * cosf(ang + 2.0943951f);
+  const float beta = 2.0f * cos_est_(iso_is_max ? ang : ang + 2.0943951f);
   double l = q + (double)(pf * beta);
   // ---- one Newton step on f(l) = det(A - l I) in fp64 ----
   {
