@@ -210,10 +210,10 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
 
 // Per-scan sums of the 12 pose-gradient values g_a * [xl, 1]_b of the 256 points of a block (gx = [g, xl] of this
 // lane; pcol0 = first pose slot of this block's partial column).  The lanes are counting-sorted by scan id (wave ballots + a tiny prefix), staged in LDS in that
-// order and every (scan, value) pair is summed by one thread over its contiguous segment: ~25 additions per pair
+// order (14 KB) and every (scan, value) pair is summed by one thread over its contiguous segment: ~25 additions per pair
 // instead of a 256-lane tree per scan, and a fixed order (wave, lane) => bitwise reproducible.  Scans absent from the
 // block keep the zeros the caller put into the workspace.
-constexpr int kPoseRow = 13;             // doubles per staged point: 12 + 1 pad (conflict-free 8-B LDS stores)
+constexpr int kPoseRow = 7;              // doubles per staged point: the factors [g, xl] + 1 pad (conflict-free 8-B LDS stores)
 constexpr int kMaxBlockScans = 64;       // more distinct scans in one block: per-scan tree reduction instead
 
 __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool active, const double* gx, int scan,
@@ -266,13 +266,18 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
     int pos = s_start[r] + rank_in_wave;
     for (int w = 0; w < wave; ++w) pos += s_cnt[w][r];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) s_val[pos * kPoseRow + q] = gx[q >> 2] * ((q & 3) == 3 ? 1.0 : gx[3 + (q & 3)]);
+    for (int q = 0; q < 6; ++q) s_val[pos * kPoseRow + q] = gx[q];
   }
   __syncthreads();
+  // the 12 products g_a * [xl, 1]_b are formed while summing (each rounded, then added: no contraction, so the sums do
+  // not depend on how many factors were staged)
   for (int item = tid; item < ns * 12; item += kBlock) {
-    const int rr = item / 12, q = item - rr * 12;
+    const int rr = item / 12, q = item - rr * 12, a = q >> 2, b = q & 3;
     double acc = 0.0;
-    for (int p = s_start[rr]; p < s_start[rr + 1]; ++p) acc += s_val[p * kPoseRow + q];
+    for (int p = s_start[rr]; p < s_start[rr + 1]; ++p) {
+      const double ga = s_val[p * kPoseRow + a];
+      acc = __dadd_rn(acc, b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
+    }
     pcol0[((s_lo + rr) * 12 + q) * rs] = acc;
   }
 }
@@ -938,8 +943,8 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   BlockTab tab{};
   size_t lds_bytes = 0;
   int lds_rows = 0;
-  // the pose variants hold 28 KB of static LDS for the per-scan sums: keep the staged records within 32 KB
-  const bool staged = !lane_perm && use_table(table, stride, point_fmt == DC_F64 ? 64u : 32u, 1, 32 * 1024, &tab, &lds_bytes, &lds_rows);
+  // the pose variants hold 16 KB of static LDS for the per-scan sums: keep the staged records within 44 KB
+  const bool staged = !lane_perm && use_table(table, stride, point_fmt == DC_F64 ? 64u : 32u, 1, 44 * 1024, &tab, &lds_bytes, &lds_rows);
   if (!staged && (!csr_ptr || !csr_src)) return table ? DC_ERR_UNSUPPORTED : DC_ERR_ARG;
   const bool params = dirs != nullptr;
   if (!params && !grad_points) return DC_ERR_ARG;
