@@ -228,7 +228,16 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
   if (tid == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
   __syncthreads();
   const bool ok = active && scan >= 0 && scan < in.n_scans;
-  if (ok) { atomicMin(&s_range[0], scan); atomicMax(&s_range[1], scan); }
+  {
+    // range of the scans present: wave-level min / max first, one LDS atomic per wavefront
+    int lo = ok ? scan : 0x7fffffff, hi = ok ? scan : -1;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      lo = min(lo, __shfl_xor(lo, off, kWave));
+      hi = max(hi, __shfl_xor(hi, off, kWave));
+    }
+    if (lane == 0 && hi >= 0) { atomicMin(&s_range[0], lo); atomicMax(&s_range[1], hi); }
+  }
   __syncthreads();
   const int s_lo = s_range[0], s_hi = s_range[1];
   if (s_hi < s_lo) return;                                  // block-uniform: nothing to add
@@ -255,11 +264,21 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
     if (r == q) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  if (tid <= ns) {                                          // s_start[ns] = number of contributing lanes
-    int start = 0;
-    for (int q = 0; q < tid; ++q)
-      for (int w = 0; w < NW; ++w) start += s_cnt[w][q];
-    s_start[tid] = start;
+  if (wave == 0) {
+    // exclusive prefix of the per-scan totals over the (at most 64) scans of the range, inside one wavefront
+    int tot = 0;
+    if (lane < ns) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += s_cnt[w][lane];
+    }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int up = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += up;
+    }
+    if (lane < ns) s_start[lane] = incl - tot;
+    if (lane == ns - 1) s_start[ns] = incl;                 // number of contributing lanes
   }
   __syncthreads();
   if (ok) {
@@ -271,14 +290,28 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
   __syncthreads();
   // the 12 products g_a * [xl, 1]_b are formed while summing (each rounded, then added: no contraction, so the sums do
   // not depend on how many factors were staged)
-  for (int item = tid; item < ns * 12; item += kBlock) {
-    const int rr = item / 12, q = item - rr * 12, a = q >> 2, b = q & 3;
-    double acc = 0.0;
-    for (int p = s_start[rr]; p < s_start[rr + 1]; ++p) {
-      const double ga = s_val[p * kPoseRow + a];
-      acc = __dadd_rn(acc, b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
+  // Two lanes per (scan, entry): even / odd elements of the segment, four independent partial sums each so that the LDS
+  // reads pipeline (a single running sum made this loop a chain of ~100 dependent LDS round trips per block).
+  for (int item = tid; item < ns * 24; item += kBlock) {
+    const int pair = item >> 1, part = item & 1;
+    const int rr = pair / 12, q = pair - rr * 12, a = q >> 2, b = q & 3;
+    const int beg = s_start[rr] + part, end = s_start[rr + 1];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int p = beg;
+    for (; p + 6 < end; p += 8) {
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        const double ga = s_val[(p + 2 * u_) * kPoseRow + a];
+        acc[u_] = __dadd_rn(acc[u_], b == 3 ? ga : __dmul_rn(ga, s_val[(p + 2 * u_) * kPoseRow + 3 + b]));
+      }
     }
-    pcol0[((s_lo + rr) * 12 + q) * rs] = acc;
+    for (; p < end; p += 2) {
+      const double ga = s_val[p * kPoseRow + a];
+      acc[0] = __dadd_rn(acc[0], b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
+    }
+    double sum = __dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3]));
+    sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));         // even + odd half (the two lanes are neighbours)
+    if (part == 0) pcol0[((s_lo + rr) * 12 + q) * rs] = sum;
   }
 }
 
