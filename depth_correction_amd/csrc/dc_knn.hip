@@ -63,36 +63,44 @@ __device__ __forceinline__ void load_xyz(const T* p, int64_t i, int stride, doub
   o[0] = (double)q[0]; o[1] = (double)q[1]; o[2] = (double)q[2];
 }
 
-// ---- bounding box (finite points only) ----------------------------------------------------------
+// ---- bounding box and first two moments per axis (finite points only) -----------------------------
+constexpr int kBoxVals = 13;             // min[3], max[3], sum[3], sum of squares[3], count
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const T* __restrict__ xyz, int stride, int64_t n,
                                                               double* __restrict__ part) {
-  __shared__ double lds[(kBlock / kWave) * 6];
-  double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  __shared__ double lds[(kBlock / kWave) * kBoxVals];
+  double v[kBoxVals] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     double p[3];
     load_xyz(xyz, i, stride, p);
+    if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (isfinite(p[a])) { v[a] = fmin(v[a], p[a]); v[3 + a] = fmax(v[3 + a], p[a]); }
+      for (int a = 0; a < 3; ++a) {
+        v[a] = fmin(v[a], p[a]); v[3 + a] = fmax(v[3 + a], p[a]);
+        v[6 + a] += p[a]; v[9 + a] += p[a] * p[a];
+      }
+      v[12] += 1.0;
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
+  for (int q = 0; q < kBoxVals; ++q) {
     double s = v[q];
     for (int off = 32; off > 0; off >>= 1) {
       double o = __shfl_down(s, off, 64);
-      s = q < 3 ? fmin(s, o) : fmax(s, o);
+      s = q < 3 ? fmin(s, o) : (q < 6 ? fmax(s, o) : s + o);
     }
-    if (lane == 0) lds[wave * 6 + q] = s;
+    if (lane == 0) lds[wave * kBoxVals + q] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < kBoxVals) {
     const int q = threadIdx.x;
     double s = lds[q];
-    for (int wv = 1; wv < kBlock / kWave; ++wv) s = q < 3 ? fmin(s, lds[wv * 6 + q]) : fmax(s, lds[wv * 6 + q]);
-    part[(int64_t)blockIdx.x * 6 + q] = s;
+    for (int wv = 1; wv < kBlock / kWave; ++wv) {
+      const double o = lds[wv * kBoxVals + q];
+      s = q < 3 ? fmin(s, o) : (q < 6 ? fmax(s, o) : s + o);
+    }
+    part[(int64_t)blockIdx.x * kBoxVals + q] = s;
   }
 }
 
@@ -105,11 +113,30 @@ __global__ void grid_setup_kernel(const double* __restrict__ part, int n_part, i
                                   Grid* __restrict__ g) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int b = 0; b < n_part; ++b)
-    for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], part[b * 6 + a]); hi[a] = fmax(hi[a], part[b * 6 + 3 + a]); }
+  double sum[3] = {0.0, 0.0, 0.0}, sq[3] = {0.0, 0.0, 0.0}, cnt = 0.0;
+  for (int b = 0; b < n_part; ++b) {
+    const double* pb = part + (int64_t)b * kBoxVals;
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], pb[a]); hi[a] = fmax(hi[a], pb[3 + a]);
+      sum[a] += pb[6 + a]; sq[a] += pb[9 + a];
+    }
+    cnt += pb[12];
+  }
+  // The grid covers the bulk of the cloud: the bounding box cut to mean +- 6 sigma per axis.  A few far outliers
+  // would otherwise inflate the box, and with it the cell size chosen from the areal density below, until whole
+  // surfaces fall into single cells; points outside the grid are clamped into its boundary cells (cell_of), which
+  // keeps every distance bound valid (their true position is farther away than the cell they sit in).
   double L[3], Lmax = 0.0;
   for (int a = 0; a < 3; ++a) {
     if (!(hi[a] >= lo[a])) { lo[a] = 0.0; hi[a] = 0.0; }
+    if (cnt > 1.0) {
+      const double mean = sum[a] / cnt;
+      double var = sq[a] / cnt - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double reach = 6.0 * sqrt(var);
+      if (isfinite(mean) && isfinite(reach)) { lo[a] = fmax(lo[a], mean - reach); hi[a] = fmin(hi[a], mean + reach); }
+      if (!(hi[a] >= lo[a])) { lo[a] = hi[a] = mean; }
+    }
     L[a] = hi[a] - lo[a];
     Lmax = fmax(Lmax, L[a]);
   }
@@ -151,7 +178,7 @@ __global__ void box_finish_kernel(const double* __restrict__ part, int n_part, d
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int b = 0; b < n_part; ++b)
-    for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], part[b * 6 + a]); hi[a] = fmax(hi[a], part[b * 6 + 3 + a]); }
+    for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], part[b * kBoxVals + a]); hi[a] = fmax(hi[a], part[b * kBoxVals + 3 + a]); }
   double Lmax = 0.0;
   for (int a = 0; a < 3; ++a) { if (!(hi[a] >= lo[a])) { lo[a] = hi[a] = 0.0; } Lmax = fmax(Lmax, hi[a] - lo[a]); }
   box[0] = lo[0]; box[1] = lo[1]; box[2] = lo[2];
@@ -283,6 +310,7 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
                                                            const double* __restrict__ queries,
                                                            const int32_t* __restrict__ qids, int64_t n_query,
                                                            const Grid* __restrict__ gp, CellTable tab, int k, double r_max,
+                                                           int64_t n_points, int r_exhaust,
                                                            int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= n_query) return;
@@ -299,32 +327,58 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
   int32_t c[3];
   cell_of(g, q, c);
   const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+  // one candidate: sorted insertion by (distance, index), cKDTree's order
+  auto offer = [&](double d, int32_t id) {
+    if (!(d < ub2)) return;
+    if (!(d < worst_d || (d == worst_d && id < worst_i))) return;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+      const bool lt = (d < bd[s]) || (d == bd[s] && id < bi[s]);
+      const double td = bd[s];
+      const int32_t ti = bi[s];
+      bd[s] = lt ? d : td; bi[s] = lt ? id : ti;
+      d = lt ? td : d; id = lt ? ti : id;
+    }
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) if (s == k - 1) { worst_d = bd[s]; worst_i = bi[s]; }
+  };
+  auto consider = [&](int32_t p) {
+    const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
+    offer(sqdist(pp, q), sids[p]);
+  };
+  bool exhaustive = false;
   for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+    if (r > r_exhaust) { exhaustive = true; break; }
     for_shell(g, c, r, [&](int x, int y, int z) {
       int32_t b, e;
       if (!find_cell(tab, morton3(x, y, z), &b, &e)) return;
-      for (int32_t p = b; p < e; ++p) {
-        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
-        double d = sqdist(pp, q);
-        int32_t id = sids[p];
-        if (!(d < ub2)) continue;
-        if (!(d < worst_d || (d == worst_d && id < worst_i))) continue;
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-          const bool lt = (d < bd[s]) || (d == bd[s] && id < bi[s]);
-          const double td = bd[s];
-          const int32_t ti = bi[s];
-          bd[s] = lt ? d : td; bi[s] = lt ? id : ti;
-          d = lt ? td : d; id = lt ? ti : id;
-        }
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) if (s == k - 1) { worst_d = bd[s]; worst_i = bi[s]; }
-      }
+      for (int32_t p = b; p < e; ++p) consider(p);
     });
     const double bound = shell_bound(g, q, c, r);
     const double b2 = bound * bound;
     if (worst_d < b2) break;              // k-th best is closer than anything unvisited
     if (b2 >= ub2) break;                 // everything unvisited is beyond the radius
+  }
+  if (exhaustive) {
+    // A query far from the bulk of the cloud (an outlier) would need thousands of empty shells, whose cell count grows
+    // with the square of the radius; past r_exhaust shells a plain scan of all points is cheaper.  Start over: the
+    // scan sees every point once.
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+    worst_d = INFINITY; worst_i = 0x7fffffff;
+    int64_t p = 0;
+    for (; p + 4 <= n_points; p += 4) {                     // four points' loads in flight per trip
+      double pp[4][3];
+      int32_t id[4];
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        pp[u_][0] = sp[(p + u_) * 3]; pp[u_][1] = sp[(p + u_) * 3 + 1]; pp[u_][2] = sp[(p + u_) * 3 + 2];
+        id[u_] = sids[p + u_];
+      }
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) offer(sqdist(pp[u_], q), id[u_]);
+    }
+    for (; p < n_points; ++p) consider((int32_t)p);
   }
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) {
@@ -438,7 +492,7 @@ struct GridWs {
 static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   GridWs g;
   Carver c(ws);
-  g.part = c.take<double>(kBoxBlocks * 6);
+  g.part = c.take<double>(kBoxBlocks * kBoxVals);
   g.grid = c.take<Grid>(1);
   g.keys = c.take<uint64_t>(n);
   g.skeys = c.take<uint64_t>(n);
@@ -474,10 +528,13 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   return DC_OK;
 }
 
-static int launch_knn(int k, const double* sp, const int32_t* sids, const double* q, const int32_t* qids, int64_t nq,
+static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, const double* q, const int32_t* qids, int64_t nq,
                       const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, hipStream_t st) {
   const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
-#define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist)
+  // shells 0..R hold (2R+1)^3 cells at ~4 candidates' worth of work each; a scan of all n points costs n candidates
+  int r_exhaust = (int)(cbrt((double)n * 0.25) * 0.5);
+  r_exhaust = r_exhaust < 4 ? 4 : (r_exhaust > 64 ? 64 : r_exhaust);
+#define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, n, r_exhaust, idx, dist)
   // the sorted insertion costs ~12 instructions per slot and runs for a whole wavefront whenever one lane accepts a
   // candidate, so the slot count follows k closely (10 = the reference's default nn_k)
   if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 10) LK(10); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
@@ -521,12 +578,12 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
   else return DC_ERR_DTYPE;
   if (rc) return rc;
   CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
-  if (!query) return launch_knn(k, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, stream);
+  if (!query) return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, stream);
   if (n_query == 0) return DC_OK;
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
   if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
   else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
-  return launch_knn(k, w.sp, w.sids, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, stream);
+  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, stream);
 }
 
 // Radius search, pass 1: per-point neighbour counts and their maximum (device scalars).
@@ -608,7 +665,7 @@ int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int64_t n_dst, int32_
 size_t dc_spatial_order_workspace_bytes(int64_t n) {
   if (n < 0) return 0;
   Carver c(nullptr);
-  c.take<double>(kBoxBlocks * 6); c.take<double>(4); c.take<uint64_t>(n); c.take<uint64_t>(n); c.take<int32_t>(n);
+  c.take<double>(kBoxBlocks * kBoxVals); c.take<double>(4); c.take<uint64_t>(n); c.take<uint64_t>(n); c.take<int32_t>(n);
   size_t sb = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                             (size_t)(n > 0 ? n : 1), 0, 63, (hipStream_t)0);
@@ -625,7 +682,7 @@ int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32
   if (ws_bytes < dc_spatial_order_workspace_bytes(n)) return DC_ERR_WORKSPACE;
   if (n == 0) return DC_OK;
   Carver c(ws);
-  double* part = c.take<double>(kBoxBlocks * 6);
+  double* part = c.take<double>(kBoxBlocks * kBoxVals);
   double* box = c.take<double>(4);
   uint64_t* keys = c.take<uint64_t>(n);
   uint64_t* skeys = c.take<uint64_t>(n);

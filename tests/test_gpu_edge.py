@@ -230,3 +230,24 @@ def test_block_table_of_empty_cloud():
     assert tab.max_rows == 0 and npy(tab.blk_ptr).tolist() == [0] and npy(tab.slot_ptr).tolist() == [0]
     x = torch.zeros((0, 4), dtype=torch.float64, device=DEV)
     assert npy(ops.consistency_fwd(x, nbr, table=tab)['sums']).tolist() == [0.0, 0.0]
+
+
+@pytest.mark.timeout(120)
+def test_knn_with_far_outliers_is_exact_and_does_not_stall():
+    """A few points far from the bulk (range outliers): the grid is sized for the bulk (bounding box cut to
+    mean +- 6 sigma) and a query that would need thousands of empty shells switches to a scan of all points.
+    Results stay bit-exact, for self queries and for cross-cloud queries far outside the cloud."""
+    from depth_correction_amd import ops
+    rng = np.random.default_rng(11)
+    bulk = _cloud(20000, 3)
+    far = np.array([[1.0e3, 0.0, 0.0], [-2.5e4, 3.0e4, 10.0], [5.0, -7.0e5, 2.0e5], [1.0e3, 0.01, 0.0]])
+    pts = np.concatenate([bulk, far])[rng.permutation(len(bulk) + len(far))]
+    x = t(pts, DEV)
+    d, i = ops.knn(x, 10)
+    dref, iref = O.knn_ckdtree(pts, 10)
+    assert np.array_equal(npy(i), iref) and np.array_equal(npy(d), dref)
+    q = np.array([[4.0e4, 1.0, -3.0], [0.0, 0.0, 9.0e6], [0.1, 0.2, 0.0]])
+    dq, iq = ops.knn(x, 3, query=t(q, DEV))
+    from scipy.spatial import cKDTree
+    dr, ir = cKDTree(pts).query(q, 3)
+    assert np.array_equal(npy(iq), ir) and np.array_equal(npy(dq), dr)
