@@ -74,6 +74,11 @@ def filter_grid(cloud, grid_res, only_mask=False, keep='random', preserve_order=
     assert isinstance(cloud, (DepthCloud, np.ndarray, torch.Tensor))
     assert isinstance(grid_res, float) and grid_res > 0.0 and keep in ('first', 'random', 'last')
     pts = cloud.get_points() if isinstance(cloud, DepthCloud) else cloud
+    if isinstance(pts, np.ndarray) and torch.cuda.is_available():
+        # host arrays (the datasets' structured clouds, preproc.filtered_cloud): filter on the GPU, index on the host
+        xyz = structured_to_unstructured(pts[['x', 'y', 'z']]) if pts.dtype.names else pts
+        if xyz.ndim == 2 and xyz.shape[1] == 3 and xyz.dtype in (np.float32, np.float64):
+            pts = torch.as_tensor(np.ascontiguousarray(xyz), device='cuda:0')
     if isinstance(pts, torch.Tensor) and pts.is_cuda and pts.dim() == 2 and pts.shape[1] == 3:
         # GPU path (dc_voxel_filter): only the processing sequence is made on the host, because numpy's generator
         # defines which point of a voxel survives a 'random' filter
@@ -89,9 +94,13 @@ def filter_grid(cloud, grid_res, only_mask=False, keep='random', preserve_order=
         if ind is not None:
             if log:
                 print('%.3f = %i / %i points kept (grid res. %.3f m).' % (len(ind) / max(n, 1), len(ind), n, grid_res))
-            return ind.tolist() if only_mask else cloud[ind]
+            if only_mask:
+                return ind.tolist()
+            return cloud[ind.cpu().numpy()] if isinstance(cloud, np.ndarray) else cloud[ind]
         if keep == 'random':
             raise RuntimeError('voxel range too large for the GPU key and the generator was already advanced')
+    # host path: CPU-only machines preparing datasets, or a voxel range beyond the GPU's 3 x 21-bit key (the
+    # reference's own dict construction; data preparation, not part of the hot path)
     if isinstance(cloud, DepthCloud):
         x = cloud.get_points().detach().cpu().numpy()
     elif isinstance(cloud, np.ndarray):

@@ -320,6 +320,15 @@ def test_voxel_grid_filter_gpu_golden(golden, dtype):
     kept = filter_grid(cloud, float(g['grid_res']), keep='random', rng=np.random.default_rng(135))
     assert len(kept) == len(g['random_0'])
     np.testing.assert_allclose(npy(kept.to_points()), g['points'][g['random_0']], rtol=1e-6, atol=1e-6)
+    # host arrays (the datasets' structured clouds) are filtered on the GPU too and indexed on the host
+    host = g['points'].astype(np.float32 if dtype == torch.float32 else np.float64)
+    rec = np.zeros(len(host), dtype=[('x', host.dtype), ('y', host.dtype), ('z', host.dtype), ('i', 'i4')])
+    rec['x'], rec['y'], rec['z'], rec['i'] = host[:, 0], host[:, 1], host[:, 2], np.arange(len(host))
+    for keep in ('first', 'random'):
+        ind = filter_grid(host, float(g['grid_res']), only_mask=True, keep=keep, rng=np.random.default_rng(135))
+        assert np.array_equal(np.asarray(ind), g['%s_0' % keep])
+        kept = filter_grid(rec, float(g['grid_res']), keep=keep, rng=np.random.default_rng(135))
+        assert np.array_equal(kept['i'], g['%s_0' % keep])
 
 
 def test_unfused_options_match_oracle(golden):
