@@ -8,8 +8,11 @@
 //   neighbours      nbr i32[N,K] row major, -1 = missing
 //   backward record rec[N,8] = {cmean.xyz, c1, v0.xyz, c2} in the point format (32 B: two 16-B loads per edge)
 //   incoming edges  csr_ptr i32[N+1], csr_src i32[E]  (transpose of nbr, built once per neighbourhood set)
-// All arithmetic on chip is fp64 (differences against the centre point are exact, covariances and the
-// eigen-solve keep LAPACK-level accuracy); only storage is T.  No atomics: block partial sums are
+//   block tables    per 256-row block the distinct rows it references + u16 block-local positions, slot-major
+//                   (dc_blocktab.hip): what the hot ("staged") kernels read instead of nbr / csr_*
+// Arithmetic on chip is fp64 (differences against the centre point are exact, covariances and the eigen-solve
+// keep LAPACK-level accuracy; the backward's per-edge term for q32 records is formed in fp32 from fp32-exact
+// inputs); only storage is T.  No atomics: block partial sums are
 // written to a workspace and reduced in a fixed order, so every result is bitwise reproducible.
 #include <type_traits>
 #include <hip/hip_ext.h>
