@@ -201,8 +201,11 @@ int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_r
   const int32_t* rows = row_ptr ? row_of : nullptr;
   DC_HIP(hipMemsetAsync(loc, 0xff, (size_t)n_slot_rows * kBlock * sizeof(uint16_t), stream));
   hipLaunchKernelGGL(bt_keys_kernel, dim3(grid_of(n_refs)), block, 0, stream, ids, rows, n_refs, k, keys, vals);
-  // all 64 key bits: invalid references carry the all-ones key and sort behind every block
-  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, vals, svals, (size_t)n_refs, 0, 64, stream));
+  // 32 id bits + enough block bits that the all-ones block of an invalid reference exceeds every real block: invalid
+  // references sort behind all blocks, and the sort runs 6 radix passes instead of 8
+  unsigned key_bits = 33;
+  while (key_bits < 64 && (((uint64_t)1 << (key_bits - 32)) - 1) < (uint64_t)nb) ++key_bits;
+  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, vals, svals, (size_t)n_refs, 0, key_bits, stream));
   hipLaunchKernelGGL(bt_heads_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, n_refs, heads);
   DC_HIP(rocprim::inclusive_scan(tmp, cb, heads, rank1, (size_t)n_refs, rocprim::plus<uint32_t>(), stream));
   hipLaunchKernelGGL(bt_blk_ptr_kernel, dim3(grid_of(nb + 1)), block, 0, stream, skeys, rank1, n_refs, nb, blk_ptr);
