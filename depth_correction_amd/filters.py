@@ -78,7 +78,7 @@ def filter_grid(cloud, grid_res, only_mask=False, keep='random', preserve_order=
         # host arrays (the datasets' structured clouds, preproc.filtered_cloud): filter on the GPU, index on the host
         xyz = structured_to_unstructured(pts[['x', 'y', 'z']]) if pts.dtype.names else pts
         if xyz.ndim == 2 and xyz.shape[1] == 3 and xyz.dtype in (np.float32, np.float64):
-            pts = torch.as_tensor(np.ascontiguousarray(xyz), device='cuda:0')
+            pts = torch.as_tensor(np.ascontiguousarray(xyz), device=torch.device('cuda', torch.cuda.current_device()))
     if isinstance(pts, torch.Tensor) and pts.is_cuda and pts.dim() == 2 and pts.shape[1] == 3:
         # GPU path (dc_voxel_filter): only the processing sequence is made on the host, because numpy's generator
         # defines which point of a voxel survives a 'random' filter
