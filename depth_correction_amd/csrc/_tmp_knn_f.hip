@@ -258,13 +258,36 @@ __global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restri
   }
 }
 
-__global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const uint64_t* __restrict__ skeys,
+// Coarser levels of the same grid: a cell of level L is a 4^L x 4^L x 4^L group of level-0 cells, its Morton key is
+// the level-0 key without its lowest 6 L bits, and -- the points being sorted by level-0 Morton key -- its points
+// are one contiguous run of the sorted array.  One more hash table per level costs two light passes over the keys.
+constexpr int kLevels = 3;
+constexpr int kLevelShift = 2;           // cells per axis merged from one level to the next: 2^kLevelShift
+
+__global__ __launch_bounds__(kBlock) void level_begin_kernel(int64_t n, const uint64_t* __restrict__ skeys, int shift3,
+                                                             uint64_t* __restrict__ tab_key, int32_t* __restrict__ tab_beg,
+                                                             uint32_t tab_mask) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t key = skeys[p] >> shift3;
+  if (p == 0 || (skeys[p - 1] >> shift3) != key) {
+    uint32_t slot = hash_key(key) & tab_mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&tab_key[slot], (unsigned long long)kEmptyKey,
+                                                (unsigned long long)key);
+      if (prev == kEmptyKey || prev == key) { tab_beg[slot] = (int32_t)p; break; }
+      slot = (slot + 1) & tab_mask;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const uint64_t* __restrict__ skeys, int shift3,
                                                           const uint64_t* __restrict__ tab_key,
                                                           int32_t* __restrict__ tab_end, uint32_t tab_mask) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  const uint64_t key = skeys[p];
-  if (p == n - 1 || skeys[p + 1] != key) {
+  const uint64_t key = skeys[p] >> shift3;
+  if (p == n - 1 || (skeys[p + 1] >> shift3) != key) {
     uint32_t slot = hash_key(key) & tab_mask;
     while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
     tab_end[slot] = (int32_t)(p + 1);
@@ -277,6 +300,18 @@ struct CellTable {
   const int32_t* end;
   uint32_t mask;
 };
+struct CellTables { CellTable lv[kLevels]; };
+
+// the grid of level L as seen from level 0 (same origin)
+__device__ __forceinline__ Grid level_grid(const Grid& g, int level) {
+  const int sh = kLevelShift * level;
+  Grid o = g;
+  o.h = g.h * (double)(1 << sh);
+  o.inv_h = 1.0 / o.h;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o.dim[a] = ((g.dim[a] - 1) >> sh) + 1;
+  return o;
+}
 
 __device__ __forceinline__ bool find_cell(const CellTable& t, uint64_t key, int32_t* b, int32_t* e) {
   uint32_t slot = hash_key(key) & t.mask;
@@ -340,7 +375,7 @@ template <int KMAX>
 __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
                                                            const double* __restrict__ queries,
                                                            const int32_t* __restrict__ qids, int64_t n_query,
-                                                           const Grid* __restrict__ gp, CellTable tab, int k, double r_max,
+                                                           const Grid* __restrict__ gp, CellTables tabs, int k, double r_max,
                                                            int64_t n_points, int r_exhaust,
                                                            int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -377,55 +412,48 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
     const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
     offer(sqdist(pp, q), sids[p]);
   };
-  bool exhaustive = false;
-  for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
-    if (r > r_exhaust) { exhaustive = true; break; }
-    // the cube of cells at Chebyshev distance <= r minus its interior (visited by the earlier shells), as one loop
-    // nest with ONE inlined copy of the candidate code: for_shell's three call sites tripled it, and with it the
-    // register count (143 -> 104 VGPRs at 10 slots, 3 -> 4 wavefronts per SIMD for a latency-bound kernel)
-    const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
-    const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
-    const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y) {
-        // cells of this row that belong to the shell: the whole row on a face, else only its two ends
-        const bool face = abs(z - c[2]) == r || abs(y - c[1]) == r;
-        int xs, cnt, step;
-        if (face) { xs = x0; cnt = x1 - x0 + 1; step = 1; }
-        else {
-          const bool lo_in = c[0] - r >= 0, hi_in = c[0] + r <= g.dim[0] - 1;
-          xs = lo_in ? c[0] - r : c[0] + r;
-          cnt = (lo_in ? 1 : 0) + ((hi_in && r > 0) ? 1 : 0);
-          step = 2 * r;
-        }
-        // Four cells per trip: their hash probes, then their (begin, end) loads, are in flight together -- a lane that
-        // walks hundreds of mostly empty cells (sparse regions, the tail of small clouds) otherwise pays one dependent
-        // load latency per probe.  The candidate code below stays a single inlined copy (runtime loop over the hits).
-        for (int j0 = 0; j0 < cnt; j0 += 4) {
-          uint64_t key[4], got[4];
-          uint32_t slot[4];
-#pragma unroll
-          for (int u_ = 0; u_ < 4; ++u_) {
-            key[u_] = morton3(xs + (j0 + u_) * step, y, z);
-            slot[u_] = hash_key(key[u_]) & tab.mask;
-            got[u_] = (j0 + u_ < cnt) ? tab.key[slot[u_]] : kEmptyKey;
-          }
-          int32_t bb[4], ee[4];
-#pragma unroll
-          for (int u_ = 0; u_ < 4; ++u_) {
-            while (got[u_] != key[u_] && got[u_] != kEmptyKey) {      // collision: linear probing (rare)
-              slot[u_] = (slot[u_] + 1) & tab.mask;
-              got[u_] = tab.key[slot[u_]];
-            }
-            const bool hit = got[u_] == key[u_];
-            bb[u_] = hit ? tab.beg[slot[u_]] : 0;
-            ee[u_] = hit ? tab.end[slot[u_]] : 0;
-          }
+  // Levels: a query starts on the fine grid; if the two innermost shells (27 cells) do not settle it -- a sparse
+  // region: lidar density falls with the square of the range, so a cell size fitted to the mean density is far too
+  // small there and the shells needed (and their cell count, cubic in the radius) explode -- it starts over on the
+  // next coarser level, where 27 cells cover 4x the radius.  The last level walks shells until done.
+  bool exhaustive = false, done = !finite_q;
 #pragma unroll 1
-          for (int u_ = 0; u_ < 4; ++u_) {
-            const int32_t b = u_ == 0 ? bb[0] : (u_ == 1 ? bb[1] : (u_ == 2 ? bb[2] : bb[3]));
-            const int32_t e = u_ == 0 ? ee[0] : (u_ == 1 ? ee[1] : (u_ == 2 ? ee[2] : ee[3]));
-            if (b >= e) continue;
+  for (int level = 0; level < kLevels && !done && !exhaustive; ++level) {
+    const Grid gl = level_grid(g, level);
+    const CellTable& tab = tabs.lv[level];
+    const int sh = kLevelShift * level;
+    const int32_t cl[3] = {c[0] >> sh, c[1] >> sh, c[2] >> sh};
+    const bool last = level == kLevels - 1;
+    if (level > 0) {
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+      worst_d = INFINITY; worst_i = 0x7fffffff;
+    }
+    int r = 0;
+    for (; shell_in_grid(gl, cl, r); ++r) {
+      if (!last && r > 2) break;                            // not settled by 125 cells: next level
+      if (r > r_exhaust) { exhaustive = true; break; }
+      // the cube of cells at Chebyshev distance <= r minus its interior (visited by the earlier shells), as one loop
+      // nest with ONE inlined copy of the candidate code: for_shell's three call sites tripled it, and with it the
+      // register count (143 -> 104 VGPRs at 10 slots, 3 -> 4 wavefronts per SIMD for a latency-bound kernel)
+      const int z0 = max(cl[2] - r, 0), z1 = min(cl[2] + r, gl.dim[2] - 1);
+      const int y0 = max(cl[1] - r, 0), y1 = min(cl[1] + r, gl.dim[1] - 1);
+      const int x0 = max(cl[0] - r, 0), x1 = min(cl[0] + r, gl.dim[0] - 1);
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+          // cells of this row that belong to the shell: the whole row on a face, else only its two ends
+          const bool face = abs(z - cl[2]) == r || abs(y - cl[1]) == r;
+          int xs, cnt, step;
+          if (face) { xs = x0; cnt = x1 - x0 + 1; step = 1; }
+          else {
+            const bool lo_in = cl[0] - r >= 0, hi_in = cl[0] + r <= gl.dim[0] - 1;
+            xs = lo_in ? cl[0] - r : cl[0] + r;
+            cnt = (lo_in ? 1 : 0) + ((hi_in && r > 0) ? 1 : 0);
+            step = 2 * r;
+          }
+          for (int j0 = 0; j0 < cnt; ++j0) {
+            int32_t b, e;
+            if (!find_cell(tab, morton3(xs + j0 * step, y, z), &b, &e)) continue;
             // the next point's coordinates are requested before the current one is offered
             double cx = sp[(int64_t)b * 3], cy = sp[(int64_t)b * 3 + 1], cz = sp[(int64_t)b * 3 + 2];
             int32_t cid = sids[b];
@@ -439,11 +467,12 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
             }
           }
         }
-      }
-    const double bound = shell_bound(g, q, c, r);
-    const double b2 = bound * bound;
-    if (worst_d < b2) break;              // k-th best is closer than anything unvisited
-    if (b2 >= ub2) break;                 // everything unvisited is beyond the radius
+      const double bound = shell_bound(gl, q, cl, r);
+      const double b2 = bound * bound;
+      if (worst_d < b2) { done = true; break; }             // k-th best is closer than anything unvisited
+      if (b2 >= ub2) { done = true; break; }                // everything unvisited is beyond the radius
+    }
+    if (!shell_in_grid(gl, cl, r)) done = true;             // the shells left the grid: every point has been seen
   }
   if (exhaustive) {
     // A query far from the bulk of the cloud (an outlier) would need thousands of empty shells, whose cell count grows
@@ -571,7 +600,7 @@ static uint32_t table_size(int64_t n) {
 
 struct GridWs {
   double* part; Grid* grid; uint64_t* keys; uint64_t* skeys; int32_t* ids; int32_t* sids; double* sp;
-  uint64_t* tab_key; int32_t* tab_beg; int32_t* tab_end; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
+  uint64_t* tab_key[kLevels]; int32_t* tab_beg[kLevels]; int32_t* tab_end[kLevels]; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
   double* qf64; size_t total;
 };
 
@@ -586,9 +615,11 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   g.sids = c.take<int32_t>(n);
   g.sp = c.take<double>(3 * n);
   g.tab_n = table_size(n);
-  g.tab_key = c.take<uint64_t>(g.tab_n);
-  g.tab_beg = c.take<int32_t>(g.tab_n);
-  g.tab_end = c.take<int32_t>(g.tab_n);
+  for (int L = 0; L < kLevels; ++L) {
+    g.tab_key[L] = c.take<uint64_t>(g.tab_n);
+    g.tab_beg[L] = c.take<int32_t>(g.tab_n);
+    g.tab_end[L] = c.take<int32_t>(g.tab_n);
+  }
   g.qf64 = c.take<double>(3 * n_query_extra);
   g.sort_bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr,
@@ -606,16 +637,21 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(kBlock), 0, st, w.part, kBoxBlocks, n, k, cell_hint, w.grid);
   hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.grid, w.keys, w.ids);
   DC_HIP(rocprim::radix_sort_pairs(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, 63, st));
-  DC_HIP(hipMemsetAsync(w.tab_key, 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
+  for (int L = 0; L < kLevels; ++L) DC_HIP(hipMemsetAsync(w.tab_key[L], 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
   hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp,
-                     w.tab_key, w.tab_beg, w.tab_n - 1);
-  hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, w.tab_key, w.tab_end, w.tab_n - 1);
+                     w.tab_key[0], w.tab_beg[0], w.tab_n - 1);
+  hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, 0, w.tab_key[0], w.tab_end[0], w.tab_n - 1);
+  for (int L = 1; L < kLevels && k > 0; ++L) {             // coarser levels: only the k-NN search uses them
+    const int shift3 = 3 * kLevelShift * L;
+    hipLaunchKernelGGL(level_begin_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, shift3, w.tab_key[L], w.tab_beg[L], w.tab_n - 1);
+    hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, shift3, w.tab_key[L], w.tab_end[L], w.tab_n - 1);
+  }
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
 
 static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, const double* q, const int32_t* qids, int64_t nq,
-                      const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, hipStream_t st) {
+                      const Grid* g, CellTables tab, double r, int32_t* idx, double* dist, hipStream_t st) {
   const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
   // shells 0..R hold (2R+1)^3 cells at ~4 candidates' worth of work each; a scan of all n points costs n candidates
   int r_exhaust = (int)(cbrt((double)n * 0.25) * 0.5);
@@ -663,7 +699,8 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
   else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, k, cell_hint, w, stream);
   else return DC_ERR_DTYPE;
   if (rc) return rc;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTables tab;
+  for (int L = 0; L < kLevels; ++L) tab.lv[L] = CellTable{w.tab_key[L], w.tab_beg[L], w.tab_end[L], w.tab_n - 1};
   if (!query) return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, stream);
   if (n_query == 0) return DC_OK;
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
@@ -686,7 +723,7 @@ int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double
   else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, 0, r, w, stream);
   else return DC_ERR_DTYPE;
   if (rc) return rc;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key[0], w.tab_beg[0], w.tab_end[0], w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, count_out, nullptr, 0);
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), block, 0, stream, count_out, n, kmax_out);
@@ -700,7 +737,7 @@ int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, si
   GridWs w = carve_grid(ws, n, 0);
   if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
   if (n == 0) return DC_OK;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key[0], w.tab_beg[0], w.tab_end[0], w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, nullptr, idx_out, kmax);
   DC_HIP(hipGetLastError());
