@@ -121,3 +121,35 @@ def test_oracle_on_200k_sample(room):
     o = npy(out)
     np.testing.assert_allclose(o[0], lo.item(), rtol=1e-5)
     np.testing.assert_allclose(o[2:4], npy(wo.grad).ravel(), rtol=1e-5, atol=1e-6 * np.abs(npy(wo.grad)).max())
+
+
+@pytest.mark.timeout(600)
+def test_c2_full_size_loss_and_gradient_vs_oracle(room):
+    """BASELINE config 2 at full size (10 x 200 k points, N = 2 M, K = 10, ScaledPolynomial, normalised min-eigenvalue
+    loss): loss, masked-point count and dL/dw of the HIP path (fp32 inputs, q32 points, block tables) against the CPU
+    oracle in fp64 on the same inputs -- the north-star tolerance 1e-5.  The neighbour table is the GPU's (bit-exact
+    against cKDTree in the tests above), so the oracle spends its time on the path proper."""
+    from depth_correction_amd.pipeline import build_sequence
+    scans, poses = room
+    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    dev = plan.device
+    out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    plan.eval_native(w, e, plan.poses12(info['poses']), out)
+    o = npy(out)
+    oc = [dict(vps=c['vps'].double().cpu(), dirs=c['dirs'].double().cpu(), depth=c['depth'].double().cpu(),
+               inc=c['inc_angles'].double().cpu(), mask=c['mask'].cpu()) for c in info['clouds']]
+    wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        lo, _ = O.eval_sequence(oc, info['poses'].cpu(), wo, e.cpu().reshape(1, -1), info['neighbors'].long().cpu(),
+                                info['mask'].cpu(), reduction='sum')
+        lo.backward()
+    finally:
+        torch.set_num_threads(threads)
+    assert o[1] == float(info['mask'].sum().item()) and o[1] > 1.0e6
+    np.testing.assert_allclose(o[0], lo.item(), rtol=1e-5)
+    g = npy(wo.grad).ravel()
+    np.testing.assert_allclose(o[2:4], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
