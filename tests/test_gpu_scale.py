@@ -153,3 +153,24 @@ def test_c2_full_size_loss_and_gradient_vs_oracle(room):
     np.testing.assert_allclose(o[0], lo.item(), rtol=1e-5)
     g = npy(wo.grad).ravel()
     np.testing.assert_allclose(o[2:4], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
+
+
+def test_c1_full_size_features_vs_oracle(room):
+    """BASELINE config 1 at full size (one 200 k-point scan, K = 10, covariance + eigen-decomposition forward through
+    DepthCloud's operator, fp32 inputs): eigenvalues within 1e-5 relative (plus LAPACK's absolute floor), covariances
+    and incidence angles against the fp64 oracle on the same fp32 points and the same (bit-exact) neighbour table."""
+    from depth_correction_amd import pipeline
+    scans, _ = room
+    loc = pipeline.local_features(scans[0], k=10, dtype=torch.float32, eigenvalue_ratio_bounds=None)
+    x = loc['points'].double().cpu()
+    _, ind = O.knn_ckdtree(x.numpy(), 10)
+    assert np.array_equal(ind, npy(loc['neighbors']))
+    ref = O.features(x, torch.as_tensor(ind), loc['dirs'].double().cpu())
+    ev, rv = npy(loc['eigvals']).astype(np.float64), npy(ref['eigvals'])
+    # the kernel stores fp32 eigenvalues: half an fp32 ulp on top of the 1e-5 bar
+    assert_eigvals = np.abs(ev - rv) <= 1e-5 * np.abs(rv) + 1e-12 * np.abs(rv).max(-1, keepdims=True) + 6e-8 * np.abs(rv)
+    assert assert_eigvals.all(), 'worst rel %.3g' % (np.abs(ev - rv) / np.abs(rv))[~assert_eigvals].max()
+    # incidence angles where the normal is well defined (lambda0 separated from lambda1)
+    ok = (rv[:, 1] - rv[:, 0]) > 1e-3 * rv[:, 2]
+    assert ok.mean() > 0.9
+    np.testing.assert_allclose(npy(loc['inc_angles']).ravel()[ok], npy(ref['inc_angles']).ravel()[ok], atol=2e-4)
