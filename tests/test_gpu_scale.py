@@ -174,3 +174,56 @@ def test_c1_full_size_features_vs_oracle(room):
     ok = (rv[:, 1] - rv[:, 0]) > 1e-3 * rv[:, 2]
     assert ok.mean() > 0.9
     np.testing.assert_allclose(npy(loc['inc_angles']).ravel()[ok], npy(ref['inc_angles']).ravel()[ok], atol=2e-4)
+
+
+@pytest.mark.timeout(600)
+def test_c4_full_size_icp_loss_and_gradients_vs_oracle():
+    """BASELINE config 4 shape at full size: KITTI-like scans of 64 x 2048 rays, depth 5-25 m and 0.2 m voxel
+    pre-filters, radius neighbourhoods (nn_r = 0.4), model + per-pose corrections, point-to-plane ICP over all
+    consecutive pairs.  The whole pipeline runs on the GPU; the oracle (fp64, CPU) takes the GPU's local features
+    (normals of collinear ring neighbourhoods are arbitrary eigenvectors) and the GPU's correspondences
+    (bit-exact vs cKDTree, tested above) and repeats model -> transform -> point_to_plane_dist and its gradients."""
+    from depth_correction_amd.config import Config, Loss, PoseCorrection
+    from depth_correction_amd.dataset import KittiLikeDataset
+    from depth_correction_amd.loss import icp_loss, icp_correspondences
+    from depth_correction_amd.model import ScaledPolynomial
+    from depth_correction_amd.preproc import filtered_cloud, local_feature_cloud
+    from depth_correction_amd.transform import xyz_axis_angle_to_matrix
+    dev = 'cuda:0'
+    cfg = Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2, min_depth=5.0,
+                 max_depth=25.0, vp_dispersion_bounds=[])
+    ds = KittiLikeDataset(n_poses=4)
+    raw = [(c, p) for c, p in ds]
+    assert all(len(c) > 120_000 for c, _ in raw)
+    clouds = [local_feature_cloud(filtered_cloud(c, cfg), cfg) for c, _ in raw]
+    assert all(5_000 < len(c) < 131_072 for c in clouds), [len(c) for c in clouds]
+    poses0 = torch.as_tensor(np.stack([p for _, p in raw]), dtype=torch.float64, device=dev)
+    pts = [c.transform(T).to_points() for c, T in zip(clouds, poses0)]
+    masks = []
+    for j in range(len(clouds) - 1):
+        m1, i2, _ = icp_correspondences(pts[j], pts[j + 1], 0.3)
+        masks.append((m1, i2))
+    model = ScaledPolynomial(w=[1e-3, -1e-3], exponent=[2.0, 4.0], device=dev)
+    pd = torch.zeros((len(clouds), 6), dtype=torch.float64, device=dev)
+    pd[1:] = torch.tensor([0.01, -0.02, 0.005, 0.002, -0.001, 0.003], dtype=torch.float64, device=dev)
+    pd.requires_grad_(True)
+    poses = torch.matmul(poses0, xyz_axis_angle_to_matrix(pd))
+    loss, _ = icp_loss([clouds], [poses], model, masks=[masks], icp_point_to_plane=True, icp_inlier_ratio=0.3)
+    loss.backward()
+    # ---- oracle on the same local clouds / correspondences
+    w = torch.tensor([[1e-3, -1e-3]], dtype=torch.float64, requires_grad=True)
+    e = torch.tensor([[2.0, 4.0]], dtype=torch.float64)
+    pdo = pd.detach().cpu().clone().requires_grad_(True)
+    To = torch.matmul(poses0.cpu(), O.xyz_axis_angle_to_matrix(pdo))
+    opts, onrm = [], []
+    for c, Ts in zip(clouds, To):
+        d = O.model_apply(c.depth.double().cpu(), c.inc_angles.double().cpu(), c.mask.cpu(), w, e)
+        v, r, n = O.transform_cloud(c.vps.double().cpu().expand(len(c), 3), c.dirs.double().cpu(), Ts,
+                                    normals=c.normals.double().cpu())
+        opts.append(O.points_from(v, r, d)), onrm.append(n)
+    lo = O.point_to_plane(opts, onrm, [(m1.cpu(), i2.cpu()) for m1, i2 in masks])
+    lo.backward()
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(npy(model.w.grad).ravel(), npy(w.grad).ravel(), rtol=1e-4, atol=1e-6 * np.abs(npy(w.grad)).max())
+    ref = npy(pdo.grad)
+    np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
