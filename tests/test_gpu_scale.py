@@ -124,14 +124,16 @@ def test_oracle_on_200k_sample(room):
 
 
 @pytest.mark.timeout(600)
-def test_c2_full_size_loss_and_gradient_vs_oracle(room):
+@pytest.mark.parametrize('dtype,rtol_loss,rtol_grad', [(torch.float32, 1e-5, 1e-5), (torch.float64, 1e-9, 1e-7)])
+def test_c2_full_size_loss_and_gradient_vs_oracle(room, dtype, rtol_loss, rtol_grad):
     """BASELINE config 2 at full size (10 x 200 k points, N = 2 M, K = 10, ScaledPolynomial, normalised min-eigenvalue
     loss): loss, masked-point count and dL/dw of the HIP path (fp32 inputs, q32 points, block tables) against the CPU
     oracle in fp64 on the same inputs -- the north-star tolerance 1e-5.  The neighbour table is the GPU's (bit-exact
-    against cKDTree in the tests above), so the oracle spends its time on the path proper."""
+    against cKDTree in the tests above), so the oracle spends its time on the path proper.  Also with fp64 device data
+    (the reference's default float type), where the bar is 1e-9."""
     from depth_correction_amd.pipeline import build_sequence
     scans, poses = room
-    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    plan, info = build_sequence(scans, poses, k=10, dtype=dtype)
     dev = plan.device
     out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
     w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
@@ -150,9 +152,9 @@ def test_c2_full_size_loss_and_gradient_vs_oracle(room):
     finally:
         torch.set_num_threads(threads)
     assert o[1] == float(info['mask'].sum().item()) and o[1] > 1.0e6
-    np.testing.assert_allclose(o[0], lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(o[0], lo.item(), rtol=rtol_loss)
     g = npy(wo.grad).ravel()
-    np.testing.assert_allclose(o[2:4], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
+    np.testing.assert_allclose(o[2:4], g, rtol=rtol_grad, atol=0.1 * rtol_grad * np.abs(g).max())
 
 
 def test_c1_full_size_features_vs_oracle(room):
