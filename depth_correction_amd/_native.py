@@ -8,11 +8,12 @@ first call raises ``RuntimeError``.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 
 import torch
 
-__all__ = ['lib', 'lib_path', 'DC_F32', 'DC_F64', 'DC_Q32', 'LOSS_KINDS', 'MODEL_KINDS']
+__all__ = ['lib', 'lib_path', 'on_device', 'DC_F32', 'DC_F64', 'DC_Q32', 'LOSS_KINDS', 'MODEL_KINDS']
 
 DC_F32, DC_F64, DC_Q32 = 0, 1, 2
 LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
@@ -124,7 +125,38 @@ def check(status, what):
 
 
 def stream_ptr():
+    """torch's current stream of the CURRENT device; launches run under ``on_device`` so that this is the operands' device."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _device_of(args, kwargs):
+    for a in tuple(args) + tuple(kwargs.values()):
+        dev = a.device if isinstance(a, torch.Tensor) else getattr(a, 'device', None)
+        if callable(dev):                       # DepthCloud.device() is a method (depth_cloud.py:170 of the reference)
+            dev = dev()
+        if isinstance(dev, torch.device) and dev.type == 'cuda':
+            return dev
+        if isinstance(a, dict):
+            a = list(a.values())
+        if isinstance(a, (list, tuple)) and a and not isinstance(a[0], (int, float, str)):
+            dev = _device_of(a[:1], {})
+            if dev is not None:
+                return dev
+    return None
+
+
+def on_device(fn):
+    """Run ``fn`` with the device of its first GPU operand (tensor, or object with a ``.device``) made current, so the
+    raw pointers, torch's current stream and every workspace the wrapper allocates belong to the same GPU.  Without
+    it a cloud on ``cuda:1`` in a process whose current device is 0 would launch device-0 kernels on device-1 pointers."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = _device_of(args, kwargs)
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return guarded
 
 
 def dtype_code(t):

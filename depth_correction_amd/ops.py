@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _native as nv
-from ._native import lib, check, need, ptr, stream_ptr, dtype_code
+from ._native import lib, check, need, ptr, stream_ptr, dtype_code, on_device
 
 __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
@@ -34,6 +34,7 @@ def as_index32(neighbors):
 # ------------------------------------------------------------------------------------------------
 # neighbourhood builder
 # ------------------------------------------------------------------------------------------------
+@on_device
 def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
     """k-NN of ``query`` (default: ``points`` itself) in ``points``: (dist f64 [M,k] | None, idx i32 [M,k])."""
     need(points, (None, 3), name='points')
@@ -56,6 +57,7 @@ def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
     return dist, idx
 
 
+@on_device
 def radius_neighbors(points, r):
     """All neighbours within ``r`` (inclusive), ascending index, padded with -1: idx i32 [N, Kmax]."""
     need(points, (None, 3), name='points')
@@ -77,6 +79,7 @@ def radius_neighbors(points, r):
     return idx
 
 
+@on_device
 def knn_transpose(nbr, n_dst=None):
     """(csr_ptr i32 [n_dst+1], csr_src i32 [rows*K]) -- for every point the rows whose neighbourhood contains it.
     ``n_dst`` (default: the number of rows) is the number of points the indices refer to."""
@@ -116,6 +119,7 @@ def _table_ref(table, n_rows):
     return table.ref()
 
 
+@on_device
 def block_table(nbr=None, csr=None):
     """BlockTable of a neighbour table ``nbr`` int32 [rows, K] (forward) or of CSR lists ``csr`` = (ptr, ids)
     (backward: knn_transpose's output).  Returns None when a block references 65535 or more distinct rows."""
@@ -147,6 +151,7 @@ def block_table(nbr=None, csr=None):
     return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows)
 
 
+@on_device
 def spatial_order(points):
     need(points, (None, 3), name='points')
     n = points.shape[0]
@@ -237,6 +242,7 @@ def _check_points(points, qfmt, name='points'):
         raise ValueError('%s must be float [N,3] or [N,4]' % name)
 
 
+@on_device
 def points_fwd(ps, poses=None, model_kind=None, w=None, e=None, stride=3, want_parts=False, qfmt=None, out=None):
     """x = pose(vps) + model(depth) * pose(dirs); optionally also (vps', dirs', depth').
     With ``qfmt`` the points are written as int32 fixed-point rows [N,4] (DC_Q32)."""
@@ -263,6 +269,7 @@ def _grads_split(g, nt, ns):
     return g[:nt], g[nt:2 * nt], g[2 * nt:].reshape(ns, 3, 4)
 
 
+@on_device
 def points_bwd(grad_points, ps, poses=None, model_kind=None, w=None, e=None, want_exponent=False, want_pose=False,
                perm=None, out=None):
     """(dL/dw [P], dL/dexponent [P], dL/d[R|t] [S,3,4]) for a given dL/dpoints; ``perm`` int32 [N]: point i uses
@@ -292,6 +299,7 @@ def points_bwd(grad_points, ps, poses=None, model_kind=None, w=None, e=None, wan
 # ------------------------------------------------------------------------------------------------
 # neighbourhood features
 # ------------------------------------------------------------------------------------------------
+@on_device
 def features_fwd(points, nbr, dirs=None, mean_weights=None, scale=None, want=('mean', 'cov', 'eigvals', 'eigvecs',
                                                                              'normals', 'inc_angles'),
                  want_saved=False, want_weights=False):
@@ -322,6 +330,7 @@ def features_fwd(points, nbr, dirs=None, mean_weights=None, scale=None, want=('m
     return out
 
 
+@on_device
 def features_bwd(points, csr_ptr, csr_src, cmean, invd, nvalid, eigvecs=None, grad_mean=None, grad_cov=None,
                  grad_eigvals=None):
     need(points, (None, None), name='points')
@@ -347,6 +356,7 @@ def features_bwd(points, csr_ptr, csr_src, cmean, invd, nvalid, eigvecs=None, gr
 # ------------------------------------------------------------------------------------------------
 # fused consistency loss
 # ------------------------------------------------------------------------------------------------
+@on_device
 def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss', normalization=True, sqrt=False,
                     rec=None, want_pointwise=False, want_eigvals=False, partials=None, sums=None, qfmt=None,
                     centre_idx=None, table=None):
@@ -397,6 +407,7 @@ def degree_lane_perm(csr_ptr, block=256):
     return torch.argsort(deg.reshape(nb, block), dim=1, stable=True).to(torch.uint8).reshape(-1).contiguous()
 
 
+@on_device
 def consistency_bwd(points, rec, csr_ptr, csr_src, ps=None, poses=None, model_kind=None, w=None, e=None,
                     want_exponent=False, want_pose=False, want_grad_points=False, partials=None, grads=None, qfmt=None,
                     lane_perm=None, table=None):
@@ -447,6 +458,7 @@ def _bound(v, default):
     return default if v != v else v        # config files encode "unbounded" as nan (config.py:41-43)
 
 
+@on_device
 def mask_bounds(mask, num, num_index=0, den=None, den_index=0, lo=None, hi=None):
     """mask &= lo <= num[:, num_index] (/ den[:, den_index]) <= hi   (in place, returns mask)."""
     n = mask.shape[0]
@@ -463,6 +475,7 @@ def mask_bounds(mask, num, num_index=0, den=None, den_index=0, lo=None, hi=None)
     return mask
 
 
+@on_device
 def valid_count(nbr):
     need(nbr, (None, None), dtype=torch.int32, name='neighbors')
     cnt = torch.empty((nbr.shape[0],), dtype=torch.int32, device=nbr.device)
@@ -470,6 +483,7 @@ def valid_count(nbr):
     return cnt
 
 
+@on_device
 def dispersion(vec, nbr, weights=None):
     need(vec, (None, 3), name='vectors')
     n = vec.shape[0]
@@ -484,6 +498,7 @@ def dispersion(vec, nbr, weights=None):
     return out
 
 
+@on_device
 def voxel_filter(points, grid_res, seq=None, preserve_order=False):
     """Indices (int64, device) of one survivor per voxel with filter_grid's dict semantics; None if the voxel range
     does not fit the 63-bit key (caller falls back to the host algorithm)."""
@@ -506,6 +521,7 @@ def voxel_filter(points, grid_res, seq=None, preserve_order=False):
 # ------------------------------------------------------------------------------------------------
 # point-to-plane ICP pair
 # ------------------------------------------------------------------------------------------------
+@on_device
 def p2plane_pair(psa, normals_a, psb, normals_b, pose_a, pose_b, idx_a, idx_b, model_kind=None, w=None, e=None):
     """Sums of point-to-plane distances over the correspondences of one scan pair and their gradients:
     returns (sums f64 [2], dw [P], de [P], dTa [3,4], dTb [3,4]) for d(sum12 + sum21)."""
@@ -538,6 +554,7 @@ class IcpSequence:
     (scan_a, scan_b, idx_a int32 [m], idx_b int32 [m]); pair weights follow icp_loss (loss.py:391-403):
     0.5 / (m * n_pairs)."""
 
+    @on_device
     def __init__(self, scans, pairs, with_model=True):
         ps0 = scans[0][0]
         self.device, self.dtype, self.n_scans = ps0.device, ps0.dtype, len(scans)
@@ -566,6 +583,7 @@ class IcpSequence:
             max_m = max(max_m, m)
         self.part = torch.empty((lib().dc_p2plane_partial_count(max_m),), dtype=torch.float64, device=self.device)
 
+    @on_device
     def eval(self, poses12, model_kind=None, w=None, e=None, out=None):
         """out fp64 [1 + 2P + 12 S] = {loss, dloss/dw, dloss/dexponent, dloss/d[R|t]}."""
         kind, nt, w, e = _model_args(model_kind, w, e, self._keep[0][0]) if self.n_scans else (0, 0, None, None)

@@ -25,12 +25,13 @@ import torch
 
 from . import ops
 from . import _native as nv
-from ._native import need, lib, check, ptr, stream_ptr
+from ._native import need, lib, check, ptr, stream_ptr, on_device
 
 __all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer']
 
 
 class SequencePlan:
+    @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True):
@@ -155,6 +156,7 @@ class SequencePlan:
             self._desc = d
         return self._desc
 
+    @on_device
     def eval_native(self, w, exponent, poses12, out, want_grad=True, want_exponent=False, want_pose=False):
         """One host call per evaluation.  w, exponent: fp64 device vectors [P]; poses12: fp64 device [S,12];
         out: fp64 device [2 + 2P + 12S] <- {sum loss, count, d/dw, d/dexponent, d/d[R|t]}."""
@@ -170,6 +172,7 @@ class SequencePlan:
         self.version += 1
         return out
 
+    @on_device
     def step_native(self, w, exponent, poses12, out, exp_avg, exp_avg_sq, t, grad_scale, lr, betas, eps, weight_decay):
         """Evaluation + Adam step of ``w`` (in place) in one host call (dc_sequence_step); out as in eval_native."""
         nt = w.numel()
@@ -338,6 +341,7 @@ class SequenceTrainer:
             from .distributed import all_reduce_sum
             self.count = float(all_reduce_sum(torch.tensor([self.count], dtype=torch.float64, device=dev), process_group).item())
 
+    @on_device
     def _adam_native(self, grad_sum):
         check(lib().dc_adam_step(ptr(self.w), ctypes.c_void_p(grad_sum.data_ptr()), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                  self.nt, self.t, 1.0 / self.count, self.lr, self.betas[0], self.betas[1], self.eps,

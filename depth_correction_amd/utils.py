@@ -27,30 +27,36 @@ def timing(f):
 
 
 def covs(x, obs_axis=-2, var_axis=-1, center=True, correction=True, weights=None):
-    """Batched (weighted) covariance of samples along ``obs_axis`` over variables along ``var_axis``.
+    """Batched (weighted) covariance matrices: samples along ``obs_axis``, variables along ``var_axis``
+    (signature and normalisation of utils.py:109-149: divide by ``sum(weights) - 1``, clamped to 1e-6 when it is a
+    float tensor).  The observation axis disappears and the variable axis becomes two adjacent axes.
 
-    Normalisation as the reference: divide by ``sum(weights) - 1`` clamped to 1e-6 (``correction``)."""
-    assert isinstance(x, torch.Tensor) and obs_axis != var_axis
-    assert weights is None or isinstance(weights, torch.Tensor)
-    total = weights.sum(dim=obs_axis, keepdim=True) if weights is not None else x.shape[obs_axis]
-    if center:
-        mean = ((weights * x).sum(dim=obs_axis, keepdim=True) / total) if weights is not None \
-            else x.mean(dim=obs_axis, keepdim=True)
-        x = x - mean
-    other = var_axis + 1 if var_axis >= 0 else var_axis - 1
-    outer = x.unsqueeze(var_axis) * x.unsqueeze(other)
+    Axes of mixed sign (e.g. obs_axis=-1, var_axis=0) follow the definition here; the reference's axis shift sums over
+    the wrong axis in that one combination, which none of its callers use.
+
+    Formed as one batched matrix product  Xc^T diag(w) Xc  on [..., K, V] views instead of a materialised
+    ``[..., K, V, V]`` outer-product tensor."""
+    assert isinstance(x, torch.Tensor) and (weights is None or isinstance(weights, torch.Tensor))
+    nd = x.dim()
+    obs, var = obs_axis % nd, var_axis % nd
+    assert obs != var
+    xs = x.movedim((obs, var), (-2, -1))                                  # [..., K, V]
     if weights is not None:
-        outer = weights.unsqueeze(var_axis) * outer
-    if obs_axis < var_axis and obs_axis < 0:
-        obs_axis -= 1
-    elif obs_axis > var_axis and obs_axis > 0:
-        obs_axis += 1
-    outer = outer.sum(dim=obs_axis)
+        ws = torch.broadcast_to(weights, x.shape).movedim((obs, var), (-2, -1))[..., :1]      # [..., K, 1]
+        norm = ws.sum(dim=-2, keepdim=True)                               # [..., 1, 1]
+    else:
+        ws, norm = None, xs.shape[-2]
+    if center:
+        xs = xs - ((ws * xs).sum(dim=-2, keepdim=True) / norm if ws is not None else xs.mean(dim=-2, keepdim=True))
+    left = xs if ws is None else ws * xs
+    cov = left.transpose(-1, -2) @ xs                                     # [..., V, V]
     if correction:
-        total = total - 1
-    if isinstance(total, torch.Tensor) and total.dtype.is_floating_point:
-        total = total.clamp(1e-6, None)
-    return outer / total
+        norm = norm - 1
+    if isinstance(norm, torch.Tensor) and norm.dtype.is_floating_point:
+        norm = norm.clamp(min=1e-6)
+    cov = cov / norm
+    at = var - (1 if obs < var else 0)                                    # where the variable axis sits without obs
+    return cov.movedim((-2, -1), (at, at + 1))
 
 
 def trace(x, dim1=-2, dim2=-1):
