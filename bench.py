@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')
     ap.add_argument('--timer-every', type=int, default=8,
                     help='HIP-event timing of every N-th launch of the hot kernels inside the timed region (0 = off)')
+    ap.add_argument('--bwd-layout', default='runs', choices=['runs', 'slots'], help='backward block-table layout (ablation)')
+    ap.add_argument('--fwd-generic', action='store_true', help='run-time slot loop in the forward kernel (ablation)')
     ap.add_argument('--no-block-tables', action='store_true', help='gather from global memory instead of LDS (ablation)')
     return ap.parse_args()
 
@@ -155,7 +157,10 @@ def main():
     t0 = time.perf_counter()
     plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, spatial_sort=not args.no_sort,
                                 point_format=args.point_format, active_only=args.active_only, degree_sort=args.degree_sort,
-                                block_tables=not args.no_block_tables)
+                                block_tables=not args.no_block_tables, bwd_layout=args.bwd_layout)
+    if args.fwd_generic:
+        from depth_correction_amd import _native as nv
+        nv.check(nv.lib().dc_set_option(1, 1), 'dc_set_option')
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     # the k-NN build alone, on the global cloud (reported separately)

@@ -16,6 +16,7 @@ import torch
 __all__ = ['lib', 'lib_path', 'on_device', 'DC_F32', 'DC_F64', 'DC_Q32', 'LOSS_KINDS', 'MODEL_KINDS']
 
 DC_F32, DC_F64, DC_Q32 = 0, 1, 2
+DC_TABLE_SLOTS, DC_TABLE_RUNS = 0, 1
 LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
 MODEL_KINDS = {None: 0, 'BaseModel': 0, 'Polynomial': 1, 'ScaledPolynomial': 2}
 MAX_MODEL_TERMS = 8
@@ -45,6 +46,8 @@ _SIGNATURES = {
     'dc_block_table_slots': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_workspace_bytes': (_sz, [_i64]),
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'dc_block_table_run_capacity': (_i64, [_i64, _i64]),
+    'dc_block_table_build_runs': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
                                   _vp, _vp, _vp, _vp]),
     'dc_consistency_bwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -71,7 +74,7 @@ _SIGNATURES = {
 class BlockTableDesc(ctypes.Structure):
     """dcBlockTable of include/dc_hip.h."""
     _fields_ = [('blk_ptr', _vp), ('blk_ids', _vp), ('slot_ptr', _vp), ('loc', _vp), ('max_rows', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('layout', ctypes.c_int32), ('run_ptr', _vp)]
 
 
 class IcpScan(ctypes.Structure):

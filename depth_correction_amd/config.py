@@ -104,6 +104,9 @@ class Config(object):
         self.optimizer_args = []
         self.optimizer_kwargs = {}
         self.lr = 2e-4
+        # not in the reference: None = shard the sequences over the ranks whenever torch.distributed is initialised with
+        # more than one (train.py of this package), False = every process trains on all sequences
+        self.distributed = None
         self.pose_correction = PoseCorrection.none
         self.train_pose_deltas = None
         self.test_pose_deltas = None

@@ -8,9 +8,11 @@
 //
 // A block table, built once per neighbourhood set, lists for every block of 256 rows the distinct rows it
 // references (`blk_ids[blk_ptr[b] .. blk_ptr[b+1])`, ascending) and replaces every reference by a 16-bit position in
-// that list, stored slot-major (`loc[(slot_ptr[b] + s) * 256 + lane]`, 0xFFFF = empty slot) so that a wavefront reads
-// its slot s with one coalesced 128-B load.  The kernels stage the distinct rows into LDS once per block and gather
-// from LDS.
+// that list (stored as the byte offset 16 x position of the row in the LDS tile).  Layouts: slot-major
+// (`loc[(slot_ptr[b] + s) * 256 + lane]`, 0xFFFF = empty slot: a wavefront reads its slot s with one coalesced 128-B
+// load; exact for the forward's [rows, K] table) or per-row runs padded to four positions (`loc[4 * run_ptr[r] + s]`:
+// the backward's incoming-edge lists, whose length varies per point).  The kernels stage the distinct rows into LDS once
+// per block and gather from LDS.
 //
 // Build: keys (block << 32 | id) of all references -> radix sort -> heads of runs -> prefix sum -> scatter.
 #include <cstring>
@@ -24,6 +26,7 @@
 namespace dc {
 
 constexpr uint64_t kNoKey = ~0ull;
+constexpr int32_t kMaxBlockRows = 0xFFF;     // 16 x position must stay below the 0xFFFF padding marker
 
 // slots per block: the longest reference list among the block's rows (fixed k: k)
 __global__ __launch_bounds__(kBlock) void bt_slot_count_kernel(const int32_t* __restrict__ row_ptr, int64_t n_rows, int k,
@@ -110,8 +113,9 @@ __global__ __launch_bounds__(kBlock) void bt_scatter_kernel(const uint64_t* __re
                                                             const uint32_t* __restrict__ heads, const uint32_t* __restrict__ rank1,
                                                             const int32_t* __restrict__ row_of, const int32_t* __restrict__ row_ptr,
                                                             int64_t n_refs, int k, const int32_t* __restrict__ blk_ptr,
-                                                            const int32_t* __restrict__ slot_ptr, int32_t* __restrict__ blk_ids,
-                                                            uint16_t* __restrict__ loc, int32_t* __restrict__ info) {
+                                                            const int32_t* __restrict__ slot_ptr, const int32_t* __restrict__ run_ptr,
+                                                            int32_t* __restrict__ blk_ids, uint16_t* __restrict__ loc,
+                                                            int32_t* __restrict__ info) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n_refs) return;
   const uint64_t key = skeys[p];
@@ -120,11 +124,20 @@ __global__ __launch_bounds__(kBlock) void bt_scatter_kernel(const uint64_t* __re
   const int32_t r = (int32_t)rank1[p] - 1;
   if (heads[p]) blk_ids[r] = (int32_t)(uint32_t)key;
   const int32_t local = r - blk_ptr[b];
-  if (local >= 0xFFFF) { atomicMax(&info[2], 1); return; }
+  if (local >= kMaxBlockRows) { atomicMax(&info[2], 1); return; }
   const int64_t e = svals[p];
   const int64_t row = row_of ? (int64_t)row_of[e] : e / k;
   const int64_t slot = row_ptr ? e - row_ptr[row] : e - row * k;
-  loc[((int64_t)slot_ptr[b] + slot) * kBlock + (row & (kBlock - 1))] = (uint16_t)local;
+  const int64_t at = run_ptr ? (int64_t)run_ptr[row] * 4 + slot : ((int64_t)slot_ptr[b] + slot) * kBlock + (row & (kBlock - 1));
+  loc[at] = (uint16_t)(local << 4);                       // byte offset of the row in the LDS tile
+}
+
+// runs per row of a CSR list: ceil(length / 4); entry n_rows = 0, so that the exclusive scan ends with the total
+__global__ __launch_bounds__(kBlock) void bt_run_len_kernel(const int32_t* __restrict__ row_ptr, int64_t n_rows,
+                                                            int32_t* __restrict__ len) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r > n_rows) return;
+  len[r] = r < n_rows ? (row_ptr[r + 1] - row_ptr[r] + 3) >> 2 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void bt_info_kernel(const int32_t* __restrict__ blk_ptr, int64_t n_blocks,
@@ -168,14 +181,16 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs) {
   return c.off + 256;
 }
 
-int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
-                         const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
-                         int32_t* info, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (n_rows < 0 || n_refs < 0 || n_slot_rows < 0 || !blk_ptr || !info || (!row_ptr && k < 1)) return DC_ERR_ARG;
+// loc_entries: number of uint16 entries of loc (all set to 0xFFFF first); run_ptr != NULL selects the run layout
+static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
+                                  const int32_t* slot_ptr, const int32_t* run_ptr, int64_t loc_entries, int32_t* blk_ptr,
+                                  int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const int64_t n_slot_rows = loc_entries / kBlock;
+  if (n_rows < 0 || n_refs < 0 || loc_entries < 0 || !blk_ptr || !info || (!row_ptr && k < 1)) return DC_ERR_ARG;
   DC_HIP(hipMemsetAsync(info, 0, 4 * sizeof(int32_t), stream));
   const int64_t nb = blocks_of(n_rows);
   if (n_rows == 0 || n_refs == 0) return (int)hipMemsetAsync(blk_ptr, 0, (size_t)(nb + 1) * sizeof(int32_t), stream);
-  if (!ids || !slot_ptr || !blk_ids || !loc || !ws) return DC_ERR_ARG;
+  if (!ids || (!slot_ptr && !run_ptr) || !blk_ids || !loc || !ws) return DC_ERR_ARG;
   if (!row_ptr && n_refs != n_rows * (int64_t)k) return DC_ERR_ARG;
   if (n_refs >= (int64_t)0x7fffffff || n_slot_rows * kBlock >= ((int64_t)1 << 40)) return DC_ERR_UNSUPPORTED;
   if (ws_bytes < dc_block_table_workspace_bytes(n_refs)) return DC_ERR_WORKSPACE;
@@ -199,7 +214,7 @@ int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_r
     hipLaunchKernelGGL(bt_row_of_kernel, dim3(grid_of(n_rows)), block, 0, stream, row_ptr, n_rows, row_of);
   }
   const int32_t* rows = row_ptr ? row_of : nullptr;
-  DC_HIP(hipMemsetAsync(loc, 0xff, (size_t)n_slot_rows * kBlock * sizeof(uint16_t), stream));
+  DC_HIP(hipMemsetAsync(loc, 0xff, (size_t)loc_entries * sizeof(uint16_t), stream));
   hipLaunchKernelGGL(bt_keys_kernel, dim3(grid_of(n_refs)), block, 0, stream, ids, rows, n_refs, k, keys, vals);
   // 32 id bits + enough block bits that the all-ones block of an invalid reference exceeds every real block: invalid
   // references sort behind all blocks, and the sort runs 6 radix passes instead of 8
@@ -210,10 +225,44 @@ int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_r
   DC_HIP(rocprim::inclusive_scan(tmp, cb, heads, rank1, (size_t)n_refs, rocprim::plus<uint32_t>(), stream));
   hipLaunchKernelGGL(bt_blk_ptr_kernel, dim3(grid_of(nb + 1)), block, 0, stream, skeys, rank1, n_refs, nb, blk_ptr);
   hipLaunchKernelGGL(bt_scatter_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, svals, heads, rank1, rows, row_ptr,
-                     n_refs, k, blk_ptr, slot_ptr, blk_ids, loc, info);
+                     n_refs, k, blk_ptr, slot_ptr, run_ptr, blk_ids, loc, info);
   hipLaunchKernelGGL(bt_info_kernel, dim3(grid_of(nb)), block, 0, stream, blk_ptr, nb, info);
   DC_HIP(hipGetLastError());
   return DC_OK;
+}
+
+int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
+                         const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
+                         int32_t* info, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n_slot_rows < 0) return DC_ERR_ARG;
+  return block_table_build_impl(row_ptr, ids, n_rows, k, n_refs, slot_ptr, nullptr, n_slot_rows * kBlock, blk_ptr, blk_ids, loc,
+                                info, ws, ws_bytes, stream);
+}
+
+// upper bound of the number of runs: every row wastes at most three positions
+int64_t dc_block_table_run_capacity(int64_t n_rows, int64_t n_refs) {
+  if (n_rows < 0 || n_refs < 0) return 0;
+  return (n_refs + 3 * n_rows) / 4 + 1;
+}
+
+int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int64_t n_refs, int32_t* run_ptr,
+                              int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  if (!row_ptr || !run_ptr || n_rows < 0 || n_refs < 0) return DC_ERR_ARG;
+  if (ws_bytes < dc_block_table_workspace_bytes(n_refs > n_rows + 1 ? n_refs : n_rows + 1) || !ws) return DC_ERR_WORKSPACE;
+  if (n_rows + 1 >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  // run_ptr = exclusive scan of ceil(length / 4); the scan's scratch and input live in the (not yet used) workspace
+  Carver c(ws);
+  int32_t* len = c.take<int32_t>((size_t)n_rows + 1);
+  size_t cb = 0;
+  (void)rocprim::exclusive_scan(nullptr, cb, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n_rows + 1, rocprim::plus<int32_t>(),
+                                (hipStream_t)0);
+  void* tmp = c.take<char>(cb);
+  if (c.off > ws_bytes) return DC_ERR_WORKSPACE;
+  hipLaunchKernelGGL(bt_run_len_kernel, dim3(grid_of(n_rows + 1)), dim3(kBlock), 0, stream, row_ptr, n_rows, len);
+  DC_HIP(rocprim::exclusive_scan(tmp, cb, len, run_ptr, 0, (size_t)n_rows + 1, rocprim::plus<int32_t>(), stream));
+  return block_table_build_impl(row_ptr, ids, n_rows, 0, n_refs, nullptr, run_ptr, dc_block_table_run_capacity(n_rows, n_refs) * 4,
+                                blk_ptr, blk_ids, loc, info, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

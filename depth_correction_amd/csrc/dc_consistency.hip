@@ -15,6 +15,8 @@
 // inputs); only storage is T.  No atomics: block partial sums are
 // written to a workspace and reduced in a fixed order, so every result is bitwise reproducible.
 #include <type_traits>
+#include <atomic>
+#include <mutex>
 #include <hip/hip_ext.h>
 #include "dc_common.h"
 #include "dc_device.h"
@@ -66,9 +68,7 @@ __device__ __forceinline__ void consistency_point(CovAcc& acc, const typename Pt
   // moments are in raw units (q32: multiples of the resolution); scale once
   const double u = Pt<PT>::unit(qp), u2 = u * u;
   double moff[3], cm[3], C[6], D, omega;
-  cov_finish(acc, 0.0, moff, cm, C, &D, &omega);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) C[q] *= u2;
+  cov_finish(acc, 0.0, moff, cm, C, &D, &omega, u2);
   const bool m = mask ? mask[i] != 0 : true;
   const double off = offset ? (double)offset[i] : 0.0;
   double lam0, v0[3], tr, c1, c2, l;
@@ -475,20 +475,23 @@ constexpr uint32_t kNoLoc = 0xFFFFu;
 // back to back (32-B records) the group would be (2 t + a) mod 16 -- only 8 of the 16 for each piece, measured as 2/3
 // of all LDS cycles lost to bank conflicts.  Piece-major, the group is t mod 16.
 template <int ROW16>
-__device__ __forceinline__ int stage_rows(const BlockTab& tab, int64_t blk, const int4* __restrict__ src, int4* tile, int cap) {
-  const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+__device__ __forceinline__ int stage_rows(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ blk_ids, int64_t blk,
+                                          const int4* __restrict__ src, int4* tile, int cap) {
+  const int32_t base = blk_ptr[blk], nd = blk_ptr[blk + 1] - base;
   for (int t = threadIdx.x; t < nd; t += kBlock) {
-    const int64_t id = tab.blk_ids[base + t];
+    const int64_t id = blk_ids[base + t];
 #pragma unroll
     for (int a = 0; a < ROW16; ++a) tile[a * cap + t] = src[id * ROW16 + a];
   }
   return nd;
 }
 
+// `off` = 16 x (row in the block's distinct list), exactly what the table stores: the LDS byte address needs no shift
 template <int ROW16>
-__device__ __forceinline__ void read_row(const int4* tile, int cap, uint32_t row, int4* q) {
+__device__ __forceinline__ void read_row(const int4* tile, int cap, uint32_t off, int4* q) {
+  const char* p = reinterpret_cast<const char*>(tile) + off;
 #pragma unroll
-  for (int a = 0; a < ROW16; ++a) q[a] = tile[a * cap + row];
+  for (int a = 0; a < ROW16; ++a) q[a] = *reinterpret_cast<const int4*>(p + (size_t)a * cap * 16);
 }
 
 constexpr int kPreSlots = 16;
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
     if (live) ci = Pt<PT>::from_row(xg + (centre_idx ? (int64_t)centre_idx[i] : i) * XR);
 #pragma unroll
     for (int q = 0; q < kPreSlots; ++q) pre[q] = (live && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
-    stage_rows<XR>(tab, blk, xg, tile, cap);
+    stage_rows<XR>(tab.blk_ptr, tab.blk_ids, blk, xg, tile, cap);
   }
   __syncthreads();
   if (live) {
@@ -588,6 +591,89 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
     acc.W = (double)n_have;
     consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
   }
+  block_sum<2>(acc2, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = acc2[0];
+    partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
+  }
+}
+
+// Fixed slot count: a forward table built from a neighbour table [rows, K] has exactly K slots in every block, so the
+// slot loop, the position loads and the validity handling are resolved at compile time (the run-time variant above
+// spends ~60 VALU instructions per point on them).  Same arithmetic in the same order => bit-identical results.
+template <typename PT, int NS, bool MISS>
+__device__ __forceinline__ int gather_fixed(const int4* tile, int cap, const typename Pt<PT>::Raw& ci, const uint32_t* pre,
+                                            CovAcc& acc) {
+  constexpr int XR = Pt<PT>::kRow16;
+  int n_have = 0;
+#pragma unroll
+  for (int q0 = 0; q0 < NS; q0 += 4) {
+    typename Pt<PT>::Raw cj[4];
+    bool have[4];
+#pragma unroll
+    for (int u_ = 0; u_ < 4; ++u_) {
+      if (q0 + u_ < NS) {
+        have[u_] = !MISS || pre[q0 + u_] != kNoLoc;
+        int4 piece[XR];
+        read_row<XR>(tile, cap, have[u_] ? pre[q0 + u_] : 0u, piece);
+        cj[u_] = Pt<PT>::from_row(piece);
+      }
+    }
+#pragma unroll
+    for (int u_ = 0; u_ < 4; ++u_) {
+      if (q0 + u_ < NS) {
+        double d[3];
+        Pt<PT>::delta(have[u_] ? cj[u_] : ci, ci, d);
+        cov_add_d(acc, d[0], d[1], d[2]);
+        n_have += have[u_] ? 1 : 0;
+      }
+    }
+  }
+  return n_have;
+}
+
+template <typename T, typename PT, bool FULL_EIG, int NS>
+__global__ __launch_bounds__(kBlock) void consistency_fwd_fixed_kernel(
+    const PT* __restrict__ x, BlockTab tab, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec,
+    T* __restrict__ pointwise, T* __restrict__ eigvals, double* __restrict__ partials) {
+  constexpr int XR = Pt<PT>::kRow16;
+  extern __shared__ int4 tile[];
+  __shared__ double lds[(kBlock / kWave) * 2];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0};
+  const int32_t s0 = blk >= 0 ? tab.slot_ptr[blk] : 0;
+  // a table with another slot count than the launch was specialised for (not a table of [rows, NS]): fail loudly
+  const bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
+  if (blk >= 0 && !bad) {
+    const int4* xg = reinterpret_cast<const int4*>(x);
+    const int64_t i = blk * kBlock + threadIdx.x;
+    const bool live = i < n;
+    // the table holds all 256 lanes of every block (0xFFFF beyond the last row): unconditional, immediate-offset loads
+    const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    uint32_t pre[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) pre[q] = (uint32_t)lrow[q * kBlock];
+    typename Pt<PT>::Raw ci = Pt<PT>::from_row(xg + (live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0) * XR);
+    stage_rows<XR>(tab.blk_ptr, tab.blk_ids, blk, xg, tile, cap);
+    __syncthreads();
+    if (live) {
+      CovAcc acc;
+      cov_init(acc);
+      uint32_t mx = pre[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
+      int n_have;
+      if (__any((int)(mx == kNoLoc))) n_have = gather_fixed<PT, NS, true>(tile, cap, ci, pre, acc);
+      else n_have = gather_fixed<PT, NS, false>(tile, cap, ci, pre, acc);
+      acc.W = (double)n_have;
+      consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
+    }
+  } else {
+    __syncthreads();
+  }
+  if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
   block_sum<2>(acc2, lds);
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = acc2[0];
@@ -632,10 +718,11 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
     }
 #pragma unroll
     for (int q = 0; q < kPreSlots; ++q) pre[q] = (active && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
-    nd = (uint32_t)stage_rows<RR>(tab, blk, reinterpret_cast<const int4*>(rec), tile, cap);
+    nd = (uint32_t)stage_rows<RR>(tab.blk_ptr, tab.blk_ids, blk, reinterpret_cast<const int4*>(rec), tile, cap);
     // row nd is an all-zero record: empty slots point there and contribute exactly nothing
     if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
   }
+  const uint32_t nd16 = nd * 16u;                           // positions are byte offsets; 0xFFFF (empty) clamps to the zero record
   __syncthreads();
   if (active) {
     double g[3] = {0.0, 0.0, 0.0};
@@ -650,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
         } else {
           int4 q[4][RR];
 #pragma unroll
-          for (int u_ = 0; u_ < 4; ++u_) read_row<RR>(tile, cap, pre[4 * t + u_] < nd ? pre[4 * t + u_] : nd, q[u_]);
+          for (int u_ = 0; u_ < 4; ++u_) read_row<RR>(tile, cap, min(pre[4 * t + u_], nd16), q[u_]);
           edge_terms4<PT>(cj, q, g);
         }
       }
@@ -668,8 +755,96 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
 #pragma unroll
         for (int u_ = 0; u_ < 4; ++u_) nxt[u_] = (q0 + 4 + u_ < nslots) ? (uint32_t)lrow[(q0 + 4 + u_) * kBlock] : kNoLoc;
 #pragma unroll
-        for (int u_ = 0; u_ < 4; ++u_) read_row<RR>(tile, cap, l[u_] < nd ? l[u_] : nd, q[u_]);
+        for (int u_ = 0; u_ < 4; ++u_) read_row<RR>(tile, cap, min(l[u_], nd16), q[u_]);
         edge_terms4<PT>(cj, q, g);
+      }
+    }
+    g[0] *= u; g[1] *= u; g[2] *= u;
+    if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
+    if (in.dirs) points_bwd_point<T>(in, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+  }
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
+}
+
+// Backward over a "lane run" table (dc_block_table_build_runs): the positions of a point's incoming edges are stored
+// per point, contiguous and padded to a multiple of four (one 8-B load = one trip of four edges) instead of slot-major
+// padded to the block's largest in-degree -- at K = 10 that is 12 instead of 16.2 stored positions per point (48 + 8 MB
+// of run pointers instead of 105 MB at C2), and every lane stops at its own in-degree.  Same edge order and the same
+// trips of four as the other backward kernels => bit-identical gradients.
+struct RunTab {
+  const int32_t* __restrict__ blk_ptr;
+  const int32_t* __restrict__ blk_ids;
+  const int32_t* __restrict__ run_ptr;     // [n + 1] in units of runs (4 positions = 8 B)
+  const uint16_t* __restrict__ loc;        // 16 x position, 0xFFFF = padding
+};
+constexpr int kPreRuns = 4;
+
+template <typename PT>
+__device__ __forceinline__ void run_edges(const int4* tile, int cap, uint2 r, uint32_t nd16, const typename Pt<PT>::Raw& cj, double* g) {
+  constexpr int RR = RecRaw<PT>::kRow16;
+  int4 q[4][RR];
+  read_row<RR>(tile, cap, min(r.x & 0xFFFFu, nd16), q[0]);
+  read_row<RR>(tile, cap, min(r.x >> 16, nd16), q[1]);
+  read_row<RR>(tile, cap, min(r.y & 0xFFFFu, nd16), q[2]);
+  read_row<RR>(tile, cap, min(r.y >> 16, nd16), q[3]);
+  edge_terms4<PT>(cj, q, g);
+}
+
+template <typename T, typename PT, bool WANT_E, bool WANT_POSE>
+__global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
+    const PT* __restrict__ x, const PT* __restrict__ rec, RunTab tab, int cap, int64_t n, PointInputs in, QParams qp,
+    T* __restrict__ grad_points, double* __restrict__ partials, int n_acc) {
+  constexpr int want_e = WANT_E, want_pose = WANT_POSE;
+  constexpr int RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
+  extern __shared__ int4 tile[];
+  __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  ModelParams mp;
+  load_model(in, mp);
+  double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[6];
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = ge[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gT[k] = 0.0;
+  int scan = -1;
+  const int64_t j = blk * kBlock + threadIdx.x;
+  const bool active = blk >= 0 && j < n;
+  typename Pt<PT>::Raw cj;
+  PointRaw<T> raw;
+  uint2 pre[kPreRuns];
+  int32_t nruns = 0;
+  uint32_t nd = 0;
+  const uint2* runs = reinterpret_cast<const uint2*>(tab.loc);
+  if (blk >= 0) {
+    if (active) {
+      // everything this lane needs later is requested before the staging loop: its latency hides behind it
+      const int32_t r0 = tab.run_ptr[j];
+      nruns = tab.run_ptr[j + 1] - r0;
+      runs += r0;
+      cj = Pt<PT>::from_row(reinterpret_cast<const int4*>(x) + j * XR);
+      if (in.dirs) raw = load_point_raw<T>(in, mp, j);
+    }
+#pragma unroll
+    for (int t = 0; t < kPreRuns; ++t) pre[t] = t < nruns ? runs[t] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    nd = (uint32_t)stage_rows<RR>(tab.blk_ptr, tab.blk_ids, blk, reinterpret_cast<const int4*>(rec), tile, cap);
+    // row nd is an all-zero record: padding positions clamp to it and contribute exactly nothing
+    if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
+  }
+  const uint32_t nd16 = nd * 16u;
+  __syncthreads();
+  if (active) {
+    double g[3] = {0.0, 0.0, 0.0};
+    const double u = Pt<PT>::unit(qp);
+#pragma unroll
+    for (int t = 0; t < kPreRuns; ++t)
+      if (__any((int)(t < nruns))) run_edges<PT>(tile, cap, pre[t], nd16, cj, g);
+    if (__any((int)(nruns > kPreRuns))) {                   // in-degrees above 16: runs fetched trip by trip, one ahead
+      uint2 nxt = kPreRuns < nruns ? runs[kPreRuns] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      for (int t = kPreRuns; __any((int)(t < nruns)); ++t) {
+        const uint2 r = nxt;
+        nxt = t + 1 < nruns ? runs[t + 1] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        run_edges<PT>(tile, cap, r, nd16, cj, g);
       }
     }
     g[0] *= u; g[1] *= u; g[2] *= u;
@@ -795,17 +970,19 @@ using namespace dc;
   } while (0)
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
-static bool g_no_tab = false;            // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements)
+// dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
+static std::atomic<bool> g_no_tab{false};
+static std::atomic<int> g_fwd_generic{0};    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
-// a usable table -> device view; LDS bytes of the staged rows (+ `extra_rows`) must fit `lds_limit`
-static bool use_table(const dcBlockTable* t, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit, BlockTab* out,
+// a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
+static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit,
                       size_t* lds_bytes, int* lds_rows) {
-  if (!t || g_no_tab || stride != 4 || !t->blk_ptr || !t->slot_ptr || !t->loc || t->max_rows < 0) return false;
+  if (!t || g_no_tab.load() || stride != 4 || t->layout != layout || !t->blk_ptr || !t->loc || t->max_rows < 0) return false;
+  if (layout == DC_TABLE_SLOTS ? !t->slot_ptr : !t->run_ptr) return false;
   if (t->max_rows > 0 && !t->blk_ids) return false;
   const size_t rows = (size_t)t->max_rows + extra_rows + (t->max_rows + extra_rows == 0 ? 1 : 0);
   const size_t need = rows * row_bytes;
-  if (need > lds_limit || t->max_rows >= 0xFFFF) return false;
-  *out = BlockTab{t->blk_ptr, t->blk_ids, t->slot_ptr, t->loc};
+  if (need > lds_limit || t->max_rows >= 0xFFF) return false;       // positions are 16 x row in 16 bits
   *lds_bytes = need;
   *lds_rows = (int)rows;
   return true;
@@ -929,7 +1106,9 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   BlockTab tab{};
   size_t lds_bytes = 0;
   int lds_rows = 0;
-  const bool staged = use_table(table, stride, point_fmt == DC_F64 ? 32u : 16u, 0, 60 * 1024, &tab, &lds_bytes, &lds_rows);
+  const bool staged = use_table(table, DC_TABLE_SLOTS, stride, point_fmt == DC_F64 ? 32u : 16u, 0, 60 * 1024, &lds_bytes, &lds_rows);
+  if (staged) tab = BlockTab{table->blk_ptr, table->blk_ids, table->slot_ptr, table->loc};
+  const int fixed_k = g_fwd_generic.load() ? 0 : k;        // a table of [rows, k] has k slots in every block
   if (!staged && !nbr) return table ? DC_ERR_UNSUPPORTED : DC_ERR_ARG;
   QParams qp;
   int rc = make_qparams(point_fmt, dtype, stride, qparams, &qp);
@@ -940,10 +1119,19 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   dim3 grid((unsigned)rows), block(kBlock);
 #define FWD_ARGS(T, PT) (const PT*)points, nbr, centre_idx, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
 #define FWD_STAGED_ARGS(T, PT) (const PT*)points, tab, lds_rows, centre_idx, n, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
+#define FWD_FIXED(T, PT, NS) \
+  do { \
+    if (eigvals) DC_TIMED_LAUNCH((consistency_fwd_fixed_kernel<T, PT, true, NS>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
+    else DC_TIMED_LAUNCH((consistency_fwd_fixed_kernel<T, PT, false, NS>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
+  } while (0)
 #define LAUNCH(T, PT, S) \
   do { \
     if (S == 4 && staged) { /* padded rows + block table: gathers served from LDS */ \
-      if (eigvals) DC_TIMED_LAUNCH((consistency_fwd_staged_kernel<T, PT, true>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
+      if (fixed_k == 10) FWD_FIXED(T, PT, 10); \
+      else if (fixed_k == 4) FWD_FIXED(T, PT, 4); \
+      else if (fixed_k == 8) FWD_FIXED(T, PT, 8); \
+      else if (fixed_k == 16) FWD_FIXED(T, PT, 16); \
+      else if (eigvals) DC_TIMED_LAUNCH((consistency_fwd_staged_kernel<T, PT, true>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
       else DC_TIMED_LAUNCH((consistency_fwd_staged_kernel<T, PT, false>), grid, block, lds_bytes, stream, FWD_STAGED_ARGS(T, PT)); \
     } else { \
       if (eigvals) DC_TIMED_LAUNCH((consistency_fwd_kernel<T, PT, S, true>), grid, block, 0, stream, FWD_ARGS(T, PT)); \
@@ -952,6 +1140,7 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   } while (0)
   { ProfScope prof(1); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
+#undef FWD_FIXED
   DC_CHECK_LAUNCH();
   if (!reduce) return DC_OK;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, sums_out);
@@ -977,10 +1166,15 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
                                 int64_t rec_rows) {
   if (n < 0 || !points || !rec || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   BlockTab tab{};
+  RunTab rtab{};
   size_t lds_bytes = 0;
   int lds_rows = 0;
   // the pose variants hold 16 KB of static LDS for the per-scan sums: keep the staged records within 44 KB
-  const bool staged = !lane_perm && use_table(table, stride, point_fmt == DC_F64 ? 64u : 32u, 1, 44 * 1024, &tab, &lds_bytes, &lds_rows);
+  const uint32_t rec_row = point_fmt == DC_F64 ? 64u : 32u;
+  const bool by_runs = !lane_perm && use_table(table, DC_TABLE_RUNS, stride, rec_row, 1, 44 * 1024, &lds_bytes, &lds_rows);
+  const bool staged = by_runs || (!lane_perm && use_table(table, DC_TABLE_SLOTS, stride, rec_row, 1, 44 * 1024, &lds_bytes, &lds_rows));
+  if (by_runs) rtab = RunTab{table->blk_ptr, table->blk_ids, table->run_ptr, table->loc};
+  else if (staged) tab = BlockTab{table->blk_ptr, table->blk_ids, table->slot_ptr, table->loc};
   if (!staged && (!csr_ptr || !csr_src)) return table ? DC_ERR_UNSUPPORTED : DC_ERR_ARG;
   const bool params = dirs != nullptr;
   if (!params && !grad_points) return DC_ERR_ARG;
@@ -1015,9 +1209,15 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   }
 #define BWD_ARGS(T, PT) (const PT*)points, (const PT*)rec, csr_ptr, csr_src, lane_perm, n, in, qp, (T*)grad_points, partials_ws, n_acc, rec_bytes
 #define BWD_STAGED_ARGS(T, PT) (const PT*)points, (const PT*)rec, tab, lds_rows, n, in, qp, (T*)grad_points, partials_ws, n_acc
+#define BWD_RUNS_ARGS(T, PT) (const PT*)points, (const PT*)rec, rtab, lds_rows, n, in, qp, (T*)grad_points, partials_ws, n_acc
 #define LAUNCH(T, PT, S) \
   do { \
-    if (S == 4 && staged) { \
+    if (S == 4 && by_runs) { \
+      if (want_pose_grad && want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_runs_kernel<T, PT, true, true>), grid, block, lds_bytes, stream, BWD_RUNS_ARGS(T, PT)); \
+      else if (want_pose_grad) DC_TIMED_LAUNCH((consistency_bwd_runs_kernel<T, PT, false, true>), grid, block, lds_bytes, stream, BWD_RUNS_ARGS(T, PT)); \
+      else if (want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_runs_kernel<T, PT, true, false>), grid, block, lds_bytes, stream, BWD_RUNS_ARGS(T, PT)); \
+      else DC_TIMED_LAUNCH((consistency_bwd_runs_kernel<T, PT, false, false>), grid, block, lds_bytes, stream, BWD_RUNS_ARGS(T, PT)); \
+    } else if (S == 4 && staged) { \
       if (want_pose_grad && want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, true, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
       else if (want_pose_grad) DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, false, true>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
       else if (want_exponent_grad) DC_TIMED_LAUNCH((consistency_bwd_staged_kernel<T, PT, true, false>), grid, block, lds_bytes, stream, BWD_STAGED_ARGS(T, PT)); \
@@ -1093,7 +1293,8 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
 
 // option 0: 1 = ignore block tables and gather from global memory (ablation / A-B measurements), 0 = default.
 int dc_set_option(int option, int value) {
-  if (option == 0) { g_no_tab = value != 0; return DC_OK; }
+  if (option == 0) { g_no_tab.store(value != 0); return DC_OK; }
+  if (option == 1) { g_fwd_generic.store(value); return DC_OK; }
   return DC_ERR_ARG;
 }
 

@@ -178,14 +178,12 @@ template <> struct Pt<q32> {
     d[0] = (double)(a.v[0] - c.v[0]); d[1] = (double)(a.v[1] - c.v[1]); d[2] = (double)(a.v[2] - c.v[2]);
   }
   static __device__ __forceinline__ double unit(const QParams& qp) { return qp.scale; }
+  // centre + offset, offset in grid steps.  The offset is a neighbourhood mean relative to its centre (|off| << 2^31);
+  // v_cvt_i32_f64 saturates and maps NaN (empty neighbourhood: the record's coefficients are zero then) to 0.
   static __device__ __forceinline__ Raw offset(const Raw& c, const double* off) {
     Raw r;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      double q = (double)c.v[a] + rint(off[a]);
-      q = q > 2147483520.0 ? 2147483520.0 : (q < -2147483520.0 ? -2147483520.0 : q);
-      r.v[a] = (q == q) ? (int32_t)q : (int32_t)0x80000000;
-    }
+    for (int a = 0; a < 3; ++a) r.v[a] = c.v[a] + (int32_t)rint(off[a]);
     return r;
   }
 };

@@ -29,11 +29,26 @@ DC_HD double recip_(double x) {
 // cos for the root estimate (argument in [0, pi], result only seeds a Newton step): the hardware cosine.  cosf() would
 // drag in the large-argument range reduction (~250 instructions, computed for every lane because it is select-based).
 DC_HD float cos_est_(float x) { return __cosf(x); }
+// raw v_sqrt_f32 / v_rcp_f32 (1 ulp, no denormal / exactness fix-up sequences): the estimate only seeds a Newton step
+DC_HD float sqrt_est_(float x) { return __builtin_amdgcn_sqrtf(x); }
+DC_HD float rcp_est_(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
 template <typename R> DC_HD R rsqrt_(R x) { return R(1) / sqrt(x); }
 DC_HD double recip_(double x) { return 1.0 / x; }
 DC_HD float cos_est_(float x) { return cosf(x); }
+DC_HD float sqrt_est_(float x) { return sqrtf(x); }
+DC_HD float rcp_est_(float x) { return 1.0f / x; }
 #endif
+
+// Which eigenvalue eig3_smallest isolates first.  With half = det(B) / (2 p^3) = cos(3 ang) the gaps of the scaled
+// spectrum are  beta1 - beta0 = 2 sqrt(3) sin(ang)  and  beta2 - beta1 = 2 sqrt(3) sin(pi/3 - ang).  The SMALLEST
+// eigenvalue is taken directly whenever its gap to the middle one is comfortable (half < 0.9: gap >= 0.52 p, so the
+// fp32 estimate + one Newton step lands within ~1e-11 and the eigenvector's cross products are well conditioned);
+// only nearly prolate spectra (half >= 0.9: lam0 ~ lam1 << lam2, collinear neighbourhoods such as a single lidar ring)
+// isolate the LARGEST one (gap >= 2.7 p there) and resolve the small pair by the exact 2x2 problem in its complement.
+// Planar and generic neighbourhoods therefore never execute the deflation code (it used to run for every wavefront
+// holding one lane with det(B) >= 0).
+constexpr float kDeflateHalf = 0.9f;
 
 template <typename R>
 DC_HD void cross3(const R* a, const R* b, R* c) {
@@ -195,12 +210,12 @@ DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double 
     return;
   }
   // ---- fp32 estimate of the isolated root of det(B - x I) = 0, x in units of p ----
-  const float pf = sqrtf((float)p2);
+  const float pf = sqrt_est_((float)p2);
   const float f00 = (float)b00, f11 = (float)b11, f22 = (float)b22, f01 = (float)a01, f02 = (float)a02, f12 = (float)a12;
   const float detf = f00 * (f11 * f22 - f12 * f12) - f01 * (f01 * f22 - f12 * f02) + f02 * (f01 * f12 - f11 * f02);
-  float half = 0.5f * detf / (pf * pf * pf);
+  float half = 0.5f * detf * rcp_est_(pf * pf * pf);
   half = fminf(fmaxf(half, -1.0f), 1.0f);
-  const bool iso_is_max = half >= 0.0f;
+  const bool iso_is_max = half >= kDeflateHalf;
   const float ang = acosf(half) * (1.0f / 3.0f);
   const float beta = 2.0f * cos_est_(iso_is_max ? ang : ang + 2.0943951f);
   double l = q + (double)(pf * beta);

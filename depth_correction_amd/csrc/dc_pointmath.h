@@ -109,8 +109,10 @@ DC_HD void cov_add(CovAcc& a, double dx, double dy, double dz, double wm) {
 // C: covariance with the weights of update_weights (validity x optional Gaussian of the distance
 // between the centre and the mean, depth_cloud.py:356-364) and utils.covs' normalisation.
 // cmean_off: the mean covs() itself subtracts (validity-weighted), returned for the backward.
+// unit2: square of the length unit of the accumulated differences (q32 grid steps; 1 for metres), folded into the
+// normalisation factor so that C comes out in m^2 without six extra multiplications.
 DC_HD void cov_finish(const CovAcc& a, double scale, double* mean_off, double* cmean_off, double* C, double* D_out,
-                      double* omega_out) {
+                      double* omega_out, double unit2 = 1.0) {
   // 0/0 -> NaN exactly like the reference when a neighbourhood has no valid member.
   const double invWm = recip_(a.Wm);        // Wm = 0 -> NaN either way (0 * inf), like the reference's 0/0
   for (int i = 0; i < 3; ++i) mean_off[i] = a.Wm > 0.0 ? a.sm[i] * invWm : a.sm[i] / a.Wm;
@@ -126,7 +128,7 @@ DC_HD void cov_finish(const CovAcc& a, double scale, double* mean_off, double* c
   const double invW = (a.W == a.Wm) ? invWm : recip_(a.W);
   const double c0 = a.s[0] * invW, c1 = a.s[1] * invW, c2 = a.s[2] * invW;
   cmean_off[0] = c0; cmean_off[1] = c1; cmean_off[2] = c2;
-  const double f = omega * recip_(D);       // D >= 1e-6
+  const double f = omega * recip_(D) * unit2;       // D >= 1e-6
   C[0] = (a.S[0] - a.s[0] * c0) * f;
   C[1] = (a.S[1] - a.s[0] * c1) * f;
   C[2] = (a.S[2] - a.s[0] * c2) * f;

@@ -63,6 +63,7 @@ class PlanCloud(object):
 
     def __init__(self, plan, w, exponent, poses):
         self._plan, self._args, self._out = plan, (w, exponent, poses), None
+        self.count = plan.count                  # pointwise terms behind the sequence's share of the mean loss
 
     def _materialize(self):
         if self._out is None:

@@ -97,19 +97,24 @@ def knn_transpose(nbr, n_dst=None):
 
 class BlockTable:
     """Block table of a reference list (dcBlockTable): per block of 256 rows the distinct rows it references and the
-    slot-major 16-bit positions of every reference in that list; lets the fused kernels gather from LDS."""
+    16-bit LDS positions (16 x index in that list) of every reference -- slot-major (``slot_ptr``; the forward's
+    [rows, K] table) or as per-row runs padded to four (``run_ptr``; the backward's incoming-edge lists).  Lets the
+    fused kernels gather from LDS."""
 
-    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows):
-        self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc = blk_ptr, blk_ids, slot_ptr, loc
+    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows, run_ptr=None):
+        self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc, self.run_ptr = blk_ptr, blk_ids, slot_ptr, loc, run_ptr
         self.max_rows, self.n_rows = int(max_rows), int(n_rows)
-        self.desc = nv.BlockTableDesc(ptr(blk_ptr), ptr(blk_ids), ptr(slot_ptr), ptr(loc), self.max_rows, 0)
+        self.layout = nv.DC_TABLE_SLOTS if run_ptr is None else nv.DC_TABLE_RUNS
+        self.device = blk_ptr.device
+        self.desc = nv.BlockTableDesc(ptr(blk_ptr), ptr(blk_ids), ptr(slot_ptr), ptr(loc), self.max_rows, self.layout, ptr(run_ptr))
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self.desc), ctypes.c_void_p)
 
     @property
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in (self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc))
+        return sum(t.numel() * t.element_size() for t in (self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc, self.run_ptr)
+                   if t is not None)
 
 
 def _table_ref(table, n_rows):
@@ -120,35 +125,53 @@ def _table_ref(table, n_rows):
 
 
 @on_device
-def block_table(nbr=None, csr=None):
-    """BlockTable of a neighbour table ``nbr`` int32 [rows, K] (forward) or of CSR lists ``csr`` = (ptr, ids)
-    (backward: knn_transpose's output).  Returns None when a block references 65535 or more distinct rows."""
+def block_table(nbr=None, csr=None, layout=None):
+    """BlockTable of a neighbour table ``nbr`` int32 [rows, K] (forward; slot-major) or of CSR lists ``csr`` = (ptr, ids)
+    (backward: knn_transpose's output; ``layout`` 'runs' (default) or 'slots').  Returns None when a block references
+    4095 or more distinct rows."""
     if nbr is not None:
         need(nbr, (None, None), dtype=torch.int32, name='neighbors')
         n_rows, k = nbr.shape
         row_ptr, ids, n_refs, dev = None, nbr, n_rows * k, nbr.device
+        layout = layout or 'slots'
+        if layout != 'slots':
+            raise ValueError('a neighbour table [rows, K] is stored slot-major')
     else:
         row_ptr, ids = csr
         need(row_ptr, (None,), dtype=torch.int32, name='csr_ptr')
         need(ids, (None,), dtype=torch.int32, name='csr_src', device=row_ptr.device)
         n_rows, k, n_refs, dev = row_ptr.shape[0] - 1, 0, ids.shape[0], row_ptr.device
+        layout = layout or 'runs'
+    assert layout in ('slots', 'runs')
     nb = (n_rows + 255) // 256
-    slot_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
-    cnt = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
-    check(lib().dc_block_table_slots(ptr(row_ptr), n_rows, k, ptr(cnt), ptr(slot_ptr), stream_ptr()), 'dc_block_table_slots')
-    n_slot_rows = int(slot_ptr[-1])                                  # one synchronisation, at set-up time
     blk_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
     blk_ids = torch.empty((max(n_refs, 1),), dtype=torch.int32, device=dev)
-    loc = torch.empty((max(n_slot_rows, 1) * 256,), dtype=torch.uint16, device=dev)
     info = torch.empty((4,), dtype=torch.int32, device=dev)
-    nbytes = lib().dc_block_table_workspace_bytes(n_refs)
+    nbytes = lib().dc_block_table_workspace_bytes(max(n_refs, n_rows + 1))
     ws = _ws(nbytes, dev)
-    check(lib().dc_block_table_build(ptr(row_ptr), ptr(ids), n_rows, k, n_refs, ptr(slot_ptr), n_slot_rows, ptr(blk_ptr),
-                                     ptr(blk_ids), ptr(loc), ptr(info), ptr(ws), nbytes, stream_ptr()), 'dc_block_table_build')
+    slot_ptr = run_ptr = None
+    if layout == 'runs':
+        run_ptr = torch.empty((n_rows + 1,), dtype=torch.int32, device=dev)
+        loc = torch.empty((lib().dc_block_table_run_capacity(n_rows, n_refs) * 4,), dtype=torch.uint16, device=dev)
+        check(lib().dc_block_table_build_runs(ptr(row_ptr), ptr(ids), n_rows, n_refs, ptr(run_ptr), ptr(blk_ptr), ptr(blk_ids),
+                                              ptr(loc), ptr(info), ptr(ws), nbytes, stream_ptr()), 'dc_block_table_build_runs')
+    else:
+        slot_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
+        if row_ptr is None:
+            # a table [rows, K]: every block has K slots, known without asking the device
+            slot_ptr.copy_(torch.arange(nb + 1, dtype=torch.int32, device=dev) * k)
+            n_slot_rows = nb * k
+        else:
+            cnt = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
+            check(lib().dc_block_table_slots(ptr(row_ptr), n_rows, k, ptr(cnt), ptr(slot_ptr), stream_ptr()), 'dc_block_table_slots')
+            n_slot_rows = int(slot_ptr[-1])                          # one synchronisation, at set-up time
+        loc = torch.empty((max(n_slot_rows, 1) * 256,), dtype=torch.uint16, device=dev)
+        check(lib().dc_block_table_build(ptr(row_ptr), ptr(ids), n_rows, k, n_refs, ptr(slot_ptr), n_slot_rows, ptr(blk_ptr),
+                                         ptr(blk_ids), ptr(loc), ptr(info), ptr(ws), nbytes, stream_ptr()), 'dc_block_table_build')
     total, max_rows, overflow, _ = info.tolist()
     if overflow:
         return None
-    return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows)
+    return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows, run_ptr=run_ptr)
 
 
 @on_device

@@ -88,7 +88,7 @@ def global_mask(local_mask, points, vps, dirs, nbr, min_valid_neighbors=5, eigen
 def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='cuda:0', min_valid_neighbors=5,
                    eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, vp_dispersion_bounds=None, model_kind='ScaledPolynomial',
                    loss='min_eigval_loss', normalization=True, sqrt=False, spatial_sort=True, point_format='auto',
-                   active_only=False, degree_sort=False, block_tables=True):
+                   active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs'):
     """Everything train.py does before its loop for one sequence; returns (plan, info)."""
     clouds = [local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype, device=device)
               for xyz in scans_xyz]
@@ -100,5 +100,5 @@ def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='
                        eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, vp_dispersion_bounds=vp_dispersion_bounds)
     plan = SequencePlan(clouds, poses_t, nbr, mask, model_kind=model_kind, loss=loss, normalization=normalization,
                         sqrt=sqrt, spatial_sort=spatial_sort, point_format=point_format, active_only=active_only,
-                        degree_sort=degree_sort, block_tables=block_tables)
+                        degree_sort=degree_sort, block_tables=block_tables, bwd_layout=bwd_layout)
     return plan, dict(clouds=clouds, poses=poses_t, neighbors=nbr, mask=mask, points0=x0)

@@ -34,7 +34,7 @@ class SequencePlan:
     @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
-                 active_only=False, block_tables=True):
+                 active_only=False, block_tables=True, bwd_layout='runs'):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -42,6 +42,7 @@ class SequencePlan:
         :param neighbors: [N,K] int neighbour indices of the global cloud (scan-major order, -1 = missing).
         :param mask: [N] bool global mask (None = all points).
         :param block_tables: build the block tables that let both hot kernels gather from LDS (ops.block_table).
+        :param bwd_layout: 'runs' (per-point runs padded to four positions) or 'slots' (slot-major, padded per block).
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
                             the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
@@ -109,7 +110,7 @@ class SequencePlan:
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
         # block tables: distinct rows per 256-point block + 16-bit block-local positions (gathers served from LDS)
         self.fwd_table = ops.block_table(nbr=nbr) if block_tables else None
-        self.bwd_table = ops.block_table(csr=(self.csr_ptr, self.csr_src)) if block_tables else None
+        self.bwd_table = ops.block_table(csr=(self.csr_ptr, self.csr_src), layout=bwd_layout) if block_tables else None
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
         # ---- internal point format -------------------------------------------------------------------

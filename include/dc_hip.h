@@ -126,21 +126,36 @@ int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* cs
  * 0xFFFF = empty slot; block b has slot_ptr[b+1] - slot_ptr[b] slots (the longest list among its rows).
  * The kernels copy the distinct rows of a block into LDS once and gather from LDS: same results bit for bit, ~7x
  * fewer L1 lookups (in Morton order a block's 2560 references at K = 10 hit ~375 rows).
+ * A stored position is the BYTE offset of the row's first 16-B piece in the LDS tile, i.e. 16 x (index in the block's
+ * distinct list); a block may therefore reference at most 4094 distinct rows (the LDS tile is smaller anyway).
  * References come either as a table ids[n_rows, k] (row_ptr == NULL; forward: the neighbour table) or as CSR lists
  * row_ptr[n_rows + 1], ids[...] (backward: dc_knn_transpose's output); negative ids are empty.
+ * Two layouts of the positions:
+ *   DC_TABLE_SLOTS  slot-major, as above (dc_block_table_slots + dc_block_table_build).  Exact for a table [rows, k]
+ *                   (every block has k slots: the forward's layout); for lists of varying length every block is padded
+ *                   to its longest list.
+ *   DC_TABLE_RUNS   per row a contiguous run padded to a multiple of FOUR positions (8 B = one trip of the backward's
+ *                   edge loop): loc[4 * run_ptr[r] + s], run_ptr int32 [n_rows + 1] in units of runs, 0xFFFF = padding
+ *                   (dc_block_table_build_runs).  The backward's layout: 12 instead of 16.2 stored positions per point
+ *                   at K = 10, and every lane stops at its own in-degree.
  *   1. dc_block_table_slots  -> slot_ptr int32 [n_blocks + 1] (device); slot_ptr[n_blocks] = number of slot rows, the
  *      host reads it to size loc (uint16 [n_slot_rows * 256]); slot_cnt_ws: int32 [n_blocks] scratch.
  *   2. dc_block_table_build  -> blk_ptr int32 [n_blocks + 1], blk_ids int32 [n_refs] (first blk_ptr[n_blocks] used),
- *      loc, info int32 [4] = {total distinct, max distinct rows of a block, overflow flag (a block with >= 65535
+ *      loc, info int32 [4] = {total distinct, max distinct rows of a block, overflow flag (a block with >= 4095
  *      distinct rows: table unusable), 0}.  n_refs = length of ids (table: n_rows * k).
+ *   or dc_block_table_build_runs (CSR lists only) -> run_ptr int32 [n_rows + 1], loc uint16 [dc_block_table_run_capacity
+ *      (n_rows, n_refs) * 4] (an upper bound known on the host: no synchronisation), blk_ptr, blk_ids, info as above.
  * n_blocks = ceil(n_rows / 256).  ws: dc_block_table_workspace_bytes(n_refs). */
+#define DC_TABLE_SLOTS 0
+#define DC_TABLE_RUNS 1
 typedef struct dcBlockTable {
   const int32_t* blk_ptr;
   const int32_t* blk_ids;
-  const int32_t* slot_ptr;
+  const int32_t* slot_ptr;    /* DC_TABLE_SLOTS */
   const uint16_t* loc;
   int32_t max_rows;           /* info[1]: sizes the LDS tile */
-  int32_t reserved;
+  int32_t layout;             /* DC_TABLE_SLOTS | DC_TABLE_RUNS */
+  const int32_t* run_ptr;     /* DC_TABLE_RUNS */
 } dcBlockTable;
 int dc_block_table_slots(const int32_t* row_ptr, int64_t n_rows, int k, int32_t* slot_cnt_ws, int32_t* slot_ptr,
                          dcStream_t stream);
@@ -148,6 +163,10 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs);
 int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
                          const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
                          int32_t* info, void* ws, size_t ws_bytes, dcStream_t stream);
+int64_t dc_block_table_run_capacity(int64_t n_rows, int64_t n_refs);
+int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int64_t n_refs, int32_t* run_ptr,
+                              int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes,
+                              dcStream_t stream);
 
 /* ---- fused map-consistency loss: compute_neighborhood_features preproc.py:195-217 + min_eigval_loss
  *      loss.py:216-294 / trace_loss :297-370 + their autograd backward (train.py:300-307) ------------------------

@@ -158,7 +158,7 @@ def _run_sequence(g, dev, dtype, prefix='', loss='min_eigval_loss', normalizatio
     mask = t(g['g_mask'], dev)
     cp, cs = ops.knn_transpose(nbr)
     ft = ops.block_table(nbr=nbr) if tables else None
-    bt = ops.block_table(csr=(cp, cs)) if tables else None
+    bt = ops.block_table(csr=(cp, cs), layout='slots' if tables == 'slots' else None) if tables else None
     fw = ops.consistency_fwd(x, nbr, mask=mask, loss=loss, normalization=normalization, sqrt=sqrt, want_pointwise=True,
                              want_eigvals=True, qfmt=qfmt, table=ft)
     gp, (gw, ge, gT) = ops.consistency_bwd(x, fw['rec'], cp, cs, ps, P, model, w, e, want_exponent=True, want_pose=True,
@@ -399,9 +399,9 @@ def test_p2plane_golden(golden, dev):
 
 
 def test_block_table_structure(golden, dev):
-    """dc_block_table_build against a direct numpy construction: per block of 256 rows the sorted distinct references,
-    every reference's position in that list (slot-major), 0xFFFF in empty slots; for a table (forward) and for CSR
-    lists (backward)."""
+    """dc_block_table_build(_runs) against a direct numpy construction: per block of 256 rows the sorted distinct
+    references and every reference's position in that list (stored as 16 x position, 0xFFFF = empty), slot-major for a
+    table (forward) and for CSR lists, and as per-row runs padded to four positions for CSR lists (backward)."""
     from depth_correction_amd import ops
     g = golden('room_k10')
     nbr = t(g['g_neighbors'], dev).clone()
@@ -410,37 +410,62 @@ def test_block_table_structure(golden, dev):
     n, k = nbr.shape
     nb = (n + 255) // 256
     cp, cs = ops.knn_transpose(nbr)
+    csr_lists = np.split(npy(cs)[:int(cp[-1])], npy(cp)[1:-1])
     for table, lists in ((ops.block_table(nbr=nbr), [r[r >= 0] for r in npy(nbr)]),
-                         (ops.block_table(csr=(cp, cs)), np.split(npy(cs)[:int(cp[-1])], npy(cp)[1:-1]))):
-        bp, ids, sp, loc = npy(table.blk_ptr), npy(table.blk_ids), npy(table.slot_ptr), npy(table.loc).reshape(-1, 256)
-        assert len(bp) == nb + 1 and len(sp) == nb + 1 and bp[0] == 0 and sp[0] == 0
+                         (ops.block_table(csr=(cp, cs), layout='slots'), csr_lists),
+                         (ops.block_table(csr=(cp, cs)), csr_lists)):
+        bp, ids = npy(table.blk_ptr), npy(table.blk_ids)
+        assert len(bp) == nb + 1 and bp[0] == 0
         assert table.max_rows == int(np.diff(bp).max())
+        loc = npy(table.loc)
+        if table.run_ptr is None:
+            sp, loc = npy(table.slot_ptr), loc.reshape(-1, 256)
+            assert len(sp) == nb + 1 and sp[0] == 0
+        else:
+            rp = npy(table.run_ptr)
+            assert len(rp) == n + 1 and rp[0] == 0
+            assert np.array_equal(np.diff(rp), [(len(r) + 3) // 4 for r in lists])
+            assert np.all(loc[4 * rp[-1]:4 * rp[-1] + 1] == 0xFFFF) or 4 * rp[-1] == len(loc)
         for b in range(nb):
             rows = lists[b * 256:(b + 1) * 256]
             want = np.unique(np.concatenate(rows)) if len(rows) else np.zeros(0, np.int64)
             assert np.array_equal(ids[bp[b]:bp[b + 1]], want)
-            assert sp[b + 1] - sp[b] == max(len(r) for r in rows)
-            blk = loc[sp[b]:sp[b + 1]]
-            for lane, r in enumerate(rows):
-                assert np.array_equal(want[blk[:len(r), lane]], r) and np.all(blk[len(r):, lane] == 0xFFFF)
-            assert np.all(blk[:, len(rows):] == 0xFFFF)
+            if table.run_ptr is None:
+                assert sp[b + 1] - sp[b] == max(len(r) for r in rows)
+                blk = loc[sp[b]:sp[b + 1]]
+                for lane, r in enumerate(rows):
+                    assert np.all(blk[:len(r), lane] % 16 == 0)
+                    assert np.array_equal(want[blk[:len(r), lane] // 16], r) and np.all(blk[len(r):, lane] == 0xFFFF)
+                assert np.all(blk[:, len(rows):] == 0xFFFF)
+            else:
+                for lane, r in enumerate(rows):
+                    row = b * 256 + lane
+                    run = loc[4 * rp[row]:4 * rp[row + 1]]
+                    assert np.all(run[:len(r)] % 16 == 0)
+                    assert np.array_equal(want[run[:len(r)] // 16], r) and np.all(run[len(r):] == 0xFFFF)
 
 
 def test_block_tables_do_not_change_results(golden, dev):
     """Gathering through block tables (LDS-staged distinct rows) is a pure data-movement change: bitwise identical
-    sums, gradients and per-point outputs with and without, for every point format."""
+    sums, gradients and per-point outputs without tables, with the default tables (fixed-K forward kernel, run-layout
+    backward) and with slot-major backward tables + the run-time-slot forward kernel, for every point format."""
+    from depth_correction_amd import _native as nv
     g = golden('room_k10')
     outs = []
-    for tables in (False, True):
-        runs = [_run_sequence(g, dev, torch.float32, stride=4, q32=True, tables=tables),
-                _run_sequence(g, dev, torch.float32, stride=4, tables=tables),
-                _run_sequence(g, dev, torch.float64, stride=4, tables=tables)]
+    for tables in (False, True, 'slots'):
+        nv.check(nv.lib().dc_set_option(1, 1 if tables == 'slots' else 0), 'dc_set_option')
+        try:
+            runs = [_run_sequence(g, dev, torch.float32, stride=4, q32=True, tables=tables),
+                    _run_sequence(g, dev, torch.float32, stride=4, tables=tables),
+                    _run_sequence(g, dev, torch.float64, stride=4, tables=tables)]
+        finally:
+            nv.check(nv.lib().dc_set_option(1, 0), 'dc_set_option')
         outs.append([npy(r[f]) for r in runs for f in ('gw', 'ge', 'gT', 'gp')]
                     + [npy(r['fw'][f]) for r in runs for f in ('sums', 'pointwise', 'eigvals', 'rec')])
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b, equal_nan=True)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b, equal_nan=True)
     # the ablation switch routes a call with tables through the gather kernels again
-    from depth_correction_amd import _native as nv
     nv.check(nv.lib().dc_set_option(0, 1), 'dc_set_option')
     try:
         r = _run_sequence(g, dev, torch.float32, stride=4, q32=True, tables=True)

@@ -63,6 +63,50 @@ def test_eig3_matches_lapack(host, case):
     assert np.abs(np.einsum('nki,nli->nkl', V, V) - np.eye(3)).max() < 1e-14
 
 
+def _eig_smallest(host, C):
+    c6 = np.ascontiguousarray(np.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1))
+    lam0, v0, tr = np.zeros(len(C)), np.zeros((len(C), 3)), np.zeros(len(C))
+    host.dc_host_eig3_smallest(_p(c6), ctypes.c_long(len(C)), _p(lam0), _p(v0), _p(tr))
+    return lam0, v0, tr
+
+
+@pytest.mark.parametrize('case', ['generic', 'planar', 'needle', 'edge', 'threshold', 'double_hi', 'tiny', 'huge'])
+def test_eig3_smallest_matches_lapack(host, case):
+    """The hot-path solver (smallest eigenpair + trace only, dc_eig3.h eig3_smallest): eigenvalue within a few
+    eps * |C| of LAPACK's for every family, including spectra on either side of the switch between the direct path and
+    the isolate-largest-then-deflate path (kDeflateHalf); eigenvector residual small wherever lam0 is separated."""
+    rng = np.random.default_rng(1)
+    n = 20000
+    u = rng.uniform
+    if case == 'threshold':
+        # scaled spectra 2 cos(ang + 2 pi k / 3) with cos(3 ang) swept across the switch at 0.9
+        ang = np.arccos(u(0.85, 0.95, n)) / 3
+        beta = np.stack([2 * np.cos(ang + 2 * np.pi / 3), 2 * np.cos(ang - 2 * np.pi / 3), 2 * np.cos(ang)], 1)
+        lams = 1.0 + 0.3 * beta
+    else:
+        lams = {'generic': u(0, 1, (n, 3)),
+                'planar': np.stack([10 ** u(-10, -3, n), u(0.3, 1, n), u(0.3, 1, n)], 1),
+                'needle': np.stack([10 ** u(-10, -4, n), 10 ** u(-10, -4, n), u(0.3, 1, n)], 1),
+                'edge': np.stack([10 ** u(-8, -3, n), 10 ** u(-3, -0.5, n), u(0.3, 1, n)], 1),
+                'double_hi': np.stack([u(0.01, 0.2, n), np.full(n, 0.5), np.full(n, 0.5)], 1),
+                'tiny': u(0, 1, (n, 3)) * 1e-14, 'huge': u(0, 1, (n, 3)) * 1e12}[case]
+    lams = np.sort(lams, axis=1)
+    C = _spd(rng, lams)
+    lam0, v0, tr = _eig_smallest(host, C)
+    ref, refV = np.linalg.eigh(C)
+    scale = np.abs(ref).max(1)
+    assert (np.abs(lam0 - ref[:, 0]) / scale).max() < 1e-14
+    np.testing.assert_allclose(tr, np.trace(C, axis1=1, axis2=2), rtol=1e-14)
+    assert np.abs(np.linalg.norm(v0, axis=1) - 1).max() < 1e-14
+    sep = (ref[:, 1] - ref[:, 0]) / scale > 1e-3                       # eigenvector defined (not a cluster)
+    resid = np.linalg.norm(np.einsum('nij,nj->ni', C, v0) - lam0[:, None] * v0, axis=1) / scale
+    align = np.abs(np.einsum('ni,ni->n', v0, refV[:, :, 0]))
+    if sep.any():
+        gap = (ref[sep, 1] - ref[sep, 0]) / scale[sep]
+        assert (resid[sep] * gap).max() < 1e-13
+        assert ((1 - align[sep]) * gap ** 2).max() < 1e-13
+
+
 def test_eig3_degenerate_inputs(host):
     lam, V = _eig(host, np.zeros((2, 3, 3)))
     assert np.all(lam == 0) and np.allclose(V, np.eye(3))
