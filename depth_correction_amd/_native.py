@@ -64,6 +64,7 @@ _SIGNATURES = {
     'dc_profiler_enable': (_i32, [_i32]),
     'dc_profiler_reset': (_i32, []),
     'dc_profiler_read': (_i32, [_i32, _vp, _vp]),
+    'dc_profiler_kernel': (_i32, [_i32, _vp, _i32]),
     'dc_p2plane_partial_count': (_i64, [_i64]),
     'dc_p2plane_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),

@@ -17,6 +17,7 @@
 #include <type_traits>
 #include <atomic>
 #include <mutex>
+#include <cstdio>
 #include <hip/hip_ext.h>
 #include "dc_common.h"
 #include "dc_device.h"
@@ -33,19 +34,27 @@ template <typename T, typename PT, int STRIDE>
 __global__ __launch_bounds__(kBlock) void points_fwd_kernel(PointInputs in, int64_t n, QParams qp, PT* __restrict__ x_out,
                                                             T* __restrict__ vps_out, T* __restrict__ dirs_out,
                                                             T* __restrict__ depth_out) {
+  __shared__ double s_pose[kLdsScans * 12];
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+  const int64_t ic = i < n ? i : n - 1;                                // lanes past the end read the last point, store nothing
   ModelParams mp;
   load_model(in, mp);
-  double vp[3], dr[3], T12[12];
-  if (in.vps) Row3<T, 3>::load((const T*)in.vps, i, vp, qp);           // NULL: viewpoints at the sensor origin
-  else { vp[0] = vp[1] = vp[2] = 0.0; }
-  Row3<T, 3>::load((const T*)in.dirs, i, dr, qp);
-  const double d = (double)((const T*)in.depth)[i];
-  const bool lm = in.lmask ? in.lmask[i] != 0 : true;
-  const double inc = (mp.kind != DC_MODEL_NONE && lm) ? (double)((const T*)in.inc)[i] : 0.0;
-  const double dc_ = model_depth(mp, d, inc, lm);
-  load_pose(in, in.scan_id ? in.scan_id[i] : 0, T12);
+  // the point's own loads are issued (raw, unconverted: no wait yet) BEFORE the poses are staged, so the two global
+  // round trips overlap
+  T vp_r[3] = {T(0), T(0), T(0)}, dr_r[3];
+  if (in.vps) { const T* q = (const T*)in.vps + ic * 3; vp_r[0] = q[0]; vp_r[1] = q[1]; vp_r[2] = q[2]; }   // NULL: sensor origin
+  { const T* q = (const T*)in.dirs + ic * 3; dr_r[0] = q[0]; dr_r[1] = q[1]; dr_r[2] = q[2]; }
+  const T d_r = ((const T*)in.depth)[ic];
+  const bool lm = in.lmask ? in.lmask[ic] != 0 : true;
+  const T inc_r = (mp.kind != DC_MODEL_NONE) ? ((const T*)in.inc)[ic] : T(0);
+  const int sid = in.scan_id ? in.scan_id[ic] : 0;
+  const PoseTile poses = stage_poses(in, s_pose);
+  __syncthreads();
+  if (i >= n) return;
+  double vp[3] = {(double)vp_r[0], (double)vp_r[1], (double)vp_r[2]}, dr[3] = {(double)dr_r[0], (double)dr_r[1], (double)dr_r[2]};
+  double T12[12];
+  const double dc_ = model_depth(mp, (double)d_r, lm ? (double)inc_r : 0.0, lm);
+  load_pose(in, poses, sid, T12);
   double vr[3], drr[3], x[3];
   rot3(T12, vp, vr);
   vr[0] += T12[3]; vr[1] += T12[7]; vr[2] += T12[11];
@@ -98,7 +107,6 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
     const uint8_t* __restrict__ mask,
     const T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec, T* __restrict__ pointwise,
     T* __restrict__ eigvals, double* __restrict__ partials) {
-  __shared__ double lds[(kBlock / kWave) * 2];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   double acc2[2] = {0.0, 0.0};
@@ -131,11 +139,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_kernel(
       consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
     }
   }
-  block_sum<2>(acc2, lds);
-  if (threadIdx.x == 0) {                       // partials are [accumulator][block]: the reduction reads rows
-    partials[blockIdx.x] = acc2[0];
-    partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
-  }
+  wave_partials<2>(acc2, partials);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,9 +166,9 @@ __device__ __forceinline__ PointRaw<T> load_point_raw(const PointInputs& in, con
 }
 
 template <typename T>
-__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j, const PointRaw<T>& raw,
-                                                 const double* g, double* gw, double* ge, double* gT, bool want_e,
-                                                 bool want_pose, int* scan) {
+__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const PoseTile& poses, const ModelParams& mp, int64_t j,
+                                                 const PointRaw<T>& raw, const double* g, double* gw, double* ge, double* gT,
+                                                 bool want_e, bool want_pose, int* scan) {
   double vp[3], dr[3], T12[12];
   const QParams qp0{};
   if (in.vps) Row3<T, 3>::load((const T*)in.vps, j, vp, qp0);
@@ -174,7 +178,7 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
   const bool lm = raw.lm;
   const int s = raw.s;
   *scan = s;
-  load_pose(in, s, T12);
+  load_pose(in, poses, s, T12);
   // dL/dd' = (R dir) . g = dir . (R^T g)
   const double rg0 = T12[0] * g[0] + T12[4] * g[1] + T12[8] * g[2];
   const double rg1 = T12[1] * g[0] + T12[5] * g[1] + T12[9] * g[2];
@@ -205,10 +209,10 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Mo
 }
 
 template <typename T>
-__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const ModelParams& mp, int64_t j,
+__device__ __forceinline__ void points_bwd_point(const PointInputs& in, const PoseTile& poses, const ModelParams& mp, int64_t j,
                                                  const double* g, double* gw, double* ge, double* gT, bool want_e,
                                                  bool want_pose, int* scan) {
-  points_bwd_point<T>(in, mp, j, load_point_raw<T>(in, mp, j), g, gw, ge, gT, want_e, want_pose, scan);
+  points_bwd_point<T>(in, poses, mp, j, load_point_raw<T>(in, mp, j), g, gw, ge, gT, want_e, want_pose, scan);
 }
 
 // Per-scan sums of the 12 pose-gradient values g_a * [xl, 1]_b of the 256 points of a block (gx = [g, xl] of this
@@ -226,7 +230,7 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
   __shared__ int s_cnt[NW][kMaxBlockScans];
   __shared__ int s_start[kMaxBlockScans + 1];
   __shared__ int s_range[2];
-  const int64_t rs = gridDim.x;
+  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   if (tid == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
   __syncthreads();
@@ -318,30 +322,27 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
   }
 }
 
-// Block-reduce the parameter gradients of one block into its partial row:
-//   [0,P) w, [P,2P) exponent, [2P, 2P + 12 S) poses.  Only the slots in use are reduced.
+// Parameter gradients of one block into the partial rows of its wavefronts (row = 4 * block + wave; no LDS, no barrier:
+// every wavefront leaves as soon as its lane 0 has written its sums):
+//   [0,P) w, [P,2P) exponent, [2P, 2P + 12 S) poses.  Only the slots in use are reduced.  The pose slots are summed per
+// block (counting sort by scan in LDS) into the row of the block's first wavefront; the others keep the caller's zeros.
 template <typename T>
 __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool active, bool want_e, bool want_pose,
                                                    double* gw, double* ge, double* gT, int scan, double* lds,
-                                                   double* __restrict__ pcol) {
-  // pcol = partials + blockIdx.x; slot a lives at pcol[a * gridDim.x]
-  const int64_t rs = gridDim.x;
+                                                   double* __restrict__ partials) {
+  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;              // slot a lives at partials[a * rs + row]
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  double* prow = partials + (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int P = in.n_terms;
-  double v[2 * DC_MAX_MODEL_TERMS];
 #pragma unroll
-  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) { v[k] = gw[k]; v[DC_MAX_MODEL_TERMS + k] = 0.0; }
-  block_sum_used<DC_MAX_MODEL_TERMS>(v, P, lds);
-  if (want_e) {
-#pragma unroll
-    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) v[DC_MAX_MODEL_TERMS + k] = ge[k];
-    block_sum_used<DC_MAX_MODEL_TERMS>(v + DC_MAX_MODEL_TERMS, P, lds);
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
+    if (k < P) {
+      const double sw = wave_sum(gw[k]);
+      const double se = want_e ? wave_sum(ge[k]) : 0.0;
+      if (lane == 0) { prow[k * rs] = sw; prow[(P + k) * rs] = se; }
+    }
   }
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k)
-      if (k < P) { pcol[k * rs] = v[k]; pcol[(P + k) * rs] = v[DC_MAX_MODEL_TERMS + k]; }
-  }
-  if (want_pose) reduce_pose_grads(in, active, gT, scan, lds, pcol + 2 * P * rs);
+  if (want_pose) reduce_pose_grads(in, active, gT, scan, lds, partials + (int64_t)blockIdx.x * kWavesPerBlock + 2 * P * rs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,6 +404,9 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
 #pragma clang fp contract(off)
   constexpr int want_e = WANT_E, want_pose = WANT_POSE;
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  __shared__ double s_pose[kLdsScans * 12];
+  const PoseTile poses = in.dirs ? stage_poses(in, s_pose) : PoseTile{nullptr};
+  __syncthreads();
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   ModelParams mp;
@@ -447,10 +451,10 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
       }
       g[0] *= u; g[1] *= u; g[2] *= u;
       if (grad_points) Row3<T, STRIDE>::store(grad_points, j, g, QParams{});
-      if (in.dirs) points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+      if (in.dirs) points_bwd_point<T>(in, poses, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
     }
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,7 +555,6 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
     T* __restrict__ pointwise, T* __restrict__ eigvals, double* __restrict__ partials) {
   constexpr int XR = Pt<PT>::kRow16;
   extern __shared__ int4 tile[];
-  __shared__ double lds[(kBlock / kWave) * 2];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   double acc2[2] = {0.0, 0.0};
@@ -591,11 +594,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
     acc.W = (double)n_have;
     consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
   }
-  block_sum<2>(acc2, lds);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = acc2[0];
-    partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
-  }
+  wave_partials<2>(acc2, partials);
 }
 
 // Fixed slot count: a forward table built from a neighbour table [rows, K] has exactly K slots in every block, so the
@@ -639,7 +638,6 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_fixed_kernel(
     T* __restrict__ pointwise, T* __restrict__ eigvals, double* __restrict__ partials) {
   constexpr int XR = Pt<PT>::kRow16;
   extern __shared__ int4 tile[];
-  __shared__ double lds[(kBlock / kWave) * 2];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   double acc2[2] = {0.0, 0.0};
@@ -674,11 +672,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_fixed_kernel(
     __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
-  block_sum<2>(acc2, lds);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = acc2[0];
-    partials[(int64_t)gridDim.x + blockIdx.x] = acc2[1];
-  }
+  wave_partials<2>(acc2, partials);
 }
 
 template <typename T, typename PT, bool WANT_E, bool WANT_POSE>
@@ -689,6 +683,8 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
   constexpr int RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
   extern __shared__ int4 tile[];
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  __shared__ double s_pose[kLdsScans * 12];
+  const PoseTile poses = in.dirs ? stage_poses(in, s_pose) : PoseTile{nullptr};      // published by the staging barrier
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   ModelParams mp;
@@ -761,9 +757,9 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
     }
     g[0] *= u; g[1] *= u; g[2] *= u;
     if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
-    if (in.dirs) points_bwd_point<T>(in, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+    if (in.dirs) points_bwd_point<T>(in, poses, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
 }
 
 // Backward over a "lane run" table (dc_block_table_build_runs): the positions of a point's incoming edges are stored
@@ -798,6 +794,8 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
   constexpr int RR = RecRaw<PT>::kRow16, XR = Pt<PT>::kRow16;
   extern __shared__ int4 tile[];
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  __shared__ double s_pose[kLdsScans * 12];
+  const PoseTile poses = in.dirs ? stage_poses(in, s_pose) : PoseTile{nullptr};      // published by the staging barrier
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   ModelParams mp;
@@ -849,9 +847,9 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
     }
     g[0] *= u; g[1] *= u; g[2] *= u;
     if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
-    if (in.dirs) points_bwd_point<T>(in, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+    if (in.dirs) points_bwd_point<T>(in, poses, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
 }
 
 // Stand-alone point epilogue for the un-fused API path (grad of points given).
@@ -860,6 +858,9 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
                                                             int64_t n, PointInputs in, int want_e, int want_pose,
                                                             double* __restrict__ partials, int n_acc) {
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
+  __shared__ double s_pose[kLdsScans * 12];
+  const PoseTile poses = stage_poses(in, s_pose);
+  __syncthreads();
   ModelParams mp;
   load_model(in, mp);
   double gw[DC_MAX_MODEL_TERMS], ge[DC_MAX_MODEL_TERMS], gT[6];
@@ -873,9 +874,9 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
   if (active) {
     double g[3];
     Row3<T, STRIDE>::load(grad_x, perm ? (int64_t)perm[j] : j, g, QParams{});      // perm: grad rows live in another point order
-    points_bwd_point<T>(in, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
+    points_bwd_point<T>(in, poses, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
-  reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials + blockIdx.x);
+  reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
 }
 
 // Sum the block partials [n_acc][n_rows] in a fixed order into out[n_acc]: one 1024-lane block per accumulator,
@@ -992,20 +993,26 @@ static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t ro
 namespace {
 constexpr int kProfKinds = 3;            // 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd
 constexpr int kProfCap = 4096;
+// Process-wide state behind a mutex: launches from different host threads (distinct streams) may time concurrently;
+// the events of one ProfScope are only touched by the thread that owns it until its destructor publishes them.
 struct ProfState {
+  std::mutex mu;
   int every = 0;                           // 0 = off, N = time every N-th launch of each kind
   int64_t seen[kProfKinds] = {0, 0, 0};
   int count[kProfKinds] = {0, 0, 0};
   hipEvent_t start[kProfKinds][kProfCap];
   hipEvent_t stop[kProfKinds][kProfCap];
   int created[kProfKinds] = {0, 0, 0};
+  const char* last_kernel[kProfKinds] = {nullptr, nullptr, nullptr};     // instantiation launched last, per kind
 } g_prof;
 
 // One timed launch: the kernel is launched through hipExtLaunchKernelGGL, which stamps the two events with the
 // dispatch's own start / end times (what rocprofv3 reports) instead of bracketing it with event packets.
 struct ProfScope {
   int kind, slot;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   explicit ProfScope(int kind_) : kind(kind_), slot(-1) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     if (g_prof.every <= 0 || g_prof.count[kind] >= kProfCap) return;
     if ((g_prof.seen[kind]++ % g_prof.every) != 0) return;
     slot = g_prof.count[kind];
@@ -1013,21 +1020,24 @@ struct ProfScope {
       if (hipEventCreate(&g_prof.start[kind][slot]) != hipSuccess || hipEventCreate(&g_prof.stop[kind][slot]) != hipSuccess) { slot = -1; return; }
       g_prof.created[kind] = slot + 1;
     }
+    g_prof.count[kind] = slot + 1;         // reserved now, so that a concurrent scope takes the next slot
+    ev0 = g_prof.start[kind][slot];
+    ev1 = g_prof.stop[kind][slot];
   }
-  hipEvent_t start() const { return slot < 0 ? nullptr : g_prof.start[kind][slot]; }
-  hipEvent_t stop() const { return slot < 0 ? nullptr : g_prof.stop[kind][slot]; }
-  ~ProfScope() { if (slot >= 0) g_prof.count[kind] = slot + 1; }
+  hipEvent_t start() const { return ev0; }
+  hipEvent_t stop() const { return ev1; }
+  void name(const char* kernel) const { g_prof.last_kernel[kind] = kernel; }
 };
 // launch of a hot kernel inside a `ProfScope prof` block
 #define DC_TIMED_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, prof.start(), prof.stop(), 0, __VA_ARGS__)
+  (prof.name(#kernel), hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, prof.start(), prof.stop(), 0, __VA_ARGS__))
 }  // namespace
 
 extern "C" {
 
 int dc_version(void) { return 100; }
 
-int64_t dc_partial_rows(int64_t n) { return xcd_grid(n_blocks(n)); }
+int64_t dc_partial_rows(int64_t n) { return xcd_grid(n_blocks(n)) * kWavesPerBlock; }
 
 int dc_param_grad_count(int n_terms, int n_scans) { return 2 * n_terms + 12 * n_scans; }
 
@@ -1143,7 +1153,7 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
 #undef FWD_FIXED
   DC_CHECK_LAUNCH();
   if (!reduce) return DC_OK;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows, sums_out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows * kWavesPerBlock, sums_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -1193,6 +1203,7 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   if (n == 0) return params ? (int)hipMemsetAsync(grads_out, 0, n_acc * sizeof(double), stream) : DC_OK;
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
   const int64_t rows = xcd_grid(n_blocks(n));
+  const int64_t prows = rows * kWavesPerBlock;               // partial rows: one per wavefront
   dim3 grid((unsigned)rows), block(kBlock);
   // byte size of the record array for the buffer resource (rows <= n; a compact centre list has fewer)
   const uint64_t rec_total = (uint64_t)(rec_rows > 0 ? rec_rows : n) * (point_fmt == DC_F64 ? 64u : 32u);
@@ -1200,7 +1211,7 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   const uint32_t rec_bytes = (uint32_t)rec_total;
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
   if (params && want_pose_grad) {
-    hipError_t err = hipMemsetAsync(partials_ws + (size_t)rows * 2 * n_terms, 0, (size_t)rows * 12 * n_scans * sizeof(double), stream);
+    hipError_t err = hipMemsetAsync(partials_ws + (size_t)prows * 2 * n_terms, 0, (size_t)prows * 12 * n_scans * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
   if (params && n_red < n_acc && reduce) {
@@ -1234,7 +1245,7 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
 #undef LAUNCH
   DC_CHECK_LAUNCH();
   if (params && n_red > 0 && reduce) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, prows, grads_out);
     DC_CHECK_LAUNCH();
   }
   return DC_OK;
@@ -1267,6 +1278,7 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
   if (n == 0) return (int)hipMemsetAsync(grads_out, 0, n_acc * sizeof(double), stream);
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
   const int64_t rows = n_blocks(n);
+  const int64_t prows = rows * kWavesPerBlock;
   dim3 grid((unsigned)rows), block(kBlock);
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;
   if (n_red < n_acc) {
@@ -1275,7 +1287,7 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
   }
   if (n_red == 0) return DC_OK;
   if (want_pose_grad) {      // blocks only write the pose slots of the scans they contain
-    hipError_t err = hipMemsetAsync(partials_ws + (size_t)rows * 2 * n_terms, 0, (size_t)rows * 12 * n_scans * sizeof(double), stream);
+    hipError_t err = hipMemsetAsync(partials_ws + (size_t)prows * 2 * n_terms, 0, (size_t)prows * 12 * n_scans * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
 #define LAUNCH(T, S) \
@@ -1286,7 +1298,7 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
   else return DC_ERR_DTYPE;
 #undef LAUNCH
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, rows, grads_out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_red), dim3(kRedBlock), 0, stream, partials_ws, prows, grads_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -1300,18 +1312,29 @@ int dc_set_option(int option, int value) {
 
 // ---- profiler control ---------------------------------------------------------------------------------------
 int dc_profiler_enable(int every) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   g_prof.every = every < 0 ? 0 : every;
   return DC_OK;
 }
 int dc_profiler_reset(void) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   for (int k = 0; k < kProfKinds; ++k) { g_prof.count[k] = 0; g_prof.seen[k] = 0; }
+  return DC_OK;
+}
+// Source-level name of the kernel instantiation the last launch of `kind` used, e.g.
+// "(consistency_fwd_fixed_kernel<float, q32, false, 10>)"; empty before the first launch.
+int dc_profiler_kernel(int kind, char* buf, int len) {
+  if (kind < 0 || kind >= kProfKinds || !buf || len < 1) return DC_ERR_ARG;
+  const char* nm = g_prof.last_kernel[kind];
+  snprintf(buf, (size_t)len, "%s", nm ? nm : "");
   return DC_OK;
 }
 // kind: 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd.  Waits for the recorded launches to finish.
 int dc_profiler_read(int kind, double* total_ms, int64_t* launches) {
   if (kind < 0 || kind >= kProfKinds || !total_ms || !launches) return DC_ERR_ARG;
   double tot = 0.0;
-  const int n = g_prof.count[kind];
+  int n;
+  { std::lock_guard<std::mutex> lock(g_prof.mu); n = g_prof.count[kind]; }
   for (int i = 0; i < n; ++i) {
     hipError_t err = hipEventSynchronize(g_prof.stop[kind][i]);
     if (err != hipSuccess) return (int)err;
@@ -1362,7 +1385,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   // forward partials live in the first 2 * rows doubles of the workspace, backward partials behind them; ONE reduction
   const int64_t n_rows = d->centre_idx ? d->n_centres : d->n;      // forward rows (centres); the backward runs over all points
   if (d->centre_idx && (d->n_centres < 0 || d->n_centres > d->n)) return DC_ERR_ARG;
-  const int64_t rows = xcd_grid(n_blocks(d->n));
+  const int64_t rows = xcd_grid(n_blocks(d->n)) * kWavesPerBlock;      // partial rows: one per wavefront
   double* p_fwd = d->partials;
   double* p_bwd = d->partials + 2 * rows;
   const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
@@ -1375,7 +1398,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                               d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false,
                               n_rows);
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)), rows,
+  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
                      n_red, out, adam);
   DC_CHECK_LAUNCH();
   return DC_OK;

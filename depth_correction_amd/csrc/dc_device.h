@@ -8,6 +8,7 @@ namespace dc {
 constexpr int kBlock = 256;          // 4 waves, one per SIMD
 constexpr int kWave = 64;
 constexpr int kXcds = 8;
+constexpr int kWavesPerBlock = kBlock / kWave;
 
 // Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Give every XCD one contiguous
 // range of the point array, so the neighbour gathers of spatially sorted points stay in that XCD's L2.
@@ -258,6 +259,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
   return v;
+}
+
+// Partial sums without LDS or barriers: lane 0 of every wavefront writes its sums to row 4 * block + wave of the
+// accumulator-major workspace partials[NV][4 * gridDim.x]; the fixed-order final reduction reads the rows.
+template <int NV>
+__device__ __forceinline__ void wave_partials(const double* v, double* __restrict__ partials) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock, row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const double s = wave_sum(v[q]);
+    if (lane == 0) partials[q * rs + row] = s;
+  }
 }
 
 // Sum `NV` per-thread doubles over the block; thread 0 receives the totals in `v`.

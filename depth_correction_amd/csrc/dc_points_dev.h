@@ -31,9 +31,25 @@ __device__ __forceinline__ void load_model(const PointInputs& in, ModelParams& m
   }
 }
 
-__device__ __forceinline__ void load_pose(const PointInputs& in, int s, double* T) {
+// Poses of a sequence are read per LANE (a block of Morton-ordered points holds points of most scans).  Every block
+// copies the (few) poses into LDS once, coalesced, and the lanes read them from there instead of gathering 12 doubles
+// each from global memory (6 x 64 L1 tag lookups per wavefront).
+constexpr int kLdsScans = 32;              // 3 KB; sequences with more scans read their poses from global memory
+
+struct PoseTile {
+  const double* lds;                       // staged poses, or nullptr: read from global memory
+};
+
+// Call from all threads of the block; the caller's next __syncthreads() publishes the tile.
+__device__ __forceinline__ PoseTile stage_poses(const PointInputs& in, double* s_pose) {
+  if (!in.poses || in.n_scans > kLdsScans) return PoseTile{nullptr};
+  for (int t = threadIdx.x; t < in.n_scans * 12; t += blockDim.x) s_pose[t] = in.poses[t];
+  return PoseTile{s_pose};
+}
+
+__device__ __forceinline__ void load_pose(const PointInputs& in, const PoseTile& tile, int s, double* T) {
   if (in.poses) {
-    const double* p = in.poses + (int64_t)s * 12;
+    const double* p = (tile.lds ? tile.lds : in.poses) + (int64_t)s * 12;
 #pragma unroll
     for (int q = 0; q < 12; ++q) T[q] = p[q];
   } else {
@@ -41,5 +57,7 @@ __device__ __forceinline__ void load_pose(const PointInputs& in, int s, double* 
     for (int q = 0; q < 12; ++q) T[q] = (q == 0 || q == 5 || q == 10) ? 1.0 : 0.0;
   }
 }
+
+__device__ __forceinline__ void load_pose(const PointInputs& in, int s, double* T) { load_pose(in, PoseTile{nullptr}, s, T); }
 
 }  // namespace dc

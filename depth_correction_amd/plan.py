@@ -310,6 +310,15 @@ class KernelTimer:
                 out[name] = (tot.value / cnt.value, cnt.value)
         return out
 
+    def kernels(self):
+        """{kind: source-level name of the kernel instantiation its last launch used}."""
+        out = {}
+        for i, name in enumerate(self.KINDS):
+            buf = ctypes.create_string_buffer(256)
+            check(lib().dc_profiler_kernel(i, buf, 256), 'dc_profiler_kernel')
+            out[name] = buf.value.decode().strip('()')
+        return out
+
 
 class SequenceTrainer:
     """The per-iteration body of train.py:220-312 for ball neighbourhoods and the min-eigenvalue / trace loss,

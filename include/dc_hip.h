@@ -303,17 +303,22 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
                     int preserve_order, int32_t* out_idx, int32_t* count_out, int32_t* status_out, void* ws, size_t ws_bytes,
                     dcStream_t stream);
 
-/* Tuning / ablation switches.  option 0: value 1 makes the fused kernels ignore block tables and gather from global
- * memory (results are identical either way). */
+/* Tuning / ablation switches (process-wide atomics, read once per launch; results are identical either way).
+ * option 0: value 1 makes the fused kernels ignore block tables and gather from global memory.
+ * option 1: value 1 makes dc_consistency_fwd use the run-time slot loop instead of the kernels specialised for
+ *           k = 4 / 8 / 10 / 16. */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
  * bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them.
  * every: 0 = off, N >= 1 = time every N-th launch of each kind (an event pair costs a few microseconds of idle GPU
- * around the kernel, so a timed production loop samples); `launches` counts the timed launches. */
+ * around the kernel, so a timed production loop samples); `launches` counts the timed launches.  The timer state is
+ * one per process behind a mutex: entry points may be called from several host threads on distinct streams. */
 int dc_profiler_enable(int every);
 int dc_profiler_reset(void);
 int dc_profiler_read(int kind, double* total_ms, int64_t* launches);
+/* Source-level name of the kernel instantiation the last launch of `kind` used (which variant the dispatch chose). */
+int dc_profiler_kernel(int kind, char* buf, int len);
 
 #ifdef __cplusplus
 }
