@@ -69,6 +69,10 @@ _SIGNATURES = {
     'dc_p2plane_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     'dc_p2plane_sequence': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'dc_p2point_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
+                               _i64, _vp, _vp, _vp]),
+    'dc_p2point_sequence': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'dc_shadow_mask': (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp]),
 }
 
 

@@ -69,6 +69,47 @@ __global__ __launch_bounds__(kBlock) void dispersion_kernel(const T* __restrict_
 }
 
 
+// Scan-shadow filter (filters.py:257-309, the laser_filters ScanShadowsFilter idea): a point is kept when the angles
+// between the ray back to its viewpoint (o - x) and the vectors to its direction-neighbours (x_j - x) all lie in
+// [lo, hi].  One lane per point walks its neighbour row; nothing of the reference's [N, K, 3] tensors is materialised.
+// Arithmetic in the cloud's dtype and in torch's operation order (cosine_similarity normalises each vector by
+// max(|v|, 1e-8) first, then sums the three products; acos of a value an ulp outside [-1, 1] is NaN and, like the
+// reference's amin / amax over a row holding a NaN, removes the point).  Missing neighbours (-1) count as `fill`
+// (the reference overwrites them with the mean of the bounds).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void shadow_mask_kernel(const T* __restrict__ x, const T* __restrict__ vps, int vps_rows,
+                                                             const int32_t* __restrict__ dnbr, int64_t n, int k, T lo, T hi,
+                                                             T fill, uint8_t* __restrict__ mask) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const T eps = (T)1e-8;
+  const T xi0 = x[i * 3], xi1 = x[i * 3 + 1], xi2 = x[i * 3 + 2];
+  const T* o = vps + (vps_rows == 1 ? 0 : i * 3);
+  T a0 = o[0] - xi0, a1 = o[1] - xi1, a2 = o[2] - xi2;
+  const T na = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const T da = na > eps ? na : eps;
+  a0 /= da; a1 /= da; a2 /= da;
+  T amin = (T)INFINITY, amax = -(T)INFINITY;
+  bool bad = false;
+  for (int q = 0; q < k; ++q) {
+    const int32_t j = dnbr[i * k + q];
+    T ang = fill;
+    if (j >= 0) {
+      T b0 = x[(int64_t)j * 3] - xi0, b1 = x[(int64_t)j * 3 + 1] - xi1, b2 = x[(int64_t)j * 3 + 2] - xi2;
+      const T nb = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+      const T db = nb > eps ? nb : eps;
+      b0 /= db; b1 /= db; b2 /= db;
+      const T c = a0 * b0 + a1 * b1 + a2 * b2;
+      ang = acos(c);
+    }
+    bad = bad || (ang != ang);
+    amin = ang < amin ? ang : amin;
+    amax = ang > amax ? ang : amax;
+  }
+  mask[i] = (!bad && amin >= lo && amax <= hi) ? 1 : 0;
+}
+
 // ---- voxel-grid filter: one survivor per voxel, the reference's dict semantics (filters.py:24-82) --------------------
 // The reference feeds points to a dict {voxel -> index} in a processing sequence (identity, reversed, or a seeded
 // shuffle): the LAST point of the sequence falling into a voxel survives, and voxels are listed in order of FIRST
@@ -206,6 +247,23 @@ static size_t voxel_ws(void* base, int64_t n, int32_t** vox, int32_t** box, uint
   *tmp_bytes = a > b ? (a > c ? a : c) : (b > c ? b : c);
   *tmp = take(*tmp_bytes);
   return off + 256;
+}
+
+// mask_out[i] = 1 when every angle of point i lies in [lo, hi]; vps [n,3] or a single row (vps_rows = 1).
+int dc_shadow_mask(const void* points, const void* vps, int vps_rows, int dtype, const int32_t* dir_nbr, int64_t n, int k,
+                   double lo, double hi, double fill, uint8_t* mask_out, hipStream_t stream) {
+  if (n < 0 || k < 1 || (n > 0 && (!points || !vps || !dir_nbr || !mask_out)) || (vps_rows != 1 && vps_rows != n)) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((shadow_mask_kernel<float>), grid, block, 0, stream, (const float*)points, (const float*)vps, vps_rows, dir_nbr,
+                       n, k, (float)lo, (float)hi, (float)fill, mask_out);
+  else if (dtype == DC_F64)
+    hipLaunchKernelGGL((shadow_mask_kernel<double>), grid, block, 0, stream, (const double*)points, (const double*)vps, vps_rows,
+                       dir_nbr, n, k, lo, hi, fill, mask_out);
+  else return DC_ERR_DTYPE;
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
 }
 
 size_t dc_voxel_filter_workspace_bytes(int64_t n) {

@@ -1,8 +1,9 @@
-// Point-to-plane ICP consistency between two consecutive scans with precomputed correspondences (gfx950).
-// Reference: loss.point_to_plane_dist loss.py:406-488 called from icp_loss :373-403 after model(c) and
-// c.transform(pose) (:381-386), correspondences from train.py:178-210.  Forward and hand-derived backward are
-// one kernel: the loss is a sum of |n . (x2 - x1)| terms, so every correspondence contributes its gradient
-// straight to the model weights and to the two scan poses (block partial sums, fixed-order reduction).
+// ICP consistency between two consecutive scans with precomputed correspondences (gfx950): point-to-plane
+// (loss.point_to_plane_dist loss.py:406-488) and point-to-point (loss.point_to_point_dist :491-565), both called from
+// icp_loss :373-403 after model(c) and c.transform(pose) (:381-386), correspondences from train.py:178-210.
+// Forward and hand-derived backward are one kernel: the loss is a sum of |n . (x2 - x1)| (or |x2 - x1|) terms, so every
+// correspondence contributes its gradient straight to the model weights and to the two scan poses (block partial
+// sums, fixed-order reduction).
 #include "dc_common.h"
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
@@ -28,7 +29,8 @@ __device__ __forceinline__ void load_scan_point(const ScanView& s, const ModelPa
   if (s.vps) Row3<T, 3>::load((const T*)s.vps, i, vp, QParams{});
   else { vp[0] = vp[1] = vp[2] = 0.0; }
   Row3<T, 3>::load((const T*)s.dirs, i, p.dr, QParams{});
-  Row3<T, 3>::load((const T*)s.normals, i, p.nl, QParams{});
+  if (s.normals) Row3<T, 3>::load((const T*)s.normals, i, p.nl, QParams{});      // NULL: point-to-point, no normals
+  else { p.nl[0] = p.nl[1] = p.nl[2] = 0.0; }
   p.d = (double)((const T*)s.depth)[i];
   p.lm = s.lmask ? s.lmask[i] != 0 : true;
   p.inc = (mp.kind != DC_MODEL_NONE && p.lm) ? (double)((const T*)s.inc)[i] : 0.0;
@@ -72,7 +74,7 @@ __device__ __forceinline__ void scan_point_bwd(const ModelParams& mp, const doub
 
 constexpr int kIcpAcc = 2 + 2 * DC_MAX_MODEL_TERMS + 24;
 
-template <typename T>
+template <typename T, bool PLANE>
 __global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanView B, const double* __restrict__ poseA,
                                                               const double* __restrict__ poseB, int model_kind, int n_terms,
                                                               const double* __restrict__ w, const double* __restrict__ e,
@@ -103,24 +105,33 @@ __global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanVi
     load_scan_point<T>(A, mp, TA, idxA[c], a);
     load_scan_point<T>(B, mp, TB, idxB[c], b);
     const double dx[3] = {b.x[0] - a.x[0], b.x[1] - a.x[1], b.x[2] - a.x[2]};
-    // 1 -> 2: | n1 . (x2 - x1) | |n1|
-    const double k12 = a.n[0] * dx[0] + a.n[1] * dx[1] + a.n[2] * dx[2];
-    const double na = sqrt(a.n[0] * a.n[0] + a.n[1] * a.n[1] + a.n[2] * a.n[2]);
-    // 2 -> 1: | n2 . (x1 - x2) | |n2|
-    const double k21 = -(b.n[0] * dx[0] + b.n[1] * dx[1] + b.n[2] * dx[2]);
-    const double nb = sqrt(b.n[0] * b.n[0] + b.n[1] * b.n[1] + b.n[2] * b.n[2]);
-    acc[0] = fabs(k12) * na;
-    acc[1] = fabs(k21) * nb;
-    const double s12 = k12 > 0.0 ? 1.0 : (k12 < 0.0 ? -1.0 : 0.0);
-    const double s21 = k21 > 0.0 ? 1.0 : (k21 < 0.0 ? -1.0 : 0.0);
     double gxa[3], gxb[3], gna[3], gnb[3];
+    if (PLANE) {
+      // 1 -> 2: | n1 . (x2 - x1) | |n1|
+      const double k12 = a.n[0] * dx[0] + a.n[1] * dx[1] + a.n[2] * dx[2];
+      const double na = sqrt(a.n[0] * a.n[0] + a.n[1] * a.n[1] + a.n[2] * a.n[2]);
+      // 2 -> 1: | n2 . (x1 - x2) | |n2|
+      const double k21 = -(b.n[0] * dx[0] + b.n[1] * dx[1] + b.n[2] * dx[2]);
+      const double nb = sqrt(b.n[0] * b.n[0] + b.n[1] * b.n[1] + b.n[2] * b.n[2]);
+      acc[0] = fabs(k12) * na;
+      acc[1] = fabs(k21) * nb;
+      const double s12 = k12 > 0.0 ? 1.0 : (k12 < 0.0 ? -1.0 : 0.0);
+      const double s21 = k21 > 0.0 ? 1.0 : (k21 < 0.0 ? -1.0 : 0.0);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const double t = s12 * na * a.n[q] - s21 * nb * b.n[q];      // d/dx2 ; d/dx1 is its negative
-      gxb[q] = t;
-      gxa[q] = -t;
-      gna[q] = s12 * na * dx[q] + (na > 0.0 ? fabs(k12) * a.n[q] / na : 0.0);
-      gnb[q] = -s21 * nb * dx[q] + (nb > 0.0 ? fabs(k21) * b.n[q] / nb : 0.0);
+      for (int q = 0; q < 3; ++q) {
+        const double t = s12 * na * a.n[q] - s21 * nb * b.n[q];      // d/dx2 ; d/dx1 is its negative
+        gxb[q] = t;
+        gxa[q] = -t;
+        gna[q] = s12 * na * dx[q] + (na > 0.0 ? fabs(k12) * a.n[q] / na : 0.0);
+        gnb[q] = -s21 * nb * dx[q] + (nb > 0.0 ? fabs(k21) * b.n[q] / nb : 0.0);
+      }
+    } else {
+      // point to point: | x2 - x1 | (loss.py:552-553); the norm's subgradient at zero is zero, as torch's
+      const double len = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+      acc[0] = len;
+      const double inv = len > 0.0 ? 1.0 / len : 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { gxb[q] = dx[q] * inv; gxa[q] = -gxb[q]; gna[q] = gnb[q] = 0.0; }
     }
     scan_point_bwd<T>(mp, TA, a, gxa, gna, gw, ge, gTA);
     scan_point_bwd<T>(mp, TB, b, gxb, gnb, gw, ge, gTB);
@@ -176,6 +187,17 @@ __global__ __launch_bounds__(kBlock) void p2plane_reduce_seq_kernel(const double
   if (dst >= 0) out[dst] += weight * v[0];
 }
 
+static void launch_pair(bool plane, int dtype, int64_t rows, hipStream_t stream, const ScanView& A, const ScanView& B,
+                        const double* poseA, const double* poseB, int model_kind, int n_terms, const double* w, const double* e,
+                        const int32_t* idxA, const int32_t* idxB, int64_t m, double* partials_ws) {
+  const dim3 grid((unsigned)rows), block(kBlock);
+#define ICP_LAUNCH(T, PLANE) \
+  hipLaunchKernelGGL((p2plane_pair_kernel<T, PLANE>), grid, block, 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, idxA, idxB, m, partials_ws)
+  if (dtype == DC_F32) { if (plane) ICP_LAUNCH(float, true); else ICP_LAUNCH(float, false); }
+  else { if (plane) ICP_LAUNCH(double, true); else ICP_LAUNCH(double, false); }
+#undef ICP_LAUNCH
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -184,14 +206,15 @@ extern "C" {
 
 int64_t dc_p2plane_partial_count(int64_t m) { return (m <= 0 ? 1 : (m + kBlock - 1) / kBlock) * kIcpAcc; }
 
-int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, const void* incA, const uint8_t* lmaskA,
+static int icp_pair_impl(bool plane, const void* vpsA, const void* dirsA, const void* depthA, const void* incA, const uint8_t* lmaskA,
                     const void* normalsA, const void* vpsB, const void* dirsB, const void* depthB, const void* incB,
                     const uint8_t* lmaskB, const void* normalsB, int dtype, const double* poseA, const double* poseB,
                     int model_kind, int n_terms, const double* w, const double* e, const int32_t* idxA,
                     const int32_t* idxB, int64_t m, int want_exponent_grad, int want_pose_grad, double* partials_ws,
                     double* out, hipStream_t stream) {
   (void)want_exponent_grad; (void)want_pose_grad;      // always produced: the kernel is tiny next to the k-NN set-up
-  if (!dirsA || !depthA || !normalsA || !dirsB || !depthB || !normalsB) return DC_ERR_ARG;
+  if (!dirsA || !depthA || !dirsB || !depthB || (plane && (!normalsA || !normalsB))) return DC_ERR_ARG;
+  if (!plane) normalsA = normalsB = nullptr;
   if (!poseA || !poseB || !idxA || !idxB || m < 0 || !partials_ws || !out) return DC_ERR_ARG;
   if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
   if (model_kind != DC_MODEL_NONE && (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !incA || !incB || !w || !e)) return DC_ERR_ARG;
@@ -202,17 +225,32 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
   if (m == 0) return DC_OK;
   ScanView A{vpsA, dirsA, depthA, incA, lmaskA, normalsA}, B{vpsB, dirsB, depthB, incB, lmaskB, normalsB};
   const int64_t rows = (m + kBlock - 1) / kBlock;
-  if (dtype == DC_F32)
-    hipLaunchKernelGGL((p2plane_pair_kernel<float>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, idxA, idxB, m, partials_ws);
-  else if (dtype == DC_F64)
-    hipLaunchKernelGGL((p2plane_pair_kernel<double>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, idxA, idxB, m, partials_ws);
-  else return DC_ERR_DTYPE;
+  if (dtype != DC_F32 && dtype != DC_F64) return DC_ERR_DTYPE;
+  launch_pair(plane, dtype, rows, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, idxA, idxB, m, partials_ws);
   hipLaunchKernelGGL(p2plane_reduce_kernel, dim3(kIcpAcc), dim3(kBlock), 0, stream, partials_ws, rows, n_terms, out);
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
 }
 
-int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, const void* incA, const uint8_t* lmaskA,
+                    const void* normalsA, const void* vpsB, const void* dirsB, const void* depthB, const void* incB,
+                    const uint8_t* lmaskB, const void* normalsB, int dtype, const double* poseA, const double* poseB,
+                    int model_kind, int n_terms, const double* w, const double* e, const int32_t* idxA,
+                    const int32_t* idxB, int64_t m, int want_exponent_grad, int want_pose_grad, double* partials_ws,
+                    double* out, hipStream_t stream) {
+  return icp_pair_impl(true, vpsA, dirsA, depthA, incA, lmaskA, normalsA, vpsB, dirsB, depthB, incB, lmaskB, normalsB, dtype, poseA,
+                       poseB, model_kind, n_terms, w, e, idxA, idxB, m, want_exponent_grad, want_pose_grad, partials_ws, out, stream);
+}
+
+int dc_p2point_pair(const void* vpsA, const void* dirsA, const void* depthA, const void* incA, const uint8_t* lmaskA,
+                    const void* vpsB, const void* dirsB, const void* depthB, const void* incB, const uint8_t* lmaskB, int dtype,
+                    const double* poseA, const double* poseB, int model_kind, int n_terms, const double* w, const double* e,
+                    const int32_t* idxA, const int32_t* idxB, int64_t m, double* partials_ws, double* out, hipStream_t stream) {
+  return icp_pair_impl(false, vpsA, dirsA, depthA, incA, lmaskA, nullptr, vpsB, dirsB, depthB, incB, lmaskB, nullptr, dtype, poseA,
+                       poseB, model_kind, n_terms, w, e, idxA, idxB, m, 1, 1, partials_ws, out, stream);
+}
+
+static int icp_sequence_impl(bool plane, const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
                         const double* poses, int model_kind, int n_terms, const double* w, const double* e,
                         double* partials_ws, double* out, hipStream_t stream) {
   if (n_scans < 0 || n_pairs < 0 || (n_scans > 0 && !scans) || (n_pairs > 0 && !pairs) || !out) return DC_ERR_ARG;
@@ -226,7 +264,7 @@ int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pa
     if (q.m < 0 || (q.m > 0 && (!q.idx_a || !q.idx_b || !poses || !partials_ws))) return DC_ERR_ARG;
     for (int side = 0; side < 2; ++side) {
       const dcIcpScan& c = scans[side ? q.scan_b : q.scan_a];
-      if (!c.dirs || !c.depth || !c.normals || (model_kind != DC_MODEL_NONE && !c.inc)) return DC_ERR_ARG;
+      if (!c.dirs || !c.depth || (plane && !c.normals) || (model_kind != DC_MODEL_NONE && !c.inc)) return DC_ERR_ARG;
     }
   }
   hipError_t err = hipMemsetAsync(out, 0, (size_t)(1 + 2 * n_terms + 12 * n_scans) * sizeof(double), stream);
@@ -235,18 +273,28 @@ int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pa
     const dcIcpPair& q = pairs[p];
     if (q.m == 0) continue;
     const dcIcpScan &a = scans[q.scan_a], &b = scans[q.scan_b];
-    ScanView A{a.vps, a.dirs, a.depth, a.inc, a.lmask, a.normals}, B{b.vps, b.dirs, b.depth, b.inc, b.lmask, b.normals};
+    ScanView A{a.vps, a.dirs, a.depth, a.inc, a.lmask, plane ? a.normals : nullptr},
+        B{b.vps, b.dirs, b.depth, b.inc, b.lmask, plane ? b.normals : nullptr};
     const double *poseA = poses + 12 * q.scan_a, *poseB = poses + 12 * q.scan_b;
     const int64_t rows = (q.m + kBlock - 1) / kBlock;
-    if (dtype == DC_F32)
-      hipLaunchKernelGGL((p2plane_pair_kernel<float>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, q.idx_a, q.idx_b, q.m, partials_ws);
-    else
-      hipLaunchKernelGGL((p2plane_pair_kernel<double>), dim3((unsigned)rows), dim3(kBlock), 0, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, q.idx_a, q.idx_b, q.m, partials_ws);
+    launch_pair(plane, dtype, rows, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, q.idx_a, q.idx_b, q.m, partials_ws);
     hipLaunchKernelGGL(p2plane_reduce_seq_kernel, dim3(kIcpAcc), dim3(kBlock), 0, stream, partials_ws, rows, n_terms,
                        q.weight, q.scan_a, q.scan_b, out);
   }
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                        const double* poses, int model_kind, int n_terms, const double* w, const double* e,
+                        double* partials_ws, double* out, hipStream_t stream) {
+  return icp_sequence_impl(true, scans, n_scans, pairs, n_pairs, dtype, poses, model_kind, n_terms, w, e, partials_ws, out, stream);
+}
+
+int dc_p2point_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                        const double* poses, int model_kind, int n_terms, const double* w, const double* e,
+                        double* partials_ws, double* out, hipStream_t stream) {
+  return icp_sequence_impl(false, scans, n_scans, pairs, n_pairs, dtype, poses, model_kind, n_terms, w, e, partials_ws, out, stream);
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ import torch
 
 from .config import Config, NeighborhoodType, PoseCorrection
 from .depth_cloud import DepthCloud
-from .plan import SequencePlan, consistency_loss
+from .plan import PlanRegistry, SequencePlan, consistency_loss
 from .preproc import (compute_neighborhood_features, global_cloud, global_cloud_mask, local_feature_cloud,
                       offset_cloud)
 from .transform import xyz_axis_angle_to_matrix
@@ -84,20 +84,23 @@ class PlanCloud(object):
         return self._plan.n
 
 
+_plans = PlanRegistry()
+
+
 def _plan_for(seq_clouds, poses, nn, mask, model, cfg):
-    """SequencePlan cached on the neighbour tensor of the sequence (constant over the optimisation)."""
+    """SequencePlan of (local clouds, neighbourhoods, mask), all constant over the optimisation: kept in a registry keyed
+    by the identity and version of every tensor it was built from (plan.PlanRegistry)."""
     neighbors = nn[0]
     kw = cfg.loss_kwargs
-    key = (tuple(id(c) for c in seq_clouds), None if mask is None else (id(mask), mask._version), neighbors._version,
-           cfg.loss, bool(kw.get('normalization', False)), bool(kw.get('sqrt', False)),
-           getattr(model, 'kernel_kind', None) if model is not None else None)
-    cached = getattr(neighbors, '_dc_plan', None)
-    if cached is None or cached[0] != key:
-        plan = SequencePlan(seq_clouds, poses.detach(), neighbors, None if mask is None else mask.to(neighbors.device),
-                            model_kind=key[-1] or 'ScaledPolynomial', loss=cfg.loss,
-                            normalization=key[4] and cfg.loss == 'min_eigval_loss', sqrt=key[5])
-        neighbors._dc_plan = cached = (key, plan)
-    return cached[1]
+    flags = (cfg.loss, bool(kw.get('normalization', False)), bool(kw.get('sqrt', False)),
+             getattr(model, 'kernel_kind', None) if model is not None else None)
+    tensors = [t for c in seq_clouds for t in (c.vps, c.dirs, c.depth, c.inc_angles, c.mask)] + [neighbors, mask]
+
+    def build():
+        return SequencePlan(seq_clouds, poses.detach(), neighbors, None if mask is None else mask.to(neighbors.device),
+                            model_kind=flags[3] or 'ScaledPolynomial', loss=cfg.loss,
+                            normalization=flags[1] and cfg.loss == 'min_eigval_loss', sqrt=flags[2])
+    return _plans.get(tensors, flags, build)
 
 
 def eval_loss_clouds(clouds, poses, pose_deltas, masks, ns, model, loss_fun, cfg: Config):

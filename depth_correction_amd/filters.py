@@ -192,12 +192,23 @@ def filter_shadow_points(cloud: DepthCloud, angle_bounds: list, only_mask: bool 
     assert cloud.vps is not None and cloud.dir_neighbors is not None
     lo = 0.0 if (angle_bounds[0] is None or not (angle_bounds[0] >= 0.0)) else float(angle_bounds[0])
     hi = torch.pi if (angle_bounds[1] is None or not (angle_bounds[1] <= torch.pi)) else float(angle_bounds[1])
+    # the reference holds the bounds in a float32 tensor (torch.as_tensor of Python floats) and fills the angles of
+    # missing neighbours with its mean
+    lo, hi = float(np.float32(lo)), float(np.float32(hi))
+    fill = float((np.float32(lo) + np.float32(hi)) / np.float32(2.0))
     x = cloud.get_points()
-    to_vp = (cloud.vps.expand_as(x) - x).unsqueeze(dim=1)
-    to_nb = x[cloud.dir_neighbors] - x.unsqueeze(dim=1)
-    ang = torch.acos(torch.nn.functional.cosine_similarity(to_vp, to_nb, dim=-1))
-    ang = torch.where(cloud.dir_neighbor_weights != 1.0, torch.full_like(ang, 0.5 * (lo + hi)), ang)
-    mask = (ang.amin(dim=-1) >= lo) & (ang.amax(dim=-1) <= hi)
+    if x.is_cuda:
+        # one kernel over the direction-neighbour rows (dc_shadow_mask): no [N, K, 3] tensors
+        with torch.no_grad():
+            mask = ops.shadow_mask(x.detach().contiguous(), cloud.vps.detach().to(x.dtype).contiguous(),
+                                   ops.as_index32(cloud.dir_neighbors), lo, hi, fill)
+    else:
+        # host tensors (data preparation on a CPU-only machine): the reference's tensor expressions
+        to_vp = (cloud.vps.expand_as(x) - x).unsqueeze(dim=1)
+        to_nb = x[cloud.dir_neighbors] - x.unsqueeze(dim=1)
+        ang = torch.acos(torch.nn.functional.cosine_similarity(to_vp, to_nb, dim=-1))
+        ang = torch.where(cloud.dir_neighbor_weights != 1.0, torch.full_like(ang, fill), ang)
+        mask = (ang.amin(dim=-1) >= lo) & (ang.amax(dim=-1) <= hi)
     if log:
         print('%.3f = %i / %i points kept (shadow points removed).' % (mask.double().mean(), mask.sum(), mask.numel()))
     return mask if only_mask else cloud[mask]

@@ -7,8 +7,9 @@ Two execution paths produce the same numbers:
     of loss.py:250-289 on ``cloud.eigvals`` / ``cloud.cov`` (small ``[M]`` tensors), differentiable down to the
     points through dc_features_bwd.  All of the reference's options are available here (mask, offset, sqrt,
     normalisation, quantile inliers, reductions).
-``icp_loss`` with point-to-plane distances and precomputed correspondences runs as one kernel per scan pair
-(dc_p2plane_pair) including its backward to the model weights and poses.
+``icp_loss`` with precomputed correspondences runs as one kernel per scan pair (dc_p2plane_sequence for
+point-to-plane, dc_p2point_sequence for point-to-point distances) including its backward to the model weights and
+poses; ``point_to_point_dist`` as a metric on GPU clouds (scripts/model_poses_learning:142-146) uses the same kernel.
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import torch
 
 from . import ops
 from .depth_cloud import DepthCloud
+from .plan import PlanRegistry
 from .utils import trace
 
 __all__ = ['batch_loss', 'create_loss', 'icp_loss', 'loss_by_name', 'min_eigval_loss', 'point_to_plane_dist',
@@ -168,21 +170,51 @@ def point_to_plane_dist(clouds: list, icp_inlier_ratio=0.5, masks=None, differen
     return torch.as_tensor(total / n_pairs)
 
 
+def _as_cloud(c):
+    return c if isinstance(c, DepthCloud) else DepthCloud.from_points(torch.as_tensor(c))
+
+
 def point_to_point_dist(clouds: list, icp_inlier_ratio=0.5, masks=None, differentiable=True, verbose=False, **kwargs):
-    """Mean point-to-point distance over consecutive scan pairs (loss.py:491-565)."""
+    """Mean point-to-point distance over consecutive scan pairs (loss.py:491-565).
+
+    On GPU clouds that carry no autograd graph (the map-accuracy metric of scripts/model_poses_learning:142-146) the
+    distances of all pairs come from one dc_p2point_sequence call; correspondences not given are found by the GPU 1-NN
+    builder.  Clouds inside an autograd graph take the reference's tensor expressions (icp_loss routes training through
+    the fused kernel with its hand-derived backward instead)."""
     assert 0.0 <= icp_inlier_ratio <= 1.0
     assert masks is None or len(clouds) == len(masks) + 1
-    total, n_pairs = 0.0, len(clouds) - 1
+    n_pairs = len(clouds) - 1
+    pts = [_pair_points(c) if isinstance(c, DepthCloud) else torch.as_tensor(c, dtype=torch.float) for c in clouds]
+    if n_pairs > 0 and all(p.is_cuda and not p.requires_grad for p in pts):
+        pairs, errs = [], []
+        for i in range(n_pairs):
+            mask1, mask2, inl_err = _pair_matches(pts[i], pts[i + 1], masks, i, icp_inlier_ratio)
+            ia = (torch.nonzero(mask1).reshape(-1) if mask1.dtype == torch.bool else mask1).to(torch.int32).contiguous()
+            ib = mask2.to(torch.int32).contiguous()
+            assert len(ia) > 0 and len(ib) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
+            pairs.append((i, i + 1, ia, ib))
+            errs.append(inl_err)
+        # the points as they are (already corrected and posed by the caller): unit "directions" x, depth 1, identity poses
+        scans = [(ops.PointSet(None, p.contiguous(), torch.ones((len(p),), dtype=p.dtype, device=p.device)), None) for p in pts]
+        seq = ops.IcpSequence(scans, pairs, with_model=False, plane=False)
+        eye = torch.eye(4, dtype=torch.float64, device=pts[0].device)[:3].reshape(1, 12).repeat(len(pts), 1).contiguous()
+        out = seq.eval(eye)
+        for i, inl_err in enumerate(errs):
+            if inl_err > 0.3:
+                warnings.warn('ICP inliers error is too big: %.3f (> 0.3) [m] for pairs (%i, %i)' % (inl_err, i, i + 1))
+        return out[0].to(torch.float32)
+    total = 0.0
     for i in range(n_pairs):
-        c1, c2 = clouds[i], clouds[i + 1]
-        p1 = _pair_points(c1) if isinstance(c1, DepthCloud) else torch.as_tensor(c1, dtype=torch.float)
-        p2 = _pair_points(c2) if isinstance(c2, DepthCloud) else torch.as_tensor(c2, dtype=torch.float)
+        p1, p2 = pts[i], pts[i + 1]
         mask1, mask2, inl_err = _pair_matches(p1, p2, masks, i, icp_inlier_ratio)
         a, b = p1[mask1], p2[mask2]
         assert len(a) > 0 and len(b) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
         total = total + torch.linalg.norm(b - a, dim=1).mean()
         if inl_err > 0.3:
             warnings.warn('ICP inliers error is too big: %.3f (> 0.3) [m] for pairs (%i, %i)' % (inl_err, i, i + 1))
+        if verbose:
+            print('Mean point to point distance: %.3f [m] for scans: (%i, %i), inliers error: %.6f'
+                  % (float(total), i, i + 1, float(inl_err)))
     return torch.as_tensor(total / n_pairs)
 
 
@@ -218,65 +250,89 @@ class _P2PlaneSequence(torch.autograd.Function):
         return gw, ge, gT, None, None
 
 
-def _icp_sequence_plan(seq_clouds, seq_masks, with_model):
-    """ops.IcpSequence of (clouds, correspondences), cached on the first correspondence tensor: an optimisation loop
-    passes the same clouds and masks every iteration (train.py:212-215)."""
-    holder = seq_masks[0][0] if len(seq_masks) and isinstance(seq_masks[0][0], torch.Tensor) else None
-    key = tuple(id(t) for c in seq_clouds for t in (c.vps, c.dirs, c.depth, c.inc_angles, c.normals, c.mask)) \
-        + tuple(id(m) for pair in seq_masks for m in pair) + (bool(with_model),)
-    cached = getattr(holder, '_dc_icp_plan', None) if holder is not None else None
-    if cached is not None and cached[0] == key:
-        return cached[1]
-    scans = []
-    for c in seq_clouds:
-        n = len(c)
-        cont = lambda t: t.detach().expand(n, t.shape[-1]).contiguous() if t.dim() == 2 else t.detach().contiguous()
-        vps = None if not bool(c.vps.any()) else cont(c.vps)
-        inc = cont(c.inc_angles) if (with_model and c.inc_angles is not None) else None
-        scans.append((ops.PointSet(vps, cont(c.dirs), cont(c.depth), inc, c.mask if with_model else None),
-                      cont(c.normals.to(c.dirs.dtype))))
-    dev = scans[0][1].device
-    pairs = []
-    for i, (m1, m2) in enumerate(seq_masks):
-        m1 = torch.as_tensor(m1, device=dev)
-        ia = (torch.nonzero(m1).reshape(-1) if m1.dtype == torch.bool else m1).to(torch.int32).contiguous()
-        ib = torch.as_tensor(m2, device=dev).to(torch.int32).contiguous()
-        assert len(ia) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
-        pairs.append((i, i + 1, ia, ib))
-    plan = ops.IcpSequence(scans, pairs, with_model=with_model)
-    plan._refs = (list(seq_clouds), list(seq_masks))          # the ids in `key` stay valid while the plan lives
-    if holder is not None:
-        holder._dc_icp_plan = (key, plan)
-    return plan
+_icp_plans = PlanRegistry()
 
 
-def _fused_icp_sequence(seq_clouds, seq_poses, model, seq_masks):
-    """Point-to-plane loss of one sequence through dc_p2plane_sequence (clouds in the sensor frame + poses + model)."""
+def _icp_sequence_plan(seq_clouds, seq_masks, with_model, plane):
+    fields = [t for c in seq_clouds for t in (c.vps, c.dirs, c.depth, c.inc_angles, c.normals if plane else None, c.mask)]
+    fields += [m for pair in seq_masks for m in pair]
+
+    def build():
+        scans = []
+        for c in seq_clouds:
+            n = len(c)
+            cont = lambda t: t.detach().expand(n, t.shape[-1]).contiguous() if t.dim() == 2 else t.detach().contiguous()
+            vps = None if not bool(c.vps.any()) else cont(c.vps)
+            inc = cont(c.inc_angles) if (with_model and c.inc_angles is not None) else None
+            scans.append((ops.PointSet(vps, cont(c.dirs), cont(c.depth), inc, c.mask if with_model else None),
+                          cont(c.normals.to(c.dirs.dtype)) if plane else None))
+        dev = scans[0][0].device
+        pairs = []
+        for i, (m1, m2) in enumerate(seq_masks):
+            m1 = torch.as_tensor(m1, device=dev)
+            ia = (torch.nonzero(m1).reshape(-1) if m1.dtype == torch.bool else m1).to(torch.int32).contiguous()
+            ib = torch.as_tensor(m2, device=dev).to(torch.int32).contiguous()
+            assert len(ia) > 0, 'Point clouds do not intersect. Try to sample lidar scans more frequently'
+            pairs.append((i, i + 1, ia, ib))
+        return ops.IcpSequence(scans, pairs, with_model=with_model, plane=plane)
+    return _icp_plans.get(fields, (bool(with_model), bool(plane)), build)
+
+
+def _fused_icp_sequence(seq_clouds, seq_poses, model, seq_masks, plane=True):
+    """ICP loss of one sequence through dc_p2plane_sequence / dc_p2point_sequence (clouds in the sensor frame + poses + model)."""
     kind = getattr(model, 'kernel_kind', None) if model is not None else None
     w = model.w if kind else None
     e = model.exponent if kind else None
-    plan = _icp_sequence_plan(seq_clouds, seq_masks, bool(kind))
+    plan = _icp_sequence_plan(seq_clouds, seq_masks, bool(kind), plane)
     poses = seq_poses if isinstance(seq_poses, torch.Tensor) else torch.stack(list(seq_poses))
     return _P2PlaneSequence.apply(w, e, poses, plan, kind)
+
+
+class _MovedClouds(object):
+    """The corrected, posed scans of a sequence (what the reference's icp_loss concatenates into its loss cloud,
+    loss.py:381-386,396-398), produced only when a caller looks at the returned cloud."""
+
+    def __init__(self, seq, poses, model, loss):
+        self._args, self._cloud, self.loss = (seq, poses, model), None, loss
+
+    def _materialize(self):
+        if self._cloud is None:
+            seq, poses, model = self._args
+            with torch.no_grad():
+                moved = [model(c) for c in seq] if model is not None else list(seq)
+                if poses is not None:
+                    moved = [c.transform(p) for c, p in zip(moved, poses)]
+                self._cloud = DepthCloud.concatenate(moved)
+                self._cloud.loss = self.loss
+        return self._cloud
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        return getattr(self._materialize(), name)
+
+    def __len__(self):
+        return sum(len(c) for c in self._args[0])
 
 
 def icp_loss(clouds, poses=None, model=None, masks=None, **kwargs):
     """ICP-like loss over lists of sequences of scans (loss.py:373-403)."""
     p2plane = kwargs['icp_point_to_plane']
-    fused = (p2plane and masks is not None and poses is not None and clouds and clouds[0][0].dirs.is_cuda
-             and all(c.normals is not None for seq in clouds for c in seq)
+    fused = (masks is not None and poses is not None and clouds and clouds[0][0].dirs.is_cuda
+             and (not p2plane or all(c.normals is not None for seq in clouds for c in seq))
              and (model is None or getattr(model, 'kernel_kind', None)))
     loss, loss_cloud = 0., []
     for i, seq in enumerate(clouds):
         if fused:
-            loss_seq = _fused_icp_sequence(seq, poses[i], model, masks[i])
-            moved = seq
-        else:
-            moved = [model(c) for c in seq] if model is not None else seq
-            if poses is not None:
-                moved = [c.transform(p) for c, p in zip(moved, poses[i])]
-            fun = point_to_plane_dist if p2plane else point_to_point_dist
-            loss_seq = fun(moved, masks=None if masks is None else masks[i], **kwargs)
+            loss_seq = _fused_icp_sequence(seq, poses[i], model, masks[i], plane=bool(p2plane))
+            loss = loss + loss_seq
+            loss_cloud.append(_MovedClouds(seq, poses[i], model, loss))
+            continue
+        moved = [model(c) for c in seq] if model is not None else seq
+        if poses is not None:
+            moved = [c.transform(p) for c, p in zip(moved, poses[i])]
+        fun = point_to_plane_dist if p2plane else point_to_point_dist
+        loss_seq = fun(moved, masks=None if masks is None else masks[i], **kwargs)
         loss = loss + loss_seq
         cloud = DepthCloud.concatenate(moved)
         cloud.loss = loss

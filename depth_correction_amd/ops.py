@@ -14,7 +14,8 @@ from ._native import lib, check, need, ptr, stream_ptr, dtype_code, on_device
 
 __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
-    'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'IcpSequence',
+    'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
+    'IcpSequence', 'shadow_mask',
     'as_index32',
 ]
 
@@ -522,6 +523,26 @@ def dispersion(vec, nbr, weights=None):
 
 
 @on_device
+def shadow_mask(points, vps, dir_nbr, lo, hi, fill):
+    """bool [N]: every angle between (vps - x) and (x_j - x), j in dir_nbr[i], within [lo, hi] (filters.py:257-309)."""
+    need(points, (None, 3), name='points')
+    n = points.shape[0]
+    dev, dt = points.device, points.dtype
+    vps = vps.reshape(-1, 3)
+    need(vps, (None, 3), dtype=dt, name='vps', device=dev)
+    if vps.shape[0] not in (1, n):
+        raise ValueError('vps must have 1 or %d rows' % n)
+    need(dir_nbr, (n, None), dtype=torch.int32, name='dir_neighbors', device=dev)
+    mask = torch.empty((n,), dtype=torch.bool, device=dev)
+    if n and dir_nbr.shape[1]:
+        check(lib().dc_shadow_mask(ptr(points), ptr(vps), vps.shape[0], dtype_code(points), ptr(dir_nbr), n, dir_nbr.shape[1],
+                                   float(lo), float(hi), float(fill), ptr(mask), stream_ptr()), 'dc_shadow_mask')
+    else:
+        mask.fill_(True)
+    return mask
+
+
+@on_device
 def voxel_filter(points, grid_res, seq=None, preserve_order=False):
     """Indices (int64, device) of one survivor per voxel with filter_grid's dict semantics; None if the voxel range
     does not fit the 63-bit key (caller falls back to the host algorithm)."""
@@ -571,22 +592,50 @@ def p2plane_pair(psa, normals_a, psb, normals_b, pose_a, pose_b, idx_a, idx_b, m
         out[14 + 2 * nt:].reshape(3, 4)
 
 
+@on_device
+def p2point_pair(psa, psb, pose_a, pose_b, idx_a, idx_b, model_kind=None, w=None, e=None):
+    """Sum of point-to-point distances over the correspondences of one scan pair and its gradients:
+    returns (sums f64 [2] = {sum |xb - xa|, 0}, dw [P], de [P], dTa [3,4], dTb [3,4])."""
+    dev, dt = psa.device, psa.dtype
+    assert psb.device == dev and psb.dtype == dt
+    need(pose_a, (12,), dtype=torch.float64, name='pose_a', device=dev)
+    need(pose_b, (12,), dtype=torch.float64, name='pose_b', device=dev)
+    need(idx_a, (None,), dtype=torch.int32, name='idx_a', device=dev)
+    m = idx_a.shape[0]
+    need(idx_b, (m,), dtype=torch.int32, name='idx_b', device=dev)
+    kind, nt, w, e = _model_args(model_kind, w, e, psa)
+    if kind != 0 and psb.inc is None:
+        raise ValueError('the model needs incidence angles')
+    part = torch.empty((lib().dc_p2plane_partial_count(m),), dtype=torch.float64, device=dev)
+    out = torch.empty((2 + 2 * nt + 24,), dtype=torch.float64, device=dev)
+    check(lib().dc_p2point_pair(ptr(psa.vps), ptr(psa.dirs), ptr(psa.depth), ptr(psa.inc), ptr(psa.lmask), ptr(psb.vps),
+                                ptr(psb.dirs), ptr(psb.depth), ptr(psb.inc), ptr(psb.lmask), dtype_code(psa.dirs), ptr(pose_a),
+                                ptr(pose_b), kind, nt, ptr(w), ptr(e), ptr(idx_a), ptr(idx_b), m, ptr(part), ptr(out),
+                                stream_ptr()), 'dc_p2point_pair')
+    return out[:2], out[2:2 + nt], out[2 + nt:2 + 2 * nt], out[2 + 2 * nt:14 + 2 * nt].reshape(3, 4), \
+        out[14 + 2 * nt:].reshape(3, 4)
+
+
 class IcpSequence:
-    """Descriptors of one sequence of scans and its pair correspondences for dc_p2plane_sequence, filled once;
-    ``eval`` is then one host call per evaluation.  ``scans``: list of (PointSet, normals [n,3]); ``pairs``: list of
-    (scan_a, scan_b, idx_a int32 [m], idx_b int32 [m]); pair weights follow icp_loss (loss.py:391-403):
-    0.5 / (m * n_pairs)."""
+    """Descriptors of one sequence of scans and its pair correspondences for dc_p2plane_sequence / dc_p2point_sequence,
+    filled once; ``eval`` is then one host call per evaluation.  ``scans``: list of (PointSet, normals [n,3] | None);
+    ``pairs``: list of (scan_a, scan_b, idx_a int32 [m], idx_b int32 [m]); pair weights follow icp_loss
+    (loss.py:391-403): 0.5 / (m * n_pairs) for point to plane (two directed sums), 1 / (m * n_pairs) for point to
+    point (``plane=False``, loss.py:553,563)."""
 
     @on_device
-    def __init__(self, scans, pairs, with_model=True):
+    def __init__(self, scans, pairs, with_model=True, plane=True):
         ps0 = scans[0][0]
         self.device, self.dtype, self.n_scans = ps0.device, ps0.dtype, len(scans)
-        self.with_model = bool(with_model)
+        self.with_model, self.plane = bool(with_model), bool(plane)
         self._keep = []
         self.scan_desc = (nv.IcpScan * max(len(scans), 1))()
         for d, (ps, normals) in zip(self.scan_desc, scans):
             assert ps.device == self.device and ps.dtype == self.dtype
-            need(normals, (ps.n, 3), dtype=self.dtype, name='normals', device=self.device)
+            if plane:
+                need(normals, (ps.n, 3), dtype=self.dtype, name='normals', device=self.device)
+            else:
+                normals = None
             if with_model and ps.inc is None:
                 raise ValueError('the model needs incidence angles')
             self._keep.append((ps, normals))
@@ -602,7 +651,7 @@ class IcpSequence:
                 raise ValueError('pair (%d, %d) outside the sequence' % (a, b))
             self._keep.append((idx_a, idx_b))
             d.scan_a, d.scan_b, d.idx_a, d.idx_b, d.m = int(a), int(b), ptr(idx_a), ptr(idx_b), m
-            d.weight = 0.5 / (max(m, 1) * len(pairs))
+            d.weight = (0.5 if plane else 1.0) / (max(m, 1) * len(pairs))
             max_m = max(max_m, m)
         self.part = torch.empty((lib().dc_p2plane_partial_count(max_m),), dtype=torch.float64, device=self.device)
 
@@ -618,8 +667,8 @@ class IcpSequence:
             out = torch.empty((n_out,), dtype=torch.float64, device=self.device)
         else:
             need(out, (n_out,), dtype=torch.float64, name='out', device=self.device)
-        check(lib().dc_p2plane_sequence(ctypes.cast(self.scan_desc, ctypes.c_void_p), self.n_scans,
-                                        ctypes.cast(self.pair_desc, ctypes.c_void_p), self.n_pairs,
-                                        0 if self.dtype == torch.float32 else 1, ptr(poses12), kind, nt, ptr(w), ptr(e),
-                                        ptr(self.part), ptr(out), stream_ptr()), 'dc_p2plane_sequence')
+        fn = lib().dc_p2plane_sequence if self.plane else lib().dc_p2point_sequence
+        check(fn(ctypes.cast(self.scan_desc, ctypes.c_void_p), self.n_scans, ctypes.cast(self.pair_desc, ctypes.c_void_p),
+                 self.n_pairs, 0 if self.dtype == torch.float32 else 1, ptr(poses12), kind, nt, ptr(w), ptr(e),
+                 ptr(self.part), ptr(out), stream_ptr()), 'dc_p2plane_sequence' if self.plane else 'dc_p2point_sequence')
         return out

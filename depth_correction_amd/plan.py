@@ -27,7 +27,7 @@ from . import ops
 from . import _native as nv
 from ._native import need, lib, check, ptr, stream_ptr, on_device
 
-__all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer']
+__all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer', 'PlanRegistry']
 
 
 class SequencePlan:
@@ -235,6 +235,35 @@ class SequencePlan:
         else:
             x = self.x[:, :3]
         return self.unpermute(x)
+
+
+class PlanRegistry(object):
+    """Plans (SequencePlan, ops.IcpSequence) of the clouds / neighbourhoods / correspondences an optimisation loop passes
+    every iteration (train.py:212-215).  An entry is keyed by the identity AND the version counter of every tensor it was built from and
+    holds references to them, so an id can neither be recycled after garbage collection nor can an in-place edit go
+    unnoticed; the registry keeps the few most recent entries (one per sequence of a training / validation set)."""
+
+    def __init__(self, capacity=64):
+        self.capacity, self.entries = capacity, []
+
+    @staticmethod
+    def key_of(tensors, extra):
+        return tuple((id(t), t._version) if isinstance(t, torch.Tensor) else t for t in tensors) + tuple(extra)
+
+    def get(self, tensors, extra, build):
+        key = self.key_of(tensors, extra)
+        for i, (k, refs, plan) in enumerate(self.entries):
+            if k == key and all(a is b for a, b in zip(refs, tensors)):
+                if i:
+                    self.entries.insert(0, self.entries.pop(i))
+                return plan
+        plan = build()
+        self.entries.insert(0, (key, list(tensors), plan))
+        del self.entries[self.capacity:]
+        return plan
+
+    def clear(self):
+        self.entries = []
 
 
 class _ConsistencyLoss(torch.autograd.Function):

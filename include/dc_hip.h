@@ -210,6 +210,14 @@ int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, dcS
 int dc_dispersion(const void* vec, int dtype, const int32_t* nbr, const void* weights, int64_t n, int k, void* out,
                   dcStream_t stream);
 
+/* Scan-shadow filter: filters.filter_shadow_points filters.py:257-309 on the direction neighbourhoods of
+ * DepthCloud.update_dir_neighbors depth_cloud.py:217-224 (radius search on the unit directions: dc_radius_*).
+ * mask_out[i] = 1 when the angles between (vps_i - x_i) and (x_j - x_i), j in dir_nbr[i, :], all lie in [lo, hi];
+ * missing neighbours (-1) count as the angle `fill` (the reference: mean of the bounds); a NaN angle removes the point.
+ * vps [n,3], or one row shared by all points (vps_rows = 1).  Arithmetic in `dtype`, torch's operation order. */
+int dc_shadow_mask(const void* points, const void* vps, int vps_rows, int dtype, const int32_t* dir_nbr, int64_t n, int k,
+                   double lo, double hi, double fill, uint8_t* mask_out, dcStream_t stream);
+
 /* ---- point-to-plane ICP loss: loss.point_to_plane_dist loss.py:406-488 inside icp_loss :373-403 (model(c),
  *      c.transform(pose) :381-386) with precomputed correspondences (train.py:178-210) ------------------------------
  * One scan pair (A, B): idxA / idxB int32 [m] index the local points of scan A / B; poseA / poseB fp64 [12]
@@ -249,6 +257,18 @@ typedef struct dcIcpPair {
   double weight;
 } dcIcpPair;
 int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                        const double* poses, int model_kind, int n_terms, const double* w, const double* e,
+                        double* partials_ws, double* out, dcStream_t stream);
+/* Point-to-point variant (loss.point_to_point_dist loss.py:491-565, what scripts/model_poses_learning_icp optimises and
+ * model_poses_learning reports as map accuracy): every correspondence contributes |xB - xA| (points rounded to fp32
+ * first, loss.py:524-525); no normals.  out of the pair call: fp64 [2 + 2 P + 24] = {sum |xB - xA|, 0, d/dw, d/dexponent,
+ * d/d[R|t]_A, d/d[R|t]_B}; the sequence call as dc_p2plane_sequence (pair weight = 1 / (m * n_pairs), loss.py:553,563),
+ * dcIcpScan.normals is ignored. */
+int dc_p2point_pair(const void* vpsA, const void* dirsA, const void* depthA, const void* incA, const uint8_t* lmaskA,
+                    const void* vpsB, const void* dirsB, const void* depthB, const void* incB, const uint8_t* lmaskB, int dtype,
+                    const double* poseA, const double* poseB, int model_kind, int n_terms, const double* w, const double* e,
+                    const int32_t* idxA, const int32_t* idxB, int64_t m, double* partials_ws, double* out, dcStream_t stream);
+int dc_p2point_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
                         const double* poses, int model_kind, int n_terms, const double* w, const double* e,
                         double* partials_ws, double* out, dcStream_t stream);
 

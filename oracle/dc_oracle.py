@@ -27,7 +27,8 @@ import numpy as np
 import torch
 
 __all__ = [
-    'axis_angle_to_matrix', 'closed_form_backward', 'covs', 'dispersion', 'eval_sequence', 'features',
+    'axis_angle_to_matrix', 'closed_form_backward', 'covs', 'dispersion', 'eval_sequence', 'features', 'point_to_point',
+    'shadow_mask',
     'global_mask', 'knn_bruteforce', 'knn_ckdtree', 'local_mask', 'model_bias', 'model_apply', 'pointwise_loss',
     'point_to_plane', 'points_from', 'radius_bruteforce', 'radius_ckdtree', 'reduce_loss', 'trace',
     'transform_cloud', 'within_bounds', 'xyz_axis_angle_to_matrix', 'nn1_correspondences',
@@ -347,6 +348,35 @@ def point_to_plane(points, normals, masks):
         d21 = torch.linalg.norm(p1i - (p1i - k * n2), dim=-1).mean()
         total = total + 0.5 * (d12 + d21)
     return torch.as_tensor(total / n_pairs)
+
+
+def point_to_point(points, masks):
+    """loss.py:491-565 with precomputed correspondences: mean |x2 - x1| per pair (points cast to fp32, :524-525),
+    averaged over the consecutive pairs."""
+    total = 0.0
+    n_pairs = len(points) - 1
+    for i in range(n_pairs):
+        p1 = torch.as_tensor(points[i], dtype=torch.float)
+        p2 = torch.as_tensor(points[i + 1], dtype=torch.float)
+        mask1, mask2 = masks[i]
+        total = total + torch.linalg.norm(p2[mask2] - p1[mask1], dim=1).mean()       # :552-553
+    return torch.as_tensor(total / n_pairs)
+
+
+def shadow_mask(points, vps, dir_neighbors, angle_bounds):
+    """filters.py:257-309: keep a point when the angles between (viewpoint - x) and (neighbour - x) over its direction
+    neighbours (depth_cloud.py:217-224; -1 = missing) all lie within the bounds.  The bounds live in a float32 tensor
+    (:277-278) and missing neighbours take their mean (:293-294)."""
+    lo = 0.0 if (angle_bounds[0] is None or not (angle_bounds[0] >= 0.0)) else angle_bounds[0]
+    hi = torch.pi if (angle_bounds[1] is None or not (angle_bounds[1] <= torch.pi)) else angle_bounds[1]
+    bounds = torch.as_tensor([lo, hi])
+    x = torch.as_tensor(points)
+    o = torch.as_tensor(vps)
+    ox = o.unsqueeze(dim=1) - x.unsqueeze(dim=1)
+    nx = x[dir_neighbors] - x.unsqueeze(dim=1)
+    a = torch.acos(torch.nn.functional.cosine_similarity(ox, nx, dim=-1))
+    a[torch.as_tensor(dir_neighbors) < 0] = bounds.mean()
+    return (a.amin(dim=-1) >= bounds[0]) & (a.amax(dim=-1) <= bounds[1]), a
 
 
 # ----------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ oracle's restatement of the published algorithm (recorded in each fixture's ``me
 Before a fixture is written, the oracle restatement (oracle/dc_oracle.py) is run on the same inputs
 and asserted equal to the reference's outputs, so a committed fixture certifies both.
 
-Usage:  python oracle/gen_golden.py            (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid}.npz, about 9 MB)
+Usage:  python oracle/gen_golden.py [names]    (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid,shadow}.npz, about 10 MB)
 """
 import os
 import sys
@@ -43,7 +43,7 @@ from depth_correction.config import Config, PoseCorrection                # noqa
 from depth_correction.depth_cloud import DepthCloud                       # noqa: E402
 from depth_correction.dataset import PlaneDataset as RefPlaneDataset      # noqa: E402
 from depth_correction.eval import eval_loss_clouds                        # noqa: E402
-from depth_correction.loss import create_loss, point_to_plane_dist        # noqa: E402
+from depth_correction.loss import create_loss, icp_loss, point_to_plane_dist, point_to_point_dist   # noqa: E402
 from depth_correction.model import ScaledPolynomial, Polynomial           # noqa: E402
 from depth_correction.nearest_neighbors import nearest_neighbors          # noqa: E402
 from depth_correction.preproc import (establish_neighborhoods, global_cloud, global_cloud_mask,
@@ -296,7 +296,73 @@ def gen_icp():
     close(w.grad, model.w.grad, rtol=1e-6, what='icp grad_w')
     close(pdo.grad, pd.grad, rtol=1e-6, atol=1e-12, what='icp grad_pose')
     print('icp_pairs: loss=%.9g grad_w=%s' % (loss.item(), npy(model.w.grad).ravel()))
+
+    # point-to-point distances on the same scans and correspondences (loss.py:491-565): through icp_loss
+    # (icp_point_to_plane=False, :373-403) for the training form, and point_to_point_dist itself for the metric form
+    model2 = ScaledPolynomial(w=[1e-3, 2e-3], exponent=[2.0, 4.0])
+    pd2 = torch.tensor(pd0, dtype=torch.float64, requires_grad=True)
+    poses_upd2 = torch.matmul(poses, xyz_axis_angle_to_matrix(pd2))
+    loss2, _ = icp_loss([clouds], [poses_upd2], model2, masks=[masks], icp_point_to_plane=False, icp_inlier_ratio=ratio)
+    loss2.backward()
+    metric = point_to_point_dist([c.transform(p) for c, p in zip(clouds, poses)], icp_inlier_ratio=ratio, masks=masks)
+    metric_nn = point_to_point_dist([c.transform(p) for c, p in zip(clouds, poses)], icp_inlier_ratio=ratio,
+                                    differentiable=False)
+    out.update(p2p_loss=npy(loss2), p2p_grad_w=npy(model2.w.grad), p2p_grad_pose_deltas=npy(pd2.grad),
+               p2p_metric=npy(metric), p2p_metric_nn=npy(metric_nn))
+    w2 = torch.tensor(npy(model2.w), requires_grad=True)
+    pdo2 = torch.tensor(pd0, dtype=torch.float64, requires_grad=True)
+    pu2 = torch.matmul(poses, O.xyz_axis_angle_to_matrix(pdo2))
+    pts2 = []
+    for c, T in zip(clouds, pu2):
+        d = O.model_apply(c.depth, c.inc_angles, c.mask, w2, model2.exponent.detach())
+        v, r = O.transform_cloud(c.vps, c.dirs, T)
+        pts2.append(O.points_from(v, r, d))
+    lo2 = O.point_to_point(pts2, masks)
+    lo2.backward()
+    close(lo2, loss2, what='p2p loss')
+    close(w2.grad, model2.w.grad, rtol=1e-6, what='p2p grad_w')
+    close(pdo2.grad, pd2.grad, rtol=1e-6, atol=1e-12, what='p2p grad_pose')
+    print('icp_pairs (point to point): loss=%.9g metric=%.9g metric_nn=%.9g grad_w=%s'
+          % (loss2.item(), metric.item(), metric_nn.item(), npy(model2.w.grad).ravel()))
     np.savez_compressed(os.path.join(GOLD, 'icp_pairs.npz'), **out)
+
+
+def gen_shadow():
+    """Scan-shadow filter (filters.py:257-309) on direction neighbourhoods (depth_cloud.py:217-224) and the depth
+    pre-filter (filters.py:116-141) of a ring scan that sees two walls and the ground behind their edges, as the online
+    node applies them (preproc.py:44-47; scripts/depth_correction:31-58)."""
+    from depth_correction.filters import filter_depth, filter_shadow_points
+    ds = KittiLikeDataset(n_poses=1, n_rings=32, n_azimuth=1024)
+    cloud, _ = ds[0]
+    out = dict(meta=np.array(META))
+    for tag, dtype in (('f64', np.float64), ('f32', np.float32)):
+        dc = DepthCloud.from_structured_array(cloud, dtype=dtype)
+        # a range step every 40 beams (an occluding pole in front of the background): shadow points at its edges
+        depth = dc.depth.clone()
+        az = torch.arange(len(depth)) % 1024
+        depth[(az % 40) < 3] *= 0.6
+        dc = DepthCloud(dc.vps, dc.dirs, depth)
+        keep = filter_depth(dc, min=1.0, max=25.0, only_mask=True)
+        dc = dc[keep]
+        dc.update_points()
+        angle = 0.017453 * 1.5                                       # config.py:204 shadow_neighborhood_angle, widened
+        dc.update_dir_neighbors(angle=angle)
+        bounds = [float(np.radians(5.0)), float('inf')]              # config.py:205
+        dc.loss = torch.arange(len(dc), dtype=dc.depth.dtype)         # a sliced field that reveals which points survive
+        kept = filter_shadow_points(dc, list(bounds), log=False)
+        mask = torch.zeros((len(dc),), dtype=torch.bool)
+        mask[kept.loss.long()] = True
+        mo, ang = O.shadow_mask(dc.points, dc.vps, dc.dir_neighbors, list(bounds))
+        assert torch.equal(mo, mask), 'shadow mask restatement differs'
+        ang[dc.dir_neighbors < 0] = float('nan')
+        out.update({tag + '_vps': npy(dc.vps), tag + '_dirs': npy(dc.dirs), tag + '_depth': npy(dc.depth),
+                    tag + '_depth_keep': npy(keep), tag + '_dir_neighbors': compact(dc.dir_neighbors),
+                    tag + '_mask': npy(mask), tag + '_angle_min': npy(torch.nan_to_num(ang, nan=10.0).amin(dim=-1)),
+                    tag + '_angle_max': npy(torch.nan_to_num(ang, nan=-10.0).amax(dim=-1))})
+        print('shadow %s: %d rays, %d after depth filter, K_dir=%d, %d kept by the shadow filter'
+              % (tag, len(keep), len(dc), dc.dir_neighbors.shape[1], int(mask.sum())))
+    out['angle'], out['bounds_deg'] = angle, 5.0
+    np.savez_compressed(os.path.join(GOLD, 'shadow.npz'), **out)
 
 
 def gen_grid():
@@ -342,7 +408,7 @@ def gen_knn():
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp']
+    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow']
     if 'grid' in which:
         gen_grid()
     if 'knn' in which:
@@ -353,3 +419,5 @@ if __name__ == '__main__':
         gen_room()
     if 'icp' in which:
         gen_icp()
+    if 'shadow' in which:
+        gen_shadow()

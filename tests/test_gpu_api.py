@@ -223,6 +223,94 @@ def test_icp_loss_golden(golden, fused):
     np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
 
 
+def _icp_golden_clouds(g, dev, normals=True):
+    from depth_correction_amd.depth_cloud import DepthCloud
+    clouds = []
+    for s in range(int(g['n_scans'])):
+        kw = dict(inc_angles=t(g['scan%d_inc_angles' % s], dev), mask=t(g['scan%d_mask' % s], dev))
+        if normals:
+            kw['normals'] = t(g['scan%d_normals' % s], dev)
+        clouds.append(DepthCloud(t(g['scan%d_vps' % s], dev), t(g['scan%d_dirs' % s], dev), t(g['scan%d_depth' % s], dev), **kw))
+    masks = [(t(g['pair%d_mask1' % j], dev), t(g['pair%d_idx2' % j], dev)) for j in range(int(g['n_scans']) - 1)]
+    return clouds, masks
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_icp_point_to_point_golden(golden, fused):
+    """icp_loss(icp_point_to_plane=False) (loss.py:373-403 -> point_to_point_dist :491-565) with model and per-pose
+    corrections against the live-reference fixture: loss, dL/dw, dL/dpose_deltas -- through dc_p2point_sequence (fused)
+    and through the tensor expressions."""
+    from depth_correction_amd.loss import icp_loss
+    from depth_correction_amd.model import ScaledPolynomial
+    from depth_correction_amd.transform import xyz_axis_angle_to_matrix
+    g = golden('icp_pairs')
+    dev = 'cuda:0'
+    clouds, masks = _icp_golden_clouds(g, dev, normals=False)       # point to point needs no normals
+    model = ScaledPolynomial(w=g['w'].reshape(-1).tolist(), exponent=g['exponent'].reshape(-1).tolist(), device=dev)
+    if not fused:
+        model.kernel_kind = None
+    pd = torch.tensor(g['pose_deltas'], device=dev, requires_grad=True)
+    poses = torch.matmul(t(g['poses'], dev), xyz_axis_angle_to_matrix(pd))
+    loss, loss_clouds = icp_loss([clouds], [poses], model, masks=[masks], icp_point_to_plane=False,
+                                 icp_inlier_ratio=float(g['ratio']))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['p2p_loss'], rtol=1e-6)
+    np.testing.assert_allclose(npy(model.w.grad), g['p2p_grad_w'], rtol=1e-5)
+    ref = g['p2p_grad_pose_deltas']
+    np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
+    # the returned loss cloud is the corrected, posed sequence (loss.py:396-398), not the sensor-frame input
+    lc = loss_clouds[0]
+    assert len(lc) == sum(len(c) for c in clouds)
+    moved = torch.cat([model(c).transform(p).to_points() for c, p in zip(clouds, poses.detach())])
+    np.testing.assert_allclose(npy(lc.to_points()), npy(moved.detach()), rtol=1e-12, atol=1e-12)
+
+
+def test_point_to_point_metric_golden(golden):
+    """point_to_point_dist as the map-accuracy metric (scripts/model_poses_learning:142-146) on GPU clouds: one
+    dc_p2point_sequence call, with given correspondences and with the GPU 1-NN builder finding them."""
+    from depth_correction_amd.loss import point_to_point_dist
+    g = golden('icp_pairs')
+    dev = 'cuda:0'
+    clouds, masks = _icp_golden_clouds(g, dev, normals=False)
+    posed = [c.transform(p) for c, p in zip(clouds, t(g['poses'], dev))]
+    d = point_to_point_dist(posed, icp_inlier_ratio=float(g['ratio']), masks=masks)
+    np.testing.assert_allclose(d.item(), g['p2p_metric'], rtol=1e-6)
+    d = point_to_point_dist(posed, icp_inlier_ratio=float(g['ratio']), differentiable=False)
+    np.testing.assert_allclose(d.item(), g['p2p_metric_nn'], rtol=1e-6)
+    # plain point tensors are accepted like clouds (loss.py:512-519)
+    d = point_to_point_dist([c.to_points() for c in posed], icp_inlier_ratio=float(g['ratio']), masks=masks)
+    np.testing.assert_allclose(d.item(), g['p2p_metric'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('tag,dtype', [('f64', torch.float64), ('f32', torch.float32)])
+def test_shadow_filter_golden(golden, tag, dtype):
+    """The online node's pre-processing (preproc.py:44-47): depth filter, direction neighbourhoods (radius search on unit
+    directions) and the scan-shadow filter (dc_shadow_mask) against the live-reference fixture.  fp64 clouds: identical
+    mask; fp32 clouds: identical except where an extreme angle lies within 1e-5 rad of a bound (acos in fp32 on the CPU
+    and on the GPU differ in the last ulp)."""
+    from depth_correction_amd.depth_cloud import DepthCloud
+    from depth_correction_amd.filters import filter_depth, filter_shadow_points
+    g = golden('shadow')
+    dev = 'cuda:0'
+    dc = DepthCloud(t(g[tag + '_vps'], dev), t(g[tag + '_dirs'], dev), t(g[tag + '_depth'], dev))
+    assert dc.depth.dtype == dtype
+    assert bool(filter_depth(dc, min=1.0, max=25.0, only_mask=True).all())           # the fixture holds the filtered scan
+    dc.update_points()
+    dc.update_dir_neighbors(angle=float(g['angle']))
+    assert np.array_equal(npy(dc.dir_neighbors), g[tag + '_dir_neighbors'])
+    bounds = [float(np.radians(float(g['bounds_deg']))), float('inf')]
+    mask = npy(filter_shadow_points(dc, list(bounds), only_mask=True))
+    want = g[tag + '_mask']
+    lo = np.float32(bounds[0])
+    near = (np.abs(g[tag + '_angle_min'] - lo) < 1e-5) | (np.abs(g[tag + '_angle_max'] - np.float32(np.pi)) < 1e-5)
+    if dtype == torch.float64:
+        near &= False
+    assert np.array_equal(mask[~near], want[~near]) and near.sum() < 20
+    assert 0.5 < mask.mean() < 0.95
+    kept = filter_shadow_points(dc, list(bounds))
+    assert len(kept) == int(mask.sum())
+
+
 def test_icp_correspondences_vs_ckdtree(golden):
     from depth_correction_amd.loss import icp_correspondences
     g = golden('room_k10')

@@ -118,3 +118,53 @@ def test_point_to_plane(golden):
     np.testing.assert_allclose(npy(loss), g['loss'], rtol=1e-9)
     np.testing.assert_allclose(npy(w.grad), g['grad_w'], rtol=1e-6)
     np.testing.assert_allclose(npy(pd.grad), g['grad_pose_deltas'], rtol=1e-6, atol=1e-12)
+
+
+def test_point_to_point(golden):
+    """loss.point_to_point_dist (loss.py:491-565) through icp_loss with model and pose corrections, and as a metric."""
+    g = golden('icp_pairs')
+    ns = int(g['n_scans'])
+    w = torch.tensor(g['w'], requires_grad=True)
+    pd = torch.tensor(g['pose_deltas'], requires_grad=True)
+    T = torch.matmul(t(g['poses']), O.xyz_axis_angle_to_matrix(pd))
+    pts, posed = [], []
+    for s in range(ns):
+        d = O.model_apply(t(g['scan%d_depth' % s]), t(g['scan%d_inc_angles' % s]), t(g['scan%d_mask' % s]), w, t(g['exponent']))
+        v, r = O.transform_cloud(t(g['scan%d_vps' % s]), t(g['scan%d_dirs' % s]), T[s])
+        pts.append(O.points_from(v, r, d))
+        v0, r0 = O.transform_cloud(t(g['scan%d_vps' % s]), t(g['scan%d_dirs' % s]), t(g['poses'])[s])
+        posed.append(O.points_from(v0, r0, t(g['scan%d_depth' % s])))
+    masks = [(t(g['pair%d_mask1' % j]), t(g['pair%d_idx2' % j])) for j in range(ns - 1)]
+    loss = O.point_to_point(pts, masks)
+    loss.backward()
+    np.testing.assert_allclose(npy(loss), g['p2p_loss'], rtol=1e-9)
+    np.testing.assert_allclose(npy(w.grad), g['p2p_grad_w'], rtol=1e-6)
+    np.testing.assert_allclose(npy(pd.grad), g['p2p_grad_pose_deltas'], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(npy(O.point_to_point(posed, masks)), g['p2p_metric'], rtol=1e-9)
+    # correspondences found as point_to_point_dist does without masks (1-NN, quantile inliers) give the same pairs
+    found = []
+    for j in range(ns - 1):
+        m1, i2, _ = O.nn1_correspondences(npy(posed[j].float()), npy(posed[j + 1].float()), float(g['ratio']))
+        found.append((t(m1), t(i2)))
+    np.testing.assert_allclose(npy(O.point_to_point(posed, found)), g['p2p_metric_nn'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f32'])
+def test_shadow_filter(golden, tag):
+    """filters.filter_shadow_points (filters.py:257-309) on the fixture's direction neighbourhoods."""
+    g = golden('shadow')
+    depth = t(g[tag + '_depth'])
+    pts = t(g[tag + '_vps']) + depth * t(g[tag + '_dirs'])
+    mask, ang = O.shadow_mask(pts, t(g[tag + '_vps']), t(g[tag + '_dir_neighbors']).long(),
+                              [float(np.radians(float(g['bounds_deg']))), float('inf')])
+    assert np.array_equal(npy(mask), g[tag + '_mask'])
+    valid = g[tag + '_dir_neighbors'] >= 0
+    a = np.where(valid, npy(ang), 10.0)
+    np.testing.assert_allclose(a.min(-1), g[tag + '_angle_min'], rtol=0, atol=0)
+    # the direction neighbourhoods themselves: radius search on the unit directions (depth_cloud.py:217-224)
+    r = float(torch.sqrt(2. * (1. - torch.cos(torch.as_tensor(float(g['angle']))))))
+    ind = O.radius_ckdtree(g[tag + '_dirs'][:4000].astype(np.float64), r)
+    sub = g[tag + '_dir_neighbors'][:4000]
+    # restricted to the first 4000 rays: neighbours beyond them are dropped from both sides
+    for row_ref, row in zip(sub[:200], ind[:200]):
+        assert sorted(x for x in row_ref if 0 <= x < 4000) == sorted(x for x in row if x >= 0)
