@@ -60,6 +60,8 @@ _SIGNATURES = {
     'dc_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp]),
     'dc_voxel_filter_workspace_bytes': (_sz, [_i64]),
     'dc_voxel_filter': (_i32, [_vp, _i32, _i32, _i64, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'dc_cloud_from_points_workspace_bytes': (_sz, [_i64]),
+    'dc_cloud_from_points': (_i32, [_vp, _i32, _i32, _vp, _i64, _f64, _f64, _f64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_set_option': (_i32, [_i32, _i32]),
     'dc_profiler_enable': (_i32, [_i32]),
     'dc_profiler_reset': (_i32, []),

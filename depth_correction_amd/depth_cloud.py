@@ -177,15 +177,24 @@ class DepthCloud(object):
             return DepthCloud.from_structured_array(pts, device=device)
         if isinstance(dtype, type) or isinstance(dtype, np.dtype):       # numpy dtype (cfg.numpy_float_type())
             dtype = getattr(torch, np.dtype(dtype).name)
-        pts = torch.as_tensor(pts, dtype=dtype, device=device)
-        vps = torch.zeros_like(pts) if vps is None else torch.as_tensor(vps, dtype=dtype, device=device)
-        assert vps.shape == pts.shape
-        rays = pts - vps
-        depth = rays.norm(dim=-1, keepdim=True)
-        dirs = torch.where(depth > 0.0, rays / depth, rays)
-        kwargs = dict(vps=vps, dirs=dirs, depth=depth)
+        pts = torch.as_tensor(pts, device=device)
+        if pts.is_cuda and pts.dim() == 2 and pts.shape[1] == 3 and pts.dtype in (torch.float32, torch.float64) \
+                and (dtype is None or dtype in (torch.float32, torch.float64)) and not pts.requires_grad:
+            # device tensors: one kernel (dc_cloud_from_points) instead of five elementwise passes
+            vps_t = None if vps is None else torch.as_tensor(vps, dtype=pts.dtype, device=pts.device).contiguous()
+            assert vps_t is None or vps_t.shape == pts.shape
+            v, dirs, depth, _ = ops.cloud_from_points(pts.contiguous(), vps_t, dtype=dtype or pts.dtype)
+            kwargs = dict(vps=torch.zeros_like(dirs) if v is None else v, dirs=dirs, depth=depth)
+        else:
+            pts = pts.to(dtype) if dtype is not None else pts
+            vps = torch.zeros_like(pts) if vps is None else torch.as_tensor(vps, dtype=dtype, device=device)
+            assert vps.shape == pts.shape
+            rays = pts - vps
+            depth = rays.norm(dim=-1, keepdim=True)
+            dirs = torch.where(depth > 0.0, rays / depth, rays)
+            kwargs = dict(vps=vps, dirs=dirs, depth=depth)
         if normals is not None:
-            kwargs['normals'] = torch.as_tensor(normals, dtype=dtype, device=device)
+            kwargs['normals'] = torch.as_tensor(normals, dtype=kwargs['dirs'].dtype, device=kwargs['dirs'].device)
         dc = DepthCloud(**kwargs)
         return dc.to(device=device) if device else dc
 

@@ -15,7 +15,7 @@ from ._native import lib, check, need, ptr, stream_ptr, dtype_code, on_device
 __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
-    'IcpSequence', 'shadow_mask',
+    'IcpSequence', 'shadow_mask', 'cloud_from_points',
     'as_index32',
 ]
 
@@ -520,6 +520,36 @@ def dispersion(vec, nbr, weights=None):
     check(lib().dc_dispersion(ptr(vec), dtype_code(vec), ptr(nbr), ptr(weights), n, k, ptr(out), stream_ptr()),
           'dc_dispersion')
     return out
+
+
+@on_device
+def cloud_from_points(points, vps=None, dtype=None, ego_box=None, min_depth=None, max_depth=None, want_index=False):
+    """Raw rows [N, >=3] on the device -> (vps [M,3] | None, dirs [M,3], depth [M,1], index int64 [M] | None) of the rows
+    that survive the ego-box crop and the depth bounds, in their original order (dc_cloud_from_points: kitti360.py:101-105,
+    filters.py:116-141, depth_cloud.py:592-638).  One synchronisation (the number of kept rows) when a filter is active."""
+    need(points, (None, None), name='points')
+    n, stride = points.shape
+    if stride < 3:
+        raise ValueError('points need at least 3 columns')
+    dev = points.device
+    dtype = points.dtype if dtype is None else dtype
+    if vps is not None:
+        need(vps, (n, 3), dtype=points.dtype, name='vps', device=dev)
+    dirs = torch.empty((n, 3), dtype=dtype, device=dev)
+    depth = torch.empty((n, 1), dtype=dtype, device=dev)
+    vps_out = torch.empty((n, 3), dtype=dtype, device=dev) if vps is not None else None
+    index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
+    count = torch.empty((1,), dtype=torch.int64, device=dev)
+    nbytes = lib().dc_cloud_from_points_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    nan = float('nan')
+    filtered = bool(ego_box and ego_box > 0) or min_depth is not None or max_depth is not None
+    check(lib().dc_cloud_from_points(ptr(points), stride, dtype_code(points), ptr(vps), n, float(ego_box or 0.0),
+                                     nan if min_depth is None else float(min_depth), nan if max_depth is None else float(max_depth),
+                                     nv.DC_F32 if dtype == torch.float32 else nv.DC_F64, ptr(dirs), ptr(depth), ptr(vps_out),
+                                     ptr(index), ptr(count), ptr(ws), nbytes, stream_ptr()), 'dc_cloud_from_points')
+    m = int(count.item()) if filtered else n
+    return (None if vps_out is None else vps_out[:m], dirs[:m], depth[:m], None if index is None else index[:m].long())
 
 
 @on_device

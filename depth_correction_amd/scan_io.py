@@ -1,5 +1,11 @@
-"""Scan and pose file formats on either side of the path, host readers that hand the rest of the package
-plain arrays (the cloud then goes to the device once, in ``local_feature_cloud``):
+"""Scan and pose file formats on either side of the path.
+
+Direct-to-device loaders (``load_*_device``, ``DeviceScanDataset``): the file's bytes go through a pinned host buffer to
+the GPU once, and ONE kernel pass (dc_cloud_from_points) applies the ego-vehicle crop, the depth pre-filter and
+``DepthCloud.from_points`` -- the reference does those three on the host, array by array.  The result is a DepthCloud on
+the device, ready for ``local_feature_cloud``.
+
+Host readers with the reference's return types (structured / plain numpy arrays), for tools that want arrays:
 
 * KITTI-360 Velodyne ``.bin``: float32 ``[N,4]`` (x, y, z, intensity) with the ego-vehicle box removed
   (datasets/kitti360.py:96-109);
@@ -17,7 +23,8 @@ import numpy as np
 from numpy.lib.recfunctions import unstructured_to_structured
 
 __all__ = ['read_kitti_bin', 'read_points_csv', 'read_points_npz', 'read_poses_csv', 'write_poses_csv',
-           'ScanFolderDataset']
+           'ScanFolderDataset', 'upload', 'cloud_on_device', 'load_kitti_bin_device', 'load_points_csv_device',
+           'load_points_npz_device', 'DeviceScanDataset']
 
 
 def read_kitti_bin(path, filter_ego_pts_depth=1.0):
@@ -84,3 +91,74 @@ class ScanFolderDataset(object):
 
     def __str__(self):
         return self.name
+
+
+# ---- direct-to-device loaders ---------------------------------------------------------------------------------------
+def upload(array, device='cuda:0'):
+    """Host array -> device tensor through a pinned staging buffer (asynchronous copy on torch's current stream)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    if torch.device(device).type != 'cuda':
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def cloud_on_device(raw, vps=None, dtype=None, device='cuda:0', ego_box=None, min_depth=None, max_depth=None):
+    """Uploaded raw rows -> DepthCloud on the device in one kernel pass: ego-box crop (kitti360.py:101-105), depth
+    pre-filter (filters.py:116-141), from_points (depth_cloud.py:592-638).  ``raw`` [N, >=3] float32 / float64 (host or
+    device), ``vps`` [N,3] or None; ``dtype`` numpy / torch float type of the cloud (default: the raw dtype)."""
+    import torch
+    from . import ops
+    from .depth_cloud import DepthCloud
+    if isinstance(dtype, type) or isinstance(dtype, np.dtype):
+        dtype = getattr(torch, np.dtype(dtype).name)
+    raw_t = raw if isinstance(raw, torch.Tensor) else upload(raw, device)
+    if vps is not None:
+        vps = (vps if isinstance(vps, torch.Tensor) else upload(vps, device)).to(raw_t.dtype).contiguous()
+    v, dirs, depth, _ = ops.cloud_from_points(raw_t.contiguous(), vps, dtype=dtype, ego_box=ego_box, min_depth=min_depth,
+                                              max_depth=max_depth)
+    return DepthCloud(torch.zeros_like(dirs) if v is None else v, dirs, depth)
+
+
+def load_kitti_bin_device(path, device='cuda:0', dtype=None, filter_ego_pts_depth=1.0, min_depth=None, max_depth=None):
+    """KITTI-360 Velodyne scan (float32 [N,4]) straight to a DepthCloud on the device."""
+    raw = np.fromfile(path, dtype=np.float32).reshape((-1, 4))
+    return cloud_on_device(raw, dtype=dtype, device=device, ego_box=filter_ego_pts_depth, min_depth=min_depth, max_depth=max_depth)
+
+
+def load_points_csv_device(path, device='cuda:0', dtype=None, min_depth=None, max_depth=None):
+    """ASL-laser point CSV (header line; id, x, y, z, ...) to a DepthCloud on the device."""
+    return cloud_on_device(read_points_csv(path), dtype=dtype, device=device, min_depth=min_depth, max_depth=max_depth)
+
+
+def load_points_npz_device(path, device='cuda:0', dtype=None, min_depth=None, max_depth=None):
+    """``.npz`` scans: plain [N,3+] arrays (asl_laser.py:40-45) or structured arrays with x, y, z [, vp_x, vp_y, vp_z]
+    (fee_corridor.py:35-38) to a DepthCloud on the device."""
+    from numpy.lib.recfunctions import structured_to_unstructured
+    arr = read_points_npz(path)
+    vps = None
+    if arr.dtype.names:
+        if 'vp_x' in arr.dtype.names:
+            vps = structured_to_unstructured(arr[['vp_x', 'vp_y', 'vp_z']])
+        arr = structured_to_unstructured(arr[['x', 'y', 'z']])
+    if arr.dtype not in (np.float32, np.float64):
+        arr = arr.astype(np.float64)
+    return cloud_on_device(arr, vps=None if vps is None else vps.astype(arr.dtype), dtype=dtype, device=device,
+                           min_depth=min_depth, max_depth=max_depth)
+
+
+class DeviceScanDataset(ScanFolderDataset):
+    """ScanFolderDataset whose items are DepthClouds already on the device (``local_feature_cloud`` accepts them as they
+    are), with the configuration's depth pre-filter fused into the load."""
+
+    def __init__(self, cloud_dir, poses_csv, pattern='%010d.bin', name=None, device='cuda:0', dtype=None, min_depth=None,
+                 max_depth=None):
+        super().__init__(cloud_dir, poses_csv, pattern=pattern, name=name)
+        self.device, self.dtype, self.min_depth, self.max_depth = device, dtype, min_depth, max_depth
+
+    def local_cloud(self, i):
+        path = os.path.join(self.cloud_dir, self.pattern % i)
+        kw = dict(device=self.device, dtype=self.dtype, min_depth=self.min_depth, max_depth=self.max_depth)
+        if path.endswith('.bin'):
+            return load_kitti_bin_device(path, **kw)
+        return load_points_csv_device(path, **kw) if path.endswith('.csv') else load_points_npz_device(path, **kw)

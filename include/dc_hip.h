@@ -323,6 +323,22 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
                     int preserve_order, int32_t* out_idx, int32_t* count_out, int32_t* status_out, void* ws, size_t ws_bytes,
                     dcStream_t stream);
 
+/* ---- scan files -> DepthCloud source fields on the device ------------------------------------------
+ * points: the uploaded raw rows [n, stride] (stride >= 3; KITTI-360 .bin: float32 [n,4] x,y,z,intensity,
+ * datasets/kitti360.py:96-99; ASL / FEE-corridor arrays: [n,3]); vps [n,3] in the same dtype or NULL (sensor origin).
+ * One flag kernel + a stable compaction apply, in the reference's order,
+ *   the ego-vehicle crop  keep = x < -d | x > d | y < -d | y > d   (kitti360.py:101-105; ego_box <= 0: off),
+ *   the depth pre-filter  min_depth <= |p - vp| <= max_depth in the raw dtype (filters.filter_depth filters.py:116-141;
+ *                         NaN / -inf / +inf: unbounded),
+ *   DepthCloud.from_points depth_cloud.py:592-638 in out_dtype: depth = |p - vp|, dirs = (p - vp) / depth, rays of zero
+ *                         depth left un-normalised (:626-627),
+ * and write dirs_out [m,3], depth_out [m], vps_out [m,3] (optional), index_out int32 [m] = kept source rows (optional),
+ * *count_out = m (device int64).  Outputs must hold n rows.  ws: dc_cloud_from_points_workspace_bytes(n). */
+size_t dc_cloud_from_points_workspace_bytes(int64_t n);
+int dc_cloud_from_points(const void* points, int stride, int in_dtype, const void* vps, int64_t n, double ego_box,
+                         double min_depth, double max_depth, int out_dtype, void* dirs_out, void* depth_out, void* vps_out,
+                         int32_t* index_out, int64_t* count_out, void* ws, size_t ws_bytes, dcStream_t stream);
+
 /* Tuning / ablation switches (process-wide atomics, read once per launch; results are identical either way).
  * option 0: value 1 makes the fused kernels ignore block tables and gather from global memory.
  * option 1: value 1 makes dc_consistency_fwd use the run-time slot loop instead of the kernels specialised for

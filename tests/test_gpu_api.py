@@ -565,3 +565,88 @@ def test_trainer_with_two_sequences_on_one_gpu(golden):
     np.testing.assert_allclose(acc[:4], singles[0][:4] + singles[1][:4], rtol=1e-13)
     assert tr.count == float(mask.sum() + mask2.sum()) and acc[1] == tr.count
     assert not np.allclose(npy(tr.w), g['w'].reshape(-1))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_device_scan_loaders_match_host_pipeline(tmp_path, dtype):
+    """Direct-to-device loaders: KITTI-360 .bin with the ego-box crop, ASL CSV, plain and structured .npz --
+    one kernel pass (dc_cloud_from_points: crop + depth pre-filter + from_points) against the reference's host pipeline
+    on the same synthetic files: numpy reader -> filter_depth on the array (filters.py:116-141) -> from_points
+    (depth_cloud.py:592-638).  Kept rows and their order identical; depth / dirs to the last ulp of the sqrt / division."""
+    from numpy.lib.recfunctions import unstructured_to_structured
+    from depth_correction_amd.scan_io import (DeviceScanDataset, load_kitti_bin_device, load_points_csv_device,
+                                              load_points_npz_device, read_kitti_bin, read_points_csv, write_poses_csv)
+    rng = np.random.default_rng(3)
+    n = 5000
+    raw = (rng.normal(size=(n, 4)) * [8, 8, 1.5, 1]).astype(np.float32)
+    raw[:50, :2] = rng.uniform(-0.95, 0.95, size=(50, 2))                 # inside the ego box
+    raw[50] = 0.0                                                          # a zero-depth ray
+    d = tmp_path / 'velodyne'
+    d.mkdir()
+    raw.tofile(str(d / ('%010d.bin' % 3)))
+    tol = dict(rtol=3e-7, atol=0) if dtype == np.float32 else dict(rtol=1e-15, atol=0)
+
+    def host_cloud(xyz, vps, lo, hi):
+        xyz, vps = np.asarray(xyz), (np.zeros_like(xyz) if vps is None else np.asarray(vps))
+        depth_raw = np.sqrt(((xyz - vps) ** 2).sum(-1, dtype=xyz.dtype))
+        keep = np.ones(len(xyz), bool)
+        if lo is not None:
+            keep &= depth_raw >= xyz.dtype.type(lo)
+        if hi is not None:
+            keep &= depth_raw <= xyz.dtype.type(hi)
+        rays = xyz[keep].astype(dtype) - vps[keep].astype(dtype)
+        depth = np.sqrt((rays ** 2).sum(-1))[:, None]
+        with np.errstate(invalid='ignore', divide='ignore'):
+            dirs = np.where(depth > 0, rays / depth, rays)
+        return keep, vps[keep].astype(dtype), dirs, depth
+
+    def check(dc, keep, vps, dirs, depth):
+        assert len(dc) == int(keep.sum()) and dc.dirs.is_cuda and dc.dirs.dtype == getattr(torch, np.dtype(dtype).name)
+        np.testing.assert_allclose(npy(dc.depth), depth, **tol)
+        np.testing.assert_allclose(npy(dc.dirs), dirs, atol=3e-7 if dtype == np.float32 else 1e-15, rtol=0)
+        np.testing.assert_array_equal(npy(dc.vps), vps)
+
+    # KITTI .bin: ego crop (reader) then depth bounds
+    host = read_kitti_bin(str(d / ('%010d.bin' % 3)))
+    xyz = np.stack([host[f] for f in 'xyz'], 1)
+    for lo, hi in ((None, None), (2.0, 15.0)):
+        keep, vps, dirs, depth = host_cloud(xyz, None, lo, hi)
+        dc = load_kitti_bin_device(str(d / ('%010d.bin' % 3)), dtype=dtype, min_depth=lo, max_depth=hi)
+        check(dc, keep, vps, dirs, depth)
+    assert len(load_kitti_bin_device(str(d / ('%010d.bin' % 3)), filter_ego_pts_depth=None)) == n
+    # ASL CSV
+    csv = tmp_path / 'scan.csv'
+    np.savetxt(str(csv), np.concatenate([np.arange(300)[:, None], raw[100:400, :3].astype(np.float64), np.ones((300, 2))], 1),
+               delimiter=',', header='id,x,y,z,a,b')
+    keep, vps, dirs, depth = host_cloud(read_points_csv(str(csv)), None, 1.0, None)
+    check(load_points_csv_device(str(csv), dtype=dtype, min_depth=1.0), keep, vps, dirs, depth)
+    # FEE-corridor style structured .npz with viewpoints
+    vp = (rng.normal(size=(n, 3)) * 0.05).astype(np.float32)
+    np.savez(str(tmp_path / 'c.npz'), cloud=unstructured_to_structured(np.concatenate([raw[:, :3], vp], 1),
+                                                                      names=['x', 'y', 'z', 'vp_x', 'vp_y', 'vp_z']))
+    keep, vps, dirs, depth = host_cloud(raw[:, :3], vp, None, 12.0)
+    check(load_points_npz_device(str(tmp_path / 'c.npz'), dtype=dtype, max_depth=12.0), keep, vps, dirs, depth)
+    # the dataset wrapper feeds local_feature_cloud / train() with device clouds
+    write_poses_csv([3], [np.eye(4)], str(tmp_path / 'poses.csv'))
+    ds = DeviceScanDataset(str(d), str(tmp_path / 'poses.csv'), dtype=dtype, min_depth=2.0, max_depth=15.0)
+    cloud, pose = ds[0]
+    keep, _, _, depth = host_cloud(xyz, None, 2.0, 15.0)
+    assert len(cloud) == int(keep.sum()) and np.allclose(pose, np.eye(4))
+
+
+def test_from_points_device_kernel_matches_torch_expressions(golden):
+    """DepthCloud.from_points on device tensors (one kernel) equals the reference's tensor expressions."""
+    from depth_correction_amd.depth_cloud import DepthCloud
+    g = golden('room_k10')
+    for dt in (torch.float64, torch.float32):
+        pts = t(g['scan0_xyz'], 'cuda:0').to(dt)
+        vps = torch.randn_like(pts) * 0.01
+        dc = DepthCloud.from_points(pts, vps=vps)
+        rays = pts - vps
+        depth = rays.norm(dim=-1, keepdim=True)
+        tol = 1e-15 if dt == torch.float64 else 3e-7
+        np.testing.assert_allclose(npy(dc.depth), npy(depth), rtol=tol)
+        np.testing.assert_allclose(npy(dc.dirs), npy(rays / depth), atol=tol, rtol=0)
+        assert torch.equal(dc.vps, vps)
+        dc32 = DepthCloud.from_points(npy(pts), dtype=np.float32, device='cuda:0')
+        assert dc32.dirs.dtype == torch.float32 and dc32.dirs.is_cuda
