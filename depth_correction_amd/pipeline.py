@@ -85,20 +85,47 @@ def global_mask(local_mask, points, vps, dirs, nbr, min_valid_neighbors=5, eigen
     return mask
 
 
+class _Stages(object):
+    """Wall-clock stage timer of the set-up phase (synchronises the device at every mark; only when asked for)."""
+
+    def __init__(self, on, device):
+        import time
+        self.on, self.device, self.t, self.out, self._time = on, device, None, {}, time
+        if on:
+            torch.cuda.synchronize(device)
+            self.t = time.perf_counter()
+
+    def mark(self, name):
+        if self.on:
+            torch.cuda.synchronize(self.device)
+            now = self._time.perf_counter()
+            self.out[name] = self.out.get(name, 0.0) + (now - self.t) * 1e3
+            self.t = now
+
+
 def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='cuda:0', min_valid_neighbors=5,
                    eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, vp_dispersion_bounds=None, model_kind='ScaledPolynomial',
                    loss='min_eigval_loss', normalization=True, sqrt=False, spatial_sort=True, point_format='auto',
-                   active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs'):
-    """Everything train.py does before its loop for one sequence; returns (plan, info)."""
+                   active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs', stage_times=False):
+    """Everything train.py does before its loop for one sequence; returns (plan, info).  ``stage_times``: info['setup_ms']
+    = wall-clock milliseconds per stage (device synchronised between stages)."""
+    st = _Stages(stage_times, device)
+    uploaded = [torch.as_tensor(np.ascontiguousarray(xyz) if isinstance(xyz, np.ndarray) else xyz, device=device) for xyz in scans_xyz]
+    st.mark('upload')
     clouds = [local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype, device=device)
-              for xyz in scans_xyz]
+              for xyz in uploaded]
+    st.mark('local_feature_clouds')
     poses_t = torch.as_tensor(np.asarray(poses), dtype=torch.float64, device=device)
     x0, vps0, dirs0, _ = global_cloud_arrays(clouds, poses_t)
+    st.mark('global_cloud')
     nbr = global_neighborhoods(x0, k=k, r=r)
+    st.mark('global_neighborhoods')
     lmask = torch.cat([c['mask'] for c in clouds])
     mask = global_mask(lmask, x0, vps0, dirs0, nbr, min_valid_neighbors=min_valid_neighbors,
                        eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, vp_dispersion_bounds=vp_dispersion_bounds)
+    st.mark('global_mask')
     plan = SequencePlan(clouds, poses_t, nbr, mask, model_kind=model_kind, loss=loss, normalization=normalization,
                         sqrt=sqrt, spatial_sort=spatial_sort, point_format=point_format, active_only=active_only,
-                        degree_sort=degree_sort, block_tables=block_tables, bwd_layout=bwd_layout)
-    return plan, dict(clouds=clouds, poses=poses_t, neighbors=nbr, mask=mask, points0=x0)
+                        degree_sort=degree_sort, block_tables=block_tables, bwd_layout=bwd_layout, stages=st)
+    st.mark('plan_other')
+    return plan, dict(clouds=clouds, poses=poses_t, neighbors=nbr, mask=mask, points0=x0, setup_ms=st.out)

@@ -34,7 +34,7 @@ class SequencePlan:
     @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
-                 active_only=False, block_tables=True, bwd_layout='runs'):
+                 active_only=False, block_tables=True, bwd_layout='runs', stages=None):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -46,6 +46,7 @@ class SequencePlan:
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
                             the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
+        mark = stages.mark if stages is not None else (lambda name: None)
         get = (lambda c, f: c[f]) if isinstance(clouds[0], dict) else getattr
         vps = torch.cat([get(c, 'vps') for c in clouds]).contiguous()
         dirs = torch.cat([get(c, 'dirs') for c in clouds]).contiguous()
@@ -68,11 +69,14 @@ class SequencePlan:
             need(mask, (self.n,), dtype=torch.bool, name='mask', device=dev)
 
         # ---- layout: Morton order of the initial global cloud ----------------------------------
+        mark('plan_concat')
         ps0 = ops.PointSet(vps if bool(vps.any()) else None, dirs, depth, inc, lmask, scan_id)
         P0 = self.poses12(poses)
         x0 = ops.points_fwd(ps0, P0)
+        mark('plan_points0')
         if spatial_sort and self.n > 1:
             order = ops.spatial_order(x0).long()
+            mark('plan_morton_order')
             if degree_sort:
                 # inside every block of 256 Morton-consecutive points, order by in-degree: the lanes of a wavefront of
                 # the backward then walk incoming-edge lists of similar length (same cache lines per block as before)
@@ -94,6 +98,7 @@ class SequencePlan:
             scan_id = scan_id[order].contiguous()
             mask = None if mask is None else mask[order].contiguous()
             self.order, self.rank = order, rank
+            mark('plan_permute')
         else:
             self.order = self.rank = None
         if not bool(vps.any()):
@@ -107,10 +112,12 @@ class SequencePlan:
             mask = None
         self.nbr, self.mask = nbr, mask
         self.csr_ptr, self.csr_src = ops.knn_transpose(nbr, n_dst=self.n)
+        mark('plan_transpose')
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
         # block tables: distinct rows per 256-point block + 16-bit block-local positions (gathers served from LDS)
         self.fwd_table = ops.block_table(nbr=nbr) if block_tables else None
         self.bwd_table = ops.block_table(csr=(self.csr_ptr, self.csr_src), layout=bwd_layout) if block_tables else None
+        mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
         # ---- internal point format -------------------------------------------------------------------
