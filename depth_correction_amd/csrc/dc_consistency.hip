@@ -882,17 +882,35 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
 // Sum the block partials [n_acc][n_rows] in a fixed order into out[n_acc]: one 1024-lane block per accumulator,
 // contiguous (coalesced) reads.
 constexpr int kRedBlock = 1024;
+// Sum of p[threadIdx.x], p[threadIdx.x + 1024], ... in a fixed order with 16 loads in flight per lane: the rows were
+// written by blocks on every XCD, so each read is a trip to the fabric, and with four in flight the ~31 rows per lane
+// (N = 2 M) took eight dependent round trips.
+__device__ __forceinline__ double strided_sum(const double* __restrict__ p, int64_t n_rows) {
+  constexpr int U = 16;
+  double acc[U];
+#pragma unroll
+  for (int u_ = 0; u_ < U; ++u_) acc[u_] = 0.0;
+  int64_t r = threadIdx.x;
+  for (; r + (U - 1) * kRedBlock < n_rows; r += U * kRedBlock) {
+#pragma unroll
+    for (int u_ = 0; u_ < U; ++u_) acc[u_] += p[r + u_ * kRedBlock];
+  }
+#pragma unroll
+  for (int u_ = 0; u_ < U; ++u_) {
+    if (r + u_ * kRedBlock < n_rows) acc[u_] += p[r + u_ * kRedBlock];
+  }
+#pragma unroll
+  for (int w = U / 2; w > 0; w >>= 1) {
+#pragma unroll
+    for (int u_ = 0; u_ < w; ++u_) acc[u_] += acc[u_ + w];
+  }
+  return acc[0];
+}
 __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double* __restrict__ partials, int64_t n_rows,
                                                                     double* __restrict__ out) {
   __shared__ double lds[kRedBlock / kWave];
   const double* p = partials + (int64_t)blockIdx.x * n_rows;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int64_t r = threadIdx.x;
-  for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {
-    s0 += p[r]; s1 += p[r + kRedBlock]; s2 += p[r + 2 * kRedBlock]; s3 += p[r + 3 * kRedBlock];
-  }
-  for (; r < n_rows; r += kRedBlock) s0 += p[r];
-  double s = wave_sum((s0 + s1) + (s2 + s3));
+  const double s = wave_sum(strided_sum(p, n_rows));
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) lds[wave] = s;
   __syncthreads();
@@ -934,13 +952,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __
   }
   const int64_t n_rows = a < 2 ? rows_fwd : rows_bwd;
   const double* p = (a < 2 ? p_fwd + (int64_t)a * rows_fwd : p_bwd + (int64_t)(a - 2) * rows_bwd);
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int64_t r = threadIdx.x;
-  for (; r + 3 * kRedBlock < n_rows; r += 4 * kRedBlock) {
-    s0 += p[r]; s1 += p[r + kRedBlock]; s2 += p[r + 2 * kRedBlock]; s3 += p[r + 3 * kRedBlock];
-  }
-  for (; r < n_rows; r += kRedBlock) s0 += p[r];
-  double s = wave_sum((s0 + s1) + (s2 + s3));
+  const double s = wave_sum(strided_sum(p, n_rows));
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) lds[wave] = s;
   __syncthreads();

@@ -39,7 +39,9 @@ class BaseModel(torch.nn.Module):
             out.depth = fun(dc.depth, dc.inc_angles)
         else:
             depth = dc.depth.clone()
-            depth[mask] = fun(dc.depth[mask], dc.inc_angles[mask])
+            # float32 clouds with the (always float64) weights: the reference's index_put raises on the dtype mismatch here;
+            # the corrected depths are rounded to the cloud's dtype instead
+            depth[mask] = fun(dc.depth[mask], dc.inc_angles[mask]).to(depth.dtype)
             out.depth = depth
         return out
 
