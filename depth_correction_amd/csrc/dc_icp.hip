@@ -298,3 +298,136 @@ int dc_p2point_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pa
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Pose-correction chain of the joint model + pose optimisation (eval.create_corrected_poses eval.py:68-82):
+//   T_s = T0_s * [ Exp(axis-angle_s) | xyz_s ]      (transform.xyz_axis_angle_to_matrix transform.py:68-78, rotation by
+//   pytorch3d's axis_angle_to_matrix: axis-angle -> quaternion with the small-angle series -> matrix)
+// and its backward dL/d(xyz, axis-angle) from dL/dT.  As torch ops this is ~50 tiny kernels forward and as many backward
+// per iteration (the largest host-side cost of a config-4 training iteration); here it is one launch each way.
+// One 6-vector per pose (PoseCorrection.pose) or one shared by all poses (common / sequence: its gradient is the sum).
+// The backward is the adjoint of the forward operation by operation, including the conventions autograd applies to it:
+// the norm's subgradient at zero is zero, and of the two branches of the small-angle switch only the taken one
+// receives a gradient.
+// ================================================================================================
+namespace dc {
+
+struct PoseChain {
+  double q[4], s, k, theta;
+  bool small;
+};
+
+__device__ __forceinline__ void pose_chain_fwd(const double* d6, double* R, PoseChain& c) {
+  const double a0 = d6[3], a1 = d6[4], a2 = d6[5];
+  c.theta = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  c.small = fabs(c.theta) < 1e-6;
+  c.k = c.small ? 0.5 - c.theta * c.theta / 48.0 : sin(0.5 * c.theta) / c.theta;
+  c.q[0] = cos(0.5 * c.theta); c.q[1] = a0 * c.k; c.q[2] = a1 * c.k; c.q[3] = a2 * c.k;
+  const double r = c.q[0], i = c.q[1], j = c.q[2], k = c.q[3];
+  c.s = 2.0 / (r * r + i * i + j * j + k * k);
+  const double s = c.s;
+  R[0] = 1.0 - s * (j * j + k * k); R[1] = s * (i * j - k * r); R[2] = s * (i * k + j * r);
+  R[3] = s * (i * j + k * r); R[4] = 1.0 - s * (i * i + k * k); R[5] = s * (j * k - i * r);
+  R[6] = s * (i * k - j * r); R[7] = s * (j * k + i * r); R[8] = 1.0 - s * (i * i + j * j);
+}
+
+// gR = dL/dR (row major 3x3) -> g6[3..5] += dL/d(axis-angle)
+__device__ __forceinline__ void pose_chain_bwd(const double* d6, const PoseChain& c, const double* gR, double* g_aa) {
+  const double r = c.q[0], i = c.q[1], j = c.q[2], k = c.q[3], s = c.s;
+  double ds = 0.0, dr = 0.0, di = 0.0, dj = 0.0, dk = 0.0;
+  ds += -(j * j + k * k) * gR[0]; dj += -2.0 * s * j * gR[0]; dk += -2.0 * s * k * gR[0];
+  ds += (i * j - k * r) * gR[1]; di += s * j * gR[1]; dj += s * i * gR[1]; dk += -s * r * gR[1]; dr += -s * k * gR[1];
+  ds += (i * k + j * r) * gR[2]; di += s * k * gR[2]; dk += s * i * gR[2]; dj += s * r * gR[2]; dr += s * j * gR[2];
+  ds += (i * j + k * r) * gR[3]; di += s * j * gR[3]; dj += s * i * gR[3]; dk += s * r * gR[3]; dr += s * k * gR[3];
+  ds += -(i * i + k * k) * gR[4]; di += -2.0 * s * i * gR[4]; dk += -2.0 * s * k * gR[4];
+  ds += (j * k - i * r) * gR[5]; dj += s * k * gR[5]; dk += s * j * gR[5]; di += -s * r * gR[5]; dr += -s * i * gR[5];
+  ds += (i * k - j * r) * gR[6]; di += s * k * gR[6]; dk += s * i * gR[6]; dj += -s * r * gR[6]; dr += -s * j * gR[6];
+  ds += (j * k + i * r) * gR[7]; dj += s * k * gR[7]; dk += s * j * gR[7]; di += s * r * gR[7]; dr += s * i * gR[7];
+  ds += -(i * i + j * j) * gR[8]; di += -2.0 * s * i * gR[8]; dj += -2.0 * s * j * gR[8];
+  const double dn = -0.5 * s * s * ds;                       // s = 2 / n
+  dr += 2.0 * r * dn; di += 2.0 * i * dn; dj += 2.0 * j * dn; dk += 2.0 * k * dn;
+  const double a0 = d6[3], a1 = d6[4], a2 = d6[5];
+  const double dkk = a0 * di + a1 * dj + a2 * dk;            // through q_vec = a * k
+  double dtheta = -0.5 * sin(0.5 * c.theta) * dr;            // through q0 = cos(theta / 2)
+  dtheta += c.small ? -(c.theta / 24.0) * dkk
+                    : (0.5 * cos(0.5 * c.theta) / c.theta - sin(0.5 * c.theta) / (c.theta * c.theta)) * dkk;
+  const double inv = c.theta > 0.0 ? 1.0 / c.theta : 0.0;     // d|a|/da = a / |a|, zero at the origin
+  g_aa[0] = c.k * di + a0 * inv * dtheta;
+  g_aa[1] = c.k * dj + a1 * inv * dtheta;
+  g_aa[2] = c.k * dk + a2 * inv * dtheta;
+}
+
+// One block; thread t handles poses t, t + 256, ...  Forward (grad_T == nullptr): T_out.  Backward: grad_delta.
+__global__ __launch_bounds__(kBlock) void pose_correct_kernel(const double* __restrict__ T0, const double* __restrict__ delta,
+                                                              int n_poses, int n_delta, double* __restrict__ T_out,
+                                                              const double* __restrict__ grad_T, double* __restrict__ grad_delta) {
+  __shared__ double lds[(kBlock / kWave) * 6];
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int p = threadIdx.x; p < n_poses; p += kBlock) {
+    const double* d6 = delta + (n_delta == 1 ? 0 : (int64_t)p * 6);
+    const double* A = T0 + (int64_t)p * 16;
+    double R[9];
+    PoseChain c;
+    pose_chain_fwd(d6, R, c);
+    if (!grad_T) {
+      double* o = T_out + (int64_t)p * 16;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {                            // every row of T0, also the last: T = T0 X in full
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[a * 4 + b] = A[a * 4] * R[b] + A[a * 4 + 1] * R[3 + b] + A[a * 4 + 2] * R[6 + b];
+        o[a * 4 + 3] = A[a * 4] * d6[0] + A[a * 4 + 1] * d6[1] + A[a * 4 + 2] * d6[2] + A[a * 4 + 3];
+      }
+    } else {
+      const double* G = grad_T + (int64_t)p * 16;
+      double gR[9], g6[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {                            // dL/dX = T0^T G restricted to X's free entries
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gR[a * 3 + b] = A[a] * G[b] + A[4 + a] * G[4 + b] + A[8 + a] * G[8 + b] + A[12 + a] * G[12 + b];
+        g6[a] = A[a] * G[3] + A[4 + a] * G[7] + A[8 + a] * G[11] + A[12 + a] * G[15];
+      }
+      pose_chain_bwd(d6, c, gR, g6 + 3);
+      if (n_delta == 1) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[q] += g6[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) grad_delta[(int64_t)p * 6 + q] = g6[q];
+      }
+    }
+  }
+  if (grad_T && n_delta == 1) {
+    block_sum<6>(acc, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) grad_delta[q] = acc[q];
+    }
+  }
+}
+
+}  // namespace dc
+
+extern "C" {
+
+int dc_pose_correct_fwd(const double* poses, const double* deltas, int n_poses, int n_deltas, double* poses_out,
+                        hipStream_t stream) {
+  if (n_poses < 0 || (n_deltas != 1 && n_deltas != n_poses) || (n_poses > 0 && (!poses || !deltas || !poses_out))) return DC_ERR_ARG;
+  if (n_poses == 0) return DC_OK;
+  hipLaunchKernelGGL(dc::pose_correct_kernel, dim3(1), dim3(dc::kBlock), 0, stream, poses, deltas, n_poses, n_deltas, poses_out,
+                     (const double*)nullptr, (double*)nullptr);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, int n_deltas, const double* grad_poses,
+                        double* grad_deltas, hipStream_t stream) {
+  if (n_poses < 0 || (n_deltas != 1 && n_deltas != n_poses) || !grad_deltas || (n_poses > 0 && (!poses || !deltas || !grad_poses)))
+    return DC_ERR_ARG;
+  if (n_poses == 0) return (int)hipMemsetAsync(grad_deltas, 0, (size_t)n_deltas * 6 * sizeof(double), stream);
+  hipLaunchKernelGGL(dc::pose_correct_kernel, dim3(1), dim3(dc::kBlock), 0, stream, poses, deltas, n_poses, n_deltas,
+                     (double*)nullptr, grad_poses, grad_deltas);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+}  // extern "C"

@@ -15,7 +15,7 @@ from .depth_cloud import DepthCloud
 from .plan import PlanRegistry, SequencePlan, consistency_loss
 from .preproc import (compute_neighborhood_features, global_cloud, global_cloud_mask, local_feature_cloud,
                       offset_cloud)
-from .transform import xyz_axis_angle_to_matrix
+from .transform import corrected_poses, xyz_axis_angle_to_matrix
 
 __all__ = ['create_corrected_poses', 'eval_loss_clouds', 'initialize_pose_corrections', 'fused_supported',
            'PlanCloud']
@@ -45,7 +45,7 @@ def create_corrected_poses(poses, pose_deltas, cfg: Config):
     assert len(poses) == len(pose_deltas)
     if cfg.pose_correction == PoseCorrection.common:
         assert all(d is pose_deltas[0] for d in pose_deltas[1:])
-    return [torch.matmul(p, xyz_axis_angle_to_matrix(d)) for p, d in zip(poses, pose_deltas)]
+    return [corrected_poses(p, d) for p, d in zip(poses, pose_deltas)]
 
 
 def fused_supported(clouds, model, cfg: Config):

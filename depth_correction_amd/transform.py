@@ -1,12 +1,14 @@
 """Pose parametrisation used by the pose-correction path (transform.py:68-91): 6-vectors (translation + axis-angle)
 to 4x4 matrices.  ``axis_angle_to_matrix`` restates the published pytorch3d algorithm the reference imports
 (axis-angle -> quaternion with the small-angle series -> rotation matrix); it is differentiable at zero, which the
-optimisation needs because pose corrections start at zero (eval.py:53-59).  Tiny tensors: plain torch."""
+optimisation needs because pose corrections start at zero (eval.py:53-59).  Tiny tensors: plain torch -- except the
+composition ``poses @ xyz_axis_angle_to_matrix(deltas)`` of the training loop (eval.py:68-82), which on the GPU is ONE
+kernel forward and one backward (``corrected_poses``: dc_pose_correct_fwd / _bwd) instead of ~50 tensor ops each way."""
 from __future__ import annotations
 
 import torch
 
-__all__ = ['axis_angle_to_matrix', 'xyz_axis_angle_to_matrix', 'matrix_to_xyz_axis_angle']
+__all__ = ['axis_angle_to_matrix', 'xyz_axis_angle_to_matrix', 'matrix_to_xyz_axis_angle', 'corrected_poses']
 
 
 def axis_angle_to_matrix(axis_angle):
@@ -42,3 +44,41 @@ def matrix_to_xyz_axis_angle(T):
     sin = torch.sin(angle)
     scale = torch.where(sin.abs() < 1e-9, torch.full_like(sin, 0.5), angle / (2 * torch.where(sin.abs() < 1e-9, torch.ones_like(sin), sin)))
     return torch.cat([T[:, :3, 3], axis * scale[:, None]], dim=1)
+
+
+class _CorrectedPoses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, poses, deltas):
+        from ._native import lib, check, ptr, stream_ptr
+        n = poses.shape[0]
+        p64 = poses.detach().to(torch.float64).reshape(n, 16).contiguous()
+        d64 = deltas.detach().to(torch.float64).contiguous()
+        out = torch.empty_like(p64)
+        with torch.cuda.device(poses.device):
+            check(lib().dc_pose_correct_fwd(ptr(p64), ptr(d64), n, d64.shape[0], ptr(out), stream_ptr()), 'dc_pose_correct_fwd')
+        ctx.save_for_backward(p64, d64)
+        ctx.meta = (deltas.dtype, poses.dtype)
+        return out.reshape(n, 4, 4).to(poses.dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        from ._native import lib, check, ptr, stream_ptr
+        p64, d64 = ctx.saved_tensors
+        n = p64.shape[0]
+        g64 = grad.to(torch.float64).reshape(n, 16).contiguous()
+        gd = torch.empty_like(d64)
+        with torch.cuda.device(p64.device):
+            check(lib().dc_pose_correct_bwd(ptr(p64), ptr(d64), n, d64.shape[0], ptr(g64), ptr(gd), stream_ptr()),
+                  'dc_pose_correct_bwd')
+        return None, gd.to(ctx.meta[0])
+
+
+def corrected_poses(poses, deltas):
+    """``poses @ xyz_axis_angle_to_matrix(deltas)`` (eval.py:68-82) for poses [S,4,4] and corrections [S,6] or [1,6].
+
+    GPU tensors (poses constant, corrections possibly requiring grad): one fused kernel each way; anything else: the
+    tensor expressions."""
+    if (poses.is_cuda and deltas.is_cuda and poses.dim() == 3 and deltas.dim() == 2 and deltas.shape[0] in (1, poses.shape[0])
+            and not poses.requires_grad and poses.dtype in (torch.float32, torch.float64)):
+        return _CorrectedPoses.apply(poses, deltas)
+    return torch.matmul(poses, xyz_axis_angle_to_matrix(deltas))

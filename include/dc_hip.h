@@ -210,6 +210,18 @@ int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, dcS
 int dc_dispersion(const void* vec, int dtype, const int32_t* nbr, const void* weights, int64_t n, int k, void* out,
                   dcStream_t stream);
 
+/* ---- pose corrections: eval.create_corrected_poses eval.py:68-82 = T0_s * xyz_axis_angle_to_matrix(delta_s)
+ *      (transform.py:68-78; rotation by pytorch3d.transforms.axis_angle_to_matrix: axis-angle -> quaternion with the
+ *      small-angle series -> matrix) and its backward, one launch each instead of ~50 tensor ops each way.
+ * poses, poses_out, grad_poses: fp64 [n_poses, 16] row-major 4x4; deltas / grad_deltas: fp64 [n_deltas, 6] =
+ * (xyz, axis-angle) with n_deltas = n_poses (PoseCorrection.pose) or 1 (common / sequence: one correction applied to
+ * every pose, its gradient is the sum over the poses).  Conventions of the reference's autograd graph are kept: zero
+ * subgradient of the norm at a zero rotation, gradient only through the taken branch of the small-angle switch. */
+int dc_pose_correct_fwd(const double* poses, const double* deltas, int n_poses, int n_deltas, double* poses_out,
+                        dcStream_t stream);
+int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, int n_deltas, const double* grad_poses,
+                        double* grad_deltas, dcStream_t stream);
+
 /* Scan-shadow filter: filters.filter_shadow_points filters.py:257-309 on the direction neighbourhoods of
  * DepthCloud.update_dir_neighbors depth_cloud.py:217-224 (radius search on the unit directions: dc_radius_*).
  * mask_out[i] = 1 when the angles between (vps_i - x_i) and (x_j - x_i), j in dir_nbr[i, :], all lie in [lo, hi];

@@ -650,3 +650,37 @@ def test_from_points_device_kernel_matches_torch_expressions(golden):
         assert torch.equal(dc.vps, vps)
         dc32 = DepthCloud.from_points(npy(pts), dtype=np.float32, device='cuda:0')
         assert dc32.dirs.dtype == torch.float32 and dc32.dirs.is_cuda
+
+
+def test_fused_pose_correction_equals_tensor_chain():
+    """eval.create_corrected_poses' fused kernel pair (dc_pose_correct_fwd / _bwd) against the tensor expressions
+    poses @ xyz_axis_angle_to_matrix(deltas) and their autograd: per-pose and shared corrections, zero (the start of every
+    optimisation), below the small-angle switch, generic and large rotations."""
+    from depth_correction_amd.transform import corrected_poses, xyz_axis_angle_to_matrix
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(0)
+    n = 7
+    poses = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
+    poses[:, :3, :] = torch.randn((n, 3, 4), generator=g, dtype=torch.float64)
+    poses = poses.to(dev)
+    cases = {'zero': torch.zeros((n, 6), dtype=torch.float64),
+             'tiny': torch.randn((n, 6), generator=g, dtype=torch.float64) * 1e-8,
+             'generic': torch.randn((n, 6), generator=g, dtype=torch.float64) * 0.3,
+             'large': torch.randn((n, 6), generator=g, dtype=torch.float64) * 2.0,
+             'shared': torch.randn((1, 6), generator=g, dtype=torch.float64) * 0.1,
+             'shared_zero': torch.zeros((1, 6), dtype=torch.float64)}
+    up = torch.randn((n, 4, 4), generator=g, dtype=torch.float64).to(dev)
+    for name, d0 in cases.items():
+        da = d0.clone().to(dev).requires_grad_(True)
+        db = d0.clone().to(dev).requires_grad_(True)
+        Ta = corrected_poses(poses, da)
+        Tb = torch.matmul(poses, xyz_axis_angle_to_matrix(db))
+        torch.testing.assert_close(Ta, Tb, rtol=1e-13, atol=1e-14, msg=name)
+        (Ta * up).sum().backward()
+        (Tb * up).sum().backward()
+        torch.testing.assert_close(da.grad, db.grad, rtol=1e-11, atol=1e-13, msg=name)
+        assert torch.isfinite(da.grad).all()
+    # float32 poses / corrections keep their dtypes
+    T32 = corrected_poses(poses.float(), cases['generic'].float().to(dev))
+    assert T32.dtype == torch.float32
+    torch.testing.assert_close(T32.double(), torch.matmul(poses, xyz_axis_angle_to_matrix(cases['generic'].to(dev))), rtol=1e-5, atol=1e-5)
