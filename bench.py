@@ -54,6 +54,8 @@ def parse():
                     help='evaluate only masked points as neighbourhood centres (identical loss / gradients, see DESIGN.md)')
     ap.add_argument('--degree-sort', action='store_true', help='order points by in-degree inside 256-point blocks (ablation)')
     ap.add_argument('--autograd', action='store_true', help='drop-in loop: torch autograd + torch.optim.Adam')
+    ap.add_argument('--graph', action='store_true',
+                    help='with --autograd: capture the whole iteration (loss, backward, Adam) into one hipGraph and replay it')
     ap.add_argument('--timer-every', type=int, default=8,
                     help='HIP-event timing of every N-th launch of the hot kernels inside the timed region (0 = off)')
     ap.add_argument('--bwd-layout', default='runs', choices=['runs', 'slots'], help='backward block-table layout (ablation)')
@@ -291,7 +293,7 @@ def main():
         total_count = float(count.item())
         w = torch.nn.Parameter(torch.tensor([w0], dtype=torch.float64, device=dev))
         exponent = torch.tensor([e0], dtype=torch.float64, device=dev)
-        opt = torch.optim.Adam([w], lr=1e-3)
+        opt = torch.optim.Adam([w], lr=1e-3, capturable=bool(args.graph))
         packed = torch.zeros((1 + w.numel(),), dtype=torch.float64, device=dev)
 
         def step():
@@ -307,6 +309,25 @@ def main():
                 loss = packed[0]
             opt.step()
             return loss.detach()
+
+        if args.graph:
+            # the kernels are launched on torch's current stream through the C ABI, so torch.cuda.graph captures them like
+            # any torch op: one hipGraph launch per iteration, no Python and no per-kernel launches on the host
+            assert dist is None, '--graph is a single-GPU mode'
+            eager_step = step
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = eager_step()
+
+            def step():
+                graph.replay()
+                return static_loss
     else:
         # native loop: one host call per evaluation (dc_sequence_eval) + dc_adam_step; with several ranks the only
         # exchange of the path is one RCCL all-reduce of [sum loss, count, dL/dw] per step
@@ -392,7 +413,7 @@ def main():
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
-                       'loop': 'autograd+torch.optim.Adam' if args.autograd else 'native (dc_sequence_step)',
+                       'loop': ('autograd+torch.optim.Adam' + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
                        'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s,

@@ -33,4 +33,32 @@ for it in range(n + 20):
         acc[k] += d
 torch.cuda.synchronize()
 total = (time.perf_counter() - t_all) / n * 1e6
+if '--graph' in sys.argv:
+    # the whole iteration captured once into a hipGraph (torch.cuda.graph) and replayed: no Python, no launches on the host
+    w2 = torch.nn.Parameter(torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, device=dev))
+    opt2 = torch.optim.Adam([w2], lr=1e-3, capturable=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            opt2.zero_grad(set_to_none=True)
+            s, cnt = consistency_loss(plan, w2, e, P)
+            (s / cnt).backward()
+            opt2.step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt2.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        s, cnt = consistency_loss(plan, w2, e, P)
+        static_loss = s / cnt
+        static_loss.backward()
+        opt2.step()
+    torch.cuda.synchronize()
+    w_before = w2.detach().clone()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        graph.replay()
+    torch.cuda.synchronize()
+    print(json.dumps({'graph_replay_us_per_step': round((time.perf_counter() - t0) / n * 1e6, 1), 'loss': float(static_loss),
+                      'w_moved': float((w2.detach() - w_before).abs().max())}))
 print(json.dumps({'fused_adam': fused, 'us_per_step_wall': round(total, 1), 'host_us': {k: round(v / n * 1e6, 1) for k, v in acc.items()}}))
