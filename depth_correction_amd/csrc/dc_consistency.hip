@@ -943,7 +943,8 @@ __device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double gra
 // the stream).
 __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __restrict__ p_fwd, const double* __restrict__ p_bwd,
                                                                 int64_t rows_fwd, int64_t rows_bwd, int n_red,
-                                                                double* __restrict__ out, AdamArgs adam) {
+                                                                double* __restrict__ out, AdamArgs adam,
+                                                                const int32_t* __restrict__ status) {
   __shared__ double lds[kRedBlock / kWave];
   const int a = blockIdx.x;
   if (a >= 2 + n_red) {
@@ -959,6 +960,8 @@ __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv];
+    // points that did not fit the fixed-point extent (or were NaN) make the evaluation meaningless: say so in the loss
+    if (a == 0 && status && *status != 0) t = __longlong_as_double(0x7ff8000000000000ll);
     out[a] = t;
     if (adam.p && a >= 2 && a - 2 < adam.n) adam_update(adam, a - 2, t);
   }
@@ -1070,8 +1073,9 @@ static int check_model(int model_kind, int n_terms, const void* inc, const doubl
   return DC_OK;
 }
 
-static int make_qparams(int point_fmt, int dtype, int stride, const double* qparams, QParams* qp) {
+static int make_qparams(int point_fmt, int dtype, int stride, const double* qparams, QParams* qp, int32_t* flag = nullptr) {
   *qp = QParams{};
+  qp->flag = flag;
   if (point_fmt == DC_Q32) {
     if (!qparams || stride != 4 || dtype != DC_F32 || !(qparams[3] > 0.0)) return DC_ERR_ARG;
     qp->origin[0] = qparams[0]; qp->origin[1] = qparams[1]; qp->origin[2] = qparams[2];
@@ -1094,14 +1098,15 @@ static int make_qparams(int point_fmt, int dtype, int stride, const double* qpar
 int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                   const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
                   const double* w, const double* e, int64_t n, int dtype, int point_fmt, const double* qparams,
-                  int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, hipStream_t stream) {
+                  int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, int32_t* status,
+                  hipStream_t stream) {
   if (n == 0) return DC_OK;
   if (n < 0 || !dirs || !depth || !points_out || (out_stride != 3 && out_stride != 4)) return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
   int rc = check_model(model_kind, n_terms, inc, w, e);
   if (rc) return rc;
   QParams qp;
-  rc = make_qparams(point_fmt, dtype, out_stride, qparams, &qp);
+  rc = make_qparams(point_fmt, dtype, out_stride, qparams, &qp, status);
   if (rc) return rc;
   if (n == 0) return DC_OK;
   if (model_kind == DC_MODEL_NONE) n_terms = 0;
@@ -1389,7 +1394,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   const int stride = 4;
   int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                          d->n_terms, w, e, d->n, d->dtype, d->point_fmt, d->qparams, stride, d->x, nullptr, nullptr,
-                         nullptr, stream);
+                         nullptr, d->status, stream);
   if (rc) return rc;
   const int n_terms = d->model_kind == DC_MODEL_NONE ? 0 : d->n_terms;
   const int n_acc = 2 * n_terms + 12 * d->n_scans;
@@ -1411,7 +1416,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                               n_rows);
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
-                     n_red, out, adam);
+                     n_red, out, adam, (const int32_t*)d->status);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

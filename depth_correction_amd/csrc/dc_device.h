@@ -24,7 +24,8 @@ inline int64_t xcd_grid(int64_t n_logical) { return ((n_logical + kXcds - 1) / k
 // ---- xyz rows: element stride 3 (API tensors) or 4 (padded internal layout) ------------------------
 // Point formats: float, double, or q32 (fixed point, DC_Q32).  All loads return fp64 absolute coordinates.
 struct q32 { int32_t v; };
-struct QParams { double origin[3]; double scale; double inv_scale; };
+// flag (optional device int): set when a coordinate does not fit the fixed-point range (or is NaN); see quantize()
+struct QParams { double origin[3]; double scale; double inv_scale; int32_t* flag; };
 
 template <typename T> struct Scalar { typedef T type; };          // element type of derived float outputs
 template <> struct Scalar<q32> { typedef float type; };
@@ -61,9 +62,15 @@ template <> struct Row3<double, 4> {
     q[1] = make_double2(v[2], 0.0);
   }
 };
-__device__ __forceinline__ int32_t quantize(double x, double origin, double inv_scale) {
+// A coordinate outside the extent the format was sized for (poses moved far beyond the initial map) or a NaN cannot be
+// represented: it is stored saturated / as INT32_MIN so that nothing faults, and `flag` is raised -- the evaluation's
+// reduction turns the loss into NaN when it is (dc_sequence_eval), so the condition cannot pass unnoticed.
+__device__ __forceinline__ int32_t quantize(double x, double origin, double inv_scale, int32_t* flag = nullptr) {
   double q = rint((x - origin) * inv_scale);
-  q = q > 2147483520.0 ? 2147483520.0 : (q < -2147483520.0 ? -2147483520.0 : q);   // saturate, NaN -> below
+  if (!(fabs(q) <= 2147483520.0)) {                                                  // also true for NaN
+    if (flag) atomicOr(flag, 1);
+    q = q > 2147483520.0 ? 2147483520.0 : (q < -2147483520.0 ? -2147483520.0 : q);   // saturate, NaN -> below
+  }
   return (q == q) ? (int32_t)q : (int32_t)0x80000000;
 }
 template <> struct Row3<q32, 4> {
@@ -74,9 +81,9 @@ template <> struct Row3<q32, 4> {
     o[2] = qp.origin[2] + (double)v.z * qp.scale;
   }
   static __device__ __forceinline__ void store(q32* p, int64_t i, const double* v, const QParams& qp) {
-    reinterpret_cast<int4*>(p)[i] = make_int4(quantize(v[0], qp.origin[0], qp.inv_scale),
-                                              quantize(v[1], qp.origin[1], qp.inv_scale),
-                                              quantize(v[2], qp.origin[2], qp.inv_scale), 0);
+    reinterpret_cast<int4*>(p)[i] = make_int4(quantize(v[0], qp.origin[0], qp.inv_scale, qp.flag),
+                                              quantize(v[1], qp.origin[1], qp.inv_scale, qp.flag),
+                                              quantize(v[2], qp.origin[2], qp.inv_scale, qp.flag), 0);
   }
 };
 

@@ -242,6 +242,12 @@ class QFormat:
         self.scale = float(scale)
         self._c = (ctypes.c_double * 4)(*self.origin, self.scale)
 
+    # Resolution up to which 32-bit fixed point keeps neighbourhood eigenvalues within 1e-5 of the fp64 result when the
+    # surfaces are as smooth as a millimetre-noise lidar sees them (lambda0 ~ 1e-6 m^2): the rounding of K = 10 points
+    # perturbs lambda0 by about 0.2 * sqrt(lambda0) * scale, i.e. 1e-5 * lambda0 at scale = 5e-8 m (a map of ~50 m with
+    # the 4x pose margin).  Larger maps keep their points in fp64 instead (SequencePlan, point_format='auto').
+    MAX_AUTO_SCALE = 2.0 ** -24
+
     @staticmethod
     def for_extent(lo, hi, margin=4.0):
         """Power-of-two resolution covering `margin` x the half extent of the box [lo, hi] about its centre."""
@@ -267,9 +273,10 @@ def _check_points(points, qfmt, name='points'):
 
 
 @on_device
-def points_fwd(ps, poses=None, model_kind=None, w=None, e=None, stride=3, want_parts=False, qfmt=None, out=None):
+def points_fwd(ps, poses=None, model_kind=None, w=None, e=None, stride=3, want_parts=False, qfmt=None, out=None, status=None):
     """x = pose(vps) + model(depth) * pose(dirs); optionally also (vps', dirs', depth').
-    With ``qfmt`` the points are written as int32 fixed-point rows [N,4] (DC_Q32)."""
+    With ``qfmt`` the points are written as int32 fixed-point rows [N,4] (DC_Q32); ``status`` (int32 [1], optional)
+    then gets bit 0 set when a coordinate does not fit the format's extent or is NaN."""
     kind, nt, w, e = _model_args(model_kind, w, e, ps)
     poses, ns = _pose_args(poses, ps)
     if qfmt is not None:
@@ -285,7 +292,7 @@ def points_fwd(ps, poses=None, model_kind=None, w=None, e=None, stride=3, want_p
         else (None, None, None)
     check(lib().dc_points_fwd(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
                               ptr(poses), ns, kind, nt, ptr(w), ptr(e), ps.n, dtype_code(ps.dirs), fmt, qptr, stride,
-                              ptr(x), ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), stream_ptr()), 'dc_points_fwd')
+                              ptr(x), ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), ptr(status), stream_ptr()), 'dc_points_fwd')
     return (x,) + parts if want_parts else x
 
 

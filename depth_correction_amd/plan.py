@@ -122,12 +122,26 @@ class SequencePlan:
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
         # ---- internal point format -------------------------------------------------------------------
-        if point_format == 'auto':
-            point_format = 'q32' if self.dtype == torch.float32 else 'float'
+        # 'q32': 32-bit fixed point sized for `margin` x the extent of the initial map; 'float': the clouds' own dtype;
+        # 'f64': float32 clouds promoted to float64 (twice the traffic, no resolution limit); 'auto': q32 for float32
+        # clouds while its resolution keeps the 1e-5 parity bar (ops.QFormat.MAX_AUTO_SCALE), otherwise f64
         self.qfmt = None
-        if point_format == 'q32':
+        self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        if point_format in ('auto', 'q32') and self.dtype == torch.float32:
             lo, hi = x0.min(0).values.tolist(), x0.max(0).values.tolist()
-            self.qfmt = ops.QFormat.for_extent(lo, hi)
+            qfmt = ops.QFormat.for_extent(lo, hi)
+            if point_format == 'q32' or qfmt.scale <= ops.QFormat.MAX_AUTO_SCALE:
+                self.qfmt = qfmt
+            else:
+                point_format = 'f64'
+        elif point_format == 'q32':
+            raise TypeError('the q32 point format goes with float32 clouds')
+        if point_format == 'f64' and self.dtype == torch.float32:
+            ps = self.ps
+            up = lambda t: None if t is None else t.double()
+            self.ps = ops.PointSet(up(ps.vps), up(ps.dirs), up(ps.depth), up(ps.inc), ps.lmask, ps.scan_id)
+            self.dtype = torch.float64
+        self.point_format = 'q32' if self.qfmt is not None else ('f64' if self.dtype == torch.float64 else 'f32')
         pdt = torch.int32 if self.qfmt is not None else self.dtype
         self.x = torch.empty((self.n, 4), dtype=pdt, device=dev)
         self.rec = torch.empty((nbr.shape[0], 8), dtype=pdt, device=dev)
@@ -158,6 +172,7 @@ class SequencePlan:
             d.bwd_table = None if self.bwd_table is None else self.bwd_table.ref()
             d.centre_idx, d.n_centres = p(self.centre_idx), (0 if self.centre_idx is None else self.centre_idx.shape[0])
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
+            d.status = p(self.status)
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
             d.loss_kind, d.normalization, d.sqrt_ = nv.LOSS_KINDS[self.loss], int(self.normalization), int(self.sqrt)
@@ -219,7 +234,7 @@ class SequencePlan:
         self.w = None if w is None else w.detach().reshape(-1).to(torch.float64).contiguous()
         self.e = None if exponent is None else exponent.detach().reshape(-1).to(device=self.device, dtype=torch.float64).contiguous()
         kind = self.model_kind if self.w is not None else None
-        ops.points_fwd(self.ps, self.P, kind, self.w, self.e, stride=4, qfmt=self.qfmt, out=self.x)
+        ops.points_fwd(self.ps, self.P, kind, self.w, self.e, stride=4, qfmt=self.qfmt, out=self.x, status=self.status)
         if self.centre_idx is not None and (want_pointwise or want_eigvals):
             # per-point outputs for ALL points: the complete neighbour table, records into a scratch buffer
             out = ops.consistency_fwd(self.x, self.nbr_full, mask=self.mask_full, loss=self.loss,
@@ -241,6 +256,11 @@ class SequencePlan:
                                        want_exponent=want_exponent, want_pose=want_pose, partials=self.partials,
                                        qfmt=self.qfmt, lane_perm=self.lane_perm, table=self.bwd_table)
         return grads
+
+    def overflowed(self):
+        """True when an evaluation produced points outside the q32 format's extent (poses moved far from the initial
+        map) or NaN points; the losses of such evaluations are NaN.  Synchronises."""
+        return bool(self.status.item())
 
     def unpermute(self, t):
         """Per-point tensor in plan order -> the caller's scan-major order."""

@@ -82,11 +82,14 @@ int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32
  * point_fmt: format of points_out -- `dtype` itself, or DC_Q32 (dtype DC_F32, stride 4) with qparams = HOST
  * fp64 [4] {origin.xyz, scale}: fixed-point rows with uniform resolution `scale` (fp32 traffic, ~2^8 finer
  * than fp32 at the range limit; used for the internal buffers of the fused loss).
- * vps_out / dirs_out [n,3], depth_out [n] are optional (NULL). */
+ * vps_out / dirs_out [n,3], depth_out [n] are optional (NULL).
+ * status: device int32 or NULL; bit 0 is raised (never cleared) when a DC_Q32 coordinate does not fit the 32-bit range
+ * around `origin` or is NaN -- the row is then stored saturated, so no kernel faults, and the condition stays visible. */
 int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                   const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
                   const double* w, const double* e, int64_t n, int dtype, int point_fmt, const double* qparams,
-                  int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, dcStream_t stream);
+                  int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, int32_t* status,
+                  dcStream_t stream);
 
 /* Backward of dc_points_fwd for a given dL/dpoints: grads_out fp64 [2*n_terms + 12*n_scans] =
  * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count].
@@ -305,6 +308,8 @@ typedef struct dcSequenceDesc {
   int32_t model_kind, n_terms, loss_kind, normalization, sqrt_, reserved;
   const dcBlockTable* fwd_table;   /* block table of nbr, or NULL */
   const dcBlockTable* bwd_table;   /* block table of (csr_ptr, csr_src), or NULL */
+  int32_t* status;                 /* device int or NULL: bit 0 raised by dc_points_fwd when a DC_Q32 coordinate overflowed /
+                                      was NaN; while it is set the evaluation's loss (out[0]) is NaN */
 } dcSequenceDesc;
 
 /* out fp64 [2 + 2 P + 12 S] = {sum of pointwise loss over mask, mask count, d(sum)/dw, /dexponent, /d[R|t]};

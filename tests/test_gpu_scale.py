@@ -229,3 +229,96 @@ def test_c4_full_size_icp_loss_and_gradients_vs_oracle():
     np.testing.assert_allclose(npy(model.w.grad).ravel(), npy(w.grad).ravel(), rtol=1e-4, atol=1e-6 * np.abs(npy(w.grad)).max())
     ref = npy(pdo.grad)
     np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+
+
+def test_global_mask_and_incidence_angles_at_full_size_vs_oracle(room):
+    """The set-up outputs the per-iteration tests above take from the GPU, now against the oracle's OWN values at the C2
+    size (N = 2 M): local incidence angles and local planarity masks of all ten 200 k-point scans, and the global mask
+    (valid-neighbour count + eigenvalue-ratio bounds on the 2 M-point cloud, preproc.py:122-164).  fp32 device data vs
+    the fp64 oracle on the same fp32 inputs: a mask entry may differ only where an eigenvalue ratio lies within 1e-4
+    relative of a bound (the eigenvalues themselves agree to 1e-5)."""
+    from depth_correction_amd.pipeline import build_sequence, DEFAULT_RATIO_BOUNDS
+    scans, poses = room
+    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        def near_bound(ev):
+            near = np.zeros(len(ev), bool)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                for i, j, lo, hi in DEFAULT_RATIO_BOUNDS:
+                    r = ev[:, int(i)] / ev[:, int(j)]
+                    for b in (lo, hi):
+                        near |= np.abs(r - b) <= 1e-4 * max(abs(b), 1e-3)
+            return near
+
+        omasks = []
+        for c in info['clouds']:
+            x = (c['depth'].double() * c['dirs'].double()).cpu()                     # the same fp32 inputs, in fp64
+            nbr = c['neighbors'].long().cpu()                                         # bit-exact vs cKDTree (tests above)
+            f = O.features(x, nbr, c['dirs'].double().cpu())
+            np.testing.assert_allclose(npy(c['inc_angles']).ravel(), npy(f['inc_angles']).ravel(), rtol=0, atol=2e-4)
+            assert np.abs(npy(c['inc_angles']).ravel() - npy(f['inc_angles']).ravel()).mean() < 2e-6
+            m = npy(O.local_mask(f['eigvals'], None, DEFAULT_RATIO_BOUNDS))
+            diff = m != npy(c['mask'])
+            assert not np.any(diff & ~near_bound(npy(f['eigvals']))) and diff.mean() < 1e-3
+            omasks.append(torch.as_tensor(m))
+        x0 = info['points0'].double().cpu()
+        nbr = info['neighbors'].long().cpu()
+        f0 = O.features(x0, nbr, torch.cat([c['dirs'] for c in info['clouds']]).double().cpu())
+        om = npy(O.global_mask(torch.cat([c['mask'] for c in info['clouds']]).cpu(), nbr, f0['eigvals'], min_valid_neighbors=5,
+                               eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS))
+    finally:
+        torch.set_num_threads(threads)
+    gm = npy(info['mask'])
+    diff = gm != om
+    assert not np.any(diff & ~near_bound(npy(f0['eigvals']))), int((diff & ~near_bound(npy(f0['eigvals']))).sum())
+    assert diff.mean() < 1e-3 and 0.5 < gm.mean() < 0.95
+
+
+def test_q32_overflow_is_reported_and_large_maps_use_fp64():
+    """The fixed-point format is sized for 4x the extent of the initial map: an evaluation whose poses carry points beyond
+    it raises the plan's status flag and returns a NaN loss instead of silently saturated coordinates; point_format='auto'
+    leaves q32 for maps whose extent would push its resolution past the 1e-5 parity bar and keeps fp64 points, with which
+    a 600 m KITTI-360-shaped sequence matches the oracle."""
+    from depth_correction_amd.dataset import KittiLikeDataset
+    from depth_correction_amd.pipeline import build_sequence
+    dev = 'cuda:0'
+    ds = KittiLikeDataset(n_poses=4, n_rings=32, n_azimuth=1024)
+    scans = [np.stack([c[f] for f in 'xyz'], 1).astype(np.float32) for c, _ in ds]
+    poses = np.stack([p for _, p in ds])
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+
+    def evaluate(plan, T):
+        out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+        plan.eval_native(w, e, plan.poses12(torch.as_tensor(T, dtype=torch.float64, device=dev)), out)
+        return npy(out)
+
+    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32, point_format='q32')
+    assert plan.point_format == 'q32'
+    ok = evaluate(plan, poses)
+    assert np.isfinite(ok[0]) and not plan.overflowed()
+    far = poses.copy()
+    far[:, 0, 3] += 5000.0                                       # far outside 4x the map's extent
+    bad = evaluate(plan, far)
+    assert np.isnan(bad[0]) and plan.overflowed()
+
+    # the same scans spread over 600 m (poses 200 m apart): q32 would have a 5e-7 m grid -> auto keeps fp64 points
+    wide = poses.copy()
+    wide[:, 0, 3] = 200.0 * np.arange(len(wide))
+    plan2, info2 = build_sequence(scans, wide, k=10, dtype=torch.float32)
+    assert plan2.point_format == 'f64' and plan2.qfmt is None
+    o = evaluate(plan2, wide)
+    oc = [dict(vps=c['vps'].double().cpu(), dirs=c['dirs'].double().cpu(), depth=c['depth'].double().cpu(),
+               inc=c['inc_angles'].double().cpu(), mask=c['mask'].cpu()) for c in info2['clouds']]
+    wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)
+    lo, _ = O.eval_sequence(oc, torch.as_tensor(wide), wo, e.cpu().reshape(1, -1), info2['neighbors'].long().cpu(),
+                            info2['mask'].cpu(), reduction='sum')
+    lo.backward()
+    np.testing.assert_allclose(o[0], lo.item(), rtol=1e-5)
+    g = npy(wo.grad).ravel()
+    np.testing.assert_allclose(o[2:4], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
+    # and a compact map still takes q32
+    plan3, _ = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    assert plan3.point_format == ('q32' if plan3.qfmt is not None else 'f64')
