@@ -31,5 +31,9 @@
 #define DC_MODEL_NONE 0
 #define DC_MODEL_POLYNOMIAL 1
 #define DC_MODEL_SCALED_POLYNOMIAL 2
+#define DC_MODEL_LINEAR 3            /* w = [w0, w1, b]: d' = w0 d + w1 gamma + b   (model.py:113-146) */
+#define DC_MODEL_INVCOS 4            /* w = [p0]: d' = d - p0 / cos(gamma)          (model.py:289-313) */
+#define DC_MODEL_SCALED_INVCOS 5     /* w = [p0]: d' = d (1 - p0 / |cos(gamma)|)    (model.py:316-349) */
+#define DC_MODEL_LAST DC_MODEL_SCALED_INVCOS
 
 #define DC_MAX_MODEL_TERMS 8

@@ -185,7 +185,13 @@ __device__ __forceinline__ void points_bwd_point(const PointInputs& in, const Po
   const double rg2 = T12[2] * g[0] + T12[6] * g[1] + T12[10] * g[2];
   const double gd = dr[0] * rg0 + dr[1] * rg1 + dr[2] * rg2;
   double dcorr = d;
-  if (mp.kind != DC_MODEL_NONE && lm) {
+  if (mp.kind > DC_MODEL_SCALED_POLYNOMIAL && lm) {          // Linear / InvCos / ScaledInvCos: no exponents
+    const double inc = (double)raw.inc;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < mp.n_terms) gw[k] += gd * model_dw_other(mp, k, d, inc);
+    dcorr = model_depth(mp, d, inc, true);
+  } else if (mp.kind != DC_MODEL_NONE && lm) {
     const double inc = (double)raw.inc;
     const double base = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d * gd : -gd;
     double bias = 0.0;
@@ -1066,9 +1072,11 @@ static PointInputs make_inputs(const void* vps, const void* dirs, const void* de
 }
 
 static int check_model(int model_kind, int n_terms, const void* inc, const double* w, const double* e) {
-  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
+  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_LAST) return DC_ERR_ARG;
   if (model_kind != DC_MODEL_NONE) {
     if (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !inc || !w || !e) return DC_ERR_ARG;
+    if (model_kind == DC_MODEL_LINEAR && n_terms != 3) return DC_ERR_ARG;
+    if ((model_kind == DC_MODEL_INVCOS || model_kind == DC_MODEL_SCALED_INVCOS) && n_terms != 1) return DC_ERR_ARG;
   }
   return DC_OK;
 }

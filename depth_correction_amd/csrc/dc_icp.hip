@@ -53,7 +53,11 @@ __device__ __forceinline__ void scan_point_bwd(const ModelParams& mp, const doub
   const double rg1 = T12[1] * gx[0] + T12[5] * gx[1] + T12[9] * gx[2];
   const double rg2 = T12[2] * gx[0] + T12[6] * gx[1] + T12[10] * gx[2];
   const double gd = p.dr[0] * rg0 + p.dr[1] * rg1 + p.dr[2] * rg2;
-  if (mp.kind != DC_MODEL_NONE && p.lm) {
+  if (mp.kind > DC_MODEL_SCALED_POLYNOMIAL && p.lm) {        // Linear / InvCos / ScaledInvCos
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < mp.n_terms) gw[k] += gd * model_dw_other(mp, k, p.d, p.inc);
+  } else if (mp.kind != DC_MODEL_NONE && p.lm) {
     const double base = mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -p.d * gd : -gd;
 #pragma unroll
     for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
@@ -216,7 +220,7 @@ static int icp_pair_impl(bool plane, const void* vpsA, const void* dirsA, const 
   if (!dirsA || !depthA || !dirsB || !depthB || (plane && (!normalsA || !normalsB))) return DC_ERR_ARG;
   if (!plane) normalsA = normalsB = nullptr;
   if (!poseA || !poseB || !idxA || !idxB || m < 0 || !partials_ws || !out) return DC_ERR_ARG;
-  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
+  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_LAST) return DC_ERR_ARG;
   if (model_kind != DC_MODEL_NONE && (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !incA || !incB || !w || !e)) return DC_ERR_ARG;
   if (model_kind == DC_MODEL_NONE) n_terms = 0;
   const int n_out = 2 + 2 * n_terms + 24;
@@ -255,7 +259,7 @@ static int icp_sequence_impl(bool plane, const dcIcpScan* scans, int n_scans, co
                         double* partials_ws, double* out, hipStream_t stream) {
   if (n_scans < 0 || n_pairs < 0 || (n_scans > 0 && !scans) || (n_pairs > 0 && !pairs) || !out) return DC_ERR_ARG;
   if (dtype != DC_F32 && dtype != DC_F64) return DC_ERR_DTYPE;
-  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_SCALED_POLYNOMIAL) return DC_ERR_ARG;
+  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_LAST) return DC_ERR_ARG;
   if (model_kind != DC_MODEL_NONE && (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !w || !e)) return DC_ERR_ARG;
   if (model_kind == DC_MODEL_NONE) n_terms = 0;
   for (int p = 0; p < n_pairs; ++p) {

@@ -49,10 +49,21 @@ DC_HD double model_bias(const ModelParams& mp, double inc) {
 }
 
 // d' = f(d, inc); points outside the local mask keep their depth (model.py:76-78, 256-260).
+// Kinds beyond the polynomials (block-uniform switch): Linear model.py:113-146, InvCos :289-313, ScaledInvCos :316-349.
 DC_HD double model_depth(const ModelParams& mp, double depth, double inc, bool in_mask) {
   if (mp.kind == DC_MODEL_NONE || !in_mask) return depth;
+  if (mp.kind == DC_MODEL_LINEAR) return mp.w[0] * depth + mp.w[1] * inc + mp.w[2];
+  if (mp.kind == DC_MODEL_INVCOS) return depth - mp.w[0] / cos(inc);
+  if (mp.kind == DC_MODEL_SCALED_INVCOS) return depth * (1.0 - mp.w[0] / fabs(cos(inc)));
   double b = model_bias(mp, inc);
   return mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? depth * (1.0 - b) : depth - b;
+}
+
+// dd'/dw_k of the non-polynomial kinds
+DC_HD double model_dw_other(const ModelParams& mp, int k, double depth, double inc) {
+  if (mp.kind == DC_MODEL_LINEAR) return k == 0 ? depth : (k == 1 ? inc : 1.0);
+  if (mp.kind == DC_MODEL_INVCOS) return -1.0 / cos(inc);
+  return -depth / fabs(cos(inc));                          // DC_MODEL_SCALED_INVCOS
 }
 
 // ---- K2/K3: rigid transform + point --------------------------------------------------------

@@ -127,8 +127,7 @@ def eval_loss_clouds(clouds, poses, pose_deltas, masks, ns, model, loss_fun, cfg
         total, count, views = 0.0, 0.0, []
         for c, p, nn, m in zip(clouds, poses_upd, ns, masks):
             plan = _plan_for(c, p, nn, m, model, cfg)
-            w = model.w if use_model else None
-            e = model.exponent if use_model else None
+            w, e = model.kernel_params() if use_model else (None, None)
             s, cnt = consistency_loss(plan, w, e, p)
             total, count = total + s, count + cnt
             views.append(PlanCloud(plan, w, e, p))

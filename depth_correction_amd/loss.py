@@ -281,8 +281,7 @@ def _icp_sequence_plan(seq_clouds, seq_masks, with_model, plane):
 def _fused_icp_sequence(seq_clouds, seq_poses, model, seq_masks, plane=True):
     """ICP loss of one sequence through dc_p2plane_sequence / dc_p2point_sequence (clouds in the sensor frame + poses + model)."""
     kind = getattr(model, 'kernel_kind', None) if model is not None else None
-    w = model.w if kind else None
-    e = model.exponent if kind else None
+    w, e = model.kernel_params() if kind else (None, None)
     plan = _icp_sequence_plan(seq_clouds, seq_masks, bool(kind), plane)
     poses = seq_poses if isinstance(seq_poses, torch.Tensor) else torch.stack(list(seq_poses))
     return _P2PlaneSequence.apply(w, e, poses, plan, kind)

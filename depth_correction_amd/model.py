@@ -45,6 +45,13 @@ class BaseModel(torch.nn.Module):
             out.depth = depth
         return out
 
+    # ---- the fused HIP kernels' view of a model: its kind and its parameters as one [1, P] tensor + exponents ------
+    kernel_kind = None        # name understood by the point kernels (_native.MODEL_KINDS); None: tensor path only
+
+    def kernel_params(self):
+        """(w [1,P], exponent [1,P]) for the kernels; ``w`` stays connected to the model's parameters by autograd."""
+        raise NotImplementedError()
+
     def __str__(self):
         return 'BaseModel()'
 
@@ -59,6 +66,12 @@ class BaseModel(torch.nn.Module):
 
 
 class Linear(BaseModel):
+    kernel_kind = 'Linear'
+
+    def kernel_params(self):
+        w = torch.stack([self.w0.reshape(()), self.w1.reshape(()), self.b.reshape(())]).reshape(1, 3)
+        return w, torch.zeros((1, 3), dtype=torch.float64, device=w.device)
+
     def __init__(self, w0=1.0, w1=0.0, b=0.0, uniform_weights=False, device=torch.device('cpu')):
         super().__init__(device=device)
         if uniform_weights:
@@ -81,7 +94,8 @@ class Linear(BaseModel):
 
 class _PolynomialBase(BaseModel):
     """bias(gamma) = sum_k w_k gamma^e_k with fixed or learnable exponents (model.py:151-179, 220-248)."""
-    kernel_kind = None        # name understood by the HIP point kernels
+    def kernel_params(self):
+        return self.w, self.exponent
 
     def __init__(self, p0=None, p1=None, w=None, exponent=None, learnable_exponents=False, device=torch.device('cpu')):
         super().__init__(device=device)
@@ -139,6 +153,12 @@ class ScaledPolynomial(_PolynomialBase):
 
 
 class InvCos(BaseModel):
+    kernel_kind = 'InvCos'
+
+    def kernel_params(self):
+        w = self.p0.reshape(1, 1)
+        return w, torch.zeros((1, 1), dtype=torch.float64, device=w.device)
+
     def __init__(self, p0=0.0, device=torch.device('cpu')):
         super().__init__(device=device)
         self.p0 = torch.nn.Parameter(torch.as_tensor(p0, device=device))
@@ -154,6 +174,12 @@ class InvCos(BaseModel):
 
 
 class ScaledInvCos(BaseModel):
+    kernel_kind = 'ScaledInvCos'
+
+    def kernel_params(self):
+        w = self.p0.reshape(1, 1)
+        return w, torch.zeros((1, 1), dtype=torch.float64, device=w.device)
+
     def __init__(self, p0=0.0, device=torch.device('cpu')):
         super().__init__(device=device)
         self.p0 = torch.nn.Parameter(torch.as_tensor(p0, device=device))

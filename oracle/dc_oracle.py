@@ -134,14 +134,23 @@ def model_bias(inc, w, exponent):
 
 
 def model_apply(depth, inc, mask, w, exponent, kind='ScaledPolynomial'):
-    """model.py:250-261 (ScaledPolynomial) / :188-199 (Polynomial): masked depth correction."""
-    assert kind in ('ScaledPolynomial', 'Polynomial')
+    """Masked depth correction: ScaledPolynomial model.py:250-261, Polynomial :188-199, Linear :113-146 (w = [[w0, w1,
+    b]]), InvCos :289-313 and ScaledInvCos :316-349 (w = [[p0]]); ``exponent`` is used by the polynomials only."""
+    assert kind in ('ScaledPolynomial', 'Polynomial', 'Linear', 'InvCos', 'ScaledInvCos')
+
+    def corrected(d, g):
+        if kind == 'Linear':
+            return w[0, 0] * d + w[0, 1] * g + w[0, 2]
+        if kind == 'InvCos':
+            return d - w[0, 0] / torch.cos(g)
+        if kind == 'ScaledInvCos':
+            return d * (1. - w[0, 0] / torch.cos(g).abs())
+        bias = model_bias(g, w, exponent)
+        return d * (1. - bias) if kind == 'ScaledPolynomial' else d - bias
     if mask is None:
-        bias = model_bias(inc, w, exponent)
-        return depth * (1. - bias) if kind == 'ScaledPolynomial' else depth - bias
-    bias = model_bias(inc[mask], w, exponent)
+        return corrected(depth, inc)
     out = depth.clone()
-    out[mask] = out[mask] * (1. - bias) if kind == 'ScaledPolynomial' else out[mask] - bias
+    out[mask] = corrected(depth[mask], inc[mask])
     return out
 
 

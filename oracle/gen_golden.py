@@ -9,7 +9,7 @@ oracle's restatement of the published algorithm (recorded in each fixture's ``me
 Before a fixture is written, the oracle restatement (oracle/dc_oracle.py) is run on the same inputs
 and asserted equal to the reference's outputs, so a committed fixture certifies both.
 
-Usage:  python oracle/gen_golden.py [names]    (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid,shadow}.npz, about 10 MB)
+Usage:  python oracle/gen_golden.py [names]    (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid,shadow,models}.npz, about 10 MB)
 """
 import os
 import sys
@@ -44,7 +44,7 @@ from depth_correction.depth_cloud import DepthCloud                       # noqa
 from depth_correction.dataset import PlaneDataset as RefPlaneDataset      # noqa: E402
 from depth_correction.eval import eval_loss_clouds                        # noqa: E402
 from depth_correction.loss import create_loss, icp_loss, point_to_plane_dist, point_to_point_dist   # noqa: E402
-from depth_correction.model import ScaledPolynomial, Polynomial           # noqa: E402
+from depth_correction.model import InvCos, Linear, Polynomial, ScaledInvCos, ScaledPolynomial   # noqa: E402
 from depth_correction.nearest_neighbors import nearest_neighbors          # noqa: E402
 from depth_correction.preproc import (establish_neighborhoods, global_cloud, global_cloud_mask,
                                       local_feature_cloud)                # noqa: E402
@@ -251,6 +251,42 @@ def gen_room():
                  out=out, prefix='poly_', grad_points_for=0)
 
 
+def gen_models():
+    """Linear / InvCos / ScaledInvCos (model.py:113-146, 289-349) through one training iteration on the room_k10 inputs
+    (same scans, poses, neighbourhoods and mask as gen_room): loss, gradients of every model parameter, corrected depth
+    of scan 0.  Outputs only -- the inputs are those of room_k10.npz."""
+    ds = RoomBoxDataset(n_pts=2000, n_poses=4)
+    scans = [c for c, _ in ds]
+    poses = torch.as_tensor(np.stack([p for _, p in ds]))
+    cfg = base_cfg(nn_k=10, min_valid_neighbors=5, vp_dispersion_bounds=[])
+    cfg.loss, cfg.pose_correction = 'min_eigval_loss', PoseCorrection.none
+    cfg.loss_kwargs.update(normalization=True, sqrt=False)
+    clouds = [local_feature_cloud(xyz.copy(), cfg) for xyz in scans]
+    g0 = global_cloud(clouds=clouds, poses=poses)
+    ns = establish_neighborhoods(cloud=g0, cfg=cfg)
+    mask = global_cloud_mask(g0, g0.mask if hasattr(g0, 'mask') else None, cfg)
+    loss_fun = create_loss(cfg)
+    out = dict(meta=np.array(META), inputs=np.array('room_k10.npz'))
+    for name, model, params in (('Linear', Linear(w0=0.995, w1=2e-3, b=1e-3), ('w0', 'w1', 'b')),
+                                ('InvCos', InvCos(p0=2e-3), ('p0',)),
+                                ('ScaledInvCos', ScaledInvCos(p0=1e-3), ('p0',))):
+        loss, loss_clouds, _, feat = eval_loss_clouds([clouds], [poses], [None], [mask], [ns], model, loss_fun, cfg)
+        loss.backward()
+        w0 = np.array([[float(getattr(model, p).detach()) for p in params]])
+        grad = np.array([[float(getattr(model, p).grad) for p in params]])
+        out[name + '_w'], out[name + '_loss'], out[name + '_grad_w'] = w0, npy(loss), grad
+        out[name + '_depth0'] = npy(model(clouds[0]).depth)
+        out[name + '_pointwise'] = npy(loss_clouds[0].loss)
+        # restatement check
+        w = torch.tensor(w0, dtype=torch.float64, requires_grad=True)
+        lo, _ = O.eval_sequence(oracle_scans(clouds), poses, w, torch.zeros_like(w), ns[0], mask, model=name, reduction='mean')
+        lo.backward()
+        close(lo, loss, what=name + ' loss')
+        close(w.grad, grad, rtol=1e-6, atol=1e-12, what=name + ' grad')
+        print('models: %-13s loss=%.9g grad=%s' % (name, loss.item(), grad.ravel()))
+    np.savez_compressed(os.path.join(GOLD, 'models.npz'), **out)
+
+
 def gen_icp():
     """Config 4 shape reduced: KITTI-like ring scans, point-to-plane with precomputed correspondences
     (train.py:178-210), gradient w.r.t. model weights and per-pose corrections."""
@@ -408,7 +444,7 @@ def gen_knn():
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow']
+    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models']
     if 'grid' in which:
         gen_grid()
     if 'knn' in which:
@@ -421,3 +457,5 @@ if __name__ == '__main__':
         gen_icp()
     if 'shadow' in which:
         gen_shadow()
+    if 'models' in which:
+        gen_models()

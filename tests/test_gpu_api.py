@@ -731,3 +731,28 @@ def test_training_iteration_replays_as_one_graph(golden):
     torch.cuda.synchronize()
     torch.testing.assert_close(w_g.detach(), w_e.detach(), rtol=1e-12, atol=0)
     assert torch.isfinite(static_loss).all()
+
+
+@pytest.mark.parametrize('name', ['Linear', 'InvCos', 'ScaledInvCos'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_other_models_iteration_golden(golden, name, fused):
+    """The reference's other depth-correction models (model.py:113-146, 289-349) through eval_loss_clouds: inside the
+    fused kernels (model kinds 3-5) and through the un-fused operators, against the live-reference fixture."""
+    from depth_correction_amd import model as M
+    from depth_correction_amd.eval import eval_loss_clouds, fused_supported
+    from depth_correction_amd.loss import create_loss
+    g, m = golden('room_k10'), golden('models')
+    cfg = _cfg(g, loss='min_eigval_loss')
+    cfg.loss_kwargs.update(normalization=True, sqrt=False)
+    cfg.fused = fused
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    w0 = m[name + '_w'].ravel()
+    kw = dict(w0=float(w0[0]), w1=float(w0[1]), b=float(w0[2])) if name == 'Linear' else dict(p0=float(w0[0]))
+    model = getattr(M, name)(device=cfg.device, **kw)
+    assert fused_supported([clouds], model, cfg) == fused
+    loss, loss_clouds, _, _ = eval_loss_clouds([clouds], [poses], [None], [mask], [ns], model, create_loss(cfg), cfg)
+    loss.backward()
+    grads = np.array([float(p.grad) for p in model.parameters()])
+    np.testing.assert_allclose(loss.item(), m[name + '_loss'], rtol=1e-9)
+    np.testing.assert_allclose(grads, m[name + '_grad_w'].ravel(), rtol=2e-6, atol=1e-10)
+    np.testing.assert_allclose(npy(model(clouds[0]).depth), m[name + '_depth0'], rtol=1e-12)

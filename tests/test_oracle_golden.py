@@ -168,3 +168,18 @@ def test_shadow_filter(golden, tag):
     # restricted to the first 4000 rays: neighbours beyond them are dropped from both sides
     for row_ref, row in zip(sub[:200], ind[:200]):
         assert sorted(x for x in row_ref if 0 <= x < 4000) == sorted(x for x in row if x >= 0)
+
+
+@pytest.mark.parametrize('name', ['Linear', 'InvCos', 'ScaledInvCos'])
+def test_other_models(golden, name):
+    """Linear / InvCos / ScaledInvCos (model.py:113-146, 289-349) through one iteration on the room_k10 inputs."""
+    g, m = golden('room_k10'), golden('models')
+    scans = scans_from_golden(g, torch.float64)
+    w = torch.tensor(m[name + '_w'], requires_grad=True)
+    loss, f = O.eval_sequence(scans, t(g['poses']), w, torch.zeros_like(w), t(g['g_neighbors']).long(), t(g['g_mask']),
+                              model=name, reduction='mean')
+    loss.backward()
+    np.testing.assert_allclose(npy(loss), m[name + '_loss'], rtol=1e-10)
+    np.testing.assert_allclose(npy(w.grad), m[name + '_grad_w'], rtol=1e-6, atol=1e-12)
+    d0 = O.model_apply(scans[0]['depth'], scans[0]['inc'], scans[0]['mask'], w.detach(), None, name)
+    np.testing.assert_allclose(npy(d0), m[name + '_depth0'], rtol=1e-12)
