@@ -18,7 +18,7 @@ from .preproc import (compute_neighborhood_features, global_cloud, global_cloud_
 from .transform import corrected_poses, xyz_axis_angle_to_matrix
 
 __all__ = ['create_corrected_poses', 'eval_loss_clouds', 'initialize_pose_corrections', 'fused_supported',
-           'PlanCloud']
+           'PlanCloud', 'LazyFeatureCloud']
 
 
 def initialize_pose_corrections(datasets, cfg: Config):
@@ -87,6 +87,31 @@ class PlanCloud(object):
 _plans = PlanRegistry()
 
 
+class LazyFeatureCloud(object):
+    """The global feature cloud of a sequence (global_cloud -> compute_neighborhood_features, eval.py:90-98), computed on
+    first access.  The reference builds it every iteration even when the ICP loss never looks at it (eval.py:100-104);
+    callers that do (callbacks logging the map) get the same cloud, everyone else pays nothing."""
+
+    def __init__(self, seq_clouds, model, poses, nn, cfg):
+        self._args, self._cloud = (seq_clouds, model, poses, nn, cfg), None
+
+    def _materialize(self):
+        if self._cloud is None:
+            seq_clouds, model, poses, nn, cfg = self._args
+            with torch.no_grad():
+                g = global_cloud(clouds=seq_clouds, model=model, poses=poses.detach())
+                self._cloud = compute_neighborhood_features(cloud=g, neighborhoods=nn, cfg=cfg)
+        return self._cloud
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        return getattr(self._materialize(), name)
+
+    def __len__(self):
+        return sum(len(c) for c in self._args[0])
+
+
 def _plan_for(seq_clouds, poses, nn, mask, model, cfg):
     """SequencePlan of (local clouds, neighbourhoods, mask), all constant over the optimisation: kept in a registry keyed
     by the identity and version of every tensor it was built from (plan.PlanRegistry)."""
@@ -113,7 +138,8 @@ def eval_loss_clouds(clouds, poses, pose_deltas, masks, ns, model, loss_fun, cfg
         if clouds[0][0].normals is None:
             clouds = [[local_feature_cloud(c, cfg) for c in seq] for seq in clouds]
         loss, loss_cloud = loss_fun(clouds, poses_upd, model, masks=masks)
-        return loss, loss_cloud, poses_upd, None
+        feat = [LazyFeatureCloud(c, model, p, nn, cfg) for c, p, nn in zip(clouds, poses_upd, ns)] if ns else None
+        return loss, loss_cloud, poses_upd, feat
 
     if fused_supported(clouds, model, cfg):
         # masks are established once (train.py:212-215); when absent they come from one un-fused evaluation

@@ -480,6 +480,9 @@ def test_icp_training_matches_oracle_loop(tmp_path):
 
         def train_loss(self, it, model, clouds, pose_deltas, poses, masks, loss):
             seen.append((loss.item(), npy(model.w).copy(), npy(pose_deltas[0]).copy()))
+            if it == 0:          # the feature clouds the reference hands to its callbacks (eval.py:90-98), built on demand
+                assert len(clouds) == 1 and len(clouds[0]) == sum(len(c) for c, _ in seq)
+                assert clouds[0].eigvals.shape == (len(clouds[0]), 3) and clouds[0].points.is_cuda
     train(cfg, callbacks=CB(), train_datasets=[seq], val_datasets=[])
 
     # ---- the same on the oracle ----
