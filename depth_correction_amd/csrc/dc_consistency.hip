@@ -858,6 +858,205 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
   if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
 }
 
+// ================================================================================================
+// Basis form of the iteration (fixed poses, fixed exponents): every model of the reference is affine in its weights
+// (Polynomial d' = d - sum w_k g^e_k, ScaledPolynomial d' = d (1 - sum w_k g^e_k), Linear, InvCos, ScaledInvCos:
+// model.py:113-349), so the world point of ray j is
+//     x_j(w) = X0_j + sum_k w_k B_kj,      X0_j = R (vp + d0 dir) + t,   B_kj = (dd'/dw_k) R dir   (zero outside the local mask)
+// with X0 and B constant while the poses do not move.  They are computed once (points_basis_kernel); an iteration then
+// needs no pass over the points to refresh x: the forward forms the rows it stages (and its centre) from X0 / B on the
+// fly, the backward its own point, and the chain to the weights is dL/dw_k = sum_j g_j . B_kj -- no model, no pose, no
+// incidence angles in the loop.  X0 lives on the q32 grid, B in float32 metres per unit weight (|w B| is centimetres,
+// so its fp32 rounding is ~1e-9 m, far below the grid).  A coordinate is the grid value X0 + rint(sum w_k B_k / step):
+// the same integer for every block that forms it, rounded twice (X0 and the increment) instead of once.
+// ================================================================================================
+struct PointBasis {
+  const int32_t* __restrict__ x0;      // [n,3]
+  const float* __restrict__ b;         // [P][n][3]
+  const double* __restrict__ w;        // [P] device weights of this evaluation
+  int n_terms;
+  double inv_scale;
+  int64_t n;
+};
+
+// s_w[k] = w_k / step for the lanes of the block (call before a barrier)
+__device__ __forceinline__ void stage_weights(const PointBasis& pb, double* s_w) {
+  if ((int)threadIdx.x < pb.n_terms) s_w[threadIdx.x] = pb.w[threadIdx.x] * pb.inv_scale;
+}
+
+__device__ __forceinline__ Pt<q32>::Raw basis_point(const PointBasis& pb, const double* s_w, int64_t row) {
+  const int32_t* q = pb.x0 + row * 3;
+  const int32_t q0 = q[0], q1 = q[1], q2 = q[2];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int k = 0; k < pb.n_terms; ++k) {
+    const float* b = pb.b + ((int64_t)k * pb.n + row) * 3;
+    const double wk = s_w[k];
+    a0 += wk * (double)b[0]; a1 += wk * (double)b[1]; a2 += wk * (double)b[2];
+  }
+  Pt<q32>::Raw r;
+  r.v[0] = q0 + (int32_t)rint(a0); r.v[1] = q1 + (int32_t)rint(a1); r.v[2] = q2 + (int32_t)rint(a2);
+  return r;
+}
+
+// X0 and B of every point (once per pose set): the same inputs and arithmetic as points_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, int64_t n, QParams qp, int32_t* __restrict__ x0,
+                                                              float* __restrict__ basis) {
+  __shared__ double s_pose[kLdsScans * 12];
+  const PoseTile poses = stage_poses(in, s_pose);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  ModelParams mp;
+  load_model(in, mp);
+  double vp[3], dr[3], T12[12];
+  if (in.vps) Row3<T, 3>::load((const T*)in.vps, i, vp, qp);
+  else { vp[0] = vp[1] = vp[2] = 0.0; }
+  Row3<T, 3>::load((const T*)in.dirs, i, dr, qp);
+  const double d = (double)((const T*)in.depth)[i];
+  const bool lm = in.lmask ? in.lmask[i] != 0 : true;
+  const double inc = (mp.kind != DC_MODEL_NONE && lm) ? (double)((const T*)in.inc)[i] : 0.0;
+  load_pose(in, poses, in.scan_id ? in.scan_id[i] : 0, T12);
+  double vr[3], drr[3];
+  rot3(T12, vp, vr);
+  vr[0] += T12[3]; vr[1] += T12[7]; vr[2] += T12[11];
+  rot3(T12, dr, drr);
+  const bool on = mp.kind != DC_MODEL_NONE && lm;
+  const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;      // d' at w = 0
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x0[i * 3 + a] = quantize(vr[a] + d0 * drr[a], qp.origin[a], qp.inv_scale, qp.flag);
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
+    if (k < mp.n_terms) {
+      double dk = 0.0;                                                  // dd'/dw_k
+      if (on) {
+        if (mp.kind > DC_MODEL_SCALED_POLYNOMIAL) dk = model_dw_other(mp, k, d, inc);
+        else dk = (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
+      }
+      float* b = basis + ((int64_t)k * n + i) * 3;
+      b[0] = (float)(dk * drr[0]); b[1] = (float)(dk * drr[1]); b[2] = (float)(dk * drr[2]);
+    }
+  }
+}
+
+template <bool FULL_EIG, int NS>
+__global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
+    PointBasis pb, BlockTab tab, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, const float* __restrict__ offset, LossParams lp, QParams qp, q32* __restrict__ rec,
+    float* __restrict__ pointwise, float* __restrict__ eigvals, double* __restrict__ partials) {
+  extern __shared__ int4 tile[];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0};
+  const int32_t s0 = blk >= 0 ? tab.slot_ptr[blk] : 0;
+  const bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
+  if (blk >= 0 && !bad) {
+    const int64_t i = blk * kBlock + threadIdx.x;
+    const bool live = i < n;
+    const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    uint32_t pre[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) pre[q] = (uint32_t)lrow[q * kBlock];
+    stage_weights(pb, s_w);
+    // ids of the rows this lane stages are requested before the weights are published
+    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nd; t += kBlock) {
+      const Pt<q32>::Raw r = basis_point(pb, s_w, tab.blk_ids[base + t]);
+      tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0);
+    }
+    const Pt<q32>::Raw ci = basis_point(pb, s_w, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    __syncthreads();
+    if (live) {
+      CovAcc acc;
+      cov_init(acc);
+      uint32_t mx = pre[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
+      int n_have;
+      if (__any((int)(mx == kNoLoc))) n_have = gather_fixed<q32, NS, true>(tile, cap, ci, pre, acc);
+      else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
+      acc.W = (double)n_have;
+      consistency_point<float, q32, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
+    }
+  } else {
+    __syncthreads();
+    __syncthreads();
+  }
+  if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
+  wave_partials<2>(acc2, partials);
+}
+
+// Backward in basis form over a run table: the point itself and the chain to the weights come from X0 / B.
+// partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
+__global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
+    PointBasis pb, const q32* __restrict__ rec, RunTab tab, int cap, int64_t n, QParams qp, double* __restrict__ partials) {
+  constexpr int RR = RecRaw<q32>::kRow16;
+  extern __shared__ int4 tile[];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double gw[DC_MAX_MODEL_TERMS];
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = 0.0;
+  const int64_t j = blk * kBlock + threadIdx.x;
+  const bool active = blk >= 0 && j < n;
+  uint2 pre[kPreRuns];
+  int32_t nruns = 0;
+  uint32_t nd = 0;
+  const uint2* runs = reinterpret_cast<const uint2*>(tab.loc);
+  if (blk >= 0) {
+    if (active) {
+      const int32_t r0 = tab.run_ptr[j];
+      nruns = tab.run_ptr[j + 1] - r0;
+      runs += r0;
+    }
+#pragma unroll
+    for (int t = 0; t < kPreRuns; ++t) pre[t] = t < nruns ? runs[t] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    stage_weights(pb, s_w);
+    nd = (uint32_t)stage_rows<RR>(tab.blk_ptr, tab.blk_ids, blk, reinterpret_cast<const int4*>(rec), tile, cap);
+    if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
+  }
+  const uint32_t nd16 = nd * 16u;
+  __syncthreads();
+  if (active) {
+    const Pt<q32>::Raw cj = basis_point(pb, s_w, j);
+    double g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < kPreRuns; ++t)
+      if (__any((int)(t < nruns))) run_edges<q32>(tile, cap, pre[t], nd16, cj, g);
+    if (__any((int)(nruns > kPreRuns))) {
+      uint2 nxt = kPreRuns < nruns ? runs[kPreRuns] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      for (int t = kPreRuns; __any((int)(t < nruns)); ++t) {
+        const uint2 r = nxt;
+        nxt = t + 1 < nruns ? runs[t + 1] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        run_edges<q32>(tile, cap, r, nd16, cj, g);
+      }
+    }
+    const double u = qp.scale;
+    g[0] *= u; g[1] *= u; g[2] *= u;
+#pragma unroll
+    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
+      if (k < pb.n_terms) {
+        const float* b = pb.b + ((int64_t)k * pb.n + j) * 3;
+        gw[k] = g[0] * (double)b[0] + g[1] * (double)b[1] + g[2] * (double)b[2];
+      }
+    }
+  }
+  // per-wavefront partial rows, as reduce_param_grads writes them
+  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  double* prow = partials + (int64_t)blockIdx.x * kWavesPerBlock + wave;
+#pragma unroll
+  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
+    if (k < pb.n_terms) {
+      const double sw = wave_sum(gw[k]);
+      if (lane == 0) { prow[k * rs] = sw; prow[(pb.n_terms + k) * rs] = 0.0; }
+    }
+  }
+}
+
 // Stand-alone point epilogue for the un-fused API path (grad of points given).
 template <typename T, int STRIDE>
 __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict__ grad_x, const int32_t* __restrict__ perm,
@@ -994,7 +1193,8 @@ using namespace dc;
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
 static std::atomic<bool> g_no_tab{false};
-static std::atomic<int> g_fwd_generic{0};    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
+static std::atomic<int> g_fwd_generic{0};
+static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's X0 / B arrays (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
 // a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
 static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit,
@@ -1124,6 +1324,26 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
   DC_TIMED_LAUNCH((points_fwd_kernel<T, PT, S>), grid, block, 0, stream, in, n, qp, (PT*)points_out, (T*)vps_out, (T*)dirs_out, (T*)depth_out)
   { ProfScope prof(0); DC_DISPATCH_FMT(dtype, point_fmt, out_stride, LAUNCH); }
 #undef LAUNCH
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                    const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* e,
+                    int64_t n, int dtype, const double* qparams, int32_t* x0_out, float* basis_out, int32_t* status,
+                    hipStream_t stream) {
+  if (n == 0) return DC_OK;
+  if (n < 0 || !dirs || !depth || !x0_out || !basis_out || !qparams) return DC_ERR_ARG;
+  if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
+  if (dtype != DC_F32) return DC_ERR_DTYPE;                 // the basis form goes with the q32 point format (float32 clouds)
+  // the weights do not enter X0 / B: a dummy non-null pointer satisfies the model check, load_model reads e only... and w
+  int rc = check_model(model_kind, n_terms, inc, e, e);
+  if (rc || model_kind == DC_MODEL_NONE) return rc ? rc : DC_ERR_ARG;
+  QParams qp;
+  rc = make_qparams(DC_Q32, dtype, 4, qparams, &qp, status);
+  if (rc) return rc;
+  PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, e, e);
+  hipLaunchKernelGGL((points_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, x0_out, basis_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -1332,6 +1552,7 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
 int dc_set_option(int option, int value) {
   if (option == 0) { g_no_tab.store(value != 0); return DC_OK; }
   if (option == 1) { g_fwd_generic.store(value); return DC_OK; }
+  if (option == 3) { g_no_basis.store(value != 0); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -1400,20 +1621,59 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                               const AdamArgs& adam) {
   if (!d || !out || !poses || !d->partials) return DC_ERR_ARG;
   const int stride = 4;
-  int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
-                         d->n_terms, w, e, d->n, d->dtype, d->point_fmt, d->qparams, stride, d->x, nullptr, nullptr,
-                         nullptr, d->status, stream);
-  if (rc) return rc;
   const int n_terms = d->model_kind == DC_MODEL_NONE ? 0 : d->n_terms;
   const int n_acc = 2 * n_terms + 12 * d->n_scans;
   if (d->n == 0) return (int)hipMemsetAsync(out, 0, (size_t)(2 + n_acc) * sizeof(double), stream);
-  // forward partials live in the first 2 * rows doubles of the workspace, backward partials behind them; ONE reduction
   const int64_t n_rows = d->centre_idx ? d->n_centres : d->n;      // forward rows (centres); the backward runs over all points
   if (d->centre_idx && (d->n_centres < 0 || d->n_centres > d->n)) return DC_ERR_ARG;
   const int64_t rows = xcd_grid(n_blocks(d->n)) * kWavesPerBlock;      // partial rows: one per wavefront
   double* p_fwd = d->partials;
   double* p_bwd = d->partials + 2 * rows;
   const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
+
+  // ---- basis form: X0 / B of the current poses and exponents are valid (the caller says so by passing them), only the
+  // weights change between evaluations -> no pass over the points, no model / pose arithmetic in the loop
+  size_t lds_f = 0, lds_b = 0;
+  int rows_f = 0, rows_b = 0;
+  const bool basis = d->x0q && d->basis && d->point_fmt == DC_Q32 && d->dtype == DC_F32 && n_terms > 0 && w &&
+                     !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
+                     (d->k == 4 || d->k == 8 || d->k == 10 || d->k == 16) &&
+                     use_table(d->fwd_table, DC_TABLE_SLOTS, stride, 16u, 0, 60 * 1024, &lds_f, &rows_f) &&
+                     (!want_grad || use_table(d->bwd_table, DC_TABLE_RUNS, stride, 32u, 1, 44 * 1024, &lds_b, &rows_b));
+  if (basis) {
+    QParams qp;
+    int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
+    if (rc) return rc;
+    PointBasis pb{d->x0q, d->basis, w, n_terms, qp.inv_scale, d->n};
+    LossParams lp{d->loss_kind, d->normalization, d->sqrt_};
+    BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
+    const dim3 block(kBlock);
+    {
+      ProfScope prof(1);
+      const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
+#define FWD_BASIS(NS) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<false, NS>), grid, block, lds_f, stream, pb, tab, rows_f, d->centre_idx, \
+                                      n_rows, d->mask, (const float*)nullptr, lp, qp, (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
+      if (d->k == 10) FWD_BASIS(10); else if (d->k == 4) FWD_BASIS(4); else if (d->k == 8) FWD_BASIS(8); else FWD_BASIS(16);
+#undef FWD_BASIS
+    }
+    DC_CHECK_LAUNCH();
+    if (want_grad) {
+      RunTab rtab{d->bwd_table->blk_ptr, d->bwd_table->blk_ids, d->bwd_table->run_ptr, d->bwd_table->loc};
+      ProfScope prof(2);
+      DC_TIMED_LAUNCH(consistency_bwd_basis_kernel, dim3((unsigned)xcd_grid(n_blocks(d->n))), block, lds_b, stream, pb,
+                      (const q32*)d->rec, rtab, rows_b, d->n, qp, p_bwd);
+      DC_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd,
+                       xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows, n_red, out, adam, (const int32_t*)d->status);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+  }
+
+  int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
+                         d->n_terms, w, e, d->n, d->dtype, d->point_fmt, d->qparams, stride, d->x, nullptr, nullptr,
+                         nullptr, d->status, stream);
+  if (rc) return rc;
   rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->centre_idx, d->fwd_table, n_rows, d->k, d->mask,
                             nullptr, d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream,
                             false);

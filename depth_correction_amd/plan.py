@@ -34,7 +34,7 @@ class SequencePlan:
     @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
-                 active_only=False, block_tables=True, bwd_layout='runs', stages=None):
+                 active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -43,6 +43,8 @@ class SequencePlan:
         :param mask: [N] bool global mask (None = all points).
         :param block_tables: build the block tables that let both hot kernels gather from LDS (ops.block_table).
         :param bwd_layout: 'runs' (per-point runs padded to four positions) or 'slots' (slot-major, padded per block).
+        :param basis: use the basis form x = X0 + sum_k w_k B_k (dc_points_basis) whenever an evaluation asks for neither pose
+                      nor exponent gradients: X0 / B are rebuilt only when the poses or the exponents change.
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
                             the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
@@ -150,6 +152,8 @@ class SequencePlan:
         self.partials = torch.empty((rows * (nacc + 2),), dtype=torch.float64, device=dev)
         self.version = 0
         self._desc = None
+        self.use_basis = bool(basis)
+        self._basis = None             # (key, x0q, B, poses12, exponent): the last two pin the storage the key names
         self._poses_key = self._poses12 = self._poses_ref = None
 
     # ------------------------------------------------------------------------------------------------
@@ -181,6 +185,29 @@ class SequencePlan:
             self._desc = d
         return self._desc
 
+    def _set_basis(self, d, w, exponent, poses12, want_exponent, want_pose):
+        """Point the descriptor at X0 / B valid for (poses12, exponent), building them when either changed; or clear the
+        fields when this evaluation cannot use the basis form (pose / exponent gradients, other formats, no tables)."""
+        ok = (self.use_basis and self.qfmt is not None and w is not None and not want_exponent and not want_pose
+              and self.fwd_table is not None and self.bwd_table is not None and self.bwd_table.run_ptr is not None
+              and self.k in (4, 8, 10, 16) and d.model_kind != 0)
+        if not ok:
+            d.x0q = d.basis = None
+            return
+        nt = w.numel()
+        b = self._basis
+        key = (poses12.data_ptr(), poses12._version, exponent.data_ptr(), exponent._version, nt)
+        if b is None or b[0] != key:
+            ps = self.ps
+            x0q = torch.empty((self.n, 3), dtype=torch.int32, device=self.device)
+            B = torch.empty((nt, self.n, 3), dtype=torch.float32, device=self.device)
+            check(lib().dc_points_basis(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
+                                        ptr(poses12), self.n_scans, d.model_kind, nt, ptr(exponent), self.n, nv.DC_F32,
+                                        self.qfmt._c, ptr(x0q), ptr(B), ptr(self.status), stream_ptr()), 'dc_points_basis')
+            # the tensors are kept alive with the entry, so their addresses cannot be recycled for other poses / exponents
+            self._basis = b = (key, x0q, B, poses12, exponent)
+        d.x0q, d.basis = b[1].data_ptr(), b[2].data_ptr()
+
     @on_device
     def eval_native(self, w, exponent, poses12, out, want_grad=True, want_exponent=False, want_pose=False):
         """One host call per evaluation.  w, exponent: fp64 device vectors [P]; poses12: fp64 device [S,12];
@@ -192,6 +219,7 @@ class SequencePlan:
         if nt:
             need(w, (nt,), dtype=torch.float64, name='w', device=self.device)
             need(exponent, (nt,), dtype=torch.float64, name='exponent', device=self.device)
+        self._set_basis(d, w, exponent, poses12, want_exponent, want_pose)
         check(lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
                                      int(want_exponent), int(want_pose), ptr(out), stream_ptr()), 'dc_sequence_eval')
         self.version += 1
@@ -206,6 +234,7 @@ class SequencePlan:
         need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
         for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
             need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
+        self._set_basis(d, w, exponent, poses12, False, False)
         check(lib().dc_sequence_step(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
                                      int(t), float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                      float(weight_decay), ptr(out), stream_ptr()), 'dc_sequence_step')

@@ -95,6 +95,16 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
                   int out_stride, void* points_out, void* vps_out, void* dirs_out, void* depth_out, int32_t* status,
                   dcStream_t stream);
 
+/* Basis form of dc_points_fwd for fixed poses and exponents.  Every model is affine in its weights, so
+ *   x_j(w) = X0_j + sum_k w_k B_kj,  X0 = R (vp + d0 dir) + t (d0 = d' at w = 0),  B_kj = (dd'/dw_k) R dir  (0 outside lmask).
+ * x0_out int32 [n,3]: X0 on the DC_Q32 grid of qparams (status as in dc_points_fwd); basis_out float32 [n_terms, n, 3] in
+ * metres per unit weight.  dtype must be DC_F32.  dc_sequence_eval / _step use the two arrays (dcSequenceDesc.x0q / .basis)
+ * instead of launching dc_points_fwd, when neither pose nor exponent gradients are requested. */
+int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
+                    const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* e,
+                    int64_t n, int dtype, const double* qparams, int32_t* x0_out, float* basis_out, int32_t* status,
+                    dcStream_t stream);
+
 /* Backward of dc_points_fwd for a given dL/dpoints: grads_out fp64 [2*n_terms + 12*n_scans] =
  * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count].
  * perm int32 [n] or NULL: point i takes its gradient from row perm[i] of grad_points (the gradient then lives in another
@@ -314,6 +324,8 @@ typedef struct dcSequenceDesc {
   const dcBlockTable* bwd_table;   /* block table of (csr_ptr, csr_src), or NULL */
   int32_t* status;                 /* device int or NULL: bit 0 raised by dc_points_fwd when a DC_Q32 coordinate overflowed /
                                       was NaN; while it is set the evaluation's loss (out[0]) is NaN */
+  const int32_t* x0q;              /* basis form (dc_points_basis), both NULL or both valid FOR THE POSES AND EXPONENTS OF THE */
+  const float* basis;              /* CALL: x = x0q + sum_k w_k basis_k; then no pass over the points per evaluation */
 } dcSequenceDesc;
 
 /* out fp64 [2 + 2 P + 12 S] = {sum of pointwise loss over mask, mask count, d(sum)/dw, /dexponent, /d[R|t]};
@@ -363,7 +375,8 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
 /* Tuning / ablation switches (process-wide atomics, read once per launch; results are identical either way).
  * option 0: value 1 makes the fused kernels ignore block tables and gather from global memory.
  * option 1: value 1 makes dc_consistency_fwd use the run-time slot loop instead of the kernels specialised for
- *           k = 4 / 8 / 10 / 16. */
+ *           k = 4 / 8 / 10 / 16.
+ * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.x0q / .basis (general path). */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)

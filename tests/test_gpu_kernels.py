@@ -472,3 +472,45 @@ def test_block_tables_do_not_change_results(golden, dev):
     finally:
         nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
     assert np.array_equal(npy(r['gw']), outs[0][0])
+
+
+@pytest.mark.parametrize('model', ['ScaledPolynomial', 'Polynomial'])
+def test_basis_form_equals_general_path(golden, dev, model):
+    """dc_sequence_eval through the basis form (x = X0 + sum_k w_k B_k, no pass over the points) against the general
+    path (dc_points_fwd every evaluation): identical count, loss and dL/dw up to the second rounding of the q32 grid, for
+    several weight vectors on one plan (X0 / B are built once) and after the poses changed (rebuilt)."""
+    from depth_correction_amd.plan import SequencePlan
+    from depth_correction_amd import _native as nv
+    g = golden('room_k10')
+    scans = scans_from_golden(g, torch.float32)
+    clouds = [dict(vps=s['vps'].to(dev), dirs=s['dirs'].to(dev), depth=s['depth'].to(dev), inc_angles=s['inc'].to(dev),
+                   mask=s['mask'].to(dev)) for s in scans]
+    poses = t(g['poses'], dev)
+    plan = SequencePlan(clouds, poses, t(g['g_neighbors'], dev), t(g['g_mask'], dev), model_kind=model)
+    assert plan.qfmt is not None
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    outs = {}
+    for basis in (True, False):
+        nv.check(nv.lib().dc_set_option(3, 0 if basis else 1), 'dc_set_option')
+        try:
+            res = []
+            P = plan.poses12(poses)
+            for wv in ([1e-3, 2e-3], [-2e-3, 5e-4], [0.0, 0.0]):
+                w = torch.tensor(wv, dtype=torch.float64, device=dev)
+                out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+                plan.eval_native(w, e, P, out)
+                res.append(npy(out))
+            moved = poses.clone()
+            moved[1, :3, 3] += 0.05
+            P2 = plan.poses12(moved)
+            out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+            plan.eval_native(torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev), e, P2, out)
+            res.append(npy(out))
+            outs[basis] = res
+        finally:
+            nv.check(nv.lib().dc_set_option(3, 0), 'dc_set_option')
+    for a, b in zip(outs[True], outs[False]):
+        assert a[1] == b[1] > 0
+        np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+        np.testing.assert_allclose(a[2:4], b[2:4], rtol=2e-5, atol=1e-7 * np.abs(b[2:4]).max())
+    assert not np.allclose(outs[True][0][0], outs[True][3][0], rtol=1e-9)          # the moved pose changed the loss

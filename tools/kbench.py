@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--bwd-layout', default='runs')
     ap.add_argument('--degree-sort', action='store_true')
     ap.add_argument('--tag', default='')
+    ap.add_argument('--no-basis', action='store_true')
     args = ap.parse_args()
     from depth_correction_amd import _native as nv, ops
     from depth_correction_amd.dataset import RoomBoxDataset
@@ -41,7 +42,7 @@ def main():
     scans_xyz = [np.stack([c[f] for f in 'xyz'], axis=1) for c, _ in ds]
     poses = np.stack([p for _, p in ds])
     plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, bwd_layout=args.bwd_layout,
-                                degree_sort=args.degree_sort)
+                                degree_sort=args.degree_sort, basis=not args.no_basis)
     for o in args.opt:
         i, v = o.split('=')
         nv.check(nv.lib().dc_set_option(int(i), int(v)), 'dc_set_option')
