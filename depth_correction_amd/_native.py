@@ -36,7 +36,7 @@ _SIGNATURES = {
     'dc_spatial_order': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
     'dc_points_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dc_points_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'dc_points_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'dc_partial_rows': (_i64, [_i64]),
     'dc_param_grad_count': (_i32, [_i32, _i32]),
     'dc_points_bwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32,
@@ -47,6 +47,7 @@ _SIGNATURES = {
     'dc_block_table_slots': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_workspace_bytes': (_sz, [_i64]),
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'dc_block_table_own_base': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'dc_block_table_run_capacity': (_i64, [_i64, _i64]),
     'dc_block_table_build_runs': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_consistency_fwd': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp,
@@ -84,7 +85,7 @@ _SIGNATURES = {
 class BlockTableDesc(ctypes.Structure):
     """dcBlockTable of include/dc_hip.h."""
     _fields_ = [('blk_ptr', _vp), ('blk_ids', _vp), ('slot_ptr', _vp), ('loc', _vp), ('max_rows', ctypes.c_int32),
-                ('layout', ctypes.c_int32), ('run_ptr', _vp)]
+                ('layout', ctypes.c_int32), ('run_ptr', _vp), ('own_base', _vp)]
 
 
 class IcpScan(ctypes.Structure):
@@ -107,7 +108,7 @@ class SequenceDesc(ctypes.Structure):
                 ('n_centres', ctypes.c_int64), ('x', _vp), ('rec', _vp),
                 ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('x0q', _vp), ('basis', _vp)]
+                ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp)]
 
 
 def lib_path():

@@ -140,6 +140,24 @@ __global__ __launch_bounds__(kBlock) void bt_run_len_kernel(const int32_t* __res
   len[r] = r < n_rows ? (row_ptr[r + 1] - row_ptr[r] + 3) >> 2 : 0;
 }
 
+// own_base[b] = position of row 256 b in block b's distinct list when ALL rows of the block appear in it (then they are
+// contiguous there, the list being sorted), else -1.  A k-NN table lists every point among its own neighbours, so the
+// forward kernels can take a lane's centre point from the staged LDS rows instead of fetching / forming it again.
+__global__ __launch_bounds__(kBlock) void bt_own_base_kernel(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ blk_ids,
+                                                             int64_t n_rows, int64_t n_blocks, int32_t* __restrict__ own_base) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_blocks) return;
+  const int32_t lo0 = blk_ptr[b], hi0 = blk_ptr[b + 1];
+  const int64_t first = b * kBlock, cnt = (first + kBlock <= n_rows ? kBlock : n_rows - first);
+  int32_t lo = lo0, hi = hi0;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if ((int64_t)blk_ids[mid] < first) lo = mid + 1; else hi = mid;
+  }
+  const bool all = lo + cnt <= hi0 && (int64_t)blk_ids[lo] == first && (int64_t)blk_ids[lo + cnt - 1] == first + cnt - 1;
+  own_base[b] = all ? lo - lo0 : -1;
+}
+
 __global__ __launch_bounds__(kBlock) void bt_info_kernel(const int32_t* __restrict__ blk_ptr, int64_t n_blocks,
                                                          int32_t* __restrict__ info) {
   const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -184,7 +202,8 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs) {
 // loc_entries: number of uint16 entries of loc (all set to 0xFFFF first); run_ptr != NULL selects the run layout
 static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
                                   const int32_t* slot_ptr, const int32_t* run_ptr, int64_t loc_entries, int32_t* blk_ptr,
-                                  int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                  int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes, hipStream_t stream,
+                                  int32_t* own_base = nullptr) {
   const int64_t n_slot_rows = loc_entries / kBlock;
   if (n_rows < 0 || n_refs < 0 || loc_entries < 0 || !blk_ptr || !info || (!row_ptr && k < 1)) return DC_ERR_ARG;
   DC_HIP(hipMemsetAsync(info, 0, 4 * sizeof(int32_t), stream));
@@ -227,6 +246,16 @@ static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, in
   hipLaunchKernelGGL(bt_scatter_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, svals, heads, rank1, rows, row_ptr,
                      n_refs, k, blk_ptr, slot_ptr, run_ptr, blk_ids, loc, info);
   hipLaunchKernelGGL(bt_info_kernel, dim3(grid_of(nb)), block, 0, stream, blk_ptr, nb, info);
+  if (own_base) hipLaunchKernelGGL(bt_own_base_kernel, dim3(grid_of(nb)), block, 0, stream, blk_ptr, blk_ids, n_rows, nb, own_base);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int64_t n_rows, int32_t* own_base, hipStream_t stream) {
+  if (n_rows < 0 || !blk_ptr || !own_base) return DC_ERR_ARG;
+  const int64_t nb = blocks_of(n_rows);
+  if (nb == 0) return DC_OK;
+  hipLaunchKernelGGL(bt_own_base_kernel, dim3(grid_of(nb)), dim3(kBlock), 0, stream, blk_ptr, blk_ids, n_rows, nb, own_base);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

@@ -871,12 +871,10 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
 // the same integer for every block that forms it, rounded twice (X0 and the increment) instead of once.
 // ================================================================================================
 struct PointBasis {
-  const int32_t* __restrict__ x0;      // [n,3]
-  const float* __restrict__ b;         // [P][n][3]
+  const int32_t* __restrict__ rows;    // [n, 3 + 3 P] dwords: X0 (int32 grid values), then B_0 .. B_{P-1} (float32 bits)
   const double* __restrict__ w;        // [P] device weights of this evaluation
   int n_terms;
   double inv_scale;
-  int64_t n;
 };
 
 // s_w[k] = w_k / step for the lanes of the block (call before a barrier)
@@ -884,24 +882,37 @@ __device__ __forceinline__ void stage_weights(const PointBasis& pb, double* s_w)
   if ((int)threadIdx.x < pb.n_terms) s_w[threadIdx.x] = pb.w[threadIdx.x] * pb.inv_scale;
 }
 
-__device__ __forceinline__ Pt<q32>::Raw basis_point(const PointBasis& pb, const double* s_w, int64_t row) {
-  const int32_t* q = pb.x0 + row * 3;
-  const int32_t q0 = q[0], q1 = q[1], q2 = q[2];
+// Grid point of `row` for the staged weights wq; P > 0: term count known at compile time (one contiguous 12 (1 + P)-byte
+// row, loads issued together), P = 0: run-time count.  bout (optional): the row's B vectors.
+template <int P>
+__device__ __forceinline__ Pt<q32>::Raw basis_point(const PointBasis& pb, const double* wq, int64_t row, float* bout = nullptr) {
+  const int np = P > 0 ? P : pb.n_terms;
+  const int32_t* r = pb.rows + row * (3 + 3 * np);
+  const int32_t q0 = r[0], q1 = r[1], q2 = r[2];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int k = 0; k < pb.n_terms; ++k) {
-    const float* b = pb.b + ((int64_t)k * pb.n + row) * 3;
-    const double wk = s_w[k];
-    a0 += wk * (double)b[0]; a1 += wk * (double)b[1]; a2 += wk * (double)b[2];
+  if constexpr (P > 0) {
+    float b[3 * P];
+#pragma unroll
+    for (int c = 0; c < 3 * P; ++c) b[c] = __int_as_float(r[3 + c]);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      a0 += wq[k] * (double)b[3 * k]; a1 += wq[k] * (double)b[3 * k + 1]; a2 += wq[k] * (double)b[3 * k + 2];
+      if (bout) { bout[3 * k] = b[3 * k]; bout[3 * k + 1] = b[3 * k + 1]; bout[3 * k + 2] = b[3 * k + 2]; }
+    }
+  } else {
+    for (int k = 0; k < np; ++k) {
+      const float b0 = __int_as_float(r[3 + 3 * k]), b1 = __int_as_float(r[4 + 3 * k]), b2 = __int_as_float(r[5 + 3 * k]);
+      a0 += wq[k] * (double)b0; a1 += wq[k] * (double)b1; a2 += wq[k] * (double)b2;
+    }
   }
-  Pt<q32>::Raw r;
-  r.v[0] = q0 + (int32_t)rint(a0); r.v[1] = q1 + (int32_t)rint(a1); r.v[2] = q2 + (int32_t)rint(a2);
-  return r;
+  Pt<q32>::Raw o;
+  o.v[0] = q0 + (int32_t)rint(a0); o.v[1] = q1 + (int32_t)rint(a1); o.v[2] = q2 + (int32_t)rint(a2);
+  return o;
 }
 
 // X0 and B of every point (once per pose set): the same inputs and arithmetic as points_fwd_kernel.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, int64_t n, QParams qp, int32_t* __restrict__ x0,
-                                                              float* __restrict__ basis) {
+__global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, int64_t n, QParams qp, int32_t* __restrict__ rows) {
   __shared__ double s_pose[kLdsScans * 12];
   const PoseTile poses = stage_poses(in, s_pose);
   __syncthreads();
@@ -923,8 +934,9 @@ __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, in
   rot3(T12, dr, drr);
   const bool on = mp.kind != DC_MODEL_NONE && lm;
   const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;      // d' at w = 0
+  int32_t* r = rows + i * (3 + 3 * mp.n_terms);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) x0[i * 3 + a] = quantize(vr[a] + d0 * drr[a], qp.origin[a], qp.inv_scale, qp.flag);
+  for (int a = 0; a < 3; ++a) r[a] = quantize(vr[a] + d0 * drr[a], qp.origin[a], qp.inv_scale, qp.flag);
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
     if (k < mp.n_terms) {
@@ -933,15 +945,15 @@ __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, in
         if (mp.kind > DC_MODEL_SCALED_POLYNOMIAL) dk = model_dw_other(mp, k, d, inc);
         else dk = (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
       }
-      float* b = basis + ((int64_t)k * n + i) * 3;
-      b[0] = (float)(dk * drr[0]); b[1] = (float)(dk * drr[1]); b[2] = (float)(dk * drr[2]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[3 + 3 * k + a] = __float_as_int((float)(dk * drr[a]));
     }
   }
 }
 
-template <bool FULL_EIG, int NS>
+template <bool FULL_EIG, int NS, int P>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
-    PointBasis pb, BlockTab tab, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, const float* __restrict__ offset, LossParams lp, QParams qp, q32* __restrict__ rec,
     float* __restrict__ pointwise, float* __restrict__ eigvals, double* __restrict__ partials) {
   extern __shared__ int4 tile[];
@@ -959,15 +971,21 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
 #pragma unroll
     for (int q = 0; q < NS; ++q) pre[q] = (uint32_t)lrow[q * kBlock];
     stage_weights(pb, s_w);
-    // ids of the rows this lane stages are requested before the weights are published
     const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    // the block's own rows sit contiguously in its list (k-NN: every point is its own neighbour): the centre comes from LDS
+    const int32_t own = (own_base && !centre_idx) ? own_base[blk] : -1;
     __syncthreads();
+    double wq[P > 0 ? P : DC_MAX_MODEL_TERMS];
+#pragma unroll
+    for (int k = 0; k < (P > 0 ? P : DC_MAX_MODEL_TERMS); ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
     for (int t = threadIdx.x; t < nd; t += kBlock) {
-      const Pt<q32>::Raw r = basis_point(pb, s_w, tab.blk_ids[base + t]);
+      const Pt<q32>::Raw r = basis_point<P>(pb, wq, tab.blk_ids[base + t]);
       tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0);
     }
-    const Pt<q32>::Raw ci = basis_point(pb, s_w, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    Pt<q32>::Raw ci;
+    if (own < 0) ci = basis_point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
     __syncthreads();
+    if (own >= 0) ci = Pt<q32>::from_row(tile + own + (live ? (int)threadIdx.x : 0));
     if (live) {
       CovAcc acc;
       cov_init(acc);
@@ -990,16 +1008,18 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
 
 // Backward in basis form over a run table: the point itself and the chain to the weights come from X0 / B.
 // partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
+template <int P>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
     PointBasis pb, const q32* __restrict__ rec, RunTab tab, int cap, int64_t n, QParams qp, double* __restrict__ partials) {
   constexpr int RR = RecRaw<q32>::kRow16;
+  constexpr int NP = P > 0 ? P : DC_MAX_MODEL_TERMS;
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
-  double gw[DC_MAX_MODEL_TERMS];
+  double gw[NP];
 #pragma unroll
-  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) gw[k] = 0.0;
+  for (int k = 0; k < NP; ++k) gw[k] = 0.0;
   const int64_t j = blk * kBlock + threadIdx.x;
   const bool active = blk >= 0 && j < n;
   uint2 pre[kPreRuns];
@@ -1021,7 +1041,11 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
   const uint32_t nd16 = nd * 16u;
   __syncthreads();
   if (active) {
-    const Pt<q32>::Raw cj = basis_point(pb, s_w, j);
+    double wq[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
+    float bj[3 * (P > 0 ? P : 1)];
+    const Pt<q32>::Raw cj = basis_point<P>(pb, wq, j, P > 0 ? bj : nullptr);
     double g[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < kPreRuns; ++t)
@@ -1036,11 +1060,16 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
     }
     const double u = qp.scale;
     g[0] *= u; g[1] *= u; g[2] *= u;
+    if constexpr (P > 0) {
 #pragma unroll
-    for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
-      if (k < pb.n_terms) {
-        const float* b = pb.b + ((int64_t)k * pb.n + j) * 3;
-        gw[k] = g[0] * (double)b[0] + g[1] * (double)b[1] + g[2] * (double)b[2];
+      for (int k = 0; k < P; ++k) gw[k] = g[0] * (double)bj[3 * k] + g[1] * (double)bj[3 * k + 1] + g[2] * (double)bj[3 * k + 2];
+    } else {
+      const int32_t* r = pb.rows + j * (3 + 3 * pb.n_terms);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (k < pb.n_terms)
+          gw[k] = g[0] * (double)__int_as_float(r[3 + 3 * k]) + g[1] * (double)__int_as_float(r[4 + 3 * k]) +
+                  g[2] * (double)__int_as_float(r[5 + 3 * k]);
       }
     }
   }
@@ -1049,7 +1078,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   double* prow = partials + (int64_t)blockIdx.x * kWavesPerBlock + wave;
 #pragma unroll
-  for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
+  for (int k = 0; k < NP; ++k) {
     if (k < pb.n_terms) {
       const double sw = wave_sum(gw[k]);
       if (lane == 0) { prow[k * rs] = sw; prow[(pb.n_terms + k) * rs] = 0.0; }
@@ -1330,10 +1359,9 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
 
 int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                     const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* e,
-                    int64_t n, int dtype, const double* qparams, int32_t* x0_out, float* basis_out, int32_t* status,
-                    hipStream_t stream) {
+                    int64_t n, int dtype, const double* qparams, int32_t* rows_out, int32_t* status, hipStream_t stream) {
   if (n == 0) return DC_OK;
-  if (n < 0 || !dirs || !depth || !x0_out || !basis_out || !qparams) return DC_ERR_ARG;
+  if (n < 0 || !dirs || !depth || !rows_out || !qparams) return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
   if (dtype != DC_F32) return DC_ERR_DTYPE;                 // the basis form goes with the q32 point format (float32 clouds)
   // the weights do not enter X0 / B: a dummy non-null pointer satisfies the model check, load_model reads e only... and w
@@ -1343,7 +1371,7 @@ int dc_points_basis(const void* vps, const void* dirs, const void* depth, const 
   rc = make_qparams(DC_Q32, dtype, 4, qparams, &qp, status);
   if (rc) return rc;
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, e, e);
-  hipLaunchKernelGGL((points_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, x0_out, basis_out);
+  hipLaunchKernelGGL((points_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, rows_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -1635,7 +1663,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   // weights change between evaluations -> no pass over the points, no model / pose arithmetic in the loop
   size_t lds_f = 0, lds_b = 0;
   int rows_f = 0, rows_b = 0;
-  const bool basis = d->x0q && d->basis && d->point_fmt == DC_Q32 && d->dtype == DC_F32 && n_terms > 0 && w &&
+  const bool basis = d->basis && d->point_fmt == DC_Q32 && d->dtype == DC_F32 && n_terms > 0 && w &&
                      !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
                      (d->k == 4 || d->k == 8 || d->k == 10 || d->k == 16) &&
                      use_table(d->fwd_table, DC_TABLE_SLOTS, stride, 16u, 0, 60 * 1024, &lds_f, &rows_f) &&
@@ -1644,24 +1672,30 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     QParams qp;
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
     if (rc) return rc;
-    PointBasis pb{d->x0q, d->basis, w, n_terms, qp.inv_scale, d->n};
+    PointBasis pb{d->basis, w, n_terms, qp.inv_scale};
     LossParams lp{d->loss_kind, d->normalization, d->sqrt_};
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     {
       ProfScope prof(1);
       const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
-#define FWD_BASIS(NS) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<false, NS>), grid, block, lds_f, stream, pb, tab, rows_f, d->centre_idx, \
-                                      n_rows, d->mask, (const float*)nullptr, lp, qp, (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
+#define FWD_BASIS_P(NS, P) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<false, NS, P>), grid, block, lds_f, stream, pb, tab, \
+                                           d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const float*)nullptr, lp, qp, \
+                                           (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
+#define FWD_BASIS(NS) do { if (n_terms == 2) FWD_BASIS_P(NS, 2); else if (n_terms == 1) FWD_BASIS_P(NS, 1); \
+                           else if (n_terms == 3) FWD_BASIS_P(NS, 3); else FWD_BASIS_P(NS, 0); } while (0)
       if (d->k == 10) FWD_BASIS(10); else if (d->k == 4) FWD_BASIS(4); else if (d->k == 8) FWD_BASIS(8); else FWD_BASIS(16);
+#undef FWD_BASIS_P
 #undef FWD_BASIS
     }
     DC_CHECK_LAUNCH();
     if (want_grad) {
       RunTab rtab{d->bwd_table->blk_ptr, d->bwd_table->blk_ids, d->bwd_table->run_ptr, d->bwd_table->loc};
       ProfScope prof(2);
-      DC_TIMED_LAUNCH(consistency_bwd_basis_kernel, dim3((unsigned)xcd_grid(n_blocks(d->n))), block, lds_b, stream, pb,
-                      (const q32*)d->rec, rtab, rows_b, d->n, qp, p_bwd);
+#define BWD_BASIS(P) DC_TIMED_LAUNCH((consistency_bwd_basis_kernel<P>), dim3((unsigned)xcd_grid(n_blocks(d->n))), block, lds_b, stream, pb, \
+                                     (const q32*)d->rec, rtab, rows_b, d->n, qp, p_bwd)
+      if (n_terms == 2) BWD_BASIS(2); else if (n_terms == 1) BWD_BASIS(1); else if (n_terms == 3) BWD_BASIS(3); else BWD_BASIS(0);
+#undef BWD_BASIS
       DC_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd,

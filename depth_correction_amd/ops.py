@@ -102,12 +102,14 @@ class BlockTable:
     [rows, K] table) or as per-row runs padded to four (``run_ptr``; the backward's incoming-edge lists).  Lets the
     fused kernels gather from LDS."""
 
-    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows, run_ptr=None):
+    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows, run_ptr=None, own_base=None):
         self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc, self.run_ptr = blk_ptr, blk_ids, slot_ptr, loc, run_ptr
+        self.own_base = own_base
         self.max_rows, self.n_rows = int(max_rows), int(n_rows)
         self.layout = nv.DC_TABLE_SLOTS if run_ptr is None else nv.DC_TABLE_RUNS
         self.device = blk_ptr.device
-        self.desc = nv.BlockTableDesc(ptr(blk_ptr), ptr(blk_ids), ptr(slot_ptr), ptr(loc), self.max_rows, self.layout, ptr(run_ptr))
+        self.desc = nv.BlockTableDesc(ptr(blk_ptr), ptr(blk_ids), ptr(slot_ptr), ptr(loc), self.max_rows, self.layout, ptr(run_ptr),
+                                      ptr(own_base))
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self.desc), ctypes.c_void_p)
@@ -126,10 +128,11 @@ def _table_ref(table, n_rows):
 
 
 @on_device
-def block_table(nbr=None, csr=None, layout=None):
+def block_table(nbr=None, csr=None, layout=None, own_rows=True):
     """BlockTable of a neighbour table ``nbr`` int32 [rows, K] (forward; slot-major) or of CSR lists ``csr`` = (ptr, ids)
-    (backward: knn_transpose's output; ``layout`` 'runs' (default) or 'slots').  Returns None when a block references
-    4095 or more distinct rows."""
+    (backward: knn_transpose's output; ``layout`` 'runs' (default) or 'slots').  ``own_rows``: the table's rows and ids
+    are the same points (not a compact centre list), so the position of each block's own rows in its list is recorded.
+    Returns None when a block references 4095 or more distinct rows."""
     if nbr is not None:
         need(nbr, (None, None), dtype=torch.int32, name='neighbors')
         n_rows, k = nbr.shape
@@ -172,7 +175,14 @@ def block_table(nbr=None, csr=None, layout=None):
     total, max_rows, overflow, _ = info.tolist()
     if overflow:
         return None
-    return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows, run_ptr=run_ptr)
+    own_base = None
+    if row_ptr is None and own_rows:
+        # rows and ids of a k-NN table share one index space: where does every block find its own rows in its list?
+        own_base = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
+        check(lib().dc_block_table_own_base(ptr(blk_ptr), ptr(blk_ids), n_rows, ptr(own_base), stream_ptr()),
+              'dc_block_table_own_base')
+    return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows, run_ptr=run_ptr,
+                      own_base=own_base)
 
 
 @on_device

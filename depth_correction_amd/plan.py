@@ -118,7 +118,7 @@ class SequencePlan:
         mark('plan_transpose')
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
         # block tables: distinct rows per 256-point block + 16-bit block-local positions (gathers served from LDS)
-        self.fwd_table = ops.block_table(nbr=nbr) if block_tables else None
+        self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None) if block_tables else None
         self.bwd_table = ops.block_table(csr=(self.csr_ptr, self.csr_src), layout=bwd_layout) if block_tables else None
         mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
@@ -153,7 +153,7 @@ class SequencePlan:
         self.version = 0
         self._desc = None
         self.use_basis = bool(basis)
-        self._basis = None             # (key, x0q, B, poses12, exponent): the last two pin the storage the key names
+        self._basis = None             # (key, rows, poses12, exponent): the last two pin the storage the key names
         self._poses_key = self._poses12 = self._poses_ref = None
 
     # ------------------------------------------------------------------------------------------------
@@ -192,21 +192,20 @@ class SequencePlan:
               and self.fwd_table is not None and self.bwd_table is not None and self.bwd_table.run_ptr is not None
               and self.k in (4, 8, 10, 16) and d.model_kind != 0)
         if not ok:
-            d.x0q = d.basis = None
+            d.basis = None
             return
         nt = w.numel()
         b = self._basis
         key = (poses12.data_ptr(), poses12._version, exponent.data_ptr(), exponent._version, nt)
         if b is None or b[0] != key:
             ps = self.ps
-            x0q = torch.empty((self.n, 3), dtype=torch.int32, device=self.device)
-            B = torch.empty((nt, self.n, 3), dtype=torch.float32, device=self.device)
+            rows = torch.empty((self.n, 3 + 3 * nt), dtype=torch.int32, device=self.device)
             check(lib().dc_points_basis(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
                                         ptr(poses12), self.n_scans, d.model_kind, nt, ptr(exponent), self.n, nv.DC_F32,
-                                        self.qfmt._c, ptr(x0q), ptr(B), ptr(self.status), stream_ptr()), 'dc_points_basis')
+                                        self.qfmt._c, ptr(rows), ptr(self.status), stream_ptr()), 'dc_points_basis')
             # the tensors are kept alive with the entry, so their addresses cannot be recycled for other poses / exponents
-            self._basis = b = (key, x0q, B, poses12, exponent)
-        d.x0q, d.basis = b[1].data_ptr(), b[2].data_ptr()
+            self._basis = b = (key, rows, poses12, exponent)
+        d.basis = b[1].data_ptr()
 
     @on_device
     def eval_native(self, w, exponent, poses12, out, want_grad=True, want_exponent=False, want_pose=False):

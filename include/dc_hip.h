@@ -97,13 +97,13 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
 
 /* Basis form of dc_points_fwd for fixed poses and exponents.  Every model is affine in its weights, so
  *   x_j(w) = X0_j + sum_k w_k B_kj,  X0 = R (vp + d0 dir) + t (d0 = d' at w = 0),  B_kj = (dd'/dw_k) R dir  (0 outside lmask).
- * x0_out int32 [n,3]: X0 on the DC_Q32 grid of qparams (status as in dc_points_fwd); basis_out float32 [n_terms, n, 3] in
- * metres per unit weight.  dtype must be DC_F32.  dc_sequence_eval / _step use the two arrays (dcSequenceDesc.x0q / .basis)
- * instead of launching dc_points_fwd, when neither pose nor exponent gradients are requested. */
+ * rows_out int32 [n, 3 + 3 n_terms]: per point X0 on the DC_Q32 grid of qparams (status as in dc_points_fwd) followed by
+ * the float32 bits of B_0 .. B_{P-1} in metres per unit weight (one contiguous row = one or two cache lines per gather).
+ * dtype must be DC_F32.  dc_sequence_eval / _step use the rows (dcSequenceDesc.basis) instead of launching dc_points_fwd
+ * when neither pose nor exponent gradients are requested. */
 int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                     const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* e,
-                    int64_t n, int dtype, const double* qparams, int32_t* x0_out, float* basis_out, int32_t* status,
-                    dcStream_t stream);
+                    int64_t n, int dtype, const double* qparams, int32_t* rows_out, int32_t* status, dcStream_t stream);
 
 /* Backward of dc_points_fwd for a given dL/dpoints: grads_out fp64 [2*n_terms + 12*n_scans] =
  * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count].
@@ -173,6 +173,9 @@ typedef struct dcBlockTable {
   int32_t max_rows;           /* info[1]: sizes the LDS tile */
   int32_t layout;             /* DC_TABLE_SLOTS | DC_TABLE_RUNS */
   const int32_t* run_ptr;     /* DC_TABLE_RUNS */
+  const int32_t* own_base;    /* int32 [n_blocks] or NULL (dc_block_table_own_base): position of row 256 b in block b's list when
+                                 all of the block's own rows are in it (a k-NN table references every point from its own row),
+                                 else -1; lets the forward take each lane's centre point from the staged rows */
 } dcBlockTable;
 int dc_block_table_slots(const int32_t* row_ptr, int64_t n_rows, int k, int32_t* slot_cnt_ws, int32_t* slot_ptr,
                          dcStream_t stream);
@@ -180,6 +183,7 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs);
 int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
                          const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
                          int32_t* info, void* ws, size_t ws_bytes, dcStream_t stream);
+int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int64_t n_rows, int32_t* own_base, dcStream_t stream);
 int64_t dc_block_table_run_capacity(int64_t n_rows, int64_t n_refs);
 int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int64_t n_refs, int32_t* run_ptr,
                               int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes,
@@ -324,8 +328,8 @@ typedef struct dcSequenceDesc {
   const dcBlockTable* bwd_table;   /* block table of (csr_ptr, csr_src), or NULL */
   int32_t* status;                 /* device int or NULL: bit 0 raised by dc_points_fwd when a DC_Q32 coordinate overflowed /
                                       was NaN; while it is set the evaluation's loss (out[0]) is NaN */
-  const int32_t* x0q;              /* basis form (dc_points_basis), both NULL or both valid FOR THE POSES AND EXPONENTS OF THE */
-  const float* basis;              /* CALL: x = x0q + sum_k w_k basis_k; then no pass over the points per evaluation */
+  const int32_t* basis;            /* basis rows of dc_points_basis, valid FOR THE POSES AND EXPONENTS OF THE CALL, or NULL:
+                                      x = X0 + sum_k w_k B_k, so an evaluation needs no pass over the points */
 } dcSequenceDesc;
 
 /* out fp64 [2 + 2 P + 12 S] = {sum of pointwise loss over mask, mask count, d(sum)/dw, /dexponent, /d[R|t]};
@@ -376,7 +380,7 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
  * option 0: value 1 makes the fused kernels ignore block tables and gather from global memory.
  * option 1: value 1 makes dc_consistency_fwd use the run-time slot loop instead of the kernels specialised for
  *           k = 4 / 8 / 10 / 16.
- * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.x0q / .basis (general path). */
+ * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.basis (general path). */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
