@@ -61,6 +61,8 @@ def parse():
     ap.add_argument('--bwd-layout', default='runs', choices=['runs', 'slots'], help='backward block-table layout (ablation)')
     ap.add_argument('--fwd-generic', action='store_true', help='run-time slot loop in the forward kernel (ablation)')
     ap.add_argument('--no-block-tables', action='store_true', help='gather from global memory instead of LDS (ablation)')
+    ap.add_argument('--no-basis', action='store_true',
+                    help='general path: dc_points_fwd every evaluation instead of the basis form x = X0 + sum w_k B_k (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
     return ap.parse_args()
 
@@ -84,6 +86,11 @@ def compulsory_bytes(plan):
     pt_in = nbytes(ps.vps, ps.dirs, ps.depth, ps.inc, ps.lmask, ps.scan_id)
     fwd_tab = nbytes(ft.blk_ptr, ft.blk_ids, ft.slot_ptr, ft.loc) if ft is not None else nbytes(plan.nbr)
     bwd_tab = nbytes(bt.blk_ptr, bt.blk_ids, bt.slot_ptr, bt.run_ptr, bt.loc) if bt is not None else nbytes(plan.csr_ptr, plan.csr_src)
+    basis = plan._basis[1] if getattr(plan, '_basis', None) else None
+    if basis is not None:
+        # basis form: the kernels form the points from the [N, 3 + 3 P] basis rows, no pass over the raw inputs
+        return dict(points_fwd=0, consistency_fwd=nbytes(basis, plan.mask, plan.rec, ft.own_base) + fwd_tab,
+                    consistency_bwd=nbytes(basis, plan.rec) + bwd_tab)
     return dict(points_fwd=pt_in + nbytes(plan.x),
                 consistency_fwd=nbytes(plan.x, plan.mask, plan.rec) + fwd_tab,
                 consistency_bwd=nbytes(plan.x, plan.rec) + pt_in + bwd_tab)
@@ -218,7 +225,7 @@ def main():
     build = lambda **kw: build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, spatial_sort=not args.no_sort,
                                         point_format=args.point_format, active_only=args.active_only,
                                         degree_sort=args.degree_sort, block_tables=not args.no_block_tables,
-                                        bwd_layout=args.bwd_layout, **kw)
+                                        bwd_layout=args.bwd_layout, basis=not args.no_basis, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     plan, info = build()
@@ -413,6 +420,8 @@ def main():
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
+                       'form': 'basis (x = X0 + sum_k w_k B_k formed inside the consistency kernels; X0 / B rebuilt only when poses or exponents change)'
+                               if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
                        'loop': ('autograd+torch.optim.Adam' + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),

@@ -411,9 +411,10 @@ def test_block_table_structure(golden, dev):
     nb = (n + 255) // 256
     cp, cs = ops.knn_transpose(nbr)
     csr_lists = np.split(npy(cs)[:int(cp[-1])], npy(cp)[1:-1])
-    for table, lists in ((ops.block_table(nbr=nbr), [r[r >= 0] for r in npy(nbr)]),
-                         (ops.block_table(csr=(cp, cs), layout='slots'), csr_lists),
-                         (ops.block_table(csr=(cp, cs)), csr_lists)):
+    blk4 = nbr[1024:1280]
+    blk4[blk4 == 1030] = 1031                                        # block 4 never references its own row 1030
+    tables = (ops.block_table(nbr=nbr), ops.block_table(csr=(cp, cs), layout='slots'), ops.block_table(csr=(cp, cs)))
+    for table, lists in zip(tables, ([r[r >= 0] for r in npy(nbr)], csr_lists, csr_lists)):
         bp, ids = npy(table.blk_ptr), npy(table.blk_ids)
         assert len(bp) == nb + 1 and bp[0] == 0
         assert table.max_rows == int(np.diff(bp).max())
@@ -426,10 +427,18 @@ def test_block_table_structure(golden, dev):
             assert len(rp) == n + 1 and rp[0] == 0
             assert np.array_equal(np.diff(rp), [(len(r) + 3) // 4 for r in lists])
             assert np.all(loc[4 * rp[-1]:4 * rp[-1] + 1] == 0xFFFF) or 4 * rp[-1] == len(loc)
+        own = None if table.own_base is None else npy(table.own_base)
+        assert (own is not None) == (table is tables[0])             # only the k-NN (forward) table carries own_base
         for b in range(nb):
             rows = lists[b * 256:(b + 1) * 256]
             want = np.unique(np.concatenate(rows)) if len(rows) else np.zeros(0, np.int64)
             assert np.array_equal(ids[bp[b]:bp[b + 1]], want)
+            if own is not None:
+                mine = np.arange(b * 256, b * 256 + len(rows))
+                if np.isin(mine, want).all():
+                    assert own[b] >= 0 and np.array_equal(want[own[b]:own[b] + len(rows)], mine)
+                else:
+                    assert own[b] == -1
             if table.run_ptr is None:
                 assert sp[b + 1] - sp[b] == max(len(r) for r in rows)
                 blk = loc[sp[b]:sp[b + 1]]
@@ -474,11 +483,15 @@ def test_block_tables_do_not_change_results(golden, dev):
     assert np.array_equal(npy(r['gw']), outs[0][0])
 
 
-@pytest.mark.parametrize('model', ['ScaledPolynomial', 'Polynomial'])
-def test_basis_form_equals_general_path(golden, dev, model):
+@pytest.mark.parametrize('model,n_terms,active_only', [('ScaledPolynomial', 2, False), ('Polynomial', 2, False),
+                                                       ('ScaledPolynomial', 1, False), ('Polynomial', 3, False),
+                                                       ('ScaledPolynomial', 4, False), ('ScaledPolynomial', 2, True)])
+def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only):
     """dc_sequence_eval through the basis form (x = X0 + sum_k w_k B_k, no pass over the points) against the general
     path (dc_points_fwd every evaluation): identical count, loss and dL/dw up to the second rounding of the q32 grid, for
-    several weight vectors on one plan (X0 / B are built once) and after the poses changed (rebuilt)."""
+    several weight vectors on one plan (X0 / B are built once) and after the poses changed (rebuilt).  Term counts 1-3
+    run the kernels specialised for them, 4 the run-time loop; active_only takes the centre from its own row instead of
+    the staged ones."""
     from depth_correction_amd.plan import SequencePlan
     from depth_correction_amd import _native as nv
     g = golden('room_k10')
@@ -486,25 +499,27 @@ def test_basis_form_equals_general_path(golden, dev, model):
     clouds = [dict(vps=s['vps'].to(dev), dirs=s['dirs'].to(dev), depth=s['depth'].to(dev), inc_angles=s['inc'].to(dev),
                    mask=s['mask'].to(dev)) for s in scans]
     poses = t(g['poses'], dev)
-    plan = SequencePlan(clouds, poses, t(g['g_neighbors'], dev), t(g['g_mask'], dev), model_kind=model)
+    plan = SequencePlan(clouds, poses, t(g['g_neighbors'], dev), t(g['g_mask'], dev), model_kind=model, active_only=active_only)
     assert plan.qfmt is not None
-    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    assert (plan.fwd_table.own_base is None) == active_only
+    e = torch.tensor([2.0, 4.0, 1.0, 3.0][:n_terms], dtype=torch.float64, device=dev)
+    nt = n_terms
     outs = {}
     for basis in (True, False):
         nv.check(nv.lib().dc_set_option(3, 0 if basis else 1), 'dc_set_option')
         try:
             res = []
             P = plan.poses12(poses)
-            for wv in ([1e-3, 2e-3], [-2e-3, 5e-4], [0.0, 0.0]):
-                w = torch.tensor(wv, dtype=torch.float64, device=dev)
-                out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+            for wv in ([1e-3, 2e-3, -1e-3, 5e-4], [-2e-3, 5e-4, 1e-3, -2e-4], [0.0, 0.0, 0.0, 0.0]):
+                w = torch.tensor(wv[:nt], dtype=torch.float64, device=dev)
+                out = torch.zeros(2 + 2 * nt + 12 * plan.n_scans, dtype=torch.float64, device=dev)
                 plan.eval_native(w, e, P, out)
                 res.append(npy(out))
             moved = poses.clone()
             moved[1, :3, 3] += 0.05
             P2 = plan.poses12(moved)
-            out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
-            plan.eval_native(torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev), e, P2, out)
+            out = torch.zeros(2 + 2 * nt + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+            plan.eval_native(torch.tensor([1e-3, 2e-3, -1e-3, 5e-4][:nt], dtype=torch.float64, device=dev), e, P2, out)
             res.append(npy(out))
             outs[basis] = res
         finally:
@@ -512,5 +527,5 @@ def test_basis_form_equals_general_path(golden, dev, model):
     for a, b in zip(outs[True], outs[False]):
         assert a[1] == b[1] > 0
         np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
-        np.testing.assert_allclose(a[2:4], b[2:4], rtol=2e-5, atol=1e-7 * np.abs(b[2:4]).max())
+        np.testing.assert_allclose(a[2:2 + nt], b[2:2 + nt], rtol=2e-5, atol=1e-7 * np.abs(b[2:2 + nt]).max())
     assert not np.allclose(outs[True][0][0], outs[True][3][0], rtol=1e-9)          # the moved pose changed the loss
