@@ -62,7 +62,7 @@ def parse():
     ap.add_argument('--fwd-generic', action='store_true', help='run-time slot loop in the forward kernel (ablation)')
     ap.add_argument('--no-block-tables', action='store_true', help='gather from global memory instead of LDS (ablation)')
     ap.add_argument('--no-basis', action='store_true',
-                    help='general path: dc_points_fwd every evaluation instead of the basis form x = X0 + sum w_k B_k (ablation)')
+                    help='general path: dc_points_fwd every evaluation instead of the basis form x = X0 + (sum w_k c_k) u (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
     return ap.parse_args()
 
@@ -88,7 +88,7 @@ def compulsory_bytes(plan):
     bwd_tab = nbytes(bt.blk_ptr, bt.blk_ids, bt.slot_ptr, bt.run_ptr, bt.loc) if bt is not None else nbytes(plan.csr_ptr, plan.csr_src)
     basis = plan._basis[1] if getattr(plan, '_basis', None) else None
     if basis is not None:
-        # basis form: the kernels form the points from the [N, 3 + 3 P] basis rows, no pass over the raw inputs
+        # basis form: the kernels form the points from the [N, 6 + P] basis rows, no pass over the raw inputs
         return dict(points_fwd=0, consistency_fwd=nbytes(basis, plan.mask, plan.rec, ft.own_base) + fwd_tab,
                     consistency_bwd=nbytes(basis, plan.rec) + bwd_tab)
     return dict(points_fwd=pt_in + nbytes(plan.x),
@@ -420,7 +420,7 @@ def main():
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
-                       'form': 'basis (x = X0 + sum_k w_k B_k formed inside the consistency kernels; X0 / B rebuilt only when poses or exponents change)'
+                       'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the consistency kernels; the basis rows are rebuilt only when poses or exponents change)'
                                if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
                        'loop': ('autograd+torch.optim.Adam' + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,

@@ -862,16 +862,17 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
 // Basis form of the iteration (fixed poses, fixed exponents): every model of the reference is affine in its weights
 // (Polynomial d' = d - sum w_k g^e_k, ScaledPolynomial d' = d (1 - sum w_k g^e_k), Linear, InvCos, ScaledInvCos:
 // model.py:113-349), so the world point of ray j is
-//     x_j(w) = X0_j + sum_k w_k B_kj,      X0_j = R (vp + d0 dir) + t,   B_kj = (dd'/dw_k) R dir   (zero outside the local mask)
-// with X0 and B constant while the poses do not move.  They are computed once (points_basis_kernel); an iteration then
-// needs no pass over the points to refresh x: the forward forms the rows it stages (and its centre) from X0 / B on the
-// fly, the backward its own point, and the chain to the weights is dL/dw_k = sum_j g_j . B_kj -- no model, no pose, no
-// incidence angles in the loop.  X0 lives on the q32 grid, B in float32 metres per unit weight (|w B| is centimetres,
-// so its fp32 rounding is ~1e-9 m, far below the grid).  A coordinate is the grid value X0 + rint(sum w_k B_k / step):
-// the same integer for every block that forms it, rounded twice (X0 and the increment) instead of once.
+//     x_j(w) = X0_j + (sum_k w_k c_kj) u_j,     X0_j = R (vp + d0 dir) + t,   u_j = R dir,   c_kj = dd'/dw_k   (zero outside the local mask)
+// with X0, u and c constant while the poses do not move.  They are computed once (points_basis_kernel); an iteration then
+// needs no pass over the points to refresh x: the forward forms the rows it stages (and its centre) from the basis rows on
+// the fly, the backward its own point, and the chain to the weights is dL/dw_k = sum_j (g_j . u_j) c_kj -- no model, no
+// pose, no incidence angles in the loop.  X0 lives on the q32 grid, u and c in float32 (the correction sum w c is
+// centimetres, so its fp32 rounding is ~1e-9 m, far below the grid).  A coordinate is the grid value
+// X0 + rint((sum w_k c_k) u / step): the same integer for every block that forms it, rounded twice (X0 and the increment)
+// instead of once.  A row is 24 + 4 P bytes: 32 for the two-term models, one aligned sector per gathered point.
 // ================================================================================================
 struct PointBasis {
-  const int32_t* __restrict__ rows;    // [n, 3 + 3 P] dwords: X0 (int32 grid values), then B_0 .. B_{P-1} (float32 bits)
+  const int32_t* __restrict__ rows;    // [n, 6 + P] dwords: X0 (int32 grid values), u (float32 bits), c_0 .. c_{P-1} (float32 bits)
   const double* __restrict__ w;        // [P] device weights of this evaluation
   int n_terms;
   double inv_scale;
@@ -882,35 +883,32 @@ __device__ __forceinline__ void stage_weights(const PointBasis& pb, double* s_w)
   if ((int)threadIdx.x < pb.n_terms) s_w[threadIdx.x] = pb.w[threadIdx.x] * pb.inv_scale;
 }
 
-// Grid point of `row` for the staged weights wq; P > 0: term count known at compile time (one contiguous 12 (1 + P)-byte
-// row, loads issued together), P = 0: run-time count.  bout (optional): the row's B vectors.
+// Grid point of `row` for the staged weights wq; P > 0: term count known at compile time (one contiguous row, loads
+// issued together), P = 0: run-time count.
 template <int P>
-__device__ __forceinline__ Pt<q32>::Raw basis_point(const PointBasis& pb, const double* wq, int64_t row, float* bout = nullptr) {
+__device__ __forceinline__ Pt<q32>::Raw basis_point(const PointBasis& pb, const double* wq, int64_t row) {
   const int np = P > 0 ? P : pb.n_terms;
-  const int32_t* r = pb.rows + row * (3 + 3 * np);
-  const int32_t q0 = r[0], q1 = r[1], q2 = r[2];
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const int32_t* r = pb.rows + row * (6 + np);
+  int32_t q[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) q[c] = r[c];
+  double sc = 0.0;
   if constexpr (P > 0) {
-    float b[3 * P];
+    float c[P];
 #pragma unroll
-    for (int c = 0; c < 3 * P; ++c) b[c] = __int_as_float(r[3 + c]);
+    for (int k = 0; k < P; ++k) c[k] = __int_as_float(r[6 + k]);
 #pragma unroll
-    for (int k = 0; k < P; ++k) {
-      a0 += wq[k] * (double)b[3 * k]; a1 += wq[k] * (double)b[3 * k + 1]; a2 += wq[k] * (double)b[3 * k + 2];
-      if (bout) { bout[3 * k] = b[3 * k]; bout[3 * k + 1] = b[3 * k + 1]; bout[3 * k + 2] = b[3 * k + 2]; }
-    }
+    for (int k = 0; k < P; ++k) sc += wq[k] * (double)c[k];
   } else {
-    for (int k = 0; k < np; ++k) {
-      const float b0 = __int_as_float(r[3 + 3 * k]), b1 = __int_as_float(r[4 + 3 * k]), b2 = __int_as_float(r[5 + 3 * k]);
-      a0 += wq[k] * (double)b0; a1 += wq[k] * (double)b1; a2 += wq[k] * (double)b2;
-    }
+    for (int k = 0; k < np; ++k) sc += wq[k] * (double)__int_as_float(r[6 + k]);
   }
   Pt<q32>::Raw o;
-  o.v[0] = q0 + (int32_t)rint(a0); o.v[1] = q1 + (int32_t)rint(a1); o.v[2] = q2 + (int32_t)rint(a2);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
   return o;
 }
 
-// X0 and B of every point (once per pose set): the same inputs and arithmetic as points_fwd_kernel.
+// X0, u and c of every point (once per pose set): the same inputs and arithmetic as points_fwd_kernel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, int64_t n, QParams qp, int32_t* __restrict__ rows) {
   __shared__ double s_pose[kLdsScans * 12];
@@ -934,9 +932,12 @@ __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, in
   rot3(T12, dr, drr);
   const bool on = mp.kind != DC_MODEL_NONE && lm;
   const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;      // d' at w = 0
-  int32_t* r = rows + i * (3 + 3 * mp.n_terms);
+  int32_t* r = rows + i * (6 + mp.n_terms);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) r[a] = quantize(vr[a] + d0 * drr[a], qp.origin[a], qp.inv_scale, qp.flag);
+  for (int a = 0; a < 3; ++a) {
+    r[a] = quantize(vr[a] + d0 * drr[a], qp.origin[a], qp.inv_scale, qp.flag);
+    r[3 + a] = __float_as_int((float)drr[a]);
+  }
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
     if (k < mp.n_terms) {
@@ -945,8 +946,7 @@ __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, in
         if (mp.kind > DC_MODEL_SCALED_POLYNOMIAL) dk = model_dw_other(mp, k, d, inc);
         else dk = (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
       }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) r[3 + 3 * k + a] = __float_as_int((float)(dk * drr[a]));
+      r[6 + k] = __float_as_int((float)dk);
     }
   }
 }
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
   wave_partials<2>(acc2, partials);
 }
 
-// Backward in basis form over a run table: the point itself and the chain to the weights come from X0 / B.
+// Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
 // partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
 template <int P>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
@@ -1044,8 +1044,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
     double wq[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
-    float bj[3 * (P > 0 ? P : 1)];
-    const Pt<q32>::Raw cj = basis_point<P>(pb, wq, j, P > 0 ? bj : nullptr);
+    const Pt<q32>::Raw cj = basis_point<P>(pb, wq, j);
     double g[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < kPreRuns; ++t)
@@ -1060,17 +1059,13 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
     }
     const double u = qp.scale;
     g[0] *= u; g[1] *= u; g[2] *= u;
-    if constexpr (P > 0) {
+    // u_j and c_j again (the row is still in the cache): holding them across the edge loop costs a wavefront of occupancy
+    const int np = P > 0 ? P : pb.n_terms;
+    const int32_t* r = pb.rows + j * (6 + np);
+    const double gu = g[0] * (double)__int_as_float(r[3]) + g[1] * (double)__int_as_float(r[4]) + g[2] * (double)__int_as_float(r[5]);
 #pragma unroll
-      for (int k = 0; k < P; ++k) gw[k] = g[0] * (double)bj[3 * k] + g[1] * (double)bj[3 * k + 1] + g[2] * (double)bj[3 * k + 2];
-    } else {
-      const int32_t* r = pb.rows + j * (3 + 3 * pb.n_terms);
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        if (k < pb.n_terms)
-          gw[k] = g[0] * (double)__int_as_float(r[3 + 3 * k]) + g[1] * (double)__int_as_float(r[4 + 3 * k]) +
-                  g[2] * (double)__int_as_float(r[5 + 3 * k]);
-      }
+    for (int k = 0; k < NP; ++k) {
+      if (k < np) gw[k] = gu * (double)__int_as_float(r[6 + k]);
     }
   }
   // per-wavefront partial rows, as reduce_param_grads writes them
@@ -1223,7 +1218,7 @@ static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
-static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's X0 / B arrays (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
+static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's basis rows (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
 // a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
 static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit,
@@ -1364,7 +1359,7 @@ int dc_points_basis(const void* vps, const void* dirs, const void* depth, const 
   if (n < 0 || !dirs || !depth || !rows_out || !qparams) return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
   if (dtype != DC_F32) return DC_ERR_DTYPE;                 // the basis form goes with the q32 point format (float32 clouds)
-  // the weights do not enter X0 / B: a dummy non-null pointer satisfies the model check, load_model reads e only... and w
+  // the weights do not enter the basis rows: a dummy non-null pointer satisfies the model check, load_model reads e only... and w
   int rc = check_model(model_kind, n_terms, inc, e, e);
   if (rc || model_kind == DC_MODEL_NONE) return rc ? rc : DC_ERR_ARG;
   QParams qp;
@@ -1659,7 +1654,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   double* p_bwd = d->partials + 2 * rows;
   const int n_red = !want_grad ? 0 : (want_pose_grad ? n_acc : 2 * n_terms);
 
-  // ---- basis form: X0 / B of the current poses and exponents are valid (the caller says so by passing them), only the
+  // ---- basis form: the basis rows of the current poses and exponents are valid (the caller says so by passing them), only the
   // weights change between evaluations -> no pass over the points, no model / pose arithmetic in the loop
   size_t lds_f = 0, lds_b = 0;
   int rows_f = 0, rows_b = 0;

@@ -43,8 +43,8 @@ class SequencePlan:
         :param mask: [N] bool global mask (None = all points).
         :param block_tables: build the block tables that let both hot kernels gather from LDS (ops.block_table).
         :param bwd_layout: 'runs' (per-point runs padded to four positions) or 'slots' (slot-major, padded per block).
-        :param basis: use the basis form x = X0 + sum_k w_k B_k (dc_points_basis) whenever an evaluation asks for neither pose
-                      nor exponent gradients: X0 / B are rebuilt only when the poses or the exponents change.
+        :param basis: use the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis) whenever an evaluation asks for neither pose
+                      nor exponent gradients: the basis rows are rebuilt only when the poses or the exponents change.
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
                             the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
@@ -186,7 +186,7 @@ class SequencePlan:
         return self._desc
 
     def _set_basis(self, d, w, exponent, poses12, want_exponent, want_pose):
-        """Point the descriptor at X0 / B valid for (poses12, exponent), building them when either changed; or clear the
+        """Point the descriptor at the basis rows valid for (poses12, exponent), building them when either changed; or clear the
         fields when this evaluation cannot use the basis form (pose / exponent gradients, other formats, no tables)."""
         ok = (self.use_basis and self.qfmt is not None and w is not None and not want_exponent and not want_pose
               and self.fwd_table is not None and self.bwd_table is not None and self.bwd_table.run_ptr is not None
@@ -199,7 +199,7 @@ class SequencePlan:
         key = (poses12.data_ptr(), poses12._version, exponent.data_ptr(), exponent._version, nt)
         if b is None or b[0] != key:
             ps = self.ps
-            rows = torch.empty((self.n, 3 + 3 * nt), dtype=torch.int32, device=self.device)
+            rows = torch.empty((self.n, 6 + nt), dtype=torch.int32, device=self.device)
             check(lib().dc_points_basis(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
                                         ptr(poses12), self.n_scans, d.model_kind, nt, ptr(exponent), self.n, nv.DC_F32,
                                         self.qfmt._c, ptr(rows), ptr(self.status), stream_ptr()), 'dc_points_basis')

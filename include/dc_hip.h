@@ -96,9 +96,9 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
                   dcStream_t stream);
 
 /* Basis form of dc_points_fwd for fixed poses and exponents.  Every model is affine in its weights, so
- *   x_j(w) = X0_j + sum_k w_k B_kj,  X0 = R (vp + d0 dir) + t (d0 = d' at w = 0),  B_kj = (dd'/dw_k) R dir  (0 outside lmask).
- * rows_out int32 [n, 3 + 3 n_terms]: per point X0 on the DC_Q32 grid of qparams (status as in dc_points_fwd) followed by
- * the float32 bits of B_0 .. B_{P-1} in metres per unit weight (one contiguous row = one or two cache lines per gather).
+ *   x_j(w) = X0_j + (sum_k w_k c_kj) u_j,  X0 = R (vp + d0 dir) + t (d0 = d' at w = 0),  u = R dir,  c_kj = dd'/dw_k  (0 outside lmask).
+ * rows_out int32 [n, 6 + n_terms]: per point X0 on the DC_Q32 grid of qparams (status as in dc_points_fwd), then the float32
+ * bits of u and of c_0 .. c_{P-1} (metres per unit weight); 32 bytes for the two-term models = one sector per gathered point.
  * dtype must be DC_F32.  dc_sequence_eval / _step use the rows (dcSequenceDesc.basis) instead of launching dc_points_fwd
  * when neither pose nor exponent gradients are requested. */
 int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
@@ -329,7 +329,7 @@ typedef struct dcSequenceDesc {
   int32_t* status;                 /* device int or NULL: bit 0 raised by dc_points_fwd when a DC_Q32 coordinate overflowed /
                                       was NaN; while it is set the evaluation's loss (out[0]) is NaN */
   const int32_t* basis;            /* basis rows of dc_points_basis, valid FOR THE POSES AND EXPONENTS OF THE CALL, or NULL:
-                                      x = X0 + sum_k w_k B_k, so an evaluation needs no pass over the points */
+                                      x = X0 + (sum_k w_k c_k) u, so an evaluation needs no pass over the points */
 } dcSequenceDesc;
 
 /* out fp64 [2 + 2 P + 12 S] = {sum of pointwise loss over mask, mask count, d(sum)/dw, /dexponent, /d[R|t]};
