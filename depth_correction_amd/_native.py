@@ -18,6 +18,7 @@ __all__ = ['lib', 'lib_path', 'on_device', 'DC_F32', 'DC_F64', 'DC_Q32', 'LOSS_K
 DC_F32, DC_F64, DC_Q32 = 0, 1, 2
 DC_TABLE_SLOTS, DC_TABLE_RUNS = 0, 1
 LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
+LOSS_RAW_POINTWISE = 0x100
 MODEL_KINDS = {None: 0, 'BaseModel': 0, 'Polynomial': 1, 'ScaledPolynomial': 2, 'Linear': 3, 'InvCos': 4, 'ScaledInvCos': 5}
 MAX_MODEL_TERMS = 8
 
@@ -36,6 +37,7 @@ _SIGNATURES = {
     'dc_spatial_order': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
     'dc_points_fwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dc_consistency_gate': (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     'dc_points_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'dc_partial_rows': (_i64, [_i64]),
     'dc_param_grad_count': (_i32, [_i32, _i32]),

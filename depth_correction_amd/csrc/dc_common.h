@@ -28,6 +28,7 @@
 // Loss kinds / model kinds (mirrors the reference's names: loss.py:216,297 ; model.py:149,218).
 #define DC_LOSS_MIN_EIGVAL 0
 #define DC_LOSS_TRACE 1
+#define DC_LOSS_RAW_POINTWISE 0x100 /* OR-ed into loss_kind of dc_consistency_fwd: `pointwise` receives the loss before relu / sqrt */
 #define DC_MODEL_NONE 0
 #define DC_MODEL_POLYNOMIAL 1
 #define DC_MODEL_SCALED_POLYNOMIAL 2

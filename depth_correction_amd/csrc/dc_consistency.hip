@@ -90,11 +90,12 @@ __device__ __forceinline__ void consistency_point(CovAcc& acc, const typename Pt
   } else {
     eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
   }
-  l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2);
+  double raw;
+  l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2, &raw);
   if (m) { acc2[0] = l; acc2[1] = 1.0; }
   // record: covariance mean in the point format; coefficients act on differences in metres
   if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
-  if (pointwise) pointwise[i] = (T)l;
+  if (pointwise) pointwise[i] = (T)(lp.raw_pointwise ? raw : l);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1081,6 +1082,38 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
   }
 }
 
+// Quantile-inlier gating of the pointwise loss (loss.py:256-277) for the fused path: `raw` is the forward's raw loss
+// (DC_LOSS_RAW_POINTWISE), *threshold the bound the caller derived from it (quantile x multiplier, or the given maximum).
+// A masked centre with raw loss above the bound (or NaN: `<=` fails as in torch) is dropped: its record's coefficients
+// are zeroed, so the backward passes nothing through it; the sums become {sum of relu / sqrt loss, count} of the inliers.
+template <typename PT> struct RecWord { using type = PT; };
+template <> struct RecWord<q32> { using type = int32_t; };          // c1 / c2 are float bits: all-zero bits = 0.0f
+template <typename T, typename PT>
+__global__ __launch_bounds__(kBlock) void consistency_gate_kernel(const T* __restrict__ raw, const uint8_t* __restrict__ mask, int64_t n,
+                                                                  const double* __restrict__ threshold, int sqrt_,
+                                                                  PT* __restrict__ rec, double* __restrict__ partials) {
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0};
+  const int64_t i = blk * kBlock + threadIdx.x;
+  if (blk >= 0 && i < n) {
+    const bool m = mask ? mask[i] != 0 : true;
+    const T r = raw[i];
+    const bool in = m && (r <= (T)*threshold);        // compared in the cloud dtype, like the reference's tensors
+    if (in) {
+      double l = (double)r;
+      l = l > 0.0 ? l : 0.0;
+      if (sqrt_) l = sqrt(l);
+      acc2[0] = l; acc2[1] = 1.0;
+    } else if (m) {
+      using W = typename RecWord<PT>::type;
+      W* row = reinterpret_cast<W*>(rec) + i * 8;
+      row[3] = W(0); row[7] = W(0);
+    }
+  }
+  wave_partials<2>(acc2, partials);
+}
+
 // Stand-alone point epilogue for the un-fused API path (grad of points given).
 template <typename T, int STRIDE>
 __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict__ grad_x, const int32_t* __restrict__ perm,
@@ -1380,7 +1413,7 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
                                 double* sums_out, hipStream_t stream, bool reduce) {
   if (n == 0 && sums_out) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
   if (n < 0 || k < 1 || !points || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
-  if (loss_kind != DC_LOSS_MIN_EIGVAL && loss_kind != DC_LOSS_TRACE) return DC_ERR_ARG;
+  if ((loss_kind & ~DC_LOSS_RAW_POINTWISE) != DC_LOSS_MIN_EIGVAL && (loss_kind & ~DC_LOSS_RAW_POINTWISE) != DC_LOSS_TRACE) return DC_ERR_ARG;
   BlockTab tab{};
   size_t lds_bytes = 0;
   int lds_rows = 0;
@@ -1392,7 +1425,7 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   int rc = make_qparams(point_fmt, dtype, stride, qparams, &qp);
   if (rc) return rc;
   if (n == 0) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
-  LossParams lp{loss_kind, normalization, sqrt_};
+  LossParams lp{loss_kind & ~DC_LOSS_RAW_POINTWISE, normalization, sqrt_, (loss_kind & DC_LOSS_RAW_POINTWISE) != 0};
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
 #define FWD_ARGS(T, PT) (const PT*)points, nbr, centre_idx, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
@@ -1668,7 +1701,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
     if (rc) return rc;
     PointBasis pb{d->basis, w, n_terms, qp.inv_scale};
-    LossParams lp{d->loss_kind, d->normalization, d->sqrt_};
+    LossParams lp{d->loss_kind, d->normalization, d->sqrt_, 0};
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     {
@@ -1714,6 +1747,28 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
                      n_red, out, adam, (const int32_t*)d->status);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, const uint8_t* mask, int64_t n,
+                        const double* threshold, int sqrt_, void* rec, double* partials_ws, double* sums_out,
+                        hipStream_t stream) {
+  if (n < 0 || !partials_ws || !sums_out || !threshold) return DC_ERR_ARG;
+  if (n == 0) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
+  if (!raw_pointwise || !rec) return DC_ERR_ARG;
+  const int64_t rows = xcd_grid(n_blocks(n));
+  const dim3 grid((unsigned)rows), block(kBlock);
+  if (point_fmt == DC_Q32 && dtype == DC_F32)
+    hipLaunchKernelGGL((consistency_gate_kernel<float, q32>), grid, block, 0, stream, (const float*)raw_pointwise, mask, n, threshold, sqrt_, (q32*)rec, partials_ws);
+  else if (point_fmt == DC_F32 && dtype == DC_F32)
+    hipLaunchKernelGGL((consistency_gate_kernel<float, float>), grid, block, 0, stream, (const float*)raw_pointwise, mask, n, threshold, sqrt_, (float*)rec, partials_ws);
+  else if (point_fmt == DC_F64 && dtype == DC_F64)
+    hipLaunchKernelGGL((consistency_gate_kernel<double, double>), grid, block, 0, stream, (const double*)raw_pointwise, mask, n, threshold, sqrt_, (double*)rec, partials_ws);
+  else
+    return DC_ERR_DTYPE;
+  DC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(2), dim3(kRedBlock), 0, stream, partials_ws, rows * kWavesPerBlock, sums_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

@@ -166,13 +166,14 @@ struct LossParams {
   int kind;            // DC_LOSS_*
   int normalization;   // min-eigenvalue / total variance (loss.py:253-254)
   int sqrt_;           // loss.py:286-287
+  int raw_pointwise;   // the optional per-point output holds the loss BEFORE relu / sqrt (what loss.py:256-277 gates on)
 };
 
 // Pointwise loss l_i (after offset, relu, sqrt) and the coefficients of
 //   dL/dx_j += c1 * (v0 . d) v0 - c2 * d,  d = x_j - cmean_i,
 // for a unit upstream weight (mask and 1/M are applied by the caller through `a`).
 DC_HD double loss_and_coeffs(const LossParams& lp, double lam0, double tr, double D, double offset, bool in_mask,
-                             double* c1, double* c2) {
+                             double* c1, double* c2, double* raw_out = nullptr) {
   double raw, g_vv = 0.0, g_eye = 0.0;    // G = g_vv * v0 v0^T + g_eye * I
   if (lp.kind == DC_LOSS_MIN_EIGVAL) {
     if (lp.normalization) {
@@ -190,6 +191,7 @@ DC_HD double loss_and_coeffs(const LossParams& lp, double lam0, double tr, doubl
     g_eye = 1.0;
   }
   double l = raw - offset;
+  if (raw_out) *raw_out = l;
   double a = (in_mask && l > 0.0) ? 1.0 : 0.0;     // relu'; NaN compares false
   l = l > 0.0 ? l : (l != l ? l : 0.0);           // relu keeps NaN
   if (lp.sqrt_) {

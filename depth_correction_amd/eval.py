@@ -1,10 +1,10 @@
 """Loss evaluation over sequences with the reference's signatures (eval.py:31-112).
 
 ``eval_loss_clouds`` is the body of one training iteration.  When the configuration is the one the fused kernels
-cover (ball neighbourhoods on the GPU, min-eigenvalue or trace loss without quantile inliers / offsets / distance
-weights, (Scaled)Polynomial or no model) every sequence is evaluated by its cached ``SequencePlan`` -- three kernel
-launches -- and the returned loss carries the hand-derived backward to ``model.w`` / ``model.exponent`` / the pose
-corrections.  Any other configuration goes through the un-fused DepthCloud operators with identical results.
+cover (ball neighbourhoods on the GPU, min-eigenvalue or trace loss -- with or without quantile inliers -- without
+offsets / distance weights, any of the reference's models or none) every sequence is evaluated by its cached
+``SequencePlan`` -- two or three kernel launches -- and the returned loss carries the hand-derived backward to
+``model.w`` / ``model.exponent`` / the pose corrections.  Any other configuration goes through the un-fused DepthCloud operators with identical results.
 """
 from __future__ import annotations
 
@@ -52,7 +52,6 @@ def fused_supported(clouds, model, cfg: Config):
     kw = cfg.loss_kwargs
     return (getattr(cfg, 'fused', True) and cfg.nn_type == NeighborhoodType.ball
             and cfg.loss in ('min_eigval_loss', 'trace_loss') and not cfg.loss_offset and not cfg.nn_scale
-            and kw.get('inlier_ratio', 1.0) == 1.0 and kw.get('inlier_max_loss') is None
             and (model is None or getattr(model, 'kernel_kind', None) is not None)
             and clouds[0][0].dirs.is_cuda and all(c.inc_angles is not None for seq in clouds for c in seq))
 
@@ -61,18 +60,24 @@ class PlanCloud(object):
     """Lazy view of a fused evaluation: the DepthCloud fields callers may inspect (points, eigvals, loss, mask) are
     produced on first access by one more forward with the per-point outputs switched on."""
 
-    def __init__(self, plan, w, exponent, poses):
+    def __init__(self, plan, w, exponent, poses, count=None, inliers=None):
         self._plan, self._args, self._out = plan, (w, exponent, poses), None
-        self.count = plan.count                  # pointwise terms behind the sequence's share of the mean loss
+        self.count = plan.count if count is None else count      # pointwise terms behind the sequence's share of the mean loss
+        self._inliers = inliers                  # gated evaluation (loss.py:256-277): the centre rows that were kept
 
     def _materialize(self):
         if self._out is None:
             p = self._plan
             w, e, poses = self._args
             out = p.forward(w, e, poses, want_pointwise=True, want_eigvals=True)
-            self._out = dict(points=p.points(), eigvals=p.unpermute(out['eigvals']),
-                             loss=p.unpermute(out['pointwise']),
-                             mask=None if p.mask_full is None else p.unpermute(p.mask_full))
+            loss = p.unpermute(out['pointwise'])
+            mask = None if p.mask_full is None else p.unpermute(p.mask_full)
+            if self._inliers is not None:        # gated evaluation: the loss cloud is the inliers (loss.py:269-277)
+                inl = self._inliers
+                if p.centre_idx is not None:     # compact centre rows -> all points
+                    inl = torch.zeros((p.n,), dtype=torch.bool, device=inl.device).index_put_((p.centre_idx.long(),), inl)
+                mask = p.unpermute(inl)
+            self._out = dict(points=p.points(), eigvals=p.unpermute(out['eigvals']), loss=loss, mask=mask)
         return self._out
 
     def __getattr__(self, name):
@@ -151,13 +156,20 @@ def eval_loss_clouds(clouds, poses, pose_deltas, masks, ns, model, loss_fun, cfg
                 masks.append(global_cloud_mask(g, g.mask, cfg))
         use_model = model is not None and getattr(model, 'kernel_kind', None) is not None
         total, count, views = 0.0, 0.0, []
+        kw = cfg.loss_kwargs
+        gating = dict(inlier_ratio=kw.get('inlier_ratio', 1.0), inlier_max_loss=kw.get('inlier_max_loss'),
+                      inlier_loss_mult=kw.get('inlier_loss_mult', 1.0))
         for c, p, nn, m in zip(clouds, poses_upd, ns, masks):
             plan = _plan_for(c, p, nn, m, model, cfg)
             w, e = model.kernel_params() if use_model else (None, None)
-            s, cnt = consistency_loss(plan, w, e, p)
+            s, cnt = consistency_loss(plan, w, e, p, **gating)          # cnt: masked points, or inliers (device scalar)
             total, count = total + s, count + cnt
-            views.append(PlanCloud(plan, w, e, p))
-        loss = total / count if count > 0 else total * float('nan')        # mean over all masked points (loss.py:211)
+            views.append(PlanCloud(plan, w, e, p, count=cnt,
+                                   inliers=plan.inlier_rows if isinstance(cnt, torch.Tensor) else None))
+        if isinstance(count, torch.Tensor):
+            loss = total / count                                          # 0 / 0 = nan, like the mean of no inliers
+        else:
+            loss = total / count if count > 0 else total * float('nan')   # mean over all masked points (loss.py:211)
         return loss, views, poses_upd, views
 
     offsets = [offset_cloud(c, model) for c in clouds] if cfg.loss_offset else None

@@ -80,7 +80,7 @@ def _pointwise(raw_fun, cloud, mask, offset, sqrt, reduction, inlier_max_loss, i
         assert offset is None
         mask = loss <= inlier_max_loss
         print('Using %i (%.3g) inliers with loss <= %.3g.' % (mask.sum().item(), mask.float().mean().item(),
-                                                              float(inlier_max_loss)))
+                                                              float(torch.as_tensor(inlier_max_loss).detach())))
         cloud, loss = cloud[mask], loss[mask]
     if offset is not None:
         loss = loss - (offset.loss if isinstance(offset, DepthCloud) else offset)

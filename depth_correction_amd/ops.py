@@ -400,7 +400,9 @@ def features_bwd(points, csr_ptr, csr_src, cmean, invd, nvalid, eigvecs=None, gr
 @on_device
 def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss', normalization=True, sqrt=False,
                     rec=None, want_pointwise=False, want_eigvals=False, partials=None, sums=None, qfmt=None,
-                    centre_idx=None, table=None):
+                    centre_idx=None, table=None, raw_pointwise=False):
+    """raw_pointwise: the pointwise output holds the loss before relu / sqrt (what the quantile-inlier gating of
+    loss.py:256-277 compares; see consistency_gate)."""
     _check_points(points, qfmt)
     n_points, stride = points.shape
     dev = points.device
@@ -434,9 +436,33 @@ def consistency_fwd(points, nbr, mask=None, offset=None, loss='min_eigval_loss',
         sums = torch.empty((2,), dtype=torch.float64, device=dev)
     check(lib().dc_consistency_fwd(ptr(points), stride, fmt if qfmt is None else nv.DC_F32, fmt, qptr, ptr(nbr),
                                    ptr(centre_idx), _table_ref(table, n), n, k,
-                                   ptr(mask), ptr(offset), nv.LOSS_KINDS[loss], int(bool(normalization)), int(bool(sqrt)), ptr(rec), ptr(pw),
+                                   ptr(mask), ptr(offset), nv.LOSS_KINDS[loss] | (nv.LOSS_RAW_POINTWISE if raw_pointwise else 0),
+                                   int(bool(normalization)), int(bool(sqrt)), ptr(rec), ptr(pw),
                                    ptr(ev), ptr(partials), ptr(sums), stream_ptr()), 'dc_consistency_fwd')
     return dict(sums=sums, rec=rec, pointwise=pw, eigvals=ev)
+
+
+@on_device
+def consistency_gate(raw, rec, threshold, mask=None, sqrt=False, partials=None, sums=None, qfmt=None):
+    """Quantile-inlier gating of a fused forward (loss.py:256-277): masked centres whose raw loss exceeds the device scalar
+    ``threshold`` stop contributing -- their records' coefficients are zeroed in place -- and ``sums`` becomes
+    {sum of the inliers' loss, number of inliers}."""
+    n = raw.shape[0]
+    dev = raw.device
+    need(rec, (n, 8), name='rec', device=dev)
+    need(threshold, (), dtype=torch.float64, name='threshold', device=dev)
+    if mask is not None:
+        need(mask, (n,), dtype=torch.bool, name='mask', device=dev)
+    fmt, _ = _fmt_args(raw.dtype, qfmt)
+    rows = lib().dc_partial_rows(n)
+    if partials is None:
+        partials = torch.empty((rows * 2,), dtype=torch.float64, device=dev)
+    if sums is None:
+        sums = torch.empty((2,), dtype=torch.float64, device=dev)
+    check(lib().dc_consistency_gate(ptr(raw), nv.DC_F32 if raw.dtype == torch.float32 else nv.DC_F64, fmt, ptr(mask), n,
+                                    ptr(threshold), int(bool(sqrt)), ptr(rec), ptr(partials), ptr(sums), stream_ptr()),
+          'dc_consistency_gate')
+    return sums
 
 
 def degree_lane_perm(csr_ptr, block=256):

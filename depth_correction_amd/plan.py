@@ -240,6 +240,45 @@ class SequencePlan:
         self.version += 1
         return out
 
+    @on_device
+    def eval_gated(self, w, exponent, poses12, out, inlier_ratio=1.0, inlier_max_loss=None, inlier_loss_mult=1.0,
+                   want_grad=True, want_exponent=False, want_pose=False):
+        """Evaluation with the quantile-inlier gating of loss.py:256-277 (per sequence, as batch_loss applies it): of the
+        masked points only those whose raw loss is <= inlier_loss_mult * quantile(raw loss, inlier_ratio) (and <=
+        inlier_max_loss) count.  out as in eval_native, out[1] = number of inliers.  Five launches + the quantile (a
+        sort of the masked losses) instead of one call: forward with raw pointwise losses -> bound -> dc_consistency_gate
+        (drops the outliers' records, re-sums) -> backward."""
+        nt = 0 if w is None else w.numel()
+        need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        self.P, self.w, self.e = poses12, w, exponent
+        kind = self.model_kind if w is not None else None
+        ops.points_fwd(self.ps, poses12, kind, w, exponent, stride=4, qfmt=self.qfmt, out=self.x, status=self.status)
+        fw = ops.consistency_fwd(self.x, self.nbr, mask=self.mask, loss=self.loss, normalization=self.normalization,
+                                 sqrt=self.sqrt, rec=self.rec, want_pointwise=True, raw_pointwise=True,
+                                 partials=self.partials, qfmt=self.qfmt, centre_idx=self.centre_idx, table=self.fwd_table)
+        raw = fw['pointwise']
+        bound = None if inlier_max_loss is None else torch.as_tensor(inlier_max_loss, dtype=raw.dtype, device=raw.device)
+        if inlier_ratio < 1.0:
+            q = _quantile(raw if self.mask is None else raw[self.mask], float(inlier_ratio))
+            if inlier_loss_mult != 1.0:
+                q = inlier_loss_mult * q
+            bound = q if bound is None else torch.min(bound, q)
+        if bound is None:
+            raise ValueError('eval_gated needs inlier_ratio < 1 or inlier_max_loss')
+        inl = raw <= bound                                   # the rows dc_consistency_gate keeps (same comparison, same dtype)
+        self.inlier_bound, self.inlier_rows = bound, (inl if self.mask is None else inl & self.mask)
+        ops.consistency_gate(raw, self.rec, bound.to(torch.float64).reshape(()), mask=self.mask, sqrt=self.sqrt,
+                             partials=self.partials, sums=out[:2], qfmt=self.qfmt)
+        if want_grad:
+            gw, ge, gp = self.backward(want_exponent=want_exponent, want_pose=want_pose)
+            out[2:2 + nt], out[2 + nt:2 + 2 * nt], out[2 + 2 * nt:] = gw, ge, gp.reshape(-1)
+        else:
+            out[2:].zero_()
+        if self.status is not None:
+            out[0] = torch.where(self.status[0] != 0, torch.full_like(out[0], float('nan')), out[0])
+        self.version += 1
+        return out
+
     # ------------------------------------------------------------------------------------------------
     def poses12(self, poses):
         """[S,4,4] poses -> contiguous fp64 [S,12] on the plan's device.  The last conversion is kept: an optimisation
@@ -340,7 +379,7 @@ class _ConsistencyLoss(torch.autograd.Function):
     (the gradients of the sum are a handful of numbers); ``backward`` only scales them by the upstream gradient."""
 
     @staticmethod
-    def forward(ctx, plan, w, exponent, poses):
+    def forward(ctx, plan, w, exponent, poses, gating=None):
         need_w = isinstance(w, torch.Tensor) and w.requires_grad
         need_e = isinstance(exponent, torch.Tensor) and exponent.requires_grad
         need_p = isinstance(poses, torch.Tensor) and poses.requires_grad
@@ -350,16 +389,24 @@ class _ConsistencyLoss(torch.autograd.Function):
         nt = 0 if wv is None else wv.numel()
         P = plan.poses12(poses)
         out = torch.empty((2 + 2 * nt + 12 * plan.n_scans,), dtype=torch.float64, device=dev)
-        plan.eval_native(wv, ev, P, out, want_grad=need_w or need_e or need_p, want_exponent=need_e, want_pose=need_p)
+        if gating:                                       # quantile inliers (loss.py:256-277): out[1] = their number
+            plan.eval_gated(wv, ev, P, out, want_grad=need_w or need_e or need_p, want_exponent=need_e, want_pose=need_p,
+                            **gating)
+        else:
+            plan.eval_native(wv, ev, P, out, want_grad=need_w or need_e or need_p, want_exponent=need_e, want_pose=need_p)
         plan.w, plan.e, plan.P = wv, ev, P              # for PlanCloud / plan.backward() users
         ctx.save_for_backward(out)
         ctx.meta = (nt, plan.n_scans, None if w is None else (w.shape, w.dtype, w.device),
                     (exponent.shape, exponent.dtype, exponent.device) if isinstance(exponent, torch.Tensor) else None,
                     (poses.dtype, poses.device) if isinstance(poses, torch.Tensor) else None)
+        if gating:
+            n_inliers = out[1]
+            ctx.mark_non_differentiable(n_inliers)
+            return out[0], n_inliers
         return out[0]                                    # a view: no copy kernel; `out` itself is what backward reads
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, *unused):
         (out,) = ctx.saved_tensors
         nt, ns, wmeta, emeta, pmeta = ctx.meta
         g = grad_out * out[2:]                           # fp64 on the plan's device, like the upstream gradient of out[0]
@@ -374,7 +421,19 @@ class _ConsistencyLoss(torch.autograd.Function):
             gp = torch.zeros((ns, 4, 4), dtype=torch.float64, device=out.device)
             gp[:, :3, :] = g[2 * nt:].reshape(ns, 3, 4)
             gp = gp.to(device=pmeta[1], dtype=pmeta[0])
-        return None, gw, ge, gp
+        return None, gw, ge, gp, None
+
+
+def _quantile(v, q):
+    """torch.quantile(v, q) (linear interpolation between the two order statistics, in v's dtype -- what loss.py:259 calls);
+    beyond torch.quantile's 16 M-element limit the same arithmetic on an explicit sort."""
+    if v.numel() <= 16_000_000:
+        return torch.quantile(v, q, dim=0)
+    s, _ = torch.sort(v)
+    rank = torch.tensor(q, dtype=v.dtype, device=v.device) * (v.numel() - 1)
+    lo = rank.floor().long()
+    hi = torch.clamp(lo + 1, max=v.numel() - 1)
+    return torch.lerp(s[lo], s[hi], rank - lo.to(v.dtype))
 
 
 def _as_f64_vector(t, dev):
@@ -385,8 +444,12 @@ def _as_f64_vector(t, dev):
     return v if v.is_contiguous() else v.contiguous()
 
 
-def consistency_loss(plan, w, exponent, poses):
-    """(sum of pointwise loss over the mask, mask count) of one sequence; the sum carries the autograd graph."""
+def consistency_loss(plan, w, exponent, poses, inlier_ratio=1.0, inlier_max_loss=None, inlier_loss_mult=1.0):
+    """(sum of pointwise loss over the mask, mask count) of one sequence; the sum carries the autograd graph.  With
+    quantile-inlier gating (loss.py:256-277) the count is the number of inliers, a device scalar."""
+    if inlier_ratio < 1.0 or inlier_max_loss is not None:
+        gating = dict(inlier_ratio=float(inlier_ratio), inlier_max_loss=inlier_max_loss, inlier_loss_mult=float(inlier_loss_mult))
+        return _ConsistencyLoss.apply(plan, w, exponent, poses, gating)
     return _ConsistencyLoss.apply(plan, w, exponent, poses), plan.count
 
 

@@ -29,6 +29,7 @@ extern "C" {
 #define DC_Q32 2 /* internal point format: int32 fixed point rows [n,4], x = origin + q * scale (16 B / point) */
 #define DC_LOSS_MIN_EIGVAL 0
 #define DC_LOSS_TRACE 1
+#define DC_LOSS_RAW_POINTWISE 0x100 /* OR-ed into loss_kind of dc_consistency_fwd: `pointwise` receives the loss before relu / sqrt */
 #define DC_MODEL_NONE 0
 #define DC_MODEL_POLYNOMIAL 1
 #define DC_MODEL_SCALED_POLYNOMIAL 2
@@ -304,6 +305,16 @@ int dc_p2point_pair(const void* vpsA, const void* dirsA, const void* depthA, con
 int dc_p2point_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
                         const double* poses, int model_kind, int n_terms, const double* w, const double* e,
                         double* partials_ws, double* out, dcStream_t stream);
+
+/* Quantile-inlier gating for the fused path (min_eigval_loss / trace_loss with inlier_ratio < 1 or inlier_max_loss,
+ * loss.py:256-277).  raw_pointwise [n] (dtype): the forward's loss before relu / sqrt (dc_consistency_fwd with
+ * loss_kind | DC_LOSS_RAW_POINTWISE); threshold: device fp64 scalar the caller derived from it (multiplier x quantile of
+ * the masked values, min with the given maximum).  Masked centres with raw loss > threshold (or NaN) are dropped: the
+ * coefficients of their record rec [n,8] (point_fmt) are zeroed, so dc_consistency_bwd passes nothing through them;
+ * sums_out fp64 [2] = {sum of relu(raw) [sqrt] over the inliers, number of inliers}.  partials_ws as dc_consistency_fwd. */
+int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, const uint8_t* mask, int64_t n,
+                        const double* threshold, int sqrt_, void* rec, double* partials_ws, double* sums_out,
+                        dcStream_t stream);
 
 /* ---- whole-sequence evaluation + optimiser step (train.py:220-312 per-iteration body for one sequence) ----------
  * The caller fills a descriptor with the device arrays of one sequence (SequencePlan in Python) once; every

@@ -309,8 +309,9 @@ def global_mask(mask, neighbors, eigvals, vps=None, dirs=None, weights=None, min
 # K14-K16: losses.  loss.py:125-150,216-370,406-488
 # ----------------------------------------------------------------------------------------------
 def pointwise_loss(eigvals=None, cov=None, kind='min_eigval_loss', mask=None, offset=None, sqrt=False,
-                   normalization=False):
-    """loss.py:250-289 / :330-363 without the quantile-inlier branch (inlier_ratio=1, default)."""
+                   normalization=False, inlier_ratio=1.0, inlier_max_loss=None, inlier_loss_mult=1.0):
+    """loss.py:250-289 / :330-363 including the quantile-inlier branch (:256-277): of the masked points only those
+    whose raw loss is <= mult * quantile(raw loss, inlier_ratio) (and <= inlier_max_loss) contribute."""
     if kind == 'min_eigval_loss':
         if mask is not None:
             eigvals = eigvals[mask]
@@ -321,6 +322,13 @@ def pointwise_loss(eigvals=None, cov=None, kind='min_eigval_loss', mask=None, of
         if mask is not None:
             cov = cov[mask]
         loss = trace(cov)
+    if inlier_ratio < 1.0:                                            # loss.py:256-267
+        q = torch.quantile(loss, inlier_ratio, dim=0)
+        if inlier_loss_mult != 1.0:
+            q = inlier_loss_mult * q
+        inlier_max_loss = q if inlier_max_loss is None else torch.min(torch.as_tensor(inlier_max_loss, dtype=q.dtype), q)
+    if inlier_max_loss is not None:                                   # :269-277
+        loss = loss[loss <= inlier_max_loss]
     if offset is not None:
         loss = loss - offset
     loss = torch.relu(loss)
@@ -392,7 +400,8 @@ def shadow_mask(points, vps, dir_neighbors, angle_bounds):
 # One training iteration for one sequence, as eval.py:85-112 -> preproc.py:80-119,195-217 -> loss
 # ----------------------------------------------------------------------------------------------
 def eval_sequence(scans, poses, w, exponent, neighbors, mask, kind='min_eigval_loss', model='ScaledPolynomial',
-                  normalization=True, sqrt=False, pose_deltas=None, reduction='none', weights=None):
+                  normalization=True, sqrt=False, pose_deltas=None, reduction='none', weights=None, inlier_ratio=1.0,
+                  inlier_max_loss=None, inlier_loss_mult=1.0):
     """scans: list of dict(vps, dirs, depth [n,1], inc [n,1], mask bool[n] or None) in the local frame.
 
     Returns (pointwise masked loss, dict of global-cloud features).  All torch ops, so
@@ -409,7 +418,8 @@ def eval_sequence(scans, poses, w, exponent, neighbors, mask, kind='min_eigval_l
     f = features(x, neighbors, dirs_g, weights=weights)
     f['points'], f['dirs'], f['depth'] = x, dirs_g, depth_g
     loss = pointwise_loss(eigvals=f['eigvals'], cov=f['cov'], kind=kind, mask=mask, sqrt=sqrt,
-                          normalization=normalization)
+                          normalization=normalization, inlier_ratio=inlier_ratio, inlier_max_loss=inlier_max_loss,
+                          inlier_loss_mult=inlier_loss_mult)
     return reduce_loss(loss, reduction), f
 
 

@@ -182,9 +182,13 @@ def run_sequence(name, scans_xyz, poses_np, cfg, w0, exponent, model_cls, varian
         w = torch.tensor([list(w0)], dtype=torch.float64, requires_grad=True)
         e = torch.tensor([list(exponent)], dtype=torch.float64)
         pdo = None if pd is None else torch.tensor(pose_deltas0, dtype=torch.float64, requires_grad=True)
+        inl = {k: cfg.loss_kwargs[k] for k in ('inlier_ratio', 'inlier_max_loss', 'inlier_loss_mult') if k in cfg.loss_kwargs}
+        gated = inl.get('inlier_ratio', 1.0) < 1.0 or inl.get('inlier_max_loss') is not None
+        if gated:
+            out['%s_n_inliers' % tag] = np.array(len(loss_clouds[0]))
         lo, fo = O.eval_sequence(oracle_scans(clouds), poses, w, e, ns[0], mask, kind=loss_name,
                                  model=model_cls.__name__, normalization=cfg.loss_kwargs['normalization'],
-                                 sqrt=cfg.loss_kwargs['sqrt'], pose_deltas=pdo, reduction='mean')
+                                 sqrt=cfg.loss_kwargs['sqrt'], pose_deltas=pdo, reduction='mean', **inl)
         fo['points'].retain_grad()
         lo.backward()
         close(lo, loss, what=tag + ' loss')
@@ -193,6 +197,9 @@ def run_sequence(name, scans_xyz, poses_np, cfg, w0, exponent, model_cls, varian
         close(fo['eigvals'], fc.eigvals, what=tag + ' eigvals')
         if pd is not None:
             close(pdo.grad, pd.grad, rtol=1e-8, atol=1e-14, what=tag + ' grad_pose')
+        if gated:
+            print('  %-22s loss=%.9g grad_w=%s inliers=%d' % (tag, loss.item(), npy(model.w.grad).ravel(), len(loss_clouds[0])))
+            continue
         # closed form vs the reference's autograd
         cf = O.closed_form_backward(npy(fc.points), npy(ns[0]), npy(mask), kind=loss_name,
                                     normalization=cfg.loss_kwargs['normalization'], sqrt=cfg.loss_kwargs['sqrt'])
@@ -249,6 +256,27 @@ def gen_room():
     variants = [('mineig_norm', 'min_eigval_loss', dict(normalization=True, sqrt=False))]
     run_sequence('room_k10', scans, poses, cfg, (2e-3, -1e-3), (1.0, 3.0), Polynomial, variants,
                  out=out, prefix='poly_', grad_points_for=0)
+
+
+def gen_inliers():
+    """Quantile-inlier gating of the pointwise loss (loss.py:256-277) on the room_k10 inputs (same scans, poses, neighbourhoods
+    and mask as tests/golden/room_k10.npz): only the results are stored."""
+    ds = RoomBoxDataset(n_pts=2000, n_poses=4)
+    scans = [c for c, _ in ds]
+    poses = np.stack([p for _, p in ds])
+    variants = [('norm_r07', 'min_eigval_loss', dict(normalization=True, sqrt=False, inlier_ratio=0.7, inlier_loss_mult=1.0)),
+                ('raw_sqrt_r09_m08', 'min_eigval_loss', dict(normalization=False, sqrt=True, inlier_ratio=0.9, inlier_loss_mult=0.8)),
+                ('trace_r05', 'trace_loss', dict(sqrt=False, inlier_ratio=0.5, inlier_loss_mult=1.0))]
+    out = dict(meta=np.array(META))
+    cfg = base_cfg(nn_k=10, min_valid_neighbors=5, vp_dispersion_bounds=[])
+    full = run_sequence(None, scans, poses, cfg, (1e-3, 2e-3), (2.0, 4.0), ScaledPolynomial, variants, out=dict(out),
+                        prefix='inl_', grad_points_for=0)
+    keep = {k: v for k, v in full.items() if k == 'meta' or (k.startswith('inl_') and not k.startswith('inl_g_')
+                                                              and not k.endswith('_pointwise'))}
+    for tag, _, kw in variants:
+        keep['inl_%s_ratio' % tag] = np.array(kw['inlier_ratio'])
+        keep['inl_%s_mult' % tag] = np.array(kw['inlier_loss_mult'])
+    np.savez_compressed(os.path.join(GOLD, 'inliers.npz'), **keep)
 
 
 def gen_models():
@@ -444,7 +472,7 @@ def gen_knn():
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models']
+    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models', 'inliers']
     if 'grid' in which:
         gen_grid()
     if 'knn' in which:
@@ -459,3 +487,5 @@ if __name__ == '__main__':
         gen_shadow()
     if 'models' in which:
         gen_models()
+    if 'inliers' in which:
+        gen_inliers()

@@ -453,6 +453,8 @@ def test_unfused_options_match_oracle(golden):
     cfg = Config(nn_k=10, nn_r=None)
     assert fused_supported([[cloud]], ScaledPolynomial(w=[0.0, 0.0], exponent=[2.0, 4.0]), cfg)
     cfg.loss_kwargs['inlier_ratio'] = 0.5
+    assert fused_supported([[cloud]], None, cfg)             # quantile inliers are gated inside the fused path
+    cfg.loss_offset = True
     assert not fused_supported([[cloud]], None, cfg)
 
 
@@ -759,3 +761,32 @@ def test_other_models_iteration_golden(golden, name, fused):
     np.testing.assert_allclose(loss.item(), m[name + '_loss'], rtol=1e-9)
     np.testing.assert_allclose(grads, m[name + '_grad_w'].ravel(), rtol=2e-6, atol=1e-10)
     np.testing.assert_allclose(npy(model(clouds[0]).depth), m[name + '_depth0'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('tag,loss,kw', [('norm_r07', 'min_eigval_loss', dict(normalization=True, sqrt=False)),
+                                         ('raw_sqrt_r09_m08', 'min_eigval_loss', dict(normalization=False, sqrt=True)),
+                                         ('trace_r05', 'trace_loss', dict(sqrt=False))])
+@pytest.mark.parametrize('fused', [True, False])
+def test_quantile_inlier_gating_golden(golden, tag, loss, kw, fused):
+    """eval_loss_clouds with inlier_ratio < 1 (loss.py:256-277) against the live reference's loss, dL/dw and number of
+    inliers (tests/golden/inliers.npz, same inputs as room_k10.npz): through the fused plan -- forward with raw pointwise
+    losses, torch.quantile bound, dc_consistency_gate, backward -- and through the un-fused operators."""
+    from depth_correction_amd.eval import eval_loss_clouds, fused_supported
+    from depth_correction_amd.loss import create_loss
+    from depth_correction_amd.model import ScaledPolynomial
+    g, gi = golden('room_k10'), golden('inliers')
+    cfg = _cfg(g, fused=fused)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    cfg.loss = loss
+    cfg.loss_kwargs.update(kw, inlier_ratio=float(gi['inl_%s_ratio' % tag]), inlier_loss_mult=float(gi['inl_%s_mult' % tag]))
+    model = ScaledPolynomial(w=gi['inl_w'].tolist(), exponent=gi['inl_exponent'].tolist(), device=cfg.device)
+    assert fused_supported([clouds], model, cfg) == fused
+    out, views, _, _ = eval_loss_clouds([clouds], [poses], [None], [mask], [ns], model, create_loss(cfg), cfg)
+    out.backward()
+    n_ref = int(gi['inl_%s_n_inliers' % tag])
+    if fused:
+        assert int(views[0].count) == n_ref == int(views[0].mask.sum())
+    else:
+        assert len(views[0]) == n_ref
+    np.testing.assert_allclose(out.item(), float(gi['inl_%s_loss' % tag]), rtol=1e-9)
+    np.testing.assert_allclose(npy(model.w.grad).ravel(), gi['inl_%s_grad_w' % tag].ravel(), rtol=1e-7)

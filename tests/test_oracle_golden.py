@@ -62,6 +62,25 @@ def test_iteration_all_variants(golden, name):
             np.testing.assert_allclose(cf['loss'], g[tag + '_loss'], rtol=1e-10)
 
 
+@pytest.mark.parametrize('tag,kind,norm,sqrt', [('norm_r07', 'min_eigval_loss', True, False),
+                                                ('raw_sqrt_r09_m08', 'min_eigval_loss', False, True),
+                                                ('trace_r05', 'trace_loss', False, False)])
+def test_quantile_inlier_gating(golden, tag, kind, norm, sqrt):
+    """loss.py:256-277 (inlier_ratio < 1, inlier_loss_mult) in the oracle vs the live reference's loss, dL/dw and
+    number of inliers on the room_k10 inputs."""
+    g, gi = golden('room_k10'), golden('inliers')
+    scans = scans_from_golden(g)
+    nbr, mask = t(g['g_neighbors']).long(), t(g['g_mask'])
+    w = torch.tensor(gi['inl_w'].reshape(1, -1), requires_grad=True)
+    ratio, mult = float(gi['inl_%s_ratio' % tag]), float(gi['inl_%s_mult' % tag])
+    loss, _ = O.eval_sequence(scans, t(g['poses']), w, t(gi['inl_exponent'].reshape(1, -1)), nbr, mask, kind=kind,
+                              normalization=norm, sqrt=sqrt, reduction='none', inlier_ratio=ratio, inlier_loss_mult=mult)
+    assert len(loss) == int(gi['inl_%s_n_inliers' % tag])
+    loss.mean().backward()
+    np.testing.assert_allclose(npy(loss.mean()), gi['inl_%s_loss' % tag], rtol=1e-10)
+    np.testing.assert_allclose(npy(w.grad), gi['inl_%s_grad_w' % tag], rtol=1e-8)
+
+
 def test_masks_and_dispersion(golden):
     for name in ('c0_plane', 'room_k10'):
         g = golden(name)
