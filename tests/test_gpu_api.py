@@ -728,11 +728,8 @@ def test_training_iteration_replays_as_one_graph(golden):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         static_loss = iteration(w_g, opt_g)
-    for _ in range(4):                       # the capture itself executed nothing: 3 + (capture: 0) + ... see below
+    for _ in range(5):                       # eager run: 8 steps; here 3 eager + 5 replays (capturing executes nothing)
         graph.replay()
-    torch.cuda.synchronize()
-    # eager: 8 steps; graphed: 3 eager + 4 replays (capture does not run the kernels) = 7 -> one more replay
-    graph.replay()
     torch.cuda.synchronize()
     torch.testing.assert_close(w_g.detach(), w_e.detach(), rtol=1e-12, atol=0)
     assert torch.isfinite(static_loss).all()
