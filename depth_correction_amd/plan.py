@@ -523,8 +523,13 @@ class SequenceTrainer:
     @on_device
     def _adam_native(self, grad_sum):
         check(lib().dc_adam_step(ptr(self.w), ctypes.c_void_p(grad_sum.data_ptr()), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                 self.nt, self.t, 1.0 / self.count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                 self.nt, self.t, self._grad_scale(), self.lr, self.betas[0], self.betas[1], self.eps,
                                  self.weight_decay, stream_ptr()), 'dc_adam_step')
+
+    def _grad_scale(self):
+        """1 / number of masked points of all sequences (the mean reduction, loss.py:205-213); no masked point at all:
+        NaN, the mean of an empty tensor, as in the reference."""
+        return 1.0 / self.count if self.count > 0 else float('nan')
 
     def step(self):
         """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
@@ -532,7 +537,7 @@ class SequenceTrainer:
         if self.fused_step:
             self.t += 1
             out = self.plans[0].step_native(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg,
-                                            self.exp_avg_sq, self.t, 1.0 / self.count, self.lr, self.betas, self.eps,
+                                            self.exp_avg_sq, self.t, self._grad_scale(), self.lr, self.betas, self.eps,
                                             self.weight_decay)
             return out[:2 + self.nt]
         for plan, P, out in zip(self.plans, self.poses12, self.outs):
