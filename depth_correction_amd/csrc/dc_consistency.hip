@@ -1007,6 +1007,66 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
   wave_partials<2>(acc2, partials);
 }
 
+// The same for any slot count (radius neighbourhoods: the reference's default nn_r = 0.25, K = the largest count; or the
+// run-time-slot ablation): the slot loop of consistency_fwd_staged_kernel over rows formed from the basis.
+template <bool FULL_EIG, int P>
+__global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
+    PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, const float* __restrict__ offset, LossParams lp, QParams qp, q32* __restrict__ rec,
+    float* __restrict__ pointwise, float* __restrict__ eigvals, double* __restrict__ partials) {
+  extern __shared__ int4 tile[];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0};
+  const int64_t i = blk * kBlock + threadIdx.x;
+  const bool live = blk >= 0 && i < n;
+  int32_t nslots = 0, own = -1;
+  const uint16_t* lrow = tab.loc;
+  uint32_t pre[kPreSlots];
+  stage_weights(pb, s_w);
+  if (blk >= 0) {
+    const int32_t s0 = tab.slot_ptr[blk];
+    nslots = tab.slot_ptr[blk + 1] - s0;
+    lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q) pre[q] = (live && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
+    own = (own_base && !centre_idx) ? own_base[blk] : -1;
+  }
+  __syncthreads();
+  double wq[P > 0 ? P : DC_MAX_MODEL_TERMS];
+#pragma unroll
+  for (int k = 0; k < (P > 0 ? P : DC_MAX_MODEL_TERMS); ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
+  Pt<q32>::Raw ci;
+  if (blk >= 0) {
+    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    for (int t = threadIdx.x; t < nd; t += kBlock) {
+      const Pt<q32>::Raw r = basis_point<P>(pb, wq, tab.blk_ids[base + t]);
+      tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0);
+    }
+    if (own < 0) ci = basis_point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+  }
+  __syncthreads();
+  if (live) {
+    if (own >= 0) ci = Pt<q32>::from_row(tile + own + (int)threadIdx.x);
+    CovAcc acc;
+    cov_init(acc);
+    bool miss = false;
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q) miss |= (q < nslots) && pre[q] == kNoLoc;
+    int n_have = 0;
+    if (__any((int)miss)) n_have = gather_slots<q32, true>(tile, cap, ci, pre, nslots, acc);
+    else n_have = gather_slots<q32, false>(tile, cap, ci, pre, nslots, acc);
+    for (int q = kPreSlots; q < nslots; ++q) {             // K > 16: one slot at a time
+      const uint32_t l = lrow[q * kBlock];
+      n_have += slot_add<q32, true>(tile, cap, ci, l, acc);
+    }
+    acc.W = (double)n_have;
+    consistency_point<float, q32, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
+  }
+  wave_partials<2>(acc2, partials);
+}
+
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
 // partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
 template <int P>
@@ -1693,7 +1753,6 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   int rows_f = 0, rows_b = 0;
   const bool basis = d->basis && d->point_fmt == DC_Q32 && d->dtype == DC_F32 && n_terms > 0 && w &&
                      !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
-                     (d->k == 4 || d->k == 8 || d->k == 10 || d->k == 16) &&
                      use_table(d->fwd_table, DC_TABLE_SLOTS, stride, 16u, 0, 60 * 1024, &lds_f, &rows_f) &&
                      (!want_grad || use_table(d->bwd_table, DC_TABLE_RUNS, stride, 32u, 1, 44 * 1024, &lds_b, &rows_b));
   if (basis) {
@@ -1712,7 +1771,15 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                                            (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
 #define FWD_BASIS(NS) do { if (n_terms == 2) FWD_BASIS_P(NS, 2); else if (n_terms == 1) FWD_BASIS_P(NS, 1); \
                            else if (n_terms == 3) FWD_BASIS_P(NS, 3); else FWD_BASIS_P(NS, 0); } while (0)
-      if (d->k == 10) FWD_BASIS(10); else if (d->k == 4) FWD_BASIS(4); else if (d->k == 8) FWD_BASIS(8); else FWD_BASIS(16);
+#define FWD_BASIS_SLOTS(P) DC_TIMED_LAUNCH((consistency_fwd_basis_slots_kernel<false, P>), grid, block, lds_f, stream, pb, tab, \
+                                          d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const float*)nullptr, lp, qp, \
+                                          (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
+      const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
+      if (fixed_k == 10) FWD_BASIS(10); else if (fixed_k == 4) FWD_BASIS(4); else if (fixed_k == 8) FWD_BASIS(8);
+      else if (fixed_k == 16) FWD_BASIS(16);
+      else if (n_terms == 2) FWD_BASIS_SLOTS(2); else if (n_terms == 1) FWD_BASIS_SLOTS(1);
+      else if (n_terms == 3) FWD_BASIS_SLOTS(3); else FWD_BASIS_SLOTS(0);
+#undef FWD_BASIS_SLOTS
 #undef FWD_BASIS_P
 #undef FWD_BASIS
     }

@@ -190,7 +190,7 @@ class SequencePlan:
         fields when this evaluation cannot use the basis form (pose / exponent gradients, other formats, no tables)."""
         ok = (self.use_basis and self.qfmt is not None and w is not None and not want_exponent and not want_pose
               and self.fwd_table is not None and self.bwd_table is not None and self.bwd_table.run_ptr is not None
-              and self.k in (4, 8, 10, 16) and d.model_kind != 0)
+              and d.model_kind != 0)
         if not ok:
             d.basis = None
             return

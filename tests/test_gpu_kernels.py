@@ -483,23 +483,33 @@ def test_block_tables_do_not_change_results(golden, dev):
     assert np.array_equal(npy(r['gw']), outs[0][0])
 
 
-@pytest.mark.parametrize('model,n_terms,active_only', [('ScaledPolynomial', 2, False), ('Polynomial', 2, False),
-                                                       ('ScaledPolynomial', 1, False), ('Polynomial', 3, False),
-                                                       ('ScaledPolynomial', 4, False), ('ScaledPolynomial', 2, True)])
-def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only):
+@pytest.mark.parametrize('model,n_terms,active_only,ragged', [
+    ('ScaledPolynomial', 2, False, False), ('Polynomial', 2, False, False), ('ScaledPolynomial', 1, False, False),
+    ('Polynomial', 3, False, False), ('ScaledPolynomial', 4, False, False), ('ScaledPolynomial', 2, True, False),
+    ('ScaledPolynomial', 2, False, True), ('Polynomial', 3, True, True)])
+def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only, ragged):
     """dc_sequence_eval through the basis form (x = X0 + sum_k w_k B_k, no pass over the points) against the general
     path (dc_points_fwd every evaluation): identical count, loss and dL/dw up to the second rounding of the q32 grid, for
     several weight vectors on one plan (X0 / B are built once) and after the poses changed (rebuilt).  Term counts 1-3
     run the kernels specialised for them, 4 the run-time loop; active_only takes the centre from its own row instead of
-    the staged ones."""
-    from depth_correction_amd.plan import SequencePlan
+    the staged ones; ragged: a radius-style table (19 columns, missing entries) through the run-time-slot kernel."""
+    from depth_correction_amd.plan import SequencePlan, KernelTimer
     from depth_correction_amd import _native as nv
     g = golden('room_k10')
     scans = scans_from_golden(g, torch.float32)
     clouds = [dict(vps=s['vps'].to(dev), dirs=s['dirs'].to(dev), depth=s['depth'].to(dev), inc_angles=s['inc'].to(dev),
                    mask=s['mask'].to(dev)) for s in scans]
     poses = t(g['poses'], dev)
-    plan = SequencePlan(clouds, poses, t(g['g_neighbors'], dev), t(g['g_mask'], dev), model_kind=model, active_only=active_only)
+    nbr = t(g['g_neighbors'], dev)
+    if ragged:
+        gen = torch.Generator(device='cpu').manual_seed(3)
+        drop = (torch.rand(nbr.shape, generator=gen) < 0.2).to(dev)
+        drop[:, :4] = False                                          # keep enough neighbours for a covariance
+        nbr = torch.where(drop, torch.full_like(nbr, -1), nbr)
+        extra = nbr[:, 1:10].flip(1).clone()                         # 19 columns: more than the 16 pre-loaded slots
+        extra[:, ::2] = -1
+        nbr = torch.cat([nbr, extra], dim=1).contiguous()
+    plan = SequencePlan(clouds, poses, nbr, t(g['g_mask'], dev), model_kind=model, active_only=active_only)
     assert plan.qfmt is not None
     assert (plan.fwd_table.own_base is None) == active_only
     e = torch.tensor([2.0, 4.0, 1.0, 3.0][:n_terms], dtype=torch.float64, device=dev)
@@ -510,11 +520,17 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
         try:
             res = []
             P = plan.poses12(poses)
-            for wv in ([1e-3, 2e-3, -1e-3, 5e-4], [-2e-3, 5e-4, 1e-3, -2e-4], [0.0, 0.0, 0.0, 0.0]):
-                w = torch.tensor(wv[:nt], dtype=torch.float64, device=dev)
-                out = torch.zeros(2 + 2 * nt + 12 * plan.n_scans, dtype=torch.float64, device=dev)
-                plan.eval_native(w, e, P, out)
-                res.append(npy(out))
+            with KernelTimer(every=1) as timer:
+                for wv in ([1e-3, 2e-3, -1e-3, 5e-4], [-2e-3, 5e-4, 1e-3, -2e-4], [0.0, 0.0, 0.0, 0.0]):
+                    w = torch.tensor(wv[:nt], dtype=torch.float64, device=dev)
+                    out = torch.zeros(2 + 2 * nt + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+                    plan.eval_native(w, e, P, out)
+                    res.append(npy(out))
+                names, timed = timer.kernels(), timer.read()
+            # the path under test really ran: basis kernels (fixed-K or run-time slots), and no pass over the points
+            want = ('consistency_fwd_basis_slots_kernel' if ragged else 'consistency_fwd_basis_kernel') if basis else 'consistency_fwd_'
+            assert names['consistency_fwd'].startswith(want) and ('basis' in names['consistency_bwd']) == basis, names
+            assert ('points_fwd' in timed) != basis
             moved = poses.clone()
             moved[1, :3, 3] += 0.05
             P2 = plan.poses12(moved)
@@ -527,5 +543,6 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
     for a, b in zip(outs[True], outs[False]):
         assert a[1] == b[1] > 0
         np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
-        np.testing.assert_allclose(a[2:2 + nt], b[2:2 + nt], rtol=2e-5, atol=1e-7 * np.abs(b[2:2 + nt]).max())
+        # thinned neighbourhoods (4-6 points) amplify the grid's second rounding in the gradient
+        np.testing.assert_allclose(a[2:2 + nt], b[2:2 + nt], rtol=1e-4 if ragged else 2e-5, atol=1e-7 * np.abs(b[2:2 + nt]).max())
     assert not np.allclose(outs[True][0][0], outs[True][3][0], rtol=1e-9)          # the moved pose changed the loss
