@@ -873,45 +873,128 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
 // instead of once.  A row is 24 + 4 P bytes: 32 for the two-term models, one aligned sector per gathered point.
 // ================================================================================================
 struct PointBasis {
-  const int32_t* __restrict__ rows;    // [n, 6 + P] dwords: X0 (int32 grid values), u (float32 bits), c_0 .. c_{P-1} (float32 bits)
+  const void* __restrict__ rows;       // [n, 6 + P] words: X0, u, c_0 .. c_{P-1} (Basis<PT>: int32 / float32 bits for q32, fp64 for double)
   const double* __restrict__ w;        // [P] device weights of this evaluation
   int n_terms;
-  double inv_scale;
+  double w_scale;                      // weights are staged as w_k * w_scale: 1 / grid step for q32, 1 for fp64 points
 };
 
-// s_w[k] = w_k / step for the lanes of the block (call before a barrier)
+// s_w[k] = w_k * w_scale for the lanes of the block (call before a barrier)
 __device__ __forceinline__ void stage_weights(const PointBasis& pb, double* s_w) {
-  if ((int)threadIdx.x < pb.n_terms) s_w[threadIdx.x] = pb.w[threadIdx.x] * pb.inv_scale;
+  if ((int)threadIdx.x < pb.n_terms) s_w[threadIdx.x] = pb.w[threadIdx.x] * pb.w_scale;
 }
 
-// Grid point of `row` for the staged weights wq; P > 0: term count known at compile time (one contiguous row, loads
-// issued together), P = 0: run-time count.
-template <int P>
-__device__ __forceinline__ Pt<q32>::Raw basis_point(const PointBasis& pb, const double* wq, int64_t row) {
-  const int np = P > 0 ? P : pb.n_terms;
-  const int32_t* r = pb.rows + row * (6 + np);
-  int32_t q[6];
+// Row layout and arithmetic of the basis per point format.  q32 (float32 clouds): X0 on the fixed-point grid, u and c in
+// float32 (the correction sum w c is centimetres, so its fp32 rounding is ~1e-9 m, far below the grid); a coordinate is
+// X0 + rint((sum w_k c_k) u / step).  double (float64 clouds, the reference's default float_type): everything fp64,
+// x = X0 + (sum w_k c_k) u -- the same point as R (vp + d' dir) + t up to the order of the fp64 operations.
+template <typename PT> struct Basis;
+template <> struct Basis<q32> {
+  using T = float;                                       // dtype of the cloud's arrays
+  // P > 0: term count known at compile time (one contiguous row, loads issued together), P = 0: run-time count
+  template <int P>
+  static __device__ __forceinline__ Pt<q32>::Raw point(const PointBasis& pb, const double* wq, int64_t row) {
+    const int np = P > 0 ? P : pb.n_terms;
+    const int32_t* r = static_cast<const int32_t*>(pb.rows) + row * (6 + np);
+    int32_t q[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) q[c] = r[c];
-  double sc = 0.0;
-  if constexpr (P > 0) {
-    float c[P];
+    for (int c = 0; c < 6; ++c) q[c] = r[c];
+    double sc = 0.0;
+    if constexpr (P > 0) {
+      float c[P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) c[k] = __int_as_float(r[6 + k]);
+      for (int k = 0; k < P; ++k) c[k] = __int_as_float(r[6 + k]);
 #pragma unroll
-    for (int k = 0; k < P; ++k) sc += wq[k] * (double)c[k];
-  } else {
-    for (int k = 0; k < np; ++k) sc += wq[k] * (double)__int_as_float(r[6 + k]);
+      for (int k = 0; k < P; ++k) sc += wq[k] * (double)c[k];
+    } else {
+      for (int k = 0; k < np; ++k) sc += wq[k] * (double)__int_as_float(r[6 + k]);
+    }
+    Pt<q32>::Raw o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
+    return o;
   }
-  Pt<q32>::Raw o;
+  static __device__ __forceinline__ void stage(int4* tile, int, int t, const Pt<q32>::Raw& r) { tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0); }
+  // gw[k] += (g . u_j) c_kj for the point's own row (g in metres^-1 units of the loss)
+  template <int NP>
+  static __device__ __forceinline__ void chain(const PointBasis& pb, int np, int64_t j, const double* g, double* gw) {
+    const int32_t* r = static_cast<const int32_t*>(pb.rows) + j * (6 + np);
+    const double gu = g[0] * (double)__int_as_float(r[3]) + g[1] * (double)__int_as_float(r[4]) + g[2] * (double)__int_as_float(r[5]);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
-  return o;
+    for (int k = 0; k < NP; ++k)
+      if (k < np) gw[k] = gu * (double)__int_as_float(r[6 + k]);
+  }
+  static __device__ __forceinline__ void write(void* rows, int64_t i, int nt, const double* x0, const double* u, const QParams& qp) {
+    int32_t* r = static_cast<int32_t*>(rows) + i * (6 + nt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      r[a] = quantize(x0[a], qp.origin[a], qp.inv_scale, qp.flag);
+      r[3 + a] = __float_as_int((float)u[a]);
+    }
+  }
+  static __device__ __forceinline__ void write_term(void* rows, int64_t i, int nt, int k, double c) {
+    static_cast<int32_t*>(rows)[i * (6 + nt) + 6 + k] = __float_as_int((float)c);
+  }
+};
+template <> struct Basis<double> {
+  using T = double;
+  template <int P>
+  static __device__ __forceinline__ Pt<double>::Raw point(const PointBasis& pb, const double* wq, int64_t row) {
+    const int np = P > 0 ? P : pb.n_terms;
+    const double* r = static_cast<const double*>(pb.rows) + row * (6 + np);
+    double q[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) q[c] = r[c];
+    double sc = 0.0;
+    if constexpr (P > 0) {
+      double c[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) c[k] = r[6 + k];
+#pragma unroll
+      for (int k = 0; k < P; ++k) sc += wq[k] * c[k];
+    } else {
+      for (int k = 0; k < np; ++k) sc += wq[k] * r[6 + k];
+    }
+    Pt<double>::Raw o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o.v[a] = q[a] + sc * q[3 + a];
+    return o;
+  }
+  // 32-B rows, piece-major like stage_rows<2>: (x, y) at tile[t], (z, -) at tile[cap + t]
+  static __device__ __forceinline__ void stage(int4* tile, int cap, int t, const Pt<double>::Raw& r) {
+    tile[t] = make_int4(__double2loint(r.v[0]), __double2hiint(r.v[0]), __double2loint(r.v[1]), __double2hiint(r.v[1]));
+    tile[cap + t] = make_int4(__double2loint(r.v[2]), __double2hiint(r.v[2]), 0, 0);
+  }
+  template <int NP>
+  static __device__ __forceinline__ void chain(const PointBasis& pb, int np, int64_t j, const double* g, double* gw) {
+    const double* r = static_cast<const double*>(pb.rows) + j * (6 + np);
+    const double gu = g[0] * r[3] + g[1] * r[4] + g[2] * r[5];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      if (k < np) gw[k] = gu * r[6 + k];
+  }
+  static __device__ __forceinline__ void write(void* rows, int64_t i, int nt, const double* x0, const double* u, const QParams&) {
+    double* r = static_cast<double*>(rows) + i * (6 + nt);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { r[a] = x0[a]; r[3 + a] = u[a]; }
+  }
+  static __device__ __forceinline__ void write_term(void* rows, int64_t i, int nt, int k, double c) {
+    static_cast<double*>(rows)[i * (6 + nt) + 6 + k] = c;
+  }
+};
+
+// the lane's centre from the staged rows (row `t` of the block's distinct list)
+template <typename PT>
+__device__ __forceinline__ typename Pt<PT>::Raw staged_point(const int4* tile, int cap, int t) {
+  int4 piece[Pt<PT>::kRow16];
+  read_row<Pt<PT>::kRow16>(tile, cap, (uint32_t)t * 16u, piece);
+  return Pt<PT>::from_row(piece);
 }
 
 // X0, u and c of every point (once per pose set): the same inputs and arithmetic as points_fwd_kernel.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, int64_t n, QParams qp, int32_t* __restrict__ rows) {
+template <typename PT>
+__global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, int64_t n, QParams qp, void* __restrict__ rows) {
+  using T = typename Basis<PT>::T;
   __shared__ double s_pose[kLdsScans * 12];
   const PoseTile poses = stage_poses(in, s_pose);
   __syncthreads();
@@ -927,18 +1010,15 @@ __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, in
   const bool lm = in.lmask ? in.lmask[i] != 0 : true;
   const double inc = (mp.kind != DC_MODEL_NONE && lm) ? (double)((const T*)in.inc)[i] : 0.0;
   load_pose(in, poses, in.scan_id ? in.scan_id[i] : 0, T12);
-  double vr[3], drr[3];
+  double vr[3], drr[3], x0[3];
   rot3(T12, vp, vr);
   vr[0] += T12[3]; vr[1] += T12[7]; vr[2] += T12[11];
   rot3(T12, dr, drr);
   const bool on = mp.kind != DC_MODEL_NONE && lm;
   const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;      // d' at w = 0
-  int32_t* r = rows + i * (6 + mp.n_terms);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    r[a] = quantize(vr[a] + d0 * drr[a], qp.origin[a], qp.inv_scale, qp.flag);
-    r[3 + a] = __float_as_int((float)drr[a]);
-  }
+  for (int a = 0; a < 3; ++a) x0[a] = vr[a] + d0 * drr[a];
+  Basis<PT>::write(rows, i, mp.n_terms, x0, drr, qp);
 #pragma unroll
   for (int k = 0; k < DC_MAX_MODEL_TERMS; ++k) {
     if (k < mp.n_terms) {
@@ -947,22 +1027,24 @@ __global__ __launch_bounds__(kBlock) void points_basis_kernel(PointInputs in, in
         if (mp.kind > DC_MODEL_SCALED_POLYNOMIAL) dk = model_dw_other(mp, k, d, inc);
         else dk = (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
       }
-      r[6 + k] = __float_as_int((float)dk);
+      Basis<PT>::write_term(rows, i, mp.n_terms, k, dk);
     }
   }
 }
 
-template <bool FULL_EIG, int NS, int P>
+template <typename PT, bool FULL_EIG, int NS, int P>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
-    const uint8_t* __restrict__ mask, const float* __restrict__ offset, LossParams lp, QParams qp, q32* __restrict__ rec,
-    float* __restrict__ pointwise, float* __restrict__ eigvals, double* __restrict__ partials) {
+    const uint8_t* __restrict__ mask, const typename Basis<PT>::T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec,
+    typename Basis<PT>::T* __restrict__ pointwise, typename Basis<PT>::T* __restrict__ eigvals, double* __restrict__ partials) {
+  using T = typename Basis<PT>::T;
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
   double acc2[2] = {0.0, 0.0};
   const int32_t s0 = blk >= 0 ? tab.slot_ptr[blk] : 0;
+  // a table with another slot count than the launch was specialised for (not a table of [rows, NS]): fail loudly
   const bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
   if (blk >= 0 && !bad) {
     const int64_t i = blk * kBlock + threadIdx.x;
@@ -979,14 +1061,12 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
     double wq[P > 0 ? P : DC_MAX_MODEL_TERMS];
 #pragma unroll
     for (int k = 0; k < (P > 0 ? P : DC_MAX_MODEL_TERMS); ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
-    for (int t = threadIdx.x; t < nd; t += kBlock) {
-      const Pt<q32>::Raw r = basis_point<P>(pb, wq, tab.blk_ids[base + t]);
-      tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0);
-    }
-    Pt<q32>::Raw ci;
-    if (own < 0) ci = basis_point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    for (int t = threadIdx.x; t < nd; t += kBlock)
+      Basis<PT>::stage(tile, cap, t, Basis<PT>::template point<P>(pb, wq, tab.blk_ids[base + t]));
+    typename Pt<PT>::Raw ci;
+    if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
     __syncthreads();
-    if (own >= 0) ci = Pt<q32>::from_row(tile + own + (live ? (int)threadIdx.x : 0));
+    if (own >= 0) ci = staged_point<PT>(tile, cap, own + (live ? (int)threadIdx.x : 0));
     if (live) {
       CovAcc acc;
       cov_init(acc);
@@ -994,10 +1074,10 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
 #pragma unroll
       for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
       int n_have;
-      if (__any((int)(mx == kNoLoc))) n_have = gather_fixed<q32, NS, true>(tile, cap, ci, pre, acc);
-      else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
+      if (__any((int)(mx == kNoLoc))) n_have = gather_fixed<PT, NS, true>(tile, cap, ci, pre, acc);
+      else n_have = gather_fixed<PT, NS, false>(tile, cap, ci, pre, acc);
       acc.W = (double)n_have;
-      consistency_point<float, q32, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
+      consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
     }
   } else {
     __syncthreads();
@@ -1009,11 +1089,12 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_kernel(
 
 // The same for any slot count (radius neighbourhoods: the reference's default nn_r = 0.25, K = the largest count; or the
 // run-time-slot ablation): the slot loop of consistency_fwd_staged_kernel over rows formed from the basis.
-template <bool FULL_EIG, int P>
+template <typename PT, bool FULL_EIG, int P>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
-    const uint8_t* __restrict__ mask, const float* __restrict__ offset, LossParams lp, QParams qp, q32* __restrict__ rec,
-    float* __restrict__ pointwise, float* __restrict__ eigvals, double* __restrict__ partials) {
+    const uint8_t* __restrict__ mask, const typename Basis<PT>::T* __restrict__ offset, LossParams lp, QParams qp, PT* __restrict__ rec,
+    typename Basis<PT>::T* __restrict__ pointwise, typename Basis<PT>::T* __restrict__ eigvals, double* __restrict__ partials) {
+  using T = typename Basis<PT>::T;
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
@@ -1037,42 +1118,40 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
   double wq[P > 0 ? P : DC_MAX_MODEL_TERMS];
 #pragma unroll
   for (int k = 0; k < (P > 0 ? P : DC_MAX_MODEL_TERMS); ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
-  Pt<q32>::Raw ci;
+  typename Pt<PT>::Raw ci;
   if (blk >= 0) {
     const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
-    for (int t = threadIdx.x; t < nd; t += kBlock) {
-      const Pt<q32>::Raw r = basis_point<P>(pb, wq, tab.blk_ids[base + t]);
-      tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0);
-    }
-    if (own < 0) ci = basis_point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    for (int t = threadIdx.x; t < nd; t += kBlock)
+      Basis<PT>::stage(tile, cap, t, Basis<PT>::template point<P>(pb, wq, tab.blk_ids[base + t]));
+    if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
   }
   __syncthreads();
   if (live) {
-    if (own >= 0) ci = Pt<q32>::from_row(tile + own + (int)threadIdx.x);
+    if (own >= 0) ci = staged_point<PT>(tile, cap, own + (int)threadIdx.x);
     CovAcc acc;
     cov_init(acc);
     bool miss = false;
 #pragma unroll
     for (int q = 0; q < kPreSlots; ++q) miss |= (q < nslots) && pre[q] == kNoLoc;
     int n_have = 0;
-    if (__any((int)miss)) n_have = gather_slots<q32, true>(tile, cap, ci, pre, nslots, acc);
-    else n_have = gather_slots<q32, false>(tile, cap, ci, pre, nslots, acc);
+    if (__any((int)miss)) n_have = gather_slots<PT, true>(tile, cap, ci, pre, nslots, acc);
+    else n_have = gather_slots<PT, false>(tile, cap, ci, pre, nslots, acc);
     for (int q = kPreSlots; q < nslots; ++q) {             // K > 16: one slot at a time
       const uint32_t l = lrow[q * kBlock];
-      n_have += slot_add<q32, true>(tile, cap, ci, l, acc);
+      n_have += slot_add<PT, true>(tile, cap, ci, l, acc);
     }
     acc.W = (double)n_have;
-    consistency_point<float, q32, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
+    consistency_point<T, PT, FULL_EIG>(acc, ci, i, mask, offset, lp, qp, rec, pointwise, eigvals, acc2);
   }
   wave_partials<2>(acc2, partials);
 }
 
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
 // partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
-template <int P>
+template <typename PT, int P>
 __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
-    PointBasis pb, const q32* __restrict__ rec, RunTab tab, int cap, int64_t n, QParams qp, double* __restrict__ partials) {
-  constexpr int RR = RecRaw<q32>::kRow16;
+    PointBasis pb, const PT* __restrict__ rec, RunTab tab, int cap, int64_t n, QParams qp, double* __restrict__ partials) {
+  constexpr int RR = RecRaw<PT>::kRow16;
   constexpr int NP = P > 0 ? P : DC_MAX_MODEL_TERMS;
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
@@ -1105,29 +1184,23 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_basis_kernel(
     double wq[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) wq[k] = (P > 0 || k < pb.n_terms) ? s_w[k] : 0.0;
-    const Pt<q32>::Raw cj = basis_point<P>(pb, wq, j);
+    const typename Pt<PT>::Raw cj = Basis<PT>::template point<P>(pb, wq, j);
     double g[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < kPreRuns; ++t)
-      if (__any((int)(t < nruns))) run_edges<q32>(tile, cap, pre[t], nd16, cj, g);
+      if (__any((int)(t < nruns))) run_edges<PT>(tile, cap, pre[t], nd16, cj, g);
     if (__any((int)(nruns > kPreRuns))) {
       uint2 nxt = kPreRuns < nruns ? runs[kPreRuns] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
       for (int t = kPreRuns; __any((int)(t < nruns)); ++t) {
         const uint2 r = nxt;
         nxt = t + 1 < nruns ? runs[t + 1] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        run_edges<q32>(tile, cap, r, nd16, cj, g);
+        run_edges<PT>(tile, cap, r, nd16, cj, g);
       }
     }
-    const double u = qp.scale;
+    const double u = Pt<PT>::unit(qp);
     g[0] *= u; g[1] *= u; g[2] *= u;
     // u_j and c_j again (the row is still in the cache): holding them across the edge loop costs a wavefront of occupancy
-    const int np = P > 0 ? P : pb.n_terms;
-    const int32_t* r = pb.rows + j * (6 + np);
-    const double gu = g[0] * (double)__int_as_float(r[3]) + g[1] * (double)__int_as_float(r[4]) + g[2] * (double)__int_as_float(r[5]);
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (k < np) gw[k] = gu * (double)__int_as_float(r[6 + k]);
-    }
+    Basis<PT>::template chain<NP>(pb, P > 0 ? P : pb.n_terms, j, g, gw);
   }
   // per-wavefront partial rows, as reduce_param_grads writes them
   const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;
@@ -1447,19 +1520,23 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
 
 int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                     const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* e,
-                    int64_t n, int dtype, const double* qparams, int32_t* rows_out, int32_t* status, hipStream_t stream) {
+                    int64_t n, int dtype, const double* qparams, void* rows_out, int32_t* status, hipStream_t stream) {
   if (n == 0) return DC_OK;
-  if (n < 0 || !dirs || !depth || !rows_out || !qparams) return DC_ERR_ARG;
+  if (n < 0 || !dirs || !depth || !rows_out) return DC_ERR_ARG;
   if (scan_id && (!poses || n_scans < 1)) return DC_ERR_ARG;
-  if (dtype != DC_F32) return DC_ERR_DTYPE;                 // the basis form goes with the q32 point format (float32 clouds)
+  if (dtype != DC_F32 && dtype != DC_F64) return DC_ERR_DTYPE;
+  if (dtype == DC_F32 && !qparams) return DC_ERR_ARG;         // float32 clouds: rows on the q32 grid
   // the weights do not enter the basis rows: a dummy non-null pointer satisfies the model check, load_model reads e only... and w
   int rc = check_model(model_kind, n_terms, inc, e, e);
   if (rc || model_kind == DC_MODEL_NONE) return rc ? rc : DC_ERR_ARG;
   QParams qp;
-  rc = make_qparams(DC_Q32, dtype, 4, qparams, &qp, status);
+  rc = make_qparams(dtype == DC_F32 ? DC_Q32 : DC_F64, dtype, 4, qparams, &qp, status);
   if (rc) return rc;
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, e, e);
-  hipLaunchKernelGGL((points_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, rows_out);
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((points_basis_kernel<q32>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, rows_out);
+  else
+    hipLaunchKernelGGL((points_basis_kernel<double>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, rows_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -1751,46 +1828,51 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   // weights change between evaluations -> no pass over the points, no model / pose arithmetic in the loop
   size_t lds_f = 0, lds_b = 0;
   int rows_f = 0, rows_b = 0;
-  const bool basis = d->basis && d->point_fmt == DC_Q32 && d->dtype == DC_F32 && n_terms > 0 && w &&
+  const bool q32_pts = d->point_fmt == DC_Q32 && d->dtype == DC_F32, f64_pts = d->point_fmt == DC_F64 && d->dtype == DC_F64;
+  const bool basis = d->basis && (q32_pts || f64_pts) && n_terms > 0 && w &&
                      !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
-                     use_table(d->fwd_table, DC_TABLE_SLOTS, stride, 16u, 0, 60 * 1024, &lds_f, &rows_f) &&
-                     (!want_grad || use_table(d->bwd_table, DC_TABLE_RUNS, stride, 32u, 1, 44 * 1024, &lds_b, &rows_b));
+                     use_table(d->fwd_table, DC_TABLE_SLOTS, stride, q32_pts ? 16u : 32u, 0, 60 * 1024, &lds_f, &rows_f) &&
+                     (!want_grad || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
   if (basis) {
     QParams qp;
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
     if (rc) return rc;
-    PointBasis pb{d->basis, w, n_terms, qp.inv_scale};
+    PointBasis pb{d->basis, w, n_terms, q32_pts ? qp.inv_scale : 1.0};
     LossParams lp{d->loss_kind, d->normalization, d->sqrt_, 0};
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     {
       ProfScope prof(1);
       const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
-#define FWD_BASIS_P(NS, P) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<false, NS, P>), grid, block, lds_f, stream, pb, tab, \
-                                           d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const float*)nullptr, lp, qp, \
-                                           (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
-#define FWD_BASIS(NS) do { if (n_terms == 2) FWD_BASIS_P(NS, 2); else if (n_terms == 1) FWD_BASIS_P(NS, 1); \
-                           else if (n_terms == 3) FWD_BASIS_P(NS, 3); else FWD_BASIS_P(NS, 0); } while (0)
-#define FWD_BASIS_SLOTS(P) DC_TIMED_LAUNCH((consistency_fwd_basis_slots_kernel<false, P>), grid, block, lds_f, stream, pb, tab, \
-                                          d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const float*)nullptr, lp, qp, \
-                                          (q32*)d->rec, (float*)nullptr, (float*)nullptr, p_fwd)
       const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
-      if (fixed_k == 10) FWD_BASIS(10); else if (fixed_k == 4) FWD_BASIS(4); else if (fixed_k == 8) FWD_BASIS(8);
-      else if (fixed_k == 16) FWD_BASIS(16);
-      else if (n_terms == 2) FWD_BASIS_SLOTS(2); else if (n_terms == 1) FWD_BASIS_SLOTS(1);
-      else if (n_terms == 3) FWD_BASIS_SLOTS(3); else FWD_BASIS_SLOTS(0);
+#define FWD_BASIS_P(PT, T, NS, P) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<PT, false, NS, P>), grid, block, lds_f, stream, pb, tab, \
+                                                 d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const T*)nullptr, lp, qp, \
+                                                 (PT*)d->rec, (T*)nullptr, (T*)nullptr, p_fwd)
+#define FWD_BASIS_SLOTS(PT, T, P) DC_TIMED_LAUNCH((consistency_fwd_basis_slots_kernel<PT, false, P>), grid, block, lds_f, stream, pb, tab, \
+                                                 d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const T*)nullptr, lp, qp, \
+                                                 (PT*)d->rec, (T*)nullptr, (T*)nullptr, p_fwd)
+#define FWD_BASIS_NS(PT, T, P) do { if (fixed_k == 10) FWD_BASIS_P(PT, T, 10, P); else if (fixed_k == 4) FWD_BASIS_P(PT, T, 4, P); \
+                                    else if (fixed_k == 8) FWD_BASIS_P(PT, T, 8, P); else if (fixed_k == 16) FWD_BASIS_P(PT, T, 16, P); \
+                                    else FWD_BASIS_SLOTS(PT, T, P); } while (0)
+#define FWD_BASIS(PT, T) do { if (n_terms == 2) FWD_BASIS_NS(PT, T, 2); else if (n_terms == 1) FWD_BASIS_NS(PT, T, 1); \
+                              else if (n_terms == 3) FWD_BASIS_NS(PT, T, 3); else FWD_BASIS_NS(PT, T, 0); } while (0)
+      if (q32_pts) FWD_BASIS(q32, float); else FWD_BASIS(double, double);
+#undef FWD_BASIS
+#undef FWD_BASIS_NS
 #undef FWD_BASIS_SLOTS
 #undef FWD_BASIS_P
-#undef FWD_BASIS
     }
     DC_CHECK_LAUNCH();
     if (want_grad) {
       RunTab rtab{d->bwd_table->blk_ptr, d->bwd_table->blk_ids, d->bwd_table->run_ptr, d->bwd_table->loc};
       ProfScope prof(2);
-#define BWD_BASIS(P) DC_TIMED_LAUNCH((consistency_bwd_basis_kernel<P>), dim3((unsigned)xcd_grid(n_blocks(d->n))), block, lds_b, stream, pb, \
-                                     (const q32*)d->rec, rtab, rows_b, d->n, qp, p_bwd)
-      if (n_terms == 2) BWD_BASIS(2); else if (n_terms == 1) BWD_BASIS(1); else if (n_terms == 3) BWD_BASIS(3); else BWD_BASIS(0);
+#define BWD_BASIS_P(PT, P) DC_TIMED_LAUNCH((consistency_bwd_basis_kernel<PT, P>), dim3((unsigned)xcd_grid(n_blocks(d->n))), block, lds_b, stream, pb, \
+                                          (const PT*)d->rec, rtab, rows_b, d->n, qp, p_bwd)
+#define BWD_BASIS(PT) do { if (n_terms == 2) BWD_BASIS_P(PT, 2); else if (n_terms == 1) BWD_BASIS_P(PT, 1); \
+                           else if (n_terms == 3) BWD_BASIS_P(PT, 3); else BWD_BASIS_P(PT, 0); } while (0)
+      if (q32_pts) BWD_BASIS(q32); else BWD_BASIS(double);
 #undef BWD_BASIS
+#undef BWD_BASIS_P
       DC_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd,

@@ -188,7 +188,9 @@ class SequencePlan:
     def _set_basis(self, d, w, exponent, poses12, want_exponent, want_pose):
         """Point the descriptor at the basis rows valid for (poses12, exponent), building them when either changed; or clear the
         fields when this evaluation cannot use the basis form (pose / exponent gradients, other formats, no tables)."""
-        ok = (self.use_basis and self.qfmt is not None and w is not None and not want_exponent and not want_pose
+        f64 = self.qfmt is None and self.x.dtype == torch.float64 and self.ps.dirs.dtype == torch.float64
+        ok = (self.use_basis and (self.qfmt is not None or f64) and w is not None
+              and not want_exponent and not want_pose
               and self.fwd_table is not None and self.bwd_table is not None and self.bwd_table.run_ptr is not None
               and d.model_kind != 0)
         if not ok:
@@ -199,10 +201,12 @@ class SequencePlan:
         key = (poses12.data_ptr(), poses12._version, exponent.data_ptr(), exponent._version, nt)
         if b is None or b[0] != key:
             ps = self.ps
-            rows = torch.empty((self.n, 6 + nt), dtype=torch.int32, device=self.device)
+            # float32 clouds: int32 / float32 words on the q32 grid; float64 clouds: fp64 words
+            rows = torch.empty((self.n, 6 + nt), dtype=torch.float64 if f64 else torch.int32, device=self.device)
             check(lib().dc_points_basis(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
-                                        ptr(poses12), self.n_scans, d.model_kind, nt, ptr(exponent), self.n, nv.DC_F32,
-                                        self.qfmt._c, ptr(rows), ptr(self.status), stream_ptr()), 'dc_points_basis')
+                                        ptr(poses12), self.n_scans, d.model_kind, nt, ptr(exponent), self.n,
+                                        nv.DC_F64 if f64 else nv.DC_F32, None if f64 else self.qfmt._c, ptr(rows),
+                                        ptr(self.status), stream_ptr()), 'dc_points_basis')
             # the tensors are kept alive with the entry, so their addresses cannot be recycled for other poses / exponents
             self._basis = b = (key, rows, poses12, exponent)
         d.basis = b[1].data_ptr()

@@ -98,13 +98,14 @@ int dc_points_fwd(const void* vps, const void* dirs, const void* depth, const vo
 
 /* Basis form of dc_points_fwd for fixed poses and exponents.  Every model is affine in its weights, so
  *   x_j(w) = X0_j + (sum_k w_k c_kj) u_j,  X0 = R (vp + d0 dir) + t (d0 = d' at w = 0),  u = R dir,  c_kj = dd'/dw_k  (0 outside lmask).
- * rows_out int32 [n, 6 + n_terms]: per point X0 on the DC_Q32 grid of qparams (status as in dc_points_fwd), then the float32
- * bits of u and of c_0 .. c_{P-1} (metres per unit weight); 32 bytes for the two-term models = one sector per gathered point.
- * dtype must be DC_F32.  dc_sequence_eval / _step use the rows (dcSequenceDesc.basis) instead of launching dc_points_fwd
- * when neither pose nor exponent gradients are requested. */
+ * dtype DC_F32 (float32 clouds, points in DC_Q32): rows_out int32 [n, 6 + n_terms]: per point X0 on the DC_Q32 grid of qparams
+ * (status as in dc_points_fwd), then the float32 bits of u and of c_0 .. c_{P-1} (metres per unit weight); 32 bytes for the
+ * two-term models = one sector per gathered point.  dtype DC_F64 (float64 clouds, points in DC_F64): rows_out fp64
+ * [n, 6 + n_terms] = X0, u, c; qparams unused.  dc_sequence_eval / _step use the rows (dcSequenceDesc.basis) instead of
+ * launching dc_points_fwd when neither pose nor exponent gradients are requested. */
 int dc_points_basis(const void* vps, const void* dirs, const void* depth, const void* inc, const uint8_t* lmask,
                     const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms, const double* e,
-                    int64_t n, int dtype, const double* qparams, int32_t* rows_out, int32_t* status, dcStream_t stream);
+                    int64_t n, int dtype, const double* qparams, void* rows_out, int32_t* status, dcStream_t stream);
 
 /* Backward of dc_points_fwd for a given dL/dpoints: grads_out fp64 [2*n_terms + 12*n_scans] =
  * {dL/dw, dL/dexponent, dL/d[R|t] per scan}.  partials_ws: fp64 [dc_partial_rows(n) * that count].
@@ -339,7 +340,7 @@ typedef struct dcSequenceDesc {
   const dcBlockTable* bwd_table;   /* block table of (csr_ptr, csr_src), or NULL */
   int32_t* status;                 /* device int or NULL: bit 0 raised by dc_points_fwd when a DC_Q32 coordinate overflowed /
                                       was NaN; while it is set the evaluation's loss (out[0]) is NaN */
-  const int32_t* basis;            /* basis rows of dc_points_basis, valid FOR THE POSES AND EXPONENTS OF THE CALL, or NULL:
+  const void* basis;               /* basis rows of dc_points_basis, valid FOR THE POSES AND EXPONENTS OF THE CALL, or NULL:
                                       x = X0 + (sum_k w_k c_k) u, so an evaluation needs no pass over the points */
 } dcSequenceDesc;
 

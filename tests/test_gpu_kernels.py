@@ -487,20 +487,24 @@ def test_block_tables_do_not_change_results(golden, dev):
     ('ScaledPolynomial', 2, False, False), ('Polynomial', 2, False, False), ('ScaledPolynomial', 1, False, False),
     ('Polynomial', 3, False, False), ('ScaledPolynomial', 4, False, False), ('ScaledPolynomial', 2, True, False),
     ('ScaledPolynomial', 2, False, True), ('Polynomial', 3, True, True)])
-def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only, ragged):
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only, ragged, dtype):
     """dc_sequence_eval through the basis form (x = X0 + sum_k w_k B_k, no pass over the points) against the general
     path (dc_points_fwd every evaluation): identical count, loss and dL/dw up to the second rounding of the q32 grid, for
     several weight vectors on one plan (X0 / B are built once) and after the poses changed (rebuilt).  Term counts 1-3
     run the kernels specialised for them, 4 the run-time loop; active_only takes the centre from its own row instead of
-    the staged ones; ragged: a radius-style table (19 columns, missing entries) through the run-time-slot kernel."""
+    the staged ones; ragged: a radius-style table (19 columns, missing entries) through the run-time-slot kernel.
+    float64 clouds (the reference's default float_type) keep fp64 points: the two paths then differ only by the order of
+    the fp64 operations."""
     from depth_correction_amd.plan import SequencePlan, KernelTimer
     from depth_correction_amd import _native as nv
     g = golden('room_k10')
-    scans = scans_from_golden(g, torch.float32)
+    scans = scans_from_golden(g, dtype)
     clouds = [dict(vps=s['vps'].to(dev), dirs=s['dirs'].to(dev), depth=s['depth'].to(dev), inc_angles=s['inc'].to(dev),
                    mask=s['mask'].to(dev)) for s in scans]
     poses = t(g['poses'], dev)
     nbr = t(g['g_neighbors'], dev)
+    f64 = dtype == torch.float64
     if ragged:
         gen = torch.Generator(device='cpu').manual_seed(3)
         drop = (torch.rand(nbr.shape, generator=gen) < 0.2).to(dev)
@@ -510,7 +514,7 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
         extra[:, ::2] = -1
         nbr = torch.cat([nbr, extra], dim=1).contiguous()
     plan = SequencePlan(clouds, poses, nbr, t(g['g_mask'], dev), model_kind=model, active_only=active_only)
-    assert plan.qfmt is not None
+    assert (plan.qfmt is None) == f64
     assert (plan.fwd_table.own_base is None) == active_only
     e = torch.tensor([2.0, 4.0, 1.0, 3.0][:n_terms], dtype=torch.float64, device=dev)
     nt = n_terms
@@ -542,7 +546,8 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
             nv.check(nv.lib().dc_set_option(3, 0), 'dc_set_option')
     for a, b in zip(outs[True], outs[False]):
         assert a[1] == b[1] > 0
-        np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-12 if f64 else 2e-6)
         # thinned neighbourhoods (4-6 points) amplify the grid's second rounding in the gradient
-        np.testing.assert_allclose(a[2:2 + nt], b[2:2 + nt], rtol=1e-4 if ragged else 2e-5, atol=1e-7 * np.abs(b[2:2 + nt]).max())
+        np.testing.assert_allclose(a[2:2 + nt], b[2:2 + nt], rtol=1e-9 if f64 else (1e-4 if ragged else 2e-5),
+                                   atol=(1e-12 if f64 else 1e-7) * np.abs(b[2:2 + nt]).max())
     assert not np.allclose(outs[True][0][0], outs[True][3][0], rtol=1e-9)          # the moved pose changed the loss
