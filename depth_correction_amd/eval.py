@@ -52,6 +52,7 @@ def fused_supported(clouds, model, cfg: Config):
     kw = cfg.loss_kwargs
     return (getattr(cfg, 'fused', True) and cfg.nn_type == NeighborhoodType.ball
             and cfg.loss in ('min_eigval_loss', 'trace_loss') and not cfg.loss_offset and not cfg.nn_scale
+            and not kw.get('only_finite') and not kw.get('skip_nans')       # NaN-dropping reductions: un-fused operators
             and (model is None or getattr(model, 'kernel_kind', None) is not None)
             and clouds[0][0].dirs.is_cuda and all(c.inc_angles is not None for seq in clouds for c in seq))
 
