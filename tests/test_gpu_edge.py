@@ -251,3 +251,57 @@ def test_knn_with_far_outliers_is_exact_and_does_not_stall():
     from scipy.spatial import cKDTree
     dr, ir = cKDTree(pts).query(q, 3)
     assert np.array_equal(npy(iq), ir) and np.array_equal(npy(dq), dr)
+
+
+def _local_scans(sizes, dtype, seed):
+    """Synthetic sensor-frame scans of a slightly noisy floor patch (dirs, depth, incidence angle, local mask) + poses."""
+    rng = np.random.default_rng(seed)
+    clouds, poses = [], []
+    for s, n in enumerate(sizes):
+        xy = rng.uniform(-1.5, 1.5, size=(n, 2))
+        p = np.concatenate([xy, -1.2 + 0.01 * rng.normal(size=(n, 1))], axis=1)
+        depth = np.linalg.norm(p, axis=1, keepdims=True)
+        dirs = p / depth
+        inc = np.arccos(np.abs(dirs[:, 2:3]))
+        T = np.eye(4)
+        T[:3, 3] = [0.2 * s, -0.1 * s, 0.01 * s]
+        clouds.append(dict(vps=torch.zeros((n, 3), dtype=dtype, device=DEV), dirs=t(dirs, DEV, dtype), depth=t(depth, DEV, dtype),
+                           inc_angles=t(inc, DEV, dtype), mask=t(rng.random(n) < 0.8, DEV)))
+        poses.append(T)
+    return clouds, t(np.stack(poses), DEV)
+
+
+@pytest.mark.parametrize('sizes,k', [((1, 1), 2), ((100, 155), 4), ((128, 128), 10), ((200, 57), 10), ((300, 213), 6),
+                                     ((700, 325), 16), ((40, 900, 84), 12)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_sequence_plan_small_and_odd_sizes(sizes, k, dtype):
+    """Whole-sequence evaluations (basis form and general path) on sequences of 2-1025 points: partial blocks, exactly one
+    block, scans of very different sizes, every supported way of choosing the forward kernel (k = 4 / 10 / 16 compiled,
+    2 / 6 / 12 run-time slots); a plan whose global mask is empty yields count 0, loss 0 and zero gradients."""
+    from depth_correction_amd import ops, _native as nv
+    from depth_correction_amd.plan import SequencePlan
+    clouds, poses = _local_scans(sizes, dtype, seed=sum(sizes) + k)
+    n = sum(sizes)
+    x = torch.cat([(c['dirs'] * c['depth']).double() @ T[:3, :3].T + T[:3, 3] for c, T in zip(clouds, poses)])
+    _, nbr = ops.knn(x, k)
+    mask = t(np.random.default_rng(1).random(n) < 0.7, DEV)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=DEV)
+    w = torch.tensor([2e-3, -1e-3], dtype=torch.float64, device=DEV)
+    for m in (mask, torch.zeros_like(mask)):
+        plan = SequencePlan(clouds, poses, nbr, m)
+        outs = {}
+        for general in (0, 1):
+            nv.check(nv.lib().dc_set_option(3, general), 'dc_set_option')
+            try:
+                out = torch.full((2 + 4 + 12 * plan.n_scans,), 3.0, dtype=torch.float64, device=DEV)
+                outs[general] = npy(plan.eval_native(w, e, plan.poses12(poses), out))
+            finally:
+                nv.check(nv.lib().dc_set_option(3, 0), 'dc_set_option')
+        a, b = outs[0], outs[1]
+        assert a[1] == b[1] == float(m.sum()) and np.all(a[4:] == 0) and np.all(b[4:] == 0)
+        if not bool(m.any()):
+            assert np.all(a[:4] == 0) and np.all(b[:4] == 0)
+            continue
+        f64 = dtype == torch.float64
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-11 if f64 else 1e-5)
+        np.testing.assert_allclose(a[2:4], b[2:4], rtol=1e-8 if f64 else 1e-3, atol=(1e-11 if f64 else 1e-5) * np.abs(b[2:4]).max())
