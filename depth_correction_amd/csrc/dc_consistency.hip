@@ -1146,6 +1146,140 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
   wave_partials<2>(acc2, partials);
 }
 
+// ---- loss AND dL/dw in one pass (forward-mode accumulation) -------------------------------------------------------------
+// With only the P model weights to differentiate, the reverse pass over the transposed table is not needed:
+//     dL/dw_k = sum_i sum_{j in N(i)} (dl_i/dx_j) . (dx_j/dw_k),   dl_i/dx_j = c1_i (v0_i . d) v0_i - c2_i d,  d = x_j - cmean_i,
+//     dx_j/dw_k = c_kj u_j
+// is a second sweep of centre i over its OWN neighbours, whose rows (x_j and now also u_j, c_kj) already sit in LDS.  No
+// backward record is written or read (64 + 64 MB per iteration at C2), no transposed table, no second launch; the terms
+// are the ones the backward kernel adds up, grouped by centre instead of by point, with c1 / c2 / cmean in fp64.
+// Staged row (piece-major, 16-B pieces): {x0, x1, x2, u0 | u1, u2, c0, c1 | c2 ...}: x on the q32 grid, u / c float32 bits.
+template <int P> struct StepRow { static constexpr int kPieces = (6 + P + 3) / 4; };
+
+template <int P>
+__device__ __forceinline__ Pt<q32>::Raw stage_step_row(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+  const int32_t* r = static_cast<const int32_t*>(pb.rows) + row * (6 + P);
+  int32_t q[6 + P];
+#pragma unroll
+  for (int c = 0; c < 6 + P; ++c) q[c] = r[c];
+  double sc = 0.0;
+#pragma unroll
+  for (int k = 0; k < P; ++k) sc += wq[k] * (double)__int_as_float(q[6 + k]);
+  Pt<q32>::Raw o;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
+  tile[t] = make_int4(o.v[0], o.v[1], o.v[2], q[3]);
+  tile[cap + t] = make_int4(q[4], q[5], q[6], P > 1 ? q[P > 1 ? 7 : 6] : 0);
+  if constexpr (P > 2) tile[2 * cap + t] = make_int4(q[8], 0, 0, 0);
+  return o;
+}
+
+// second sweep over a centre's NS slots: gw[k] += sum_j t_j c_kj, t_j = c1 (v . e)(v . u_j) - c2 (e . u_j), e = x_j - x_i - cm
+template <int NS, int P, bool MISS>
+__device__ __forceinline__ void weight_chain_fixed(const int4* tile, int cap, const Pt<q32>::Raw& ci, const uint32_t* pre,
+                                                   const double* cm, const double* v, double c1, double c2, double* gw) {
+  const char* base = reinterpret_cast<const char*>(tile);
+#pragma unroll
+  for (int q0 = 0; q0 < NS; q0 += 2) {
+    int4 p0[2], p1[2], p2[2];
+    bool have[2];
+#pragma unroll
+    for (int u_ = 0; u_ < 2; ++u_) {
+      if (q0 + u_ < NS) {
+        have[u_] = !MISS || pre[q0 + u_] != kNoLoc;
+        const char* row = base + (have[u_] ? pre[q0 + u_] : 0u);
+        p0[u_] = *reinterpret_cast<const int4*>(row);
+        p1[u_] = *reinterpret_cast<const int4*>(row + (size_t)cap * 16);
+        if constexpr (P > 2) p2[u_] = *reinterpret_cast<const int4*>(row + (size_t)cap * 32);
+      }
+    }
+#pragma unroll
+    for (int u_ = 0; u_ < 2; ++u_) {
+      if (q0 + u_ < NS) {
+        const double e0 = (double)(p0[u_].x - ci.v[0]) - cm[0], e1 = (double)(p0[u_].y - ci.v[1]) - cm[1],
+                     e2 = (double)(p0[u_].z - ci.v[2]) - cm[2];
+        const double u0 = (double)__int_as_float(p0[u_].w), u1 = (double)__int_as_float(p1[u_].x), u2 = (double)__int_as_float(p1[u_].y);
+        const double al = v[0] * e0 + v[1] * e1 + v[2] * e2;
+        const double be = v[0] * u0 + v[1] * u1 + v[2] * u2;
+        const double ga = e0 * u0 + e1 * u1 + e2 * u2;
+        double tj = c1 * al * be - c2 * ga;
+        if (MISS && !have[u_]) tj = 0.0;
+        gw[0] = fma(tj, (double)__int_as_float(p1[u_].z), gw[0]);
+        if constexpr (P > 1) gw[1] = fma(tj, (double)__int_as_float(p1[u_].w), gw[1]);
+        if constexpr (P > 2) gw[2] = fma(tj, (double)__int_as_float(p2[u_].x), gw[2]);
+      }
+    }
+  }
+}
+
+// partial rows: columns {sum loss, count} at p_fwd (stride gridDim * 4) and [0, P) dL/dw at p_bwd (same stride)
+template <int NS, int P>
+__global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
+    PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+  extern __shared__ int4 tile[];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0}, gw[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) gw[k] = 0.0;
+  const int32_t s0 = blk >= 0 ? tab.slot_ptr[blk] : 0;
+  const bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
+  if (blk >= 0 && !bad) {
+    const int64_t i = blk * kBlock + threadIdx.x;
+    const bool live = i < n;
+    const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    uint32_t pre[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) pre[q] = (uint32_t)lrow[q * kBlock];
+    stage_weights(pb, s_w);
+    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    const int32_t own = (own_base && !centre_idx) ? own_base[blk] : -1;
+    __syncthreads();
+    double wq[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+    for (int t = threadIdx.x; t < nd; t += kBlock) stage_step_row<P>(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    Pt<q32>::Raw ci;
+    if (own < 0) ci = Basis<q32>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    __syncthreads();
+    if (own >= 0) ci = staged_point<q32>(tile, cap, own + (live ? (int)threadIdx.x : 0));
+    if (live) {
+      CovAcc acc;
+      cov_init(acc);
+      uint32_t mx = pre[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
+      const bool any_miss = __any((int)(mx == kNoLoc)) != 0;
+      int n_have;
+      if (any_miss) n_have = gather_fixed<q32, NS, true>(tile, cap, ci, pre, acc);
+      else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
+      acc.W = (double)n_have;
+      cov_same_weights(acc);
+      const double u = qp.scale;
+      double moff[3], cm[3], C[6], D, omega, lam0, v0[3], tr, c1, c2;
+      cov_finish(acc, 0.0, moff, cm, C, &D, &omega, u * u);
+      const bool m = mask ? mask[i] != 0 : true;
+      eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
+      const double l = loss_and_coeffs(lp, lam0, tr, D, 0.0, m, &c1, &c2);
+      if (m) { acc2[0] = l; acc2[1] = 1.0; }
+      // an empty neighbourhood has a NaN mean and zero coefficients: keep its (zero) contribution finite
+      if (!(c1 != 0.0 || c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
+      if (any_miss) weight_chain_fixed<NS, P, true>(tile, cap, ci, pre, cm, v0, c1, c2, gw);
+      else weight_chain_fixed<NS, P, false>(tile, cap, ci, pre, cm, v0, c1, c2, gw);
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] *= u;            // differences were in grid steps
+    }
+  } else {
+    __syncthreads();
+    __syncthreads();
+  }
+  if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
+  wave_partials<2>(acc2, p_fwd);
+  wave_partials<P>(gw, p_bwd);
+}
+
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
 // partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
 template <typename PT, int P>
@@ -1384,6 +1518,7 @@ static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
+static std::atomic<bool> g_two_pass{false};     // dc_set_option(4, 1): basis form with separate forward and backward kernels
 static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's basis rows (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
 // a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
@@ -1746,6 +1881,7 @@ int dc_set_option(int option, int value) {
   if (option == 0) { g_no_tab.store(value != 0); return DC_OK; }
   if (option == 1) { g_fwd_generic.store(value); return DC_OK; }
   if (option == 3) { g_no_basis.store(value != 0); return DC_OK; }
+  if (option == 4) { g_two_pass.store(value != 0); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -1841,10 +1977,34 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     LossParams lp{d->loss_kind, d->normalization, d->sqrt_, 0};
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
+    const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
+    // loss and dL/dw in ONE pass (forward-mode): float32 clouds, up to three weights, compiled slot counts
+    size_t lds_s = 0;
+    int rows_s = 0;
+    const bool one_pass = want_grad && q32_pts && n_terms <= 3 && !g_two_pass.load() &&
+                          (fixed_k == 4 || fixed_k == 8 || fixed_k == 10 || fixed_k == 16) &&
+                          use_table(d->fwd_table, DC_TABLE_SLOTS, stride, 16u * (unsigned)((6 + n_terms + 3) / 4), 0, 60 * 1024, &lds_s, &rows_s);
+    if (one_pass) {
+      const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
+      {
+        ProfScope prof(1);
+#define STEP_P(NS, P) DC_TIMED_LAUNCH((consistency_step_basis_kernel<NS, P>), grid, block, lds_s, stream, pb, tab, d->fwd_table->own_base, \
+                                      rows_s, d->centre_idx, n_rows, d->mask, lp, qp, p_fwd, p_bwd)
+#define STEP(NS) do { if (n_terms == 2) STEP_P(NS, 2); else if (n_terms == 1) STEP_P(NS, 1); else STEP_P(NS, 3); } while (0)
+        if (fixed_k == 10) STEP(10); else if (fixed_k == 4) STEP(4); else if (fixed_k == 8) STEP(8); else STEP(16);
+#undef STEP
+#undef STEP_P
+      }
+      DC_CHECK_LAUNCH();
+      const int64_t rows_g = (int64_t)grid.x * kWavesPerBlock;
+      hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_g, rows_g, n_terms, out,
+                         adam, (const int32_t*)d->status);
+      DC_CHECK_LAUNCH();
+      return DC_OK;
+    }
     {
       ProfScope prof(1);
       const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
-      const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
 #define FWD_BASIS_P(PT, T, NS, P) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<PT, false, NS, P>), grid, block, lds_f, stream, pb, tab, \
                                                  d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const T*)nullptr, lp, qp, \
                                                  (PT*)d->rec, (T*)nullptr, (T*)nullptr, p_fwd)

@@ -392,7 +392,9 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
  * option 0: value 1 makes the fused kernels ignore block tables and gather from global memory.
  * option 1: value 1 makes dc_consistency_fwd use the run-time slot loop instead of the kernels specialised for
  *           k = 4 / 8 / 10 / 16.
- * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.basis (general path). */
+ * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.basis (general path).
+ * option 4: value 1 makes basis-form evaluations run the forward and the backward kernel separately instead of the one-pass
+ *           loss + dL/dw kernel. */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
