@@ -63,6 +63,7 @@ def parse():
     ap.add_argument('--no-block-tables', action='store_true', help='gather from global memory instead of LDS (ablation)')
     ap.add_argument('--no-basis', action='store_true',
                     help='general path: dc_points_fwd every evaluation instead of the basis form x = X0 + (sum w_k c_k) u (ablation)')
+    ap.add_argument('--two-pass', action='store_true', help='basis form with separate forward and backward kernels (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
     return ap.parse_args()
 
@@ -88,9 +89,11 @@ def compulsory_bytes(plan):
     bwd_tab = nbytes(bt.blk_ptr, bt.blk_ids, bt.slot_ptr, bt.run_ptr, bt.loc) if bt is not None else nbytes(plan.csr_ptr, plan.csr_src)
     basis = plan._basis[1] if getattr(plan, '_basis', None) else None
     if basis is not None:
-        # basis form: the kernels form the points from the [N, 6 + P] basis rows, no pass over the raw inputs
+        # basis form: the kernels form the points from the [N, 6 + P] basis rows, no pass over the raw inputs;
+        # consistency_step: the one-pass loss + dL/dw kernel (no record written, no backward launch)
         return dict(points_fwd=0, consistency_fwd=nbytes(basis, plan.mask, plan.rec, ft.own_base) + fwd_tab,
-                    consistency_bwd=nbytes(basis, plan.rec) + bwd_tab)
+                    consistency_bwd=nbytes(basis, plan.rec) + bwd_tab,
+                    consistency_step=nbytes(basis, plan.mask, ft.own_base) + fwd_tab)
     return dict(points_fwd=pt_in + nbytes(plan.x),
                 consistency_fwd=nbytes(plan.x, plan.mask, plan.rec) + fwd_tab,
                 consistency_bwd=nbytes(plan.x, plan.rec) + pt_in + bwd_tab)
@@ -236,9 +239,11 @@ def main():
     plan, info = build(stage_times=True)
     torch.cuda.synchronize()
     setup_ms = (time.perf_counter() - t0) * 1e3
+    from depth_correction_amd import _native as nv
     if args.fwd_generic:
-        from depth_correction_amd import _native as nv
         nv.check(nv.lib().dc_set_option(1, 1), 'dc_set_option')
+    if args.two_pass:
+        nv.check(nv.lib().dc_set_option(4, 1), 'dc_set_option')
     # the k-NN build alone, on the global cloud (reported separately)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -374,9 +379,14 @@ def main():
         ab = algorithmic_bytes(args.k, (plan.count / n_local) if args.active_only else 1.0)
         value = n_local * world * args.steps / elapsed
         roofline = None
-        if 'consistency_fwd' in ms and 'consistency_bwd' in ms:
+        if 'consistency_fwd' in ms:
             table = load_profile_table()
             comp = compulsory_bytes(plan)
+            # the one-pass kernel (loss + dL/dw) is launched and timed in the forward's place; there is no backward launch then
+            one_pass = 'consistency_step' in kernel_names.get('consistency_fwd', '')
+            if one_pass:
+                comp['consistency_fwd'] = comp['consistency_step']
+                ab['consistency_fwd'] = ab['path']
             per_kernel = {}
             for name in ('points_fwd', 'consistency_fwd', 'consistency_bwd'):
                 if name not in ms:
@@ -394,10 +404,11 @@ def main():
                     'valu_frac': None if insts is None else (insts * n_local / 64) / (t_s * N_SIMD * CLOCK_GHZ * 1e9 / 4),
                     'profile': None if prof is None else prof.get('source'),
                     'algorithmic_GBps': ab[name] * n_local / t_s / 1e9}
-            dom = max(('consistency_fwd', 'consistency_bwd'), key=lambda n_: ms[n_])
+            dom = max((n_ for n_ in ('consistency_fwd', 'consistency_bwd') if n_ in ms), key=lambda n_: ms[n_])
             d = per_kernel[dom]
             bound = 'valu' if (d['valu_frac'] or 0.0) > d['hbm_frac'] else 'hbm'
-            roofline = {'bound': bound, 'kernel': 'dc_' + dom, 'instantiation': d['kernel'],
+            roofline = {'bound': bound, 'kernel': 'dc_sequence_step (one-pass loss + dL/dw kernel)' if one_pass else 'dc_' + dom,
+                        'instantiation': d['kernel'],
                         'achieved': d['hbm_GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': d['hbm_frac'],
                         'traffic': d['traffic'],
                         'traffic_source': d['profile'] or 'no committed PMC profile of this instantiation: achieved uses compulsory_bytes',
@@ -422,7 +433,7 @@ def main():
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
-                       'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the consistency kernels; the basis rows are rebuilt only when poses or exponents change)'
+                       'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the kernel; loss and dL/dw in one pass over each centre\'s neighbours; the basis rows are rebuilt only when poses or exponents change)'
                                if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
                        'loop': ('autograd+torch.optim.Adam' + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,

@@ -21,7 +21,7 @@ def main(run_dir, n, commit=''):
             table = {k: v for k, v in json.load(f).items() if isinstance(v, dict)}
     for kernel, d in summary.items():
         name = kernel.replace('dc::', '').strip()
-        if not any(s in name for s in ('consistency_fwd', 'consistency_bwd', 'points_fwd_kernel<float, q32')):
+        if not any(s in name for s in ('consistency_fwd', 'consistency_bwd', 'consistency_step', 'points_fwd_kernel<float, q32')):
             continue
         if 'hbm_bytes' not in d or 'valu_insts_per_wave' not in d:
             continue
