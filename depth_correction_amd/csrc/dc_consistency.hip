@@ -1153,67 +1153,107 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
 // is a second sweep of centre i over its OWN neighbours, whose rows (x_j and now also u_j, c_kj) already sit in LDS.  No
 // backward record is written or read (64 + 64 MB per iteration at C2), no transposed table, no second launch; the terms
 // are the ones the backward kernel adds up, grouped by centre instead of by point, with c1 / c2 / cmean in fp64.
-// Staged row (piece-major, 16-B pieces): {x0, x1, x2, u0 | u1, u2, c0, c1 | c2 ...}: x on the q32 grid, u / c float32 bits.
-template <int P> struct StepRow { static constexpr int kPieces = (6 + P + 3) / 4; };
+// Staged row (piece-major, 16-B pieces; piece 0 starts with the point in its usual row format, so the first sweep and the
+// centre read it as before):  q32: {x0, x1, x2, u0 | u1, u2, c0, c1 | c2}, x on the grid, u / c float32 bits;
+// double: {x0, x1 | x2, u0 | u1, u2 | c0, c1 | c2, -}.
+template <typename PT, int P> struct StepRow;
+template <int P> struct StepRow<q32, P> {
+  static constexpr int kPieces = (6 + P + 3) / 4;
+  static __device__ __forceinline__ void stage(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+    const int32_t* r = static_cast<const int32_t*>(pb.rows) + row * (6 + P);
+    int32_t q[6 + P];
+#pragma unroll
+    for (int c = 0; c < 6 + P; ++c) q[c] = r[c];
+    double sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) sc += wq[k] * (double)__int_as_float(q[6 + k]);
+    int32_t x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
+    tile[t] = make_int4(x[0], x[1], x[2], q[3]);
+    tile[cap + t] = make_int4(q[4], q[5], q[6], P > 1 ? q[P > 1 ? 7 : 6] : 0);
+    if constexpr (P > 2) tile[2 * cap + t] = make_int4(q[8], 0, 0, 0);
+  }
+  // e = x_j - x_i - cm (grid steps), u_j, c_kj of the staged row at byte offset `off`
+  static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const Pt<q32>::Raw& ci, const double* cm,
+                                              double* e, double* u, double* c) {
+    const char* row = reinterpret_cast<const char*>(tile) + off;
+    const int4 p0 = *reinterpret_cast<const int4*>(row);
+    const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)cap * 16);
+    e[0] = (double)(p0.x - ci.v[0]) - cm[0]; e[1] = (double)(p0.y - ci.v[1]) - cm[1]; e[2] = (double)(p0.z - ci.v[2]) - cm[2];
+    u[0] = (double)__int_as_float(p0.w); u[1] = (double)__int_as_float(p1.x); u[2] = (double)__int_as_float(p1.y);
+    c[0] = (double)__int_as_float(p1.z);
+    if constexpr (P > 1) c[1] = (double)__int_as_float(p1.w);
+    if constexpr (P > 2) c[2] = (double)__int_as_float(reinterpret_cast<const int4*>(row + (size_t)cap * 32)->x);
+  }
+};
+template <int P> struct StepRow<double, P> {
+  static constexpr int kPieces = (6 + P + 1) / 2;
+  static __device__ __forceinline__ int4 pack(double a, double b) {
+    return make_int4(__double2loint(a), __double2hiint(a), __double2loint(b), __double2hiint(b));
+  }
+  static __device__ __forceinline__ void stage(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+    const double* r = static_cast<const double*>(pb.rows) + row * (6 + P);
+    double q[6 + P + 1];
+#pragma unroll
+    for (int c = 0; c < 6 + P; ++c) q[c] = r[c];
+    q[6 + P] = 0.0;
+    double sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) sc += wq[k] * q[6 + k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[a] += sc * q[3 + a];
+#pragma unroll
+    for (int a = 0; a < kPieces; ++a) tile[a * cap + t] = pack(q[2 * a], q[2 * a + 1]);
+  }
+  static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const Pt<double>::Raw& ci, const double* cm,
+                                              double* e, double* u, double* c) {
+    const char* row = reinterpret_cast<const char*>(tile) + off;
+    double q[2 * kPieces];
+#pragma unroll
+    for (int a = 0; a < kPieces; ++a) {
+      const int4 p = *reinterpret_cast<const int4*>(row + (size_t)a * cap * 16);
+      q[2 * a] = __hiloint2double(p.y, p.x); q[2 * a + 1] = __hiloint2double(p.w, p.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { e[a] = (q[a] - ci.v[a]) - cm[a]; u[a] = q[3 + a]; }
+#pragma unroll
+    for (int k = 0; k < P; ++k) c[k] = q[6 + k];
+  }
+};
 
-template <int P>
-__device__ __forceinline__ Pt<q32>::Raw stage_step_row(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
-  const int32_t* r = static_cast<const int32_t*>(pb.rows) + row * (6 + P);
-  int32_t q[6 + P];
+// one neighbour's share of dL/dw: gw[k] += t c_kj, t = c1 (v . e)(v . u_j) - c2 (e . u_j); have = false: nothing
+template <typename PT, int P>
+__device__ __forceinline__ void chain_term(const int4* tile, int cap, uint32_t off, bool have, const typename Pt<PT>::Raw& ci,
+                                           const double* cm, const double* v, double c1, double c2, double* gw) {
+  double e[3], u[3], c[P];
+  StepRow<PT, P>::load(tile, cap, have ? off : 0u, ci, cm, e, u, c);
+  const double al = v[0] * e[0] + v[1] * e[1] + v[2] * e[2];
+  const double be = v[0] * u[0] + v[1] * u[1] + v[2] * u[2];
+  const double ga = e[0] * u[0] + e[1] * u[1] + e[2] * u[2];
+  double tj = c1 * al * be - c2 * ga;
+  if (!have) tj = 0.0;
 #pragma unroll
-  for (int c = 0; c < 6 + P; ++c) q[c] = r[c];
-  double sc = 0.0;
-#pragma unroll
-  for (int k = 0; k < P; ++k) sc += wq[k] * (double)__int_as_float(q[6 + k]);
-  Pt<q32>::Raw o;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
-  tile[t] = make_int4(o.v[0], o.v[1], o.v[2], q[3]);
-  tile[cap + t] = make_int4(q[4], q[5], q[6], P > 1 ? q[P > 1 ? 7 : 6] : 0);
-  if constexpr (P > 2) tile[2 * cap + t] = make_int4(q[8], 0, 0, 0);
-  return o;
+  for (int k = 0; k < P; ++k) gw[k] = fma(tj, c[k], gw[k]);
 }
 
-// second sweep over a centre's NS slots: gw[k] += sum_j t_j c_kj, t_j = c1 (v . e)(v . u_j) - c2 (e . u_j), e = x_j - x_i - cm
-template <int NS, int P, bool MISS>
-__device__ __forceinline__ void weight_chain_fixed(const int4* tile, int cap, const Pt<q32>::Raw& ci, const uint32_t* pre,
-                                                   const double* cm, const double* v, double c1, double c2, double* gw) {
-  const char* base = reinterpret_cast<const char*>(tile);
-#pragma unroll
-  for (int q0 = 0; q0 < NS; q0 += 2) {
-    int4 p0[2], p1[2], p2[2];
-    bool have[2];
-#pragma unroll
-    for (int u_ = 0; u_ < 2; ++u_) {
-      if (q0 + u_ < NS) {
-        have[u_] = !MISS || pre[q0 + u_] != kNoLoc;
-        const char* row = base + (have[u_] ? pre[q0 + u_] : 0u);
-        p0[u_] = *reinterpret_cast<const int4*>(row);
-        p1[u_] = *reinterpret_cast<const int4*>(row + (size_t)cap * 16);
-        if constexpr (P > 2) p2[u_] = *reinterpret_cast<const int4*>(row + (size_t)cap * 32);
-      }
-    }
-#pragma unroll
-    for (int u_ = 0; u_ < 2; ++u_) {
-      if (q0 + u_ < NS) {
-        const double e0 = (double)(p0[u_].x - ci.v[0]) - cm[0], e1 = (double)(p0[u_].y - ci.v[1]) - cm[1],
-                     e2 = (double)(p0[u_].z - ci.v[2]) - cm[2];
-        const double u0 = (double)__int_as_float(p0[u_].w), u1 = (double)__int_as_float(p1[u_].x), u2 = (double)__int_as_float(p1[u_].y);
-        const double al = v[0] * e0 + v[1] * e1 + v[2] * e2;
-        const double be = v[0] * u0 + v[1] * u1 + v[2] * u2;
-        const double ga = e0 * u0 + e1 * u1 + e2 * u2;
-        double tj = c1 * al * be - c2 * ga;
-        if (MISS && !have[u_]) tj = 0.0;
-        gw[0] = fma(tj, (double)__int_as_float(p1[u_].z), gw[0]);
-        if constexpr (P > 1) gw[1] = fma(tj, (double)__int_as_float(p1[u_].w), gw[1]);
-        if constexpr (P > 2) gw[2] = fma(tj, (double)__int_as_float(p2[u_].x), gw[2]);
-      }
-    }
-  }
+// everything of a centre after its moments are gathered: covariance -> smallest eigenpair -> loss (acc2) and the
+// coefficients of its neighbours' terms; an empty neighbourhood (NaN mean, zero coefficients) contributes exactly nothing
+template <typename PT>
+__device__ __forceinline__ void step_point(CovAcc& acc, bool m, const LossParams& lp, const QParams& qp, double* acc2, double* cm,
+                                           double* v0, double* c1, double* c2) {
+  cov_same_weights(acc);
+  const double u = Pt<PT>::unit(qp);
+  double moff[3], C[6], D, omega, lam0, tr;
+  cov_finish(acc, 0.0, moff, cm, C, &D, &omega, u * u);
+  eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
+  const double l = loss_and_coeffs(lp, lam0, tr, D, 0.0, m, c1, c2);
+  if (m) { acc2[0] = l; acc2[1] = 1.0; }
+  if (!(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
 }
 
 // partial rows: columns {sum loss, count} at p_fwd (stride gridDim * 4) and [0, P) dL/dw at p_bwd (same stride)
-template <int NS, int P>
+template <typename PT, int NS, int P>
 __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
@@ -1240,11 +1280,11 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     double wq[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) wq[k] = s_w[k];
-    for (int t = threadIdx.x; t < nd; t += kBlock) stage_step_row<P>(pb, wq, tab.blk_ids[base + t], tile, cap, t);
-    Pt<q32>::Raw ci;
-    if (own < 0) ci = Basis<q32>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    for (int t = threadIdx.x; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    typename Pt<PT>::Raw ci;
+    if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
     __syncthreads();
-    if (own >= 0) ci = staged_point<q32>(tile, cap, own + (live ? (int)threadIdx.x : 0));
+    if (own >= 0) ci = staged_point<PT>(tile, cap, own + (live ? (int)threadIdx.x : 0));
     if (live) {
       CovAcc acc;
       cov_init(acc);
@@ -1253,21 +1293,20 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
       for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
       const bool any_miss = __any((int)(mx == kNoLoc)) != 0;
       int n_have;
-      if (any_miss) n_have = gather_fixed<q32, NS, true>(tile, cap, ci, pre, acc);
-      else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
+      if (any_miss) n_have = gather_fixed<PT, NS, true>(tile, cap, ci, pre, acc);
+      else n_have = gather_fixed<PT, NS, false>(tile, cap, ci, pre, acc);
       acc.W = (double)n_have;
-      cov_same_weights(acc);
-      const double u = qp.scale;
-      double moff[3], cm[3], C[6], D, omega, lam0, v0[3], tr, c1, c2;
-      cov_finish(acc, 0.0, moff, cm, C, &D, &omega, u * u);
-      const bool m = mask ? mask[i] != 0 : true;
-      eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
-      const double l = loss_and_coeffs(lp, lam0, tr, D, 0.0, m, &c1, &c2);
-      if (m) { acc2[0] = l; acc2[1] = 1.0; }
-      // an empty neighbourhood has a NaN mean and zero coefficients: keep its (zero) contribution finite
-      if (!(c1 != 0.0 || c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
-      if (any_miss) weight_chain_fixed<NS, P, true>(tile, cap, ci, pre, cm, v0, c1, c2, gw);
-      else weight_chain_fixed<NS, P, false>(tile, cap, ci, pre, cm, v0, c1, c2, gw);
+      double cm[3], v0[3], c1, c2;
+      step_point<PT>(acc, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+      // second sweep over the same slots (full wavefronts skip the validity selects)
+      if (any_miss) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cm, v0, c1, c2, gw);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], true, ci, cm, v0, c1, c2, gw);
+      }
+      const double u = Pt<PT>::unit(qp);
 #pragma unroll
       for (int k = 0; k < P; ++k) gw[k] *= u;            // differences were in grid steps
     }
@@ -1276,6 +1315,72 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
+  wave_partials<2>(acc2, p_fwd);
+  wave_partials<P>(gw, p_bwd);
+}
+
+// the same for any slot count (radius neighbourhoods): run-time slot loops, as consistency_fwd_basis_slots_kernel
+template <typename PT, int P>
+__global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
+    PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+  extern __shared__ int4 tile[];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  double acc2[2] = {0.0, 0.0}, gw[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) gw[k] = 0.0;
+  const int64_t i = blk * kBlock + threadIdx.x;
+  const bool live = blk >= 0 && i < n;
+  int32_t nslots = 0, own = -1;
+  const uint16_t* lrow = tab.loc;
+  uint32_t pre[kPreSlots];
+  stage_weights(pb, s_w);
+  if (blk >= 0) {
+    const int32_t s0 = tab.slot_ptr[blk];
+    nslots = tab.slot_ptr[blk + 1] - s0;
+    lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q) pre[q] = (live && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
+    own = (own_base && !centre_idx) ? own_base[blk] : -1;
+  }
+  __syncthreads();
+  double wq[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+  typename Pt<PT>::Raw ci;
+  if (blk >= 0) {
+    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    for (int t = threadIdx.x; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+  }
+  __syncthreads();
+  if (live) {
+    if (own >= 0) ci = staged_point<PT>(tile, cap, own + (int)threadIdx.x);
+    CovAcc acc;
+    cov_init(acc);
+    bool miss = false;
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q) miss |= (q < nslots) && pre[q] == kNoLoc;
+    int n_have = 0;
+    if (__any((int)miss)) n_have = gather_slots<PT, true>(tile, cap, ci, pre, nslots, acc);
+    else n_have = gather_slots<PT, false>(tile, cap, ci, pre, nslots, acc);
+    for (int q = kPreSlots; q < nslots; ++q) n_have += slot_add<PT, true>(tile, cap, ci, lrow[q * kBlock], acc);
+    acc.W = (double)n_have;
+    double cm[3], v0[3], c1, c2;
+    step_point<PT>(acc, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+#pragma unroll
+    for (int q = 0; q < kPreSlots; ++q)
+      if (q < nslots) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cm, v0, c1, c2, gw);
+    for (int q = kPreSlots; q < nslots; ++q) {
+      const uint32_t l = lrow[q * kBlock];
+      chain_term<PT, P>(tile, cap, l, l != kNoLoc, ci, cm, v0, c1, c2, gw);
+    }
+    const double u = Pt<PT>::unit(qp);
+#pragma unroll
+    for (int k = 0; k < P; ++k) gw[k] *= u;
+  }
   wave_partials<2>(acc2, p_fwd);
   wave_partials<P>(gw, p_bwd);
 }
@@ -1978,22 +2083,28 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
-    // loss and dL/dw in ONE pass (forward-mode): float32 clouds, up to three weights, compiled slot counts
+    // loss and dL/dw in ONE pass (forward-mode) for up to three weights: no record, no backward launch
     size_t lds_s = 0;
     int rows_s = 0;
-    const bool one_pass = want_grad && q32_pts && n_terms <= 3 && !g_two_pass.load() &&
-                          (fixed_k == 4 || fixed_k == 8 || fixed_k == 10 || fixed_k == 16) &&
-                          use_table(d->fwd_table, DC_TABLE_SLOTS, stride, 16u * (unsigned)((6 + n_terms + 3) / 4), 0, 60 * 1024, &lds_s, &rows_s);
+    const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : (6 + n_terms + 1) / 2);
+    const bool one_pass = want_grad && n_terms <= 3 && !g_two_pass.load() &&
+                          use_table(d->fwd_table, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s);
     if (one_pass) {
       const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
       {
         ProfScope prof(1);
-#define STEP_P(NS, P) DC_TIMED_LAUNCH((consistency_step_basis_kernel<NS, P>), grid, block, lds_s, stream, pb, tab, d->fwd_table->own_base, \
-                                      rows_s, d->centre_idx, n_rows, d->mask, lp, qp, p_fwd, p_bwd)
-#define STEP(NS) do { if (n_terms == 2) STEP_P(NS, 2); else if (n_terms == 1) STEP_P(NS, 1); else STEP_P(NS, 3); } while (0)
-        if (fixed_k == 10) STEP(10); else if (fixed_k == 4) STEP(4); else if (fixed_k == 8) STEP(8); else STEP(16);
+#define STEP_LAUNCH(K) DC_TIMED_LAUNCH(K, grid, block, lds_s, stream, pb, tab, d->fwd_table->own_base, rows_s, d->centre_idx, n_rows, \
+                                       d->mask, lp, qp, p_fwd, p_bwd)
+#define STEP_NS(PT, P) do { if (fixed_k == 10) STEP_LAUNCH((consistency_step_basis_kernel<PT, 10, P>)); \
+                            else if (fixed_k == 4) STEP_LAUNCH((consistency_step_basis_kernel<PT, 4, P>)); \
+                            else if (fixed_k == 8) STEP_LAUNCH((consistency_step_basis_kernel<PT, 8, P>)); \
+                            else if (fixed_k == 16) STEP_LAUNCH((consistency_step_basis_kernel<PT, 16, P>)); \
+                            else STEP_LAUNCH((consistency_step_basis_slots_kernel<PT, P>)); } while (0)
+#define STEP(PT) do { if (n_terms == 2) STEP_NS(PT, 2); else if (n_terms == 1) STEP_NS(PT, 1); else STEP_NS(PT, 3); } while (0)
+        if (q32_pts) STEP(q32); else STEP(double);
 #undef STEP
-#undef STEP_P
+#undef STEP_NS
+#undef STEP_LAUNCH
       }
       DC_CHECK_LAUNCH();
       const int64_t rows_g = (int64_t)grid.x * kWavesPerBlock;

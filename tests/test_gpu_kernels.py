@@ -519,9 +519,9 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
     e = torch.tensor([2.0, 4.0, 1.0, 3.0][:n_terms], dtype=torch.float64, device=dev)
     nt = n_terms
     outs = {}
-    # three ways through the same evaluation: the one-pass loss + dL/dw kernel (float32 clouds, <= 3 weights, compiled slot
-    # counts), the basis form with separate forward / backward kernels, the general path (dc_points_fwd every evaluation)
-    one_pass_expected = not f64 and not ragged and n_terms <= 3
+    # three ways through the same evaluation: the one-pass loss + dL/dw kernel (<= 3 weights), the basis form with separate
+    # forward / backward kernels, the general path (dc_points_fwd every evaluation)
+    one_pass_expected = n_terms <= 3
     for path in ('default', 'two_pass', 'general'):
         nv.check(nv.lib().dc_set_option(3, 1 if path == 'general' else 0), 'dc_set_option')
         nv.check(nv.lib().dc_set_option(4, 1 if path == 'two_pass' else 0), 'dc_set_option')
@@ -539,7 +539,7 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
             if path == 'general':
                 assert 'basis' not in names['consistency_fwd'] and 'basis' not in names['consistency_bwd'] and 'points_fwd' in timed, names
             elif path == 'default' and one_pass_expected:
-                assert names['consistency_fwd'].startswith('consistency_step_basis_kernel'), names
+                assert names['consistency_fwd'].startswith('consistency_step_basis_slots_kernel' if ragged else 'consistency_step_basis_kernel'), names
                 assert 'consistency_bwd' not in timed and 'points_fwd' not in timed
             else:
                 want = 'consistency_fwd_basis_slots_kernel' if ragged else 'consistency_fwd_basis_kernel'
