@@ -1174,13 +1174,17 @@ template <int P> struct StepRow<q32, P> {
     tile[cap + t] = make_int4(q[4], q[5], q[6], P > 1 ? q[P > 1 ? 7 : 6] : 0);
     if constexpr (P > 2) tile[2 * cap + t] = make_int4(q[8], 0, 0, 0);
   }
-  // e = x_j - x_i - cm (grid steps), u_j, c_kj of the staged row at byte offset `off`
-  static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const Pt<q32>::Raw& ci, const double* cm,
-                                              double* e, double* u, double* c) {
+  // the neighbourhood mean in the staged rows' units: x_i + cm (grid steps; exact in fp64)
+  static __device__ __forceinline__ void mean_of(const Pt<q32>::Raw& ci, const double* cm, double* mean) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] = (double)ci.v[a] + cm[a];
+  }
+  // e = x_j - mean (grid steps), u_j, c_kj of the staged row at byte offset `off`
+  static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const double* mean, double* e, double* u, double* c) {
     const char* row = reinterpret_cast<const char*>(tile) + off;
     const int4 p0 = *reinterpret_cast<const int4*>(row);
     const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)cap * 16);
-    e[0] = (double)(p0.x - ci.v[0]) - cm[0]; e[1] = (double)(p0.y - ci.v[1]) - cm[1]; e[2] = (double)(p0.z - ci.v[2]) - cm[2];
+    e[0] = (double)p0.x - mean[0]; e[1] = (double)p0.y - mean[1]; e[2] = (double)p0.z - mean[2];
     u[0] = (double)__int_as_float(p0.w); u[1] = (double)__int_as_float(p1.x); u[2] = (double)__int_as_float(p1.y);
     c[0] = (double)__int_as_float(p1.z);
     if constexpr (P > 1) c[1] = (double)__int_as_float(p1.w);
@@ -1206,8 +1210,11 @@ template <int P> struct StepRow<double, P> {
 #pragma unroll
     for (int a = 0; a < kPieces; ++a) tile[a * cap + t] = pack(q[2 * a], q[2 * a + 1]);
   }
-  static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const Pt<double>::Raw& ci, const double* cm,
-                                              double* e, double* u, double* c) {
+  static __device__ __forceinline__ void mean_of(const Pt<double>::Raw& ci, const double* cm, double* mean) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mean[a] = ci.v[a] + cm[a];
+  }
+  static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const double* mean, double* e, double* u, double* c) {
     const char* row = reinterpret_cast<const char*>(tile) + off;
     double q[2 * kPieces];
 #pragma unroll
@@ -1216,7 +1223,7 @@ template <int P> struct StepRow<double, P> {
       q[2 * a] = __hiloint2double(p.y, p.x); q[2 * a + 1] = __hiloint2double(p.w, p.z);
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { e[a] = (q[a] - ci.v[a]) - cm[a]; u[a] = q[3 + a]; }
+    for (int a = 0; a < 3; ++a) { e[a] = q[a] - mean[a]; u[a] = q[3 + a]; }
 #pragma unroll
     for (int k = 0; k < P; ++k) c[k] = q[6 + k];
   }
@@ -1224,10 +1231,10 @@ template <int P> struct StepRow<double, P> {
 
 // one neighbour's share of dL/dw: gw[k] += t c_kj, t = c1 (v . e)(v . u_j) - c2 (e . u_j); have = false: nothing
 template <typename PT, int P>
-__device__ __forceinline__ void chain_term(const int4* tile, int cap, uint32_t off, bool have, const typename Pt<PT>::Raw& ci,
-                                           const double* cm, const double* v, double c1, double c2, double* gw) {
+__device__ __forceinline__ void chain_term(const int4* tile, int cap, uint32_t off, bool have, const double* mean, const double* v,
+                                           double c1, double c2, double* gw) {
   double e[3], u[3], c[P];
-  StepRow<PT, P>::load(tile, cap, have ? off : 0u, ci, cm, e, u, c);
+  StepRow<PT, P>::load(tile, cap, have ? off : 0u, mean, e, u, c);
   const double al = v[0] * e[0] + v[1] * e[1] + v[2] * e[2];
   const double be = v[0] * u[0] + v[1] * u[1] + v[2] * u[2];
   const double ga = e[0] * u[0] + e[1] * u[1] + e[2] * u[2];
@@ -1250,6 +1257,25 @@ __device__ __forceinline__ void step_point(CovAcc& acc, bool m, const LossParams
   const double l = loss_and_coeffs(lp, lam0, tr, D, 0.0, m, c1, c2);
   if (m) { acc2[0] = l; acc2[1] = 1.0; }
   if (!(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
+}
+
+// {sum loss, count} -> p_fwd columns, dL/dw -> p_bwd columns (same row stride: one row per wavefront), through one packed
+// wavefront reduction of the 2 + P values
+template <int P>
+__device__ __forceinline__ void step_partials(const double* acc2, const double* gw, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+  constexpr int NV = 2 + P, NP2 = NV <= 4 ? 4 : 8;
+  double v[NP2];
+  v[0] = acc2[0]; v[1] = acc2[1];
+#pragma unroll
+  for (int k = 0; k < NP2 - 2; ++k) v[2 + k] = k < P ? gw[k] : 0.0;
+  const double tot = wave_sum_packed<NP2>(v);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock, row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (lane < NP2) {
+    const int q = packed_value_of_lane<NP2>(lane);
+    if (q < 2) p_fwd[q * rs + row] = tot;
+    else if (q < NV) p_bwd[(q - 2) * rs + row] = tot;
+  }
 }
 
 // partial rows: columns {sum loss, count} at p_fwd (stride gridDim * 4) and [0, P) dL/dw at p_bwd (same stride)
@@ -1298,13 +1324,15 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
       acc.W = (double)n_have;
       double cm[3], v0[3], c1, c2;
       step_point<PT>(acc, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+      double mean[3];
+      StepRow<PT, P>::mean_of(ci, cm, mean);
       // second sweep over the same slots (full wavefronts skip the validity selects)
       if (any_miss) {
 #pragma unroll
-        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cm, v0, c1, c2, gw);
+        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
       } else {
 #pragma unroll
-        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], true, ci, cm, v0, c1, c2, gw);
+        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], true, mean, v0, c1, c2, gw);
       }
       const double u = Pt<PT>::unit(qp);
 #pragma unroll
@@ -1315,8 +1343,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
-  wave_partials<2>(acc2, p_fwd);
-  wave_partials<P>(gw, p_bwd);
+  step_partials<P>(acc2, gw, p_fwd, p_bwd);
 }
 
 // the same for any slot count (radius neighbourhoods): run-time slot loops, as consistency_fwd_basis_slots_kernel
@@ -1370,19 +1397,20 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     acc.W = (double)n_have;
     double cm[3], v0[3], c1, c2;
     step_point<PT>(acc, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+    double mean[3];
+    StepRow<PT, P>::mean_of(ci, cm, mean);
 #pragma unroll
     for (int q = 0; q < kPreSlots; ++q)
-      if (q < nslots) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cm, v0, c1, c2, gw);
+      if (q < nslots) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
     for (int q = kPreSlots; q < nslots; ++q) {
       const uint32_t l = lrow[q * kBlock];
-      chain_term<PT, P>(tile, cap, l, l != kNoLoc, ci, cm, v0, c1, c2, gw);
+      chain_term<PT, P>(tile, cap, l, l != kNoLoc, mean, v0, c1, c2, gw);
     }
     const double u = Pt<PT>::unit(qp);
 #pragma unroll
     for (int k = 0; k < P; ++k) gw[k] *= u;
   }
-  wave_partials<2>(acc2, p_fwd);
-  wave_partials<P>(gw, p_bwd);
+  step_partials<P>(acc2, gw, p_fwd, p_bwd);
 }
 
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
