@@ -319,7 +319,10 @@ int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, con
 
 /* ---- whole-sequence evaluation + optimiser step (train.py:220-312 per-iteration body for one sequence) ----------
  * The caller fills a descriptor with the device arrays of one sequence (SequencePlan in Python) once; every
- * iteration is then ONE host call that launches dc_points_fwd, dc_consistency_fwd and dc_consistency_bwd.
+ * iteration is then ONE host call that launches dc_points_fwd, dc_consistency_fwd and dc_consistency_bwd -- or, with
+ * dcSequenceDesc.basis set and no pose / exponent gradient requested, the basis form: no pass over the points, and for up
+ * to three weights a single kernel that returns the loss AND dL/dw (second sweep over each centre's own neighbours; no
+ * backward record, no transposed table).
  * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_partial_rows(n) * (2 + 2 P + 12 S)] are scratch. */
 typedef struct dcSequenceDesc {
   int64_t n;
