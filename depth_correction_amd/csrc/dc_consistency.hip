@@ -1544,11 +1544,11 @@ __global__ __launch_bounds__(kBlock) void points_bwd_kernel(const T* __restrict_
 // Sum the block partials [n_acc][n_rows] in a fixed order into out[n_acc]: one 1024-lane block per accumulator,
 // contiguous (coalesced) reads.
 constexpr int kRedBlock = 1024;
-// Sum of p[threadIdx.x], p[threadIdx.x + 1024], ... in a fixed order with 16 loads in flight per lane: the rows were
+// Sum of p[threadIdx.x], p[threadIdx.x + 1024], ... in a fixed order with 32 loads in flight per lane: the rows were
 // written by blocks on every XCD, so each read is a trip to the fabric, and with four in flight the ~31 rows per lane
 // (N = 2 M) took eight dependent round trips.
 __device__ __forceinline__ double strided_sum(const double* __restrict__ p, int64_t n_rows) {
-  constexpr int U = 16;
+  constexpr int U = 32;                  // 32 k rows (N = 2 M: one row per wavefront) in ONE round trip per lane
   double acc[U];
 #pragma unroll
   for (int u_ = 0; u_ < U; ++u_) acc[u_] = 0.0;
@@ -1557,9 +1557,12 @@ __device__ __forceinline__ double strided_sum(const double* __restrict__ p, int6
 #pragma unroll
     for (int u_ = 0; u_ < U; ++u_) acc[u_] += p[r + u_ * kRedBlock];
   }
+  {
+    double last[U];                      // the tail's loads are issued together, too
 #pragma unroll
-  for (int u_ = 0; u_ < U; ++u_) {
-    if (r + u_ * kRedBlock < n_rows) acc[u_] += p[r + u_ * kRedBlock];
+    for (int u_ = 0; u_ < U; ++u_) last[u_] = (r + u_ * kRedBlock < n_rows) ? p[r + u_ * kRedBlock] : 0.0;
+#pragma unroll
+    for (int u_ = 0; u_ < U; ++u_) acc[u_] += last[u_];
   }
 #pragma unroll
   for (int w = U / 2; w > 0; w >>= 1) {
@@ -1589,32 +1592,36 @@ struct AdamArgs {
   int n;
   double grad_scale, lr, b1, b2, eps, weight_decay, bias1, bias2_sqrt;
 };
-__device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double grad) {
+// (p0, m0, v0: the parameter's state, loaded by the caller -- early, so the trip hides behind its own work)
+__device__ __forceinline__ void adam_apply(const AdamArgs& a, int i, double grad, double p0, double m0, double v0) {
   double g = grad * a.grad_scale;
-  if (a.weight_decay != 0.0) g += a.weight_decay * a.p[i];
-  const double mi = a.m[i] + (g - a.m[i]) * (1.0 - a.b1);          // exp_avg.lerp_(grad, 1 - beta1)
-  const double vi = a.v[i] * a.b2 + (1.0 - a.b2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  if (a.weight_decay != 0.0) g += a.weight_decay * p0;
+  const double mi = m0 + (g - m0) * (1.0 - a.b1);                   // exp_avg.lerp_(grad, 1 - beta1)
+  const double vi = v0 * a.b2 + (1.0 - a.b2) * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
   a.m[i] = mi; a.v[i] = vi;
   const double denom = sqrt(vi) / a.bias2_sqrt + a.eps;
-  a.p[i] = a.p[i] + (-(a.lr / a.bias1)) * (mi / denom);
+  a.p[i] = p0 + (-(a.lr / a.bias1)) * (mi / denom);
 }
+__device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double grad) { adam_apply(a, i, grad, a.p[i], a.m[i], a.v[i]); }
 
 // One launch for a whole evaluation: out[0..2) <- forward partials, out[2..2+n_red) <- backward partials,
 // out[2+n_red..2+n_acc) <- 0 (gradient slots that were not requested).  With `adam.p` the block that finishes
 // dL/dw_i also takes the Adam step of w_i (dc_sequence_step: the kernels of the next evaluation come after it on
 // the stream).
 __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __restrict__ p_fwd, const double* __restrict__ p_bwd,
-                                                                int64_t rows_fwd, int64_t rows_bwd, int n_red,
+                                                                int64_t rows_fwd, int64_t rows_bwd, int n_red, int n_out,
                                                                 double* __restrict__ out, AdamArgs adam,
                                                                 const int32_t* __restrict__ status) {
   __shared__ double lds[kRedBlock / kWave];
-  const int a = blockIdx.x;
-  if (a >= 2 + n_red) {
-    if (threadIdx.x == 0) out[a] = 0.0;
-    return;
-  }
+  const int a = blockIdx.x;                // grid = 2 + n_red blocks: only the sums that were asked for get a block
+  if (a == 0)                              // block 0 also clears the slots of gradients that were not requested
+    for (int z = 2 + n_red + threadIdx.x; z < n_out; z += kRedBlock) out[z] = 0.0;
+  const bool flagged = a == 0 && threadIdx.x == 0 && status && *status != 0;      // requested before the rows, not after
   const int64_t n_rows = a < 2 ? rows_fwd : rows_bwd;
   const double* p = (a < 2 ? p_fwd + (int64_t)a * rows_fwd : p_bwd + (int64_t)(a - 2) * rows_bwd);
+  const bool step = adam.p && a >= 2 && a - 2 < adam.n && threadIdx.x == 0;
+  double p0 = 0.0, m0 = 0.0, v0 = 0.0;
+  if (step) { p0 = adam.p[a - 2]; m0 = adam.m[a - 2]; v0 = adam.v[a - 2]; }      // in flight together with the partial rows
   const double s = wave_sum(strided_sum(p, n_rows));
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) lds[wave] = s;
@@ -1623,9 +1630,9 @@ __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __
     double t = 0.0;
     for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv];
     // points that did not fit the fixed-point extent (or were NaN) make the evaluation meaningless: say so in the loss
-    if (a == 0 && status && *status != 0) t = __longlong_as_double(0x7ff8000000000000ll);
+    if (flagged) t = __longlong_as_double(0x7ff8000000000000ll);
     out[a] = t;
-    if (adam.p && a >= 2 && a - 2 < adam.n) adam_update(adam, a - 2, t);
+    if (step) adam_apply(adam, a - 2, t, p0, m0, v0);
   }
 }
 
@@ -2136,7 +2143,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       }
       DC_CHECK_LAUNCH();
       const int64_t rows_g = (int64_t)grid.x * kWavesPerBlock;
-      hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_g, rows_g, n_terms, out,
+      hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_terms), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_g, rows_g, n_terms, 2 + n_acc, out,
                          adam, (const int32_t*)d->status);
       DC_CHECK_LAUNCH();
       return DC_OK;
@@ -2174,8 +2181,8 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
 #undef BWD_BASIS_P
       DC_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd,
-                       xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows, n_red, out, adam, (const int32_t*)d->status);
+    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_red), dim3(kRedBlock), 0, stream, p_fwd, p_bwd,
+                       xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows, n_red, 2 + n_acc, out, adam, (const int32_t*)d->status);
     DC_CHECK_LAUNCH();
     return DC_OK;
   }
@@ -2193,8 +2200,8 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                               d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false,
                               n_rows);
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
-                     n_red, out, adam, (const int32_t*)d->status);
+  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_red), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
+                     n_red, 2 + n_acc, out, adam, (const int32_t*)d->status);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
