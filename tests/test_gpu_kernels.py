@@ -581,3 +581,36 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
             np.testing.assert_allclose(a[0], b[0], rtol=1e-14)
     outs = {True: outs['default']}
     assert not np.allclose(outs[True][0][0], outs[True][3][0], rtol=1e-9)          # the moved pose changed the loss
+
+
+@pytest.mark.parametrize('tag,loss,norm,sqrt', VARIANTS)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_one_pass_step_all_loss_variants_vs_oracle(golden, dev, tag, loss, norm, sqrt, dtype):
+    """The one-pass loss + dL/dw kernel (q32 and fp64 points) for every loss variant of the reference -- min-eigenvalue
+    raw / normalised, trace, each with and without sqrt -- against the fp64 oracle on the same inputs."""
+    from depth_correction_amd.plan import SequencePlan, KernelTimer
+    g = golden('room_k10')
+    scans = scans_from_golden(g, dtype)
+    clouds = [dict(vps=s['vps'].to(dev), dirs=s['dirs'].to(dev), depth=s['depth'].to(dev), inc_angles=s['inc'].to(dev),
+                   mask=s['mask'].to(dev)) for s in scans]
+    poses = t(g['poses'], dev)
+    plan = SequencePlan(clouds, poses, t(g['g_neighbors'], dev), t(g['g_mask'], dev), loss=loss, normalization=norm, sqrt=sqrt)
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+    with KernelTimer(every=1) as timer:
+        plan.eval_native(w, e, plan.poses12(poses), out)
+        names = timer.kernels()
+    assert names['consistency_fwd'].startswith('consistency_step_basis_kernel<%s' % ('double' if dtype == torch.float64 else 'q32'))
+    sc64 = [dict(vps=s['vps'].double(), dirs=s['dirs'].double(), depth=s['depth'].double().reshape(-1, 1),
+                 inc=s['inc'].double().reshape(-1, 1), mask=s['mask']) for s in scans]
+    wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)
+    lo, _ = O.eval_sequence(sc64, t(g['poses']), wo, e.cpu().reshape(1, -1), t(g['g_neighbors']).long(), t(g['g_mask']), kind=loss,
+                            model='ScaledPolynomial', normalization=norm, sqrt=sqrt, reduction='sum')
+    lo.backward()
+    o = npy(out)
+    f64 = dtype == torch.float64
+    assert o[1] == float(g['g_mask'].sum())
+    np.testing.assert_allclose(o[0], lo.item(), rtol=1e-11 if f64 else 1e-5)
+    ref = wo.grad.numpy().ravel()
+    np.testing.assert_allclose(o[2:4], ref, rtol=1e-8 if f64 else 1e-5, atol=(1e-10 if f64 else 2e-5) * np.abs(ref).max())
