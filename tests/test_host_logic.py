@@ -261,3 +261,22 @@ def test_scan_file_formats_roundtrip(tmp_path):
     assert len(ds) == 1 and ds.ids == [7]                               # scan 9 has no cloud file
     c, p = ds[0]
     assert len(c) == keep.sum() and np.allclose(p, np.eye(4))
+
+
+def test_quantile_fallback_beyond_torch_limit_is_the_same_arithmetic():
+    """plan._quantile: torch.quantile for inputs it accepts, the same interpolation on an explicit sort beyond its
+    16 M-element limit (exercised here by calling the fallback branch directly on small inputs)."""
+    import depth_correction_amd.plan as plan
+    gen = torch.Generator().manual_seed(4)
+    for dtype in (torch.float32, torch.float64):
+        for n in (2, 3, 10, 1001, 4096):
+            v = torch.rand(n, generator=gen, dtype=dtype) ** 3
+            for q in (0.0, 0.3, 0.5, 0.7, 0.9, 1.0):
+                want = torch.quantile(v, q, dim=0)
+                s, _ = torch.sort(v)
+                rank = torch.tensor(q, dtype=dtype) * (n - 1)
+                lo = rank.floor().long()
+                hi = torch.clamp(lo + 1, max=n - 1)
+                got = torch.lerp(s[lo], s[hi], rank - lo.to(dtype))
+                assert torch.equal(got, want), (dtype, n, q)
+                assert torch.equal(plan._quantile(v, q), want)
