@@ -144,8 +144,12 @@ def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
         params.append({'params': [common], 'lr': cfg.lr})
     elif cfg.pose_correction != PoseCorrection.none and train_pose_deltas:
         params.append({'params': train_pose_deltas, 'lr': cfg.lr})
-    make_opt = lambda p: getattr(torch.optim, cfg.optimizer.split('.')[-1])(p, *(cfg.optimizer_args or []),
-                                                                           **(cfg.optimizer_kwargs or {}))
+    def make_opt(p):
+        name, args, kw = cfg.optimizer.split('.')[-1], list(cfg.optimizer_args or []), dict(cfg.optimizer_kwargs or {})
+        if name == 'Adam' and not args and set(kw) <= {'lr', 'betas', 'eps', 'weight_decay'} and torch.device(cfg.device).type == 'cuda':
+            from .optim import Adam                   # torch.optim.Adam's update, one launch per parameter (optim.py)
+            return Adam(p, **kw)
+        return getattr(torch.optim, name)(p, *args, **kw)
     optimizer = make_opt(params) if params else None
     val_optimizer = None
     if cfg.pose_correction in (PoseCorrection.sequence, PoseCorrection.pose) and val_datasets:

@@ -787,3 +787,28 @@ def test_quantile_inlier_gating_golden(golden, tag, loss, kw, fused):
         assert len(views[0]) == n_ref
     np.testing.assert_allclose(out.item(), float(gi['inl_%s_loss' % tag]), rtol=1e-9)
     np.testing.assert_allclose(npy(model.w.grad).ravel(), gi['inl_%s_grad_w' % tag].ravel(), rtol=1e-7)
+
+
+def test_dc_adam_equals_torch_adam():
+    """optim.Adam (one dc_adam_step launch per fp64 GPU parameter) takes torch.optim.Adam's steps: 60 iterations on two
+    parameters of the shapes train() optimises, with and without weight decay, to round-off; fp32 parameters take the tensor
+    expressions of the same update (torch's multi-tensor path orders a few operations differently: float32 round-off); the
+    version counter of a parameter written through its pointer moves."""
+    from depth_correction_amd.optim import Adam
+    torch.manual_seed(0)
+    for dtype, wd, tol in ((torch.float64, 0.0, 1e-13), (torch.float64, 0.05, 1e-13), (torch.float32, 0.0, 2e-6)):
+        ps = [[torch.nn.Parameter(torch.randn(s, dtype=dtype, device='cuda:0') * 0.1) for s in ((1, 2), (10, 6))]]
+        ps.append([torch.nn.Parameter(p.detach().clone()) for p in ps[0]])
+        opts = [Adam([{'params': ps[0][:1], 'lr': 2e-3}, {'params': ps[0][1:], 'lr': 1e-3}], weight_decay=wd),
+                torch.optim.Adam([{'params': ps[1][:1], 'lr': 2e-3}, {'params': ps[1][1:], 'lr': 1e-3}], weight_decay=wd)]
+        target = torch.linspace(-1, 1, 60, dtype=dtype, device='cuda:0').reshape(10, 6)
+        v0 = ps[0][0]._version
+        for it in range(60):
+            for params, opt in zip(ps, opts):
+                opt.zero_grad()
+                loss = (params[0] ** 2).sum() * (1 + 0.1 * it) + ((params[1] - target) ** 2 * (params[0].sum() + 2)).sum()
+                loss.backward()
+                opt.step()
+        assert ps[0][0]._version > v0
+        for a, b in zip(ps[0], ps[1]):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=tol, atol=tol * 1e-2)
