@@ -3,7 +3,7 @@
 ``eval_loss_clouds`` is the body of one training iteration.  When the configuration is the one the fused kernels
 cover (ball neighbourhoods on the GPU, min-eigenvalue or trace loss -- with or without quantile inliers -- without
 offsets / distance weights, any of the reference's models or none) every sequence is evaluated by its cached
-``SequencePlan`` -- two or three kernel launches -- and the returned loss carries the hand-derived backward to
+``SequencePlan`` -- one to three kernel launches -- and the returned loss carries the hand-derived backward to
 ``model.w`` / ``model.exponent`` / the pose corrections.  Any other configuration goes through the un-fused DepthCloud operators with identical results.
 """
 from __future__ import annotations

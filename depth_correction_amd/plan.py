@@ -507,7 +507,7 @@ class SequenceTrainer:
         self.w = torch.as_tensor(w, dtype=torch.float64).reshape(-1).to(dev).contiguous()
         self.exponent = torch.as_tensor(exponent, dtype=torch.float64).reshape(-1).to(dev).contiguous()
         self.nt = self.w.numel()
-        # a single local sequence with the native evaluation and optimiser: one host call, Adam inside the last kernel
+        # a single local sequence with the native evaluation and optimiser: one host call, Adam inside the reduction kernel
         self.fused_step = evaluate is None and adam is None and len(self.plans) == 1 and not distributed and self.nt > 0
         self.evaluate = evaluate or (lambda plan, w_, e_, P, out: plan.eval_native(w_, e_, P, out))
         self.adam = adam or self._adam_native

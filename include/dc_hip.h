@@ -352,7 +352,7 @@ typedef struct dcSequenceDesc {
 int dc_sequence_eval(const dcSequenceDesc* desc, const double* w, const double* e, const double* poses, int want_grad,
                      int want_exponent_grad, int want_pose_grad, double* out, dcStream_t stream);
 /* The same followed by torch.optim.Adam's step on w (dc_adam_step semantics, grad = grad_scale * d(sum)/dw) inside the
- * final reduction kernel: one host call and four launches per optimisation step of a single sequence (train.py:220-312).
+ * final reduction kernel: one host call and two to four launches per optimisation step of a single sequence (train.py:220-312).
  * out as in dc_sequence_eval (exponent / pose gradients are not requested). */
 int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
                      double* exp_avg_sq, int64_t step, double grad_scale, double lr, double beta1, double beta2, double eps,
