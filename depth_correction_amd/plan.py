@@ -9,6 +9,11 @@ for the GPU, and evaluates one training iteration (eval.py:85-112: model -> pose
     dc_consistency_fwd  covariance, smallest eigenpair, loss, bwd record (K5-K15)
     dc_consistency_bwd  dL/dx gather + dL/dw, dL/dexponent, dL/dpose     (K18)
 
+or -- whenever only the model weights are differentiated, i.e. poses and exponents are constants of the loop -- in ONE:
+the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis, rebuilt when poses / exponents change) needs no pass over the
+points, and for up to three weights the kernel that computes the loss also finishes dL/dw by a second sweep over each
+centre's own neighbours (consistency_step_basis_kernel).
+
 Layout decisions:
   * points are permuted once into Morton order of the initial global cloud, so the K neighbours of
     consecutive lanes share cache lines (the reference's scan-major order has no locality at all);
