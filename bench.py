@@ -83,10 +83,12 @@ def nbytes(*tensors):
 def compulsory_bytes(plan):
     """Bytes every hot kernel has to move at least once per launch: the arrays it reads and writes, each counted once
     (what the Morton layout + LDS staging reduce the traffic to; rocprofv3's FETCH_SIZE / WRITE_SIZE agree within ~10 %)."""
-    ps, ft, bt = plan.ps, plan.fwd_table, plan.bwd_table
+    ps, ft = plan.ps, plan.fwd_table
+    built = plan._csr is not None            # the backward structures exist only if an evaluation needed them (lazy)
+    bt = plan._bwd_table if built else None
     pt_in = nbytes(ps.vps, ps.dirs, ps.depth, ps.inc, ps.lmask, ps.scan_id)
     fwd_tab = nbytes(ft.blk_ptr, ft.blk_ids, ft.slot_ptr, ft.loc) if ft is not None else nbytes(plan.nbr)
-    bwd_tab = nbytes(bt.blk_ptr, bt.blk_ids, bt.slot_ptr, bt.run_ptr, bt.loc) if bt is not None else nbytes(plan.csr_ptr, plan.csr_src)
+    bwd_tab = nbytes(bt.blk_ptr, bt.blk_ids, bt.slot_ptr, bt.run_ptr, bt.loc) if bt is not None else (nbytes(*plan._csr) if built else 0)
     basis = plan._basis[1] if getattr(plan, '_basis', None) else None
     if basis is not None:
         # basis form: the kernels form the points from the [N, 6 + P] basis rows, no pass over the raw inputs;

@@ -19,6 +19,7 @@ DC_F32, DC_F64, DC_Q32 = 0, 1, 2
 DC_TABLE_SLOTS, DC_TABLE_RUNS = 0, 1
 LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
 LOSS_RAW_POINTWISE = 0x100
+DC_ERR_BACKWARD_TABLES = -5
 MODEL_KINDS = {None: 0, 'BaseModel': 0, 'Polynomial': 1, 'ScaledPolynomial': 2, 'Linear': 3, 'InvCos': 4, 'ScaledInvCos': 5}
 MAX_MODEL_TERMS = 8
 
@@ -136,7 +137,7 @@ def lib():
 def check(status, what):
     if status != 0:
         kind = {-1: 'invalid argument', -2: 'unsupported dtype', -3: 'workspace too small',
-                -4: 'unsupported size'}.get(status, 'HIP error %d' % status)
+                -4: 'unsupported size', -5: 'backward tables missing'}.get(status, 'HIP error %d' % status)
         raise RuntimeError('%s failed: %s' % (what, kind))
 
 

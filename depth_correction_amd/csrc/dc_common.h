@@ -18,6 +18,7 @@
 #define DC_ERR_DTYPE (-2)
 #define DC_ERR_WORKSPACE (-3)
 #define DC_ERR_UNSUPPORTED (-4)
+#define DC_ERR_BACKWARD_TABLES (-5) /* dc_sequence_eval / _step: this evaluation needs dcSequenceDesc.csr_ptr / csr_src (and bwd_table) */
 
 #define DC_F32 0
 #define DC_F64 1

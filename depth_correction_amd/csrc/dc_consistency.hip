@@ -2105,10 +2105,19 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   size_t lds_f = 0, lds_b = 0;
   int rows_f = 0, rows_b = 0;
   const bool q32_pts = d->point_fmt == DC_Q32 && d->dtype == DC_F32, f64_pts = d->point_fmt == DC_F64 && d->dtype == DC_F64;
-  const bool basis = d->basis && (q32_pts || f64_pts) && n_terms > 0 && w &&
-                     !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
-                     use_table(d->fwd_table, DC_TABLE_SLOTS, stride, q32_pts ? 16u : 32u, 0, 60 * 1024, &lds_f, &rows_f) &&
-                     (!want_grad || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
+  const bool basis_fwd = d->basis && (q32_pts || f64_pts) && n_terms > 0 && w &&
+                         !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
+                         use_table(d->fwd_table, DC_TABLE_SLOTS, stride, q32_pts ? 16u : 32u, 0, 60 * 1024, &lds_f, &rows_f);
+  // loss and dL/dw in ONE pass (forward-mode) for up to three weights: no record, no backward launch, no transposed table
+  size_t lds_s = 0;
+  int rows_s = 0;
+  const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : (6 + n_terms + 1) / 2);
+  const bool one_pass = basis_fwd && want_grad && n_terms <= 3 && !g_two_pass.load() &&
+                        use_table(d->fwd_table, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s);
+  // every other way to a gradient walks the transposed neighbour lists: the caller provides them on demand
+  if (want_grad && !one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
+  const bool basis = basis_fwd &&
+                     (!want_grad || one_pass || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
   if (basis) {
     QParams qp;
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
@@ -2118,12 +2127,6 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
-    // loss and dL/dw in ONE pass (forward-mode) for up to three weights: no record, no backward launch
-    size_t lds_s = 0;
-    int rows_s = 0;
-    const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : (6 + n_terms + 1) / 2);
-    const bool one_pass = want_grad && n_terms <= 3 && !g_two_pass.load() &&
-                          use_table(d->fwd_table, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s);
     if (one_pass) {
       const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
       {

@@ -39,7 +39,7 @@ class SequencePlan:
     @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
-                 active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True):
+                 active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -48,6 +48,7 @@ class SequencePlan:
         :param mask: [N] bool global mask (None = all points).
         :param block_tables: build the block tables that let both hot kernels gather from LDS (ops.block_table).
         :param bwd_layout: 'runs' (per-point runs padded to four positions) or 'slots' (slot-major, padded per block).
+        :param lazy_backward: build the transposed neighbour lists / backward block table on first need instead of up front.
         :param basis: use the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis) whenever an evaluation asks for neither pose
                       nor exponent gradients: the basis rows are rebuilt only when the poses or the exponents change.
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
@@ -119,12 +120,17 @@ class SequencePlan:
             nbr = nbr[self.centre_idx.long()].contiguous()
             mask = None
         self.nbr, self.mask = nbr, mask
-        self.csr_ptr, self.csr_src = ops.knn_transpose(nbr, n_dst=self.n)
+        # the transposed neighbour lists and their block table serve the backward kernels (pose / exponent gradients, models
+        # with more than three weights, the two-kernel ablations); the one-pass evaluation never reads them, so they are
+        # built on first need (ensure_backward_tables: 0.7 + 1.9 ms at C2)
+        self._csr = self._bwd_table = None
+        self._bwd_layout, self._block_tables = bwd_layout, bool(block_tables)
+        if not lazy_backward:
+            self.ensure_backward_tables()
         mark('plan_transpose')
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
         # block tables: distinct rows per 256-point block + 16-bit block-local positions (gathers served from LDS)
         self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None) if block_tables else None
-        self.bwd_table = ops.block_table(csr=(self.csr_ptr, self.csr_src), layout=bwd_layout) if block_tables else None
         mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
@@ -135,7 +141,7 @@ class SequencePlan:
         self.qfmt = None
         self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
         if point_format in ('auto', 'q32') and self.dtype == torch.float32:
-            lo, hi = x0.min(0).values.tolist(), x0.max(0).values.tolist()
+            lo, hi = (v.tolist() for v in torch.aminmax(x0, dim=0))          # one reduction, one synchronisation
             qfmt = ops.QFormat.for_extent(lo, hi)
             if point_format == 'q32' or qfmt.scale <= ops.QFormat.MAX_AUTO_SCALE:
                 self.qfmt = qfmt
@@ -162,6 +168,23 @@ class SequencePlan:
         self._poses_key = self._poses12 = self._poses_ref = None
 
     # ------------------------------------------------------------------------------------------------
+    @on_device
+    def ensure_backward_tables(self):
+        """Transposed neighbour lists (incoming edges per point) + their block table, built once."""
+        if self._csr is None:
+            self._csr = ops.knn_transpose(self.nbr, n_dst=self.n)
+            self._bwd_table = ops.block_table(csr=self._csr, layout=self._bwd_layout) if self._block_tables else None
+            self._desc = None                  # the descriptor carries their addresses
+        return self._csr
+
+    csr_ptr = property(lambda self: self.ensure_backward_tables()[0])
+    csr_src = property(lambda self: self.ensure_backward_tables()[1])
+
+    @property
+    def bwd_table(self):
+        self.ensure_backward_tables()
+        return self._bwd_table
+
     def desc(self, n_terms):
         """dcSequenceDesc for the one-call native evaluation (dc_sequence_eval)."""
         if self._desc is None or self._desc.n_terms != n_terms:
@@ -175,10 +198,11 @@ class SequencePlan:
             p = lambda t: None if t is None else t.data_ptr()
             ps = self.ps
             d.vps, d.dirs, d.depth, d.inc, d.lmask, d.scan_id = p(ps.vps), p(ps.dirs), p(ps.depth), p(ps.inc), p(ps.lmask), p(ps.scan_id)
-            d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(self.csr_ptr), p(self.csr_src), p(self.mask)
+            csr = self._csr or (None, None)           # absent until an evaluation needs them (DC_ERR_BACKWARD_TABLES)
+            d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(csr[0]), p(csr[1]), p(self.mask)
             d.lane_perm = p(self.lane_perm)
             d.fwd_table = None if self.fwd_table is None else self.fwd_table.ref()
-            d.bwd_table = None if self.bwd_table is None else self.bwd_table.ref()
+            d.bwd_table = None if self._bwd_table is None else self._bwd_table.ref()
             d.centre_idx, d.n_centres = p(self.centre_idx), (0 if self.centre_idx is None else self.centre_idx.shape[0])
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
             d.status = p(self.status)
@@ -196,7 +220,7 @@ class SequencePlan:
         f64 = self.qfmt is None and self.x.dtype == torch.float64 and self.ps.dirs.dtype == torch.float64
         ok = (self.use_basis and (self.qfmt is not None or f64) and w is not None
               and not want_exponent and not want_pose
-              and self.fwd_table is not None and self.bwd_table is not None and self.bwd_table.run_ptr is not None
+              and self.fwd_table is not None and self._block_tables and self._bwd_layout == 'runs'
               and d.model_kind != 0)
         if not ok:
             d.basis = None
@@ -227,9 +251,15 @@ class SequencePlan:
         if nt:
             need(w, (nt,), dtype=torch.float64, name='w', device=self.device)
             need(exponent, (nt,), dtype=torch.float64, name='exponent', device=self.device)
-        self._set_basis(d, w, exponent, poses12, want_exponent, want_pose)
-        check(lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
-                                     int(want_exponent), int(want_pose), ptr(out), stream_ptr()), 'dc_sequence_eval')
+        for attempt in (0, 1):
+            self._set_basis(d, w, exponent, poses12, want_exponent, want_pose)
+            rc = lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
+                                        int(want_exponent), int(want_pose), ptr(out), stream_ptr())
+            if rc != nv.DC_ERR_BACKWARD_TABLES or attempt:
+                break
+            self.ensure_backward_tables()          # this evaluation walks the transposed lists: build them now, once
+            d = self.desc(nt)
+        check(rc, 'dc_sequence_eval')
         self.version += 1
         return out
 
@@ -242,10 +272,16 @@ class SequencePlan:
         need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
         for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
             need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
-        self._set_basis(d, w, exponent, poses12, False, False)
-        check(lib().dc_sequence_step(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
-                                     int(t), float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                     float(weight_decay), ptr(out), stream_ptr()), 'dc_sequence_step')
+        for attempt in (0, 1):
+            self._set_basis(d, w, exponent, poses12, False, False)
+            rc = lib().dc_sequence_step(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
+                                        int(t), float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                        float(weight_decay), ptr(out), stream_ptr())
+            if rc != nv.DC_ERR_BACKWARD_TABLES or attempt:
+                break
+            self.ensure_backward_tables()
+            d = self.desc(nt)
+        check(rc, 'dc_sequence_step')
         self.version += 1
         return out
 
