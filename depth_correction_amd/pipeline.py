@@ -11,7 +11,7 @@ import torch
 from . import ops
 from .plan import SequencePlan
 
-__all__ = ['local_features', 'global_neighborhoods', 'global_mask', 'build_sequence', 'DEFAULT_RATIO_BOUNDS']
+__all__ = ['local_features', 'global_neighborhoods', 'global_mask', 'build_sequence', 'on_streams', 'DEFAULT_RATIO_BOUNDS']
 
 # config.py:218 default eigenvalue_ratio_bounds
 DEFAULT_RATIO_BOUNDS = [[0, 1, 0.0, 0.25], [1, 2, 0.25, 1.0]]
@@ -85,6 +85,27 @@ def global_mask(local_mask, points, vps, dirs, nbr, min_valid_neighbors=5, eigen
     return mask
 
 
+def on_streams(jobs, device, n_streams=4):
+    """Run independent jobs (callables issuing GPU work on torch's current stream) round robin on ``n_streams`` side streams
+    and join them with the caller's stream; results in job order.  Tensors the jobs allocate belong to the side streams'
+    pools; the join makes every later use on the caller's stream ordered after their producers."""
+    jobs = list(jobs)
+    if n_streams <= 1 or len(jobs) <= 1 or not torch.cuda.is_available():
+        return [job() for job in jobs]
+    dev = torch.device(device)
+    main = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(min(n_streams, len(jobs)))]
+    for s_ in streams:
+        s_.wait_stream(main)
+    out = []
+    for i, job in enumerate(jobs):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            out.append(job())
+    for s_ in streams:
+        main.wait_stream(s_)
+    return out
+
+
 class _Stages(object):
     """Wall-clock stage timer of the set-up phase (synchronises the device at every mark; only when asked for)."""
 
@@ -106,14 +127,17 @@ class _Stages(object):
 def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='cuda:0', min_valid_neighbors=5,
                    eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, vp_dispersion_bounds=None, model_kind='ScaledPolynomial',
                    loss='min_eigval_loss', normalization=True, sqrt=False, spatial_sort=True, point_format='auto',
-                   active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs', stage_times=False, basis=True):
+                   active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs', stage_times=False, basis=True,
+                   local_streams=4):
     """Everything train.py does before its loop for one sequence; returns (plan, info).  ``stage_times``: info['setup_ms']
     = wall-clock milliseconds per stage (device synchronised between stages)."""
     st = _Stages(stage_times, device)
     uploaded = [torch.as_tensor(np.ascontiguousarray(xyz) if isinstance(xyz, np.ndarray) else xyz, device=device) for xyz in scans_xyz]
     st.mark('upload')
-    clouds = [local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype, device=device)
-              for xyz in uploaded]
+    # the scans are independent and one 200 k-point scan does not fill the chip (782 blocks for > 1024 resident): their
+    # pipelines go to a few streams side by side
+    clouds = on_streams([lambda xyz=xyz: local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype,
+                                                          device=device) for xyz in uploaded], device, n_streams=local_streams)
     st.mark('local_feature_clouds')
     poses_t = torch.as_tensor(np.asarray(poses), dtype=torch.float64, device=device)
     x0, vps0, dirs0, _ = global_cloud_arrays(clouds, poses_t)

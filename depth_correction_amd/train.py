@@ -53,10 +53,16 @@ class TrainCallbacks(object):
 def _load_sequences(datasets, cfg):
     all_clouds, all_poses = [], []
     for ds in datasets:
-        clouds, poses = [], []
+        raw, poses = [], []
         for cloud, pose in ds:
-            clouds.append(local_feature_cloud(cloud, cfg))
+            raw.append(cloud)
             poses.append(pose)
+        # independent scans that do not fill the chip one at a time: a few streams side by side (pipeline.on_streams)
+        if torch.device(cfg.device).type == 'cuda':
+            from .pipeline import on_streams
+            clouds = on_streams([lambda c=c: local_feature_cloud(c, cfg) for c in raw], cfg.device)
+        else:
+            clouds = [local_feature_cloud(c, cfg) for c in raw]
         all_clouds.append(clouds)
         all_poses.append(torch.as_tensor(np.stack(poses).astype(cfg.numpy_float_type()), device=cfg.device))
     return all_clouds, all_poses
