@@ -272,12 +272,12 @@ def _local_scans(sizes, dtype, seed):
 
 
 @pytest.mark.parametrize('sizes,k', [((1, 1), 2), ((100, 155), 4), ((128, 128), 10), ((200, 57), 10), ((300, 213), 6),
-                                     ((700, 325), 16), ((40, 900, 84), 12)])
+                                     ((700, 325), 16), ((40, 900, 84), 12), ((600, 500), 33)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_sequence_plan_small_and_odd_sizes(sizes, k, dtype):
     """Whole-sequence evaluations (basis form and general path) on sequences of 2-1025 points: partial blocks, exactly one
     block, scans of very different sizes, every supported way of choosing the forward kernel (k = 4 / 10 / 16 compiled,
-    2 / 6 / 12 run-time slots); a plan whose global mask is empty yields count 0, loss 0 and zero gradients."""
+    2 / 6 / 12 / 33 run-time slots -- 33 beyond the 16 positions kept in registers); a plan whose global mask is empty yields count 0, loss 0 and zero gradients."""
     from depth_correction_amd import ops, _native as nv
     from depth_correction_amd.plan import SequencePlan
     clouds, poses = _local_scans(sizes, dtype, seed=sum(sizes) + k)
