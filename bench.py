@@ -376,6 +376,26 @@ def main():
                                        'what': 'from_points + dir neighbours + shadow filter + k-NN + features + mask + model, '
                                                'scan resident on the device; median of 5'}
 
+        # the same step without the loop-invariant hoisting (general path: dc_points_fwd + forward + backward every iteration,
+        # what the reference's own loop recomputes) and with separate forward / backward kernels, for comparison
+        if not args.autograd and not args.no_basis and not args.two_pass:
+            abl = {}
+            for name, opt in (('two_pass_basis_form', 4), ('general_path', 3)):
+                nv.check(nv.lib().dc_set_option(opt, 1), 'dc_set_option')
+                try:
+                    tr = SequenceTrainer([plan], w0, e0, [poses_t], lr=1e-3)
+                    for _ in range(5):
+                        tr.step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        tr.step()
+                    torch.cuda.synchronize()
+                    abl[name + '_ms_per_step'] = (time.perf_counter() - t0) / 50 * 1e3
+                finally:
+                    nv.check(nv.lib().dc_set_option(opt, 0), 'dc_set_option')
+            extras['same_step_other_forms'] = abl
+
     if rank == 0:
         ms = {name: v[0] for name, v in kernel_ms.items()}
         ab = algorithmic_bytes(args.k, (plan.count / n_local) if args.active_only else 1.0)
