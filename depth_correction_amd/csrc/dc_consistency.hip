@@ -2156,10 +2156,10 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
 #define FWD_BASIS_P(PT, T, NS, P) DC_TIMED_LAUNCH((consistency_fwd_basis_kernel<PT, false, NS, P>), grid, block, lds_f, stream, pb, tab, \
                                                  d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const T*)nullptr, lp, qp, \
-                                                 (PT*)d->rec, (T*)nullptr, (T*)nullptr, p_fwd)
+                                                 (PT*)(want_grad ? d->rec : nullptr), (T*)nullptr, (T*)nullptr, p_fwd)
 #define FWD_BASIS_SLOTS(PT, T, P) DC_TIMED_LAUNCH((consistency_fwd_basis_slots_kernel<PT, false, P>), grid, block, lds_f, stream, pb, tab, \
                                                  d->fwd_table->own_base, rows_f, d->centre_idx, n_rows, d->mask, (const T*)nullptr, lp, qp, \
-                                                 (PT*)d->rec, (T*)nullptr, (T*)nullptr, p_fwd)
+                                                 (PT*)(want_grad ? d->rec : nullptr), (T*)nullptr, (T*)nullptr, p_fwd)
 #define FWD_BASIS_NS(PT, T, P) do { if (fixed_k == 10) FWD_BASIS_P(PT, T, 10, P); else if (fixed_k == 4) FWD_BASIS_P(PT, T, 4, P); \
                                     else if (fixed_k == 8) FWD_BASIS_P(PT, T, 8, P); else if (fixed_k == 16) FWD_BASIS_P(PT, T, 16, P); \
                                     else FWD_BASIS_SLOTS(PT, T, P); } while (0)
@@ -2195,7 +2195,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                          nullptr, d->status, stream);
   if (rc) return rc;
   rc = consistency_fwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->nbr, d->centre_idx, d->fwd_table, n_rows, d->k, d->mask,
-                            nullptr, d->loss_kind, d->normalization, d->sqrt_, d->rec, nullptr, nullptr, p_fwd, out, stream,
+                            nullptr, d->loss_kind, d->normalization, d->sqrt_, want_grad ? d->rec : nullptr, nullptr, nullptr, p_fwd, out, stream,
                             false);
   if (!rc && want_grad)
     rc = consistency_bwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
