@@ -63,6 +63,7 @@ def parse():
     ap.add_argument('--no-block-tables', action='store_true', help='gather from global memory instead of LDS (ablation)')
     ap.add_argument('--no-basis', action='store_true',
                     help='general path: dc_points_fwd every evaluation instead of the basis form x = X0 + (sum w_k c_k) u (ablation)')
+    ap.add_argument('--dc-adam', action='store_true', help='with --autograd: depth_correction_amd.optim.Adam (what train() uses) instead of torch.optim.Adam')
     ap.add_argument('--two-pass', action='store_true', help='basis form with separate forward and backward kernels (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
     return ap.parse_args()
@@ -266,7 +267,11 @@ def main():
         total_count = float(count.item())
         w = torch.nn.Parameter(torch.tensor([w0], dtype=torch.float64, device=dev))
         exponent = torch.tensor([e0], dtype=torch.float64, device=dev)
-        opt = torch.optim.Adam([w], lr=1e-3, capturable=bool(args.graph))
+        if args.dc_adam:
+            from depth_correction_amd.optim import Adam as DcAdam
+            opt = DcAdam([w], lr=1e-3)                      # torch.optim.Adam's update as one launch (capturable as it is)
+        else:
+            opt = torch.optim.Adam([w], lr=1e-3, capturable=bool(args.graph))
         packed = torch.zeros((1 + w.numel(),), dtype=torch.float64, device=dev)
 
         def step():
@@ -457,7 +462,7 @@ def main():
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
                        'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the kernel; loss and dL/dw in one pass over each centre\'s neighbours; the basis rows are rebuilt only when poses or exponents change)'
                                if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
-                       'loop': ('autograd+torch.optim.Adam' + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
+                       'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
                        'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s,
