@@ -1641,6 +1641,17 @@ __global__ void adam_kernel(const double* __restrict__ grad, AdamArgs adam) {
   if (i < adam.n) adam_update(adam, i, grad[i]);
 }
 
+// The same with the step counter on the device (one block): t = *step + 1 enters the bias corrections and is written back,
+// so the launch can be captured into a hipGraph and replayed -- a host-side counter would be frozen into the graph.
+__global__ __launch_bounds__(256) void adam_device_step_kernel(const double* __restrict__ grad, AdamArgs adam, int64_t* __restrict__ step) {
+  const double t = (double)(*step + 1);
+  adam.bias1 = 1.0 - pow(adam.b1, t);
+  adam.bias2_sqrt = sqrt(1.0 - pow(adam.b2, t));
+  for (int i = threadIdx.x; i < adam.n; i += blockDim.x) adam_update(adam, i, grad[i]);
+  __syncthreads();                                   // every lane has read the counter
+  if (threadIdx.x == 0) *step = (int64_t)t;
+}
+
 }  // namespace dc
 
 // ================================================================================================
@@ -2079,6 +2090,17 @@ int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp
   if (rc || !grad) return rc ? rc : DC_ERR_ARG;
   if (n == 0) return DC_OK;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, grad, a);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_adam_step_device(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t* step,
+                        double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        hipStream_t stream) {
+  AdamArgs a;
+  int rc = make_adam(param, exp_avg, exp_avg_sq, n, 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &a);
+  if (rc || !grad || !step) return rc ? rc : DC_ERR_ARG;
+  hipLaunchKernelGGL(adam_device_step_kernel, dim3(1), dim3(256), 0, stream, grad, a, step);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

@@ -1,6 +1,6 @@
 """torch.optim.Adam for the handful of small parameter tensors this path optimises (model weights [1,P], pose corrections
 [S,6]; train.py:138-160): the single-tensor update of torch.optim.Adam (no amsgrad / maximize) as ONE launch per fp64 GPU
-parameter (dc_adam_step) instead of ~10 tensor operations and their Python dispatch -- 80 us of host time per step for two
+parameter (dc_adam_step_device: step counter on the device, so a captured iteration replays correctly) instead of ~10 tensor operations and their Python dispatch -- 80 us of host time per step for two
 parameters otherwise, more than the GPU needs for a whole C2 iteration.  Same arithmetic in the same order
 (tests/test_gpu_api.py::test_dc_adam_equals_torch_adam); parameters that are not contiguous fp64 GPU tensors take the
 tensor expressions of the same formulas."""
@@ -32,20 +32,26 @@ class Adam(torch.optim.Optimizer):
                 if g is None:
                     continue
                 st = self.state[p]
+                native = (p.is_cuda and p.dtype == torch.float64 and g.dtype == torch.float64 and p.is_contiguous()
+                          and g.is_contiguous())
                 if not st:
-                    st['step'] = 0
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['step'] += 1
-                t, m, v = st['step'], st['exp_avg'], st['exp_avg_sq']
-                if (p.is_cuda and p.dtype == torch.float64 and g.dtype == torch.float64 and p.is_contiguous()
-                        and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
+                    # the native path counts its steps on the device, so that a captured iteration replays correctly
+                    st['step'] = torch.zeros((), dtype=torch.int64, device=p.device) if native else 0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format if native else torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(st['exp_avg'])
+                m, v = st['exp_avg'], st['exp_avg_sq']
+                if native and isinstance(st['step'], torch.Tensor):
                     from ._native import lib, check, ptr, stream_ptr
                     with torch.cuda.device(p.device):
-                        check(lib().dc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), t, 1.0, float(lr), float(b1), float(b2),
-                                                 float(eps), float(wd), stream_ptr()), 'dc_adam_step')
+                        check(lib().dc_adam_step_device(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(st['step']), 1.0, float(lr),
+                                                        float(b1), float(b2), float(eps), float(wd), stream_ptr()),
+                              'dc_adam_step_device')
                     torch.autograd.graph.increment_version(p)         # written through its pointer
                     continue
+                if isinstance(st['step'], torch.Tensor):               # the parameter stopped qualifying: count on the host from here
+                    st['step'] = int(st['step'].item())
+                st['step'] += 1
+                t = st['step']
                 if wd != 0.0:
                     g = g.add(p, alpha=wd)
                 m.lerp_(g, 1.0 - b1)

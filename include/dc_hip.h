@@ -364,6 +364,13 @@ int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const 
 int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t step,
                  double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
                  dcStream_t stream);
+/* The same with the step counter on the device: step (device int64, 0 before the first update) is read, t = step + 1 enters
+ * the bias corrections, and t is written back -- capturable into a hipGraph (dc_adam_step / dc_sequence_step take the step
+ * from the host: a captured launch would replay one and the same step number).  One block; meant for the small tensors of
+ * this path (model weights, pose corrections). */
+int dc_adam_step_device(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t* step,
+                        double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        dcStream_t stream);
 
 /* ---- voxel-grid pre-filter (next row): filters.filter_grid filters.py:24-82 -------------------------------
  * One survivor per voxel of edge grid_res with the reference's dict semantics: points are offered in the sequence

@@ -691,9 +691,12 @@ def test_fused_pose_correction_equals_tensor_chain():
     torch.testing.assert_close(T32.double(), torch.matmul(poses, xyz_axis_angle_to_matrix(cases['generic'].to(dev))), rtol=1e-5, atol=1e-5)
 
 
-def test_training_iteration_replays_as_one_graph(golden):
-    """The drop-in iteration (fused loss -> backward -> torch.optim.Adam) captured by torch.cuda.graph: the library's
-    launches go to torch's current stream, so the capture holds them; replaying it takes the same steps as the eager loop."""
+@pytest.mark.parametrize('optimizer', ['torch', 'dc'])
+def test_training_iteration_replays_as_one_graph(golden, optimizer):
+    """The drop-in iteration (fused loss -> backward -> Adam) captured by torch.cuda.graph: the library's launches go to
+    torch's current stream, so the capture holds them; replaying it takes the same steps as the eager loop -- with
+    torch.optim.Adam(capturable=True) and with optim.Adam, whose step counter lives on the device for exactly this reason
+    (a host-side counter would be frozen into the graph and every replay would apply the same bias correction)."""
     from depth_correction_amd.plan import consistency_loss
     g = golden('room_k10')
     cfg = _cfg(g)
@@ -704,8 +707,9 @@ def test_training_iteration_replays_as_one_graph(golden):
     e = torch.tensor(g['exponent'].reshape(1, -1), device=dev)
 
     def make():
+        from depth_correction_amd.optim import Adam as DcAdam
         w = torch.nn.Parameter(torch.tensor(g['w'].reshape(1, -1), device=dev))
-        return w, torch.optim.Adam([w], lr=1e-3, capturable=True)
+        return w, (torch.optim.Adam([w], lr=1e-3, capturable=True) if optimizer == 'torch' else DcAdam([w], lr=1e-3))
 
     def iteration(w, opt):
         opt.zero_grad(set_to_none=False)
