@@ -64,6 +64,9 @@ def parse():
     ap.add_argument('--no-basis', action='store_true',
                     help='general path: dc_points_fwd every evaluation instead of the basis form x = X0 + (sum w_k c_k) u (ablation)')
     ap.add_argument('--dc-adam', action='store_true', help='with --autograd: depth_correction_amd.optim.Adam (what train() uses) instead of torch.optim.Adam')
+    ap.add_argument('--device-warmup-ms', type=float, default=40.0,
+                    help='untimed evaluations of the same sequence before the W warm-up steps, for about this long: after an idle or '
+                         'host-bound phase (the set-up) the GPU needs ~30 ms of sustained load to reach its clocks (0 = off)')
     ap.add_argument('--two-pass', action='store_true', help='basis form with separate forward and backward kernels (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
     return ap.parse_args()
@@ -316,6 +319,25 @@ def main():
             acc = trainer.step()
             return acc
 
+    # ---- device warm-up (not optimisation steps: evaluations that leave the weights alone).  From an idle GPU the same step
+    # takes 85 us, 77 us after 10 ms and 69 us from 30 ms on (clock ramp); the set-up phase is host-bound, so the
+    # timed region would otherwise start on a half-idle device.  The per-window times are reported (config.clock_ramp).
+    ramp = None
+    if args.device_warmup_ms > 0:
+        wv, ev_ = torch.tensor(w0, dtype=torch.float64, device=dev), torch.tensor(e0, dtype=torch.float64, device=dev)
+        P12 = plan.poses12(poses_t)
+        scratch_out = torch.zeros((2 + 2 * len(w0) + 12 * plan.n_scans,), dtype=torch.float64, device=dev)
+        marks = [torch.cuda.Event(enable_timing=True)]
+        marks[0].record()
+        t_start = time.perf_counter()
+        while (time.perf_counter() - t_start) * 1e3 < args.device_warmup_ms and len(marks) < 200:
+            for _ in range(25):
+                plan.eval_native(wv, ev_, P12, scratch_out)
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
+            marks[-1].synchronize() if len(marks) % 8 == 0 else None      # the host must not run far ahead of the clock it watches
+        torch.cuda.synchronize()
+        ramp = [marks[i].elapsed_time(marks[i + 1]) / 25 * 1e3 for i in range(len(marks) - 1)]
     for _ in range(args.warmup):
         loss = step()
     if dist is not None:
@@ -471,6 +493,12 @@ def main():
                                      'holds the one-time code-object load and allocator warm-up'},
             'roofline': roofline,
         }
+        if ramp:
+            out['config']['device_warmup'] = {
+                'evaluations': 25 * len(ramp), 'ms': sum(ramp) * 25 / 1e3,
+                'us_per_evaluation_per_window_of_25': [round(v, 1) for v in ramp],
+                'what': 'untimed dc_sequence_eval calls (loss + dL/dw, no optimiser step) before the W warm-up steps: the GPU reaches '
+                        'its clocks only after ~30 ms of sustained load; --device-warmup-ms 0 turns this off'}
         out['config'].update(extras)
         if world == 1 and args.cpu_scans > 0:
             torch.cuda.empty_cache()
