@@ -816,3 +816,21 @@ def test_dc_adam_equals_torch_adam():
         assert ps[0][0]._version > v0
         for a, b in zip(ps[0], ps[1]):
             torch.testing.assert_close(a.detach(), b.detach(), rtol=tol, atol=tol * 1e-2)
+
+
+def test_local_clouds_on_several_streams_are_identical():
+    """pipeline.on_streams: the scans' local feature clouds issued round robin on four streams give bit for bit what one
+    stream gives (independent jobs; the join orders every later use after their producers)."""
+    from depth_correction_amd.dataset import RoomBoxDataset
+    from depth_correction_amd.pipeline import build_sequence
+    ds = RoomBoxDataset(n_pts=20000, n_poses=6, dtype=np.float32)
+    scans = [np.stack([c[f] for f in 'xyz'], 1) for c, _ in ds]
+    poses = np.stack([p for _, p in ds])
+    ref_plan, ref = build_sequence(scans, poses, local_streams=1)
+    for _ in range(3):
+        plan, info = build_sequence(scans, poses, local_streams=4)
+        assert plan.count == ref_plan.count
+        for a, b in zip(info['clouds'], ref['clouds']):
+            for f in ('dirs', 'depth', 'inc_angles', 'mask', 'normals', 'eigvals', 'neighbors'):
+                assert torch.equal(a[f], b[f]), f
+        assert torch.equal(info['neighbors'], ref['neighbors']) and torch.equal(info['mask'], ref['mask'])
