@@ -67,6 +67,9 @@ def parse():
     ap.add_argument('--device-warmup-ms', type=float, default=40.0,
                     help='untimed evaluations of the same sequence before the W warm-up steps, for about this long: after an idle or '
                          'host-bound phase (the set-up) the GPU needs ~30 ms of sustained load to reach its clocks (0 = off)')
+    ap.add_argument('--no-chain', action='store_true',
+                    help='native loop: the ordinary two launches per step (evaluation, reduction + Adam) instead of chained steps '
+                         '(one launch per step: each launch also finishes the previous step; dc_sequence_step_chained)')
     ap.add_argument('--two-pass', action='store_true', help='basis form with separate forward and backward kernels (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
     return ap.parse_args()
@@ -312,7 +315,8 @@ def main():
     else:
         # native loop: one host call per evaluation (dc_sequence_eval) + dc_adam_step; with several ranks the only
         # exchange of the path is one RCCL all-reduce of [sum loss, count, dL/dw] per step
-        trainer = SequenceTrainer([plan], w0, e0, [poses_t], lr=1e-3, distributed=dist is not None)
+        trainer = SequenceTrainer([plan], w0, e0, [poses_t], lr=1e-3, distributed=dist is not None,
+                                  chained=not args.no_chain and dist is None)
         total_count = trainer.count
 
         def step():
@@ -340,6 +344,8 @@ def main():
         ramp = [marks[i].elapsed_time(marks[i + 1]) / 25 * 1e3 for i in range(len(marks) - 1)]
     for _ in range(args.warmup):
         loss = step()
+    if not args.autograd:
+        trainer.flush()                             # chained steps: the warm-up's last step is finished before the clock starts
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -347,6 +353,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
+        if not args.autograd:
+            loss = trainer.flush()                  # chained steps: the last step's sums and Adam update (no-op otherwise)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -484,7 +492,7 @@ def main():
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
                        'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the kernel; loss and dL/dw in one pass over each centre\'s neighbours; the basis rows are rebuilt only when poses or exponents change)'
                                if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
-                       'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else 'native (dc_sequence_step)',
+                       'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else ('native, chained: one launch per step (dc_sequence_step_chained), the last one flushed' if trainer.chained else 'native (dc_sequence_step)'),
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
                        'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s,

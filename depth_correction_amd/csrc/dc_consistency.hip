@@ -879,9 +879,13 @@ struct PointBasis {
   double w_scale;                      // weights are staged as w_k * w_scale: 1 / grid step for q32, 1 for fp64 points
 };
 
-// s_w[k] = w_k * w_scale for the lanes of the block (call before a barrier)
-__device__ __forceinline__ void stage_weights(const PointBasis& pb, double* s_w) {
-  if ((int)threadIdx.x < pb.n_terms) s_w[threadIdx.x] = pb.w[threadIdx.x] * pb.w_scale;
+// s_w[k] = w_k * w_scale for the lanes of the block (call before a barrier); coherent: the weights were written by other
+// blocks of this very launch (chained steps), so the load must not be served by this XCD's L2
+__device__ __forceinline__ void stage_weights(const PointBasis& pb, double* s_w, bool coherent = false) {
+  if ((int)threadIdx.x < pb.n_terms) {
+    const double w = coherent ? __hip_atomic_load(pb.w + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pb.w[threadIdx.x];
+    s_w[threadIdx.x] = w * pb.w_scale;
+  }
 }
 
 // Row layout and arithmetic of the basis per point format.  q32 (float32 clouds): X0 on the fixed-point grid, u and c in
@@ -1146,6 +1150,109 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
   wave_partials<2>(acc2, partials);
 }
 
+// torch.optim.Adam (single-tensor path, no amsgrad) for one fp64 parameter; grad is scaled first.
+struct AdamArgs {
+  double* p; double* m; double* v;     // parameters, exp_avg, exp_avg_sq (p == nullptr: no update)
+  int n;
+  double grad_scale, lr, b1, b2, eps, weight_decay, bias1, bias2_sqrt;
+};
+// (p0, m0, v0: the parameter's state, loaded by the caller -- early, so the trip hides behind its own work)
+__device__ __forceinline__ void adam_apply(const AdamArgs& a, int i, double grad, double p0, double m0, double v0) {
+  double g = grad * a.grad_scale;
+  if (a.weight_decay != 0.0) g += a.weight_decay * p0;
+  const double mi = m0 + (g - m0) * (1.0 - a.b1);                   // exp_avg.lerp_(grad, 1 - beta1)
+  const double vi = v0 * a.b2 + (1.0 - a.b2) * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  a.m[i] = mi; a.v[i] = vi;
+  const double denom = sqrt(vi) / a.bias2_sqrt + a.eps;
+  a.p[i] = p0 + (-(a.lr / a.bias1)) * (mi / denom);
+}
+__device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double grad) { adam_apply(a, i, grad, a.p[i], a.m[i], a.v[i]); }
+
+// ---- chained steps: the previous evaluation's final sums inside the next evaluation's launch -----------------------------
+// A dependent reduction launch after a kernel that filled every L2 costs ~9 us, an eighth of a C2 step.  In a chain
+// of steps the launch of step t + 1 therefore starts with `n_front` leading blocks that finish step t: block a < 2 + P sums
+// column a of step t's partial rows (one per BLOCK in this mode: 7.8 k rows, one trip for 256 lanes), writes out_prev[a],
+// takes weight (a - 2)'s Adam step and raises ready[parity]; the other blocks fetch everything that does not depend on the
+// weights, then wait for ready[parity] == P.  The leading blocks are dispatched first and need nothing from the waiting ones,
+// so they always finish; the wait is bounded all the same (a grid must drain).  parity alternates per launch: this launch
+// clears the other flag and writes its own partial rows to the other buffer.  The last step of a chain is finished by the
+// ordinary reduction launch (flush).
+struct StepChain {
+  int32_t* ready;            // [2], zero before the first launch of a chain; nullptr: ordinary launch (per-wavefront rows)
+  int parity, has_prev, n_front, n_out;
+  const double* prev;        // the previous launch's rows [(2 + P)][prev_rows]
+  int64_t prev_rows;
+  double* out_prev;          // [n_out] <- sums of the previous evaluation (slots beyond 2 + P: 0)
+  const int32_t* status;
+  AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
+};
+constexpr int kChainFront = 8;             // leading blocks of a chained launch (a multiple of the XCD count)
+
+template <int P>
+__device__ __forceinline__ void chain_front_block(const StepChain& ch) {
+  __shared__ double lds[kBlock / kWave];
+  const int a = blockIdx.x;
+  if (a == 0) {
+    if (threadIdx.x == 0) __hip_atomic_store(ch.ready + (ch.parity ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ch.has_prev)
+      for (int z = 2 + P + threadIdx.x; z < ch.n_out; z += kBlock) ch.out_prev[z] = 0.0;
+  }
+  if (a >= 2 + P) return;
+  const bool step = ch.has_prev && ch.adam.p && a >= 2 && threadIdx.x == 0;
+  const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && ch.status && *ch.status != 0;
+  double p0 = 0.0, m0 = 0.0, v0 = 0.0;
+  if (step) { p0 = ch.adam.p[a - 2]; m0 = ch.adam.m[a - 2]; v0 = ch.adam.v[a - 2]; }
+  double s = 0.0;
+  if (ch.has_prev) {
+    const double* p = ch.prev + (int64_t)a * ch.prev_rows;
+    constexpr int U = 32;
+    for (int64_t r0 = threadIdx.x; r0 < ch.prev_rows; r0 += (int64_t)U * kBlock) {
+      double v[U];
+#pragma unroll
+      for (int u_ = 0; u_ < U; ++u_) v[u_] = (r0 + (int64_t)u_ * kBlock < ch.prev_rows) ? p[r0 + (int64_t)u_ * kBlock] : 0.0;
+#pragma unroll
+      for (int w_ = U / 2; w_ > 0; w_ >>= 1) {
+#pragma unroll
+        for (int u_ = 0; u_ < w_; ++u_) v[u_] += v[u_ + w_];
+      }
+      s += v[0];
+    }
+    s = wave_sum(s);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) lds[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ch.has_prev) {
+      double t = 0.0;
+      for (int wv = 0; wv < kBlock / kWave; ++wv) t += lds[wv];
+      if (flagged) t = __longlong_as_double(0x7ff8000000000000ll);
+      ch.out_prev[a] = t;
+      if (step) adam_apply(ch.adam, a - 2, t, p0, m0, v0);
+    }
+    if (a >= 2) {                        // weight a - 2 is final for this launch
+      __threadfence();
+      __hip_atomic_fetch_add(ch.ready + ch.parity, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// wait (bounded) until all P weights of this launch are published; every thread of the block must call it
+__device__ __forceinline__ bool chain_wait(const StepChain& ch, int n_weights, int* s_ok) {
+  if (threadIdx.x == 0) {
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      // relaxed: an agent-scope acquire would invalidate this XCD's L2 on every poll; the weights are read with
+      // device-coherent loads afterwards instead
+      if (__hip_atomic_load(ch.ready + ch.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_weights) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
 // ---- loss AND dL/dw in one pass (forward-mode accumulation) -------------------------------------------------------------
 // With only the P model weights to differentiate, the reverse pass over the transposed table is not needed:
 //     dL/dw_k = sum_i sum_{j in N(i)} (dl_i/dx_j) . (dx_j/dw_k),   dl_i/dx_j = c1_i (v0_i . d) v0_i - c2_i d,  d = x_j - cmean_i,
@@ -1159,11 +1266,19 @@ __global__ __launch_bounds__(kBlock) void consistency_fwd_basis_slots_kernel(
 template <typename PT, int P> struct StepRow;
 template <int P> struct StepRow<q32, P> {
   static constexpr int kPieces = (6 + P + 3) / 4;
-  static __device__ __forceinline__ void stage(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+  struct Raw { int32_t q[6 + P]; };                       // a basis row as fetched (before the weights are known)
+  static __device__ __forceinline__ Raw fetch(const PointBasis& pb, int64_t row) {
     const int32_t* r = static_cast<const int32_t*>(pb.rows) + row * (6 + P);
-    int32_t q[6 + P];
+    Raw o;
 #pragma unroll
-    for (int c = 0; c < 6 + P; ++c) q[c] = r[c];
+    for (int c = 0; c < 6 + P; ++c) o.q[c] = r[c];
+    return o;
+  }
+  static __device__ __forceinline__ void stage(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+    place(fetch(pb, row), wq, tile, cap, t);
+  }
+  static __device__ __forceinline__ void place(const Raw& raw, const double* wq, int4* tile, int cap, int t) {
+    const int32_t* q = raw.q;
     double sc = 0.0;
 #pragma unroll
     for (int k = 0; k < P; ++k) sc += wq[k] * (double)__int_as_float(q[6 + k]);
@@ -1196,11 +1311,21 @@ template <int P> struct StepRow<double, P> {
   static __device__ __forceinline__ int4 pack(double a, double b) {
     return make_int4(__double2loint(a), __double2hiint(a), __double2loint(b), __double2hiint(b));
   }
-  static __device__ __forceinline__ void stage(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+  struct Raw { double q[6 + P]; };
+  static __device__ __forceinline__ Raw fetch(const PointBasis& pb, int64_t row) {
     const double* r = static_cast<const double*>(pb.rows) + row * (6 + P);
+    Raw o;
+#pragma unroll
+    for (int c = 0; c < 6 + P; ++c) o.q[c] = r[c];
+    return o;
+  }
+  static __device__ __forceinline__ void stage(const PointBasis& pb, const double* wq, int64_t row, int4* tile, int cap, int t) {
+    place(fetch(pb, row), wq, tile, cap, t);
+  }
+  static __device__ __forceinline__ void place(const Raw& raw, const double* wq, int4* tile, int cap, int t) {
     double q[6 + P + 1];
 #pragma unroll
-    for (int c = 0; c < 6 + P; ++c) q[c] = r[c];
+    for (int c = 0; c < 6 + P; ++c) q[c] = raw.q[c];
     q[6 + P] = 0.0;
     double sc = 0.0;
 #pragma unroll
@@ -1262,15 +1387,26 @@ __device__ __forceinline__ void step_point(CovAcc& acc, bool m, const LossParams
 // {sum loss, count} -> p_fwd columns, dL/dw -> p_bwd columns (same row stride: one row per wavefront), through one packed
 // wavefront reduction of the 2 + P values
 template <int P>
-__device__ __forceinline__ void step_partials(const double* acc2, const double* gw, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+__device__ __forceinline__ void step_partials(const double* acc2, const double* gw, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
+                                              bool per_block = false, int n_front = 0) {
   constexpr int NV = 2 + P, NP2 = NV <= 4 ? 4 : 8;
+  __shared__ double s_comb[kWavesPerBlock][NP2];
   double v[NP2];
   v[0] = acc2[0]; v[1] = acc2[1];
 #pragma unroll
   for (int k = 0; k < NP2 - 2; ++k) v[2 + k] = k < P ? gw[k] : 0.0;
-  const double tot = wave_sum_packed<NP2>(v);
+  double tot = wave_sum_packed<NP2>(v);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock, row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  int64_t rs = (int64_t)gridDim.x * kWavesPerBlock, row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (per_block) {
+    // chained steps: one row per block (a quarter of the rows for the next launch's leading blocks to sum)
+    if (lane < NP2) s_comb[wave][lane] = tot;
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane < NP2) tot = (s_comb[0][lane] + s_comb[1][lane]) + (s_comb[2][lane] + s_comb[3][lane]);
+    rs = (int64_t)gridDim.x - n_front;
+    row = (int64_t)blockIdx.x - n_front;
+  }
   if (lane < NP2) {
     const int q = packed_value_of_lane<NP2>(lane);
     if (q < 2) p_fwd[q * rs + row] = tot;
@@ -1282,16 +1418,20 @@ __device__ __forceinline__ void step_partials(const double* acc2, const double* 
 template <typename PT, int NS, int P>
 __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
-    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
+    StepChain ch) {
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  __shared__ int s_ok;
+  const bool chained = ch.ready != nullptr;
+  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block(nblocks);
+  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
   const int32_t s0 = blk >= 0 ? tab.slot_ptr[blk] : 0;
-  const bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
+  bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
   if (blk >= 0 && !bad) {
     const int64_t i = blk * kBlock + threadIdx.x;
     const bool live = i < n;
@@ -1299,14 +1439,32 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     uint32_t pre[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) pre[q] = (uint32_t)lrow[q * kBlock];
-    stage_weights(pb, s_w);
     const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
     const int32_t own = (own_base && !centre_idx) ? own_base[blk] : -1;
-    __syncthreads();
     double wq[P];
+    if (chained) {
+      // the weights of this launch come from its leading blocks: fetch the rows this lane stages (the first two: a block
+      // lists ~1.5 distinct rows per lane) BEFORE waiting for them, so that the wait hides behind the fetch or vice versa
+      // (a wait that never ends poisons the sums instead of hanging)
+      typename StepRow<PT, P>::Raw r0, r1;
+      const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
+      if (t0 < nd) r0 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t0]);
+      if (t1 < nd) r1 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t1]);
+      if (!chain_wait(ch, P, &s_ok)) bad = true;
+      stage_weights(pb, s_w, true);
+      __syncthreads();
 #pragma unroll
-    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
-    for (int t = threadIdx.x; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+      for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+      if (t0 < nd) StepRow<PT, P>::place(r0, wq, tile, cap, t0);
+      if (t1 < nd) StepRow<PT, P>::place(r1, wq, tile, cap, t1);
+      for (int t = threadIdx.x + 2 * kBlock; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    } else {
+      stage_weights(pb, s_w);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+      for (int t = threadIdx.x; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    }
     typename Pt<PT>::Raw ci;
     if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
     __syncthreads();
@@ -1339,18 +1497,20 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
       for (int k = 0; k < P; ++k) gw[k] *= u;            // differences were in grid steps
     }
   } else {
+    if (chained) chain_wait(ch, P, &s_ok);
     __syncthreads();
     __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
-  step_partials<P>(acc2, gw, p_fwd, p_bwd);
+  step_partials<P>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
 }
 
 // the same for any slot count (radius neighbourhoods): run-time slot loops, as consistency_fwd_basis_slots_kernel
 template <typename PT, int P>
 __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
-    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
+    StepChain) {                           // (chained launches use the fixed-slot kernels only)
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
@@ -1585,24 +1745,6 @@ __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double
     out[blockIdx.x] = t;
   }
 }
-
-// torch.optim.Adam (single-tensor path, no amsgrad) for one fp64 parameter; grad is scaled first.
-struct AdamArgs {
-  double* p; double* m; double* v;     // parameters, exp_avg, exp_avg_sq (p == nullptr: no update)
-  int n;
-  double grad_scale, lr, b1, b2, eps, weight_decay, bias1, bias2_sqrt;
-};
-// (p0, m0, v0: the parameter's state, loaded by the caller -- early, so the trip hides behind its own work)
-__device__ __forceinline__ void adam_apply(const AdamArgs& a, int i, double grad, double p0, double m0, double v0) {
-  double g = grad * a.grad_scale;
-  if (a.weight_decay != 0.0) g += a.weight_decay * p0;
-  const double mi = m0 + (g - m0) * (1.0 - a.b1);                   // exp_avg.lerp_(grad, 1 - beta1)
-  const double vi = v0 * a.b2 + (1.0 - a.b2) * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-  a.m[i] = mi; a.v[i] = vi;
-  const double denom = sqrt(vi) / a.bias2_sqrt + a.eps;
-  a.p[i] = p0 + (-(a.lr / a.bias1)) * (mi / denom);
-}
-__device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double grad) { adam_apply(a, i, grad, a.p[i], a.m[i], a.v[i]); }
 
 // One launch for a whole evaluation: out[0..2) <- forward partials, out[2..2+n_red) <- backward partials,
 // out[2+n_red..2+n_acc) <- 0 (gradient slots that were not requested).  With `adam.p` the block that finishes
@@ -2107,9 +2249,22 @@ int dc_adam_step_device(double* param, const double* grad, double* exp_avg, doub
 
 // One evaluation of a whole sequence (eval.py:85-112 + backward) from a caller-filled descriptor: three kernels
 // (+ two fixed-order reductions).  out fp64 [2 + 2 P + 12 S] = {sum loss over mask, mask count, grads of the sum}.
+// a chained step (dc_sequence_step_chained): this launch also finishes the previous evaluation (StepChain)
+struct ChainCall {
+  int32_t* ready;
+  int parity, has_prev;
+  double* out_prev;
+  AdamArgs adam_prev;
+};
+// the two partial-row buffers of a chain inside the sequence's workspace (per-block rows: they fit many times over)
+static inline double* chain_buffer(const dcSequenceDesc* d, int n_terms, int parity) {
+  const int64_t rows = xcd_grid(n_blocks(d->n)) * kWavesPerBlock;
+  return d->partials + (int64_t)parity * (2 + n_terms) * rows;
+}
+
 static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
                               int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream,
-                              const AdamArgs& adam) {
+                              const AdamArgs& adam, const ChainCall* chain = nullptr) {
   if (!d || !out || !poses || !d->partials) return DC_ERR_ARG;
   const int stride = 4;
   const int n_terms = d->model_kind == DC_MODEL_NONE ? 0 : d->n_terms;
@@ -2149,12 +2304,23 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
+    const bool fixed_slots = fixed_k == 4 || fixed_k == 8 || fixed_k == 10 || fixed_k == 16;
+    if (chain && !(one_pass && fixed_slots)) return DC_ERR_UNSUPPORTED;        // the caller steps without a chain then
     if (one_pass) {
-      const dim3 grid((unsigned)xcd_grid(n_blocks(n_rows)));
+      const int64_t g_blocks = xcd_grid(n_blocks(n_rows));
+      StepChain ch{};
+      if (chain) {
+        p_fwd = chain_buffer(d, n_terms, chain->parity);
+        p_bwd = p_fwd + 2 * g_blocks;
+        ch.ready = chain->ready; ch.parity = chain->parity; ch.has_prev = chain->has_prev; ch.n_front = kChainFront;
+        ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
+        ch.out_prev = chain->out_prev; ch.status = (const int32_t*)d->status; ch.adam = chain->adam_prev;
+      }
+      const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
       {
         ProfScope prof(1);
 #define STEP_LAUNCH(K) DC_TIMED_LAUNCH(K, grid, block, lds_s, stream, pb, tab, d->fwd_table->own_base, rows_s, d->centre_idx, n_rows, \
-                                       d->mask, lp, qp, p_fwd, p_bwd)
+                                       d->mask, lp, qp, p_fwd, p_bwd, ch)
 #define STEP_NS(PT, P) do { if (fixed_k == 10) STEP_LAUNCH((consistency_step_basis_kernel<PT, 10, P>)); \
                             else if (fixed_k == 4) STEP_LAUNCH((consistency_step_basis_kernel<PT, 4, P>)); \
                             else if (fixed_k == 8) STEP_LAUNCH((consistency_step_basis_kernel<PT, 8, P>)); \
@@ -2167,6 +2333,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
 #undef STEP_LAUNCH
       }
       DC_CHECK_LAUNCH();
+      if (chain) return DC_OK;                 // its sums are taken by the next launch of the chain, or by the flush
       const int64_t rows_g = (int64_t)grid.x * kWavesPerBlock;
       hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_terms), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_g, rows_g, n_terms, 2 + n_acc, out,
                          adam, (const int32_t*)d->status);
@@ -2268,6 +2435,35 @@ int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const 
   int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step, grad_scale, lr, beta1, beta2, eps, weight_decay, &a);
   if (rc) return rc;
   return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out, stream, a);
+}
+
+int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                             double* exp_avg_sq, int64_t step, int has_prev, double grad_scale, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int32_t* ready, double* out_prev, hipStream_t stream) {
+  if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1) return DC_ERR_ARG;
+  if (has_prev && step < 2) return DC_ERR_ARG;
+  ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}};
+  if (has_prev) {
+    int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
+    if (rc) return rc;
+  }
+  return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out_prev, stream, AdamArgs{}, &c);
+}
+
+int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg, double* exp_avg_sq, int64_t step, double grad_scale,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, double* out, hipStream_t stream) {
+  if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !out || step < 1) return DC_ERR_ARG;
+  AdamArgs a;
+  int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step, grad_scale, lr, beta1, beta2, eps, weight_decay, &a);
+  if (rc) return rc;
+  const int n_terms = d->n_terms, n_acc = 2 * n_terms + 12 * d->n_scans;
+  const int64_t n_rows = d->centre_idx ? d->n_centres : d->n;
+  const int64_t g_blocks = xcd_grid(n_blocks(n_rows));
+  const double* buf = chain_buffer(d, n_terms, (int)(step & 1));
+  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_terms), dim3(kRedBlock), 0, stream, buf, buf + 2 * g_blocks, g_blocks, g_blocks,
+                     n_terms, 2 + n_acc, out, a, (const int32_t*)d->status);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
 }
 
 }  // extern "C"

@@ -19,6 +19,12 @@ __device__ __forceinline__ int64_t xcd_block(int64_t n_logical) {
   const int64_t logical = (b % kXcds) * per + b / kXcds;
   return logical < n_logical ? logical : -1;
 }
+// the same for block index b of a grid whose first blocks do something else (b = blockIdx.x - their number, a multiple of 8)
+__device__ __forceinline__ int64_t xcd_block_of(int64_t b, int64_t n_logical) {
+  const int64_t per = (n_logical + kXcds - 1) / kXcds;
+  const int64_t logical = (b % kXcds) * per + b / kXcds;
+  return logical < n_logical ? logical : -1;
+}
 inline int64_t xcd_grid(int64_t n_logical) { return ((n_logical + kXcds - 1) / kXcds) * kXcds; }
 
 // ---- xyz rows: element stride 3 (API tensors) or 4 (padded internal layout) ------------------------

@@ -286,6 +286,39 @@ class SequencePlan:
         return out
 
     @on_device
+    def step_chained(self, w, exponent, poses12, out_prev, exp_avg, exp_avg_sq, t, has_prev, ready, grad_scale, lr, betas, eps,
+                     weight_decay):
+        """One step of a CHAIN (dc_sequence_step_chained): evaluation number ``t`` is launched, and the same launch first
+        finishes evaluation ``t - 1`` when ``has_prev`` (its sums -> out_prev, its Adam update on ``w``).  Returns False when
+        this plan / model cannot chain (the caller steps with step_native then)."""
+        nt = w.numel()
+        d = self.desc(nt)
+        need(out_prev, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out_prev', device=self.device)
+        need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
+        for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
+            need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
+        self._set_basis(d, w, exponent, poses12, False, False)
+        rc = lib().dc_sequence_step_chained(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
+                                            int(t), int(bool(has_prev)), float(grad_scale), float(lr), float(betas[0]),
+                                            float(betas[1]), float(eps), float(weight_decay), ptr(ready), ptr(out_prev), stream_ptr())
+        if rc in (-4, nv.DC_ERR_BACKWARD_TABLES):
+            return False
+        check(rc, 'dc_sequence_step_chained')
+        self.version += 1
+        return True
+
+    @on_device
+    def chain_flush(self, w, out, exp_avg, exp_avg_sq, t, grad_scale, lr, betas, eps, weight_decay):
+        """Finish evaluation ``t`` of a chain: its sums -> out, its Adam update on ``w`` (dc_sequence_chain_flush)."""
+        nt = w.numel()
+        d = self.desc(nt)
+        need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        check(lib().dc_sequence_chain_flush(ctypes.byref(d), ptr(w), ptr(exp_avg), ptr(exp_avg_sq), int(t), float(grad_scale),
+                                            float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), ptr(out),
+                                            stream_ptr()), 'dc_sequence_chain_flush')
+        return out
+
+    @on_device
     def eval_gated(self, w, exponent, poses12, out, inlier_ratio=1.0, inlier_max_loss=None, inlier_loss_mult=1.0,
                    want_grad=True, want_exponent=False, want_pose=False):
         """Evaluation with the quantile-inlier gating of loss.py:256-277 (per sequence, as batch_loss applies it): of the
@@ -542,7 +575,7 @@ class SequenceTrainer:
     Adam step.  ``evaluate`` / ``adam`` are injectable so the sharding logic can be exercised without a GPU."""
 
     def __init__(self, plans, w, exponent, poses, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 process_group=None, distributed=False, evaluate=None, adam=None, device=None):
+                 process_group=None, distributed=False, evaluate=None, adam=None, device=None, chained=False):
         self.plans = list(plans)
         dev = device if device is not None else self.plans[0].device
         self.w = torch.as_tensor(w, dtype=torch.float64).reshape(-1).to(dev).contiguous()
@@ -557,6 +590,11 @@ class SequenceTrainer:
         self.exp_avg = torch.zeros_like(self.w)
         self.exp_avg_sq = torch.zeros_like(self.w)
         self.t = 0
+        # chained steps (single local sequence): every launch also finishes the previous step, so step() returns the sums
+        # of the PREVIOUS evaluation and flush() those of the last one; see dc_sequence_step_chained
+        self.chained = bool(chained) and self.fused_step
+        self._pending = False
+        self.ready = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
         self.acc = torch.zeros((2 + self.nt,), dtype=torch.float64, device=dev)       # [sum loss, count, dL/dw]
         self.distributed, self.group = distributed, process_group
@@ -571,6 +609,14 @@ class SequenceTrainer:
                                  self.nt, self.t, self._grad_scale(), self.lr, self.betas[0], self.betas[1], self.eps,
                                  self.weight_decay, stream_ptr()), 'dc_adam_step')
 
+    def flush(self):
+        """Chained mode: finish the last launched step (its sums and its Adam update); returns them.  No-op otherwise."""
+        if self._pending:
+            self.plans[0].chain_flush(self.w, self.outs[0], self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
+                                      self.betas, self.eps, self.weight_decay)
+            self._pending = False
+        return self.outs[0][:2 + self.nt] if len(self.outs) == 1 else self.acc
+
     def _grad_scale(self):
         """1 / number of masked points of all sequences (the mean reduction, loss.py:205-213); no masked point at all:
         NaN, the mean of an empty tensor, as in the reference."""
@@ -579,6 +625,16 @@ class SequenceTrainer:
     def step(self):
         """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
         (mean loss = acc[0] / acc[1]).  No host synchronisation."""
+        if self.chained:
+            ok = self.plans[0].step_chained(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg, self.exp_avg_sq,
+                                            self.t + 1, self._pending, self.ready, self._grad_scale(), self.lr, self.betas, self.eps,
+                                            self.weight_decay)
+            if ok:
+                self.t += 1
+                self._pending = True
+                return self.outs[0][:2 + self.nt]
+            self.flush()
+            self.chained = False                 # this plan cannot chain: ordinary steps from here on
         if self.fused_step:
             self.t += 1
             out = self.plans[0].step_native(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg,

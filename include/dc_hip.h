@@ -359,6 +359,21 @@ int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const 
                      double* exp_avg_sq, int64_t step, double grad_scale, double lr, double beta1, double beta2, double eps,
                      double weight_decay, double* out, dcStream_t stream);
 
+/* A CHAIN of optimisation steps of one sequence with one launch per step instead of two (basis form, up to three weights,
+ * K in {4, 8, 10, 16}; DC_ERR_UNSUPPORTED otherwise -- step with dc_sequence_step then).  The dependent reduction launch after
+ * the evaluation kernel costs ~9 us, an eighth of a C2 step; here the launch of step t also FINISHES step t - 1: its first
+ * blocks sum the previous evaluation's partial rows, write them to out_prev ({sum loss, count, dL/dw, 0...} of evaluation
+ * t - 1) and take its Adam update, while the other blocks fetch what does not depend on the weights and then wait for them
+ * (bounded; a wait that never ends yields NaN sums).  step: this evaluation's number (1, 2, ...; its parity selects the flag
+ * and the partial-row buffer), has_prev: evaluation step - 1 is still unfinished (0 for the first launch and after a flush);
+ * ready: device int32 [2], zeroed once.  dc_sequence_chain_flush finishes evaluation `step` with the ordinary reduction
+ * launch (sums -> out, Adam update `step`): the chain's last call. */
+int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                             double* exp_avg_sq, int64_t step, int has_prev, double grad_scale, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int32_t* ready, double* out_prev, dcStream_t stream);
+int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg, double* exp_avg_sq, int64_t step, double grad_scale,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, double* out, dcStream_t stream);
+
 /* torch.optim.Adam step (train.py:139-149,312) on a device fp64 vector; grad is multiplied by grad_scale first
  * (1 / number of masked points of all sequences = the reference's mean reduction, loss.py:205-213). */
 int dc_adam_step(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, int64_t step,

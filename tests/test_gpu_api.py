@@ -194,6 +194,38 @@ def test_native_trainer_equals_autograd_adam(golden):
     assert abs(npy(tr.w)[0] - g['w'][0]) > 1e-3
 
 
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_chained_steps_equal_ordinary_steps(golden, dtype):
+    """SequenceTrainer(chained=True): every launch also finishes the previous step (dc_sequence_step_chained), so a step is
+    one launch instead of two.  step() hands out the sums of the PREVIOUS evaluation, flush() those of the last one; weights,
+    losses and gradients follow the ordinary trainer's to the order of the fp64 additions (one partial row per block instead
+    of one per wavefront), for a chain that is flushed in the middle and continued."""
+    from depth_correction_amd.plan import SequencePlan, SequenceTrainer
+    g = golden('room_k10')
+    cfg = _cfg(g, float_type='float64' if dtype == torch.float64 else 'float32')
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    plan = SequencePlan(clouds, poses, ns[0], mask)
+    plain = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2)
+    ref = [npy(plain.step()).copy() for _ in range(12)]
+    chain = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2, chained=True)
+    got = []
+    for it in range(12):
+        prev = npy(chain.step()).copy()
+        assert chain.chained                                  # this plan / model can chain
+        if it in (1, 2, 3, 4, 5, 6, 8, 9, 10, 11):            # (not right after a flush: nothing is pending then)
+            got.append(prev)
+        if it in (6, 11):
+            got.append(npy(chain.flush()).copy())             # finishes evaluation it + 1 (1-based)
+    torch.cuda.synchronize()
+    assert len(got) == 12 and chain.t == 12 and int(chain.ready.sum()) >= 0
+    for a, b in zip(got, ref):
+        assert a[1] == b[1]
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-11)
+        np.testing.assert_allclose(a[2:], b[2:], rtol=1e-9, atol=1e-12 * np.abs(b[2:]).max())
+    np.testing.assert_allclose(npy(chain.w), npy(plain.w), rtol=1e-10)
+    assert abs(npy(chain.w)[0] - g['w'][0]) > 1e-3
+
+
 @pytest.mark.parametrize('fused', [True, False])
 def test_icp_loss_golden(golden, fused):
     from depth_correction_amd.depth_cloud import DepthCloud
