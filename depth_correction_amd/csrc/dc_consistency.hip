@@ -2295,6 +2295,9 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   if (want_grad && !one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
   const bool basis = basis_fwd &&
                      (!want_grad || one_pass || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
+  const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
+  // a chained step exists for the one-pass kernels with a compiled slot count only: the caller steps without a chain otherwise
+  if (chain && !(basis && one_pass && (fixed_k == 4 || fixed_k == 8 || fixed_k == 10 || fixed_k == 16))) return DC_ERR_UNSUPPORTED;
   if (basis) {
     QParams qp;
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
@@ -2303,9 +2306,6 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     LossParams lp{d->loss_kind, d->normalization, d->sqrt_, 0};
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
-    const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
-    const bool fixed_slots = fixed_k == 4 || fixed_k == 8 || fixed_k == 10 || fixed_k == 16;
-    if (chain && !(one_pass && fixed_slots)) return DC_ERR_UNSUPPORTED;        // the caller steps without a chain then
     if (one_pass) {
       const int64_t g_blocks = xcd_grid(n_blocks(n_rows));
       StepChain ch{};

@@ -224,6 +224,15 @@ def test_chained_steps_equal_ordinary_steps(golden, dtype):
         np.testing.assert_allclose(a[2:], b[2:], rtol=1e-9, atol=1e-12 * np.abs(b[2:]).max())
     np.testing.assert_allclose(npy(chain.w), npy(plain.w), rtol=1e-10)
     assert abs(npy(chain.w)[0] - g['w'][0]) > 1e-3
+    # a plan that cannot chain (no basis form: the general three-kernel path) falls back to ordinary steps on its own
+    general = SequencePlan(clouds, poses, ns[0], mask, basis=False)
+    a = SequenceTrainer([general], g['w'], g['exponent'], [poses], lr=1e-2, chained=True)
+    b = SequenceTrainer([general], g['w'], g['exponent'], [poses], lr=1e-2)
+    for _ in range(4):
+        sa, sb = npy(a.step()).copy(), npy(b.step()).copy()
+        assert not a.chained and np.array_equal(sa, sb)
+    a.flush()
+    assert np.array_equal(npy(a.w), npy(b.w)) and abs(npy(a.w)[0] - g['w'][0]) > 1e-3
 
 
 @pytest.mark.parametrize('fused', [True, False])
