@@ -2256,10 +2256,12 @@ struct ChainCall {
   double* out_prev;
   AdamArgs adam_prev;
 };
-// the two partial-row buffers of a chain inside the sequence's workspace (per-block rows: they fit many times over)
+// the two partial-row buffers of a chain: behind the columns ordinary evaluations use, so that an evaluation of the same
+// sequence between two chained steps (a validation pass, a lazily produced loss cloud) cannot overwrite a pending step
 static inline double* chain_buffer(const dcSequenceDesc* d, int n_terms, int parity) {
   const int64_t rows = xcd_grid(n_blocks(d->n)) * kWavesPerBlock;
-  return d->partials + (int64_t)parity * (2 + n_terms) * rows;
+  const int n_acc = 2 * n_terms + 12 * d->n_scans;
+  return d->partials + (int64_t)(2 + n_acc) * rows + (int64_t)parity * (2 + n_terms) * rows;
 }
 
 static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,

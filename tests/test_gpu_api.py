@@ -199,7 +199,8 @@ def test_chained_steps_equal_ordinary_steps(golden, dtype):
     """SequenceTrainer(chained=True): every launch also finishes the previous step (dc_sequence_step_chained), so a step is
     one launch instead of two.  step() hands out the sums of the PREVIOUS evaluation, flush() those of the last one; weights,
     losses and gradients follow the ordinary trainer's to the order of the fp64 additions (one partial row per block instead
-    of one per wavefront), for a chain that is flushed in the middle and continued."""
+    of one per wavefront), for a chain that is flushed in the middle and continued, with an unrelated evaluation of the same
+    sequence in between (the chain's rows live behind the columns ordinary evaluations write)."""
     from depth_correction_amd.plan import SequencePlan, SequenceTrainer
     g = golden('room_k10')
     cfg = _cfg(g, float_type='float64' if dtype == torch.float64 else 'float32')
@@ -209,9 +210,12 @@ def test_chained_steps_equal_ordinary_steps(golden, dtype):
     ref = [npy(plain.step()).copy() for _ in range(12)]
     chain = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2, chained=True)
     got = []
+    scratch = torch.zeros((2 + 4 + 12 * plan.n_scans,), dtype=torch.float64, device='cuda:0')
     for it in range(12):
         prev = npy(chain.step()).copy()
         assert chain.chained                                  # this plan / model can chain
+        if it == 4:                                            # another evaluation of the same sequence between two chained steps
+            plan.eval_native(torch.tensor([5e-3, -1e-3], dtype=torch.float64, device='cuda:0'), chain.exponent, chain.poses12[0], scratch)
         if it in (1, 2, 3, 4, 5, 6, 8, 9, 10, 11):            # (not right after a flush: nothing is pending then)
             got.append(prev)
         if it in (6, 11):
