@@ -1510,20 +1510,22 @@ template <typename PT, int P>
 __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
-    StepChain) {                           // (chained launches use the fixed-slot kernels only)
+    StepChain ch) {
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  __shared__ int s_ok;
+  const bool chained = ch.ready != nullptr;
+  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block(nblocks);
+  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
   const int64_t i = blk * kBlock + threadIdx.x;
   const bool live = blk >= 0 && i < n;
-  int32_t nslots = 0, own = -1;
+  int32_t nslots = 0, own = -1, base = 0, nd = 0;
   const uint16_t* lrow = tab.loc;
   uint32_t pre[kPreSlots];
-  stage_weights(pb, s_w);
   if (blk >= 0) {
     const int32_t s0 = tab.slot_ptr[blk];
     nslots = tab.slot_ptr[blk + 1] - s0;
@@ -1531,17 +1533,33 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
 #pragma unroll
     for (int q = 0; q < kPreSlots; ++q) pre[q] = (live && q < nslots) ? (uint32_t)lrow[q * kBlock] : kNoLoc;
     own = (own_base && !centre_idx) ? own_base[blk] : -1;
+    base = tab.blk_ptr[blk];
+    nd = tab.blk_ptr[blk + 1] - base;
   }
-  __syncthreads();
   double wq[P];
-#pragma unroll
-  for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+  bool timed_out = false;
   typename Pt<PT>::Raw ci;
-  if (blk >= 0) {
-    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+  if (chained) {                           // as in consistency_step_basis_kernel: fetch, wait for the weights, place
+    typename StepRow<PT, P>::Raw r0, r1;
+    const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
+    if (t0 < nd) r0 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t0]);
+    if (t1 < nd) r1 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t1]);
+    timed_out = !chain_wait(ch, P, &s_ok);
+    stage_weights(pb, s_w, true);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+    if (t0 < nd) StepRow<PT, P>::place(r0, wq, tile, cap, t0);
+    if (t1 < nd) StepRow<PT, P>::place(r1, wq, tile, cap, t1);
+    for (int t = threadIdx.x + 2 * kBlock; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+  } else {
+    stage_weights(pb, s_w);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
     for (int t = threadIdx.x; t < nd; t += kBlock) StepRow<PT, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
-    if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
   }
+  if (blk >= 0 && own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
   __syncthreads();
   if (live) {
     if (own >= 0) ci = staged_point<PT>(tile, cap, own + (int)threadIdx.x);
@@ -1570,7 +1588,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
 #pragma unroll
     for (int k = 0; k < P; ++k) gw[k] *= u;
   }
-  step_partials<P>(acc2, gw, p_fwd, p_bwd);
+  if (timed_out) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
+  step_partials<P>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
 }
 
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
@@ -2298,8 +2317,8 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   const bool basis = basis_fwd &&
                      (!want_grad || one_pass || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
   const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
-  // a chained step exists for the one-pass kernels with a compiled slot count only: the caller steps without a chain otherwise
-  if (chain && !(basis && one_pass && (fixed_k == 4 || fixed_k == 8 || fixed_k == 10 || fixed_k == 16))) return DC_ERR_UNSUPPORTED;
+  // a chained step exists for the one-pass kernels only: the caller steps without a chain otherwise
+  if (chain && !(basis && one_pass)) return DC_ERR_UNSUPPORTED;
   if (basis) {
     QParams qp;
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);

@@ -359,8 +359,8 @@ int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const 
                      double* exp_avg_sq, int64_t step, double grad_scale, double lr, double beta1, double beta2, double eps,
                      double weight_decay, double* out, dcStream_t stream);
 
-/* A CHAIN of optimisation steps of one sequence with one launch per step instead of two (basis form, up to three weights,
- * K in {4, 8, 10, 16}; DC_ERR_UNSUPPORTED otherwise -- step with dc_sequence_step then).  The dependent reduction launch after
+/* A CHAIN of optimisation steps of one sequence with one launch per step instead of two (basis form, up to three weights;
+ * DC_ERR_UNSUPPORTED otherwise -- step with dc_sequence_step then).  The dependent reduction launch after
  * the evaluation kernel costs ~9 us, an eighth of a C2 step; here the launch of step t also FINISHES step t - 1: its first
  * blocks sum the previous evaluation's partial rows, write them to out_prev ({sum loss, count, dL/dw, 0...} of evaluation
  * t - 1) and take its Adam update, while the other blocks fetch what does not depend on the weights and then wait for them

@@ -194,8 +194,9 @@ def test_native_trainer_equals_autograd_adam(golden):
     assert abs(npy(tr.w)[0] - g['w'][0]) > 1e-3
 
 
+@pytest.mark.parametrize('ragged', [False, True])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
-def test_chained_steps_equal_ordinary_steps(golden, dtype):
+def test_chained_steps_equal_ordinary_steps(golden, dtype, ragged):
     """SequenceTrainer(chained=True): every launch also finishes the previous step (dc_sequence_step_chained), so a step is
     one launch instead of two.  step() hands out the sums of the PREVIOUS evaluation, flush() those of the last one; weights,
     losses and gradients follow the ordinary trainer's to the order of the fp64 additions (one partial row per block instead
@@ -205,7 +206,14 @@ def test_chained_steps_equal_ordinary_steps(golden, dtype):
     g = golden('room_k10')
     cfg = _cfg(g, float_type='float64' if dtype == torch.float64 else 'float32')
     clouds, poses, _, ns, mask = _setup(g, cfg)
-    plan = SequencePlan(clouds, poses, ns[0], mask)
+    nbr = ns[0]
+    if ragged:                                                 # a radius-style table: 13 columns, missing entries -> run-time slots
+        gen = torch.Generator(device='cpu').manual_seed(3)
+        drop = (torch.rand(nbr.shape, generator=gen) < 0.2).to(nbr.device)
+        drop[:, :4] = False
+        nbr = torch.where(drop, torch.full_like(nbr, -1), nbr)
+        nbr = torch.cat([nbr, torch.full_like(nbr[:, :3], -1)], dim=1).contiguous()
+    plan = SequencePlan(clouds, poses, nbr, mask)
     plain = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2)
     ref = [npy(plain.step()).copy() for _ in range(12)]
     chain = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2, chained=True)
@@ -229,7 +237,7 @@ def test_chained_steps_equal_ordinary_steps(golden, dtype):
     np.testing.assert_allclose(npy(chain.w), npy(plain.w), rtol=1e-10)
     assert abs(npy(chain.w)[0] - g['w'][0]) > 1e-3
     # a plan that cannot chain (no basis form: the general three-kernel path) falls back to ordinary steps on its own
-    general = SequencePlan(clouds, poses, ns[0], mask, basis=False)
+    general = SequencePlan(clouds, poses, nbr, mask, basis=False)
     a = SequenceTrainer([general], g['w'], g['exponent'], [poses], lr=1e-2, chained=True)
     b = SequenceTrainer([general], g['w'], g['exponent'], [poses], lr=1e-2)
     for _ in range(4):
