@@ -216,7 +216,19 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)
+        # RCCL prints a version banner to stdout when the communicator comes up; the contract is ONE JSON line there, so file
+        # descriptor 1 points at stderr while it does (communicator creation is forced here by a first collective)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=dev)
+            dist.all_reduce(torch.zeros((1,), device=dev))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from depth_correction_amd.dataset import RoomBoxDataset
     from depth_correction_amd.pipeline import build_sequence
@@ -316,7 +328,7 @@ def main():
         # native loop: one host call per evaluation (dc_sequence_eval) + dc_adam_step; with several ranks the only
         # exchange of the path is one RCCL all-reduce of [sum loss, count, dL/dw] per step
         trainer = SequenceTrainer([plan], w0, e0, [poses_t], lr=1e-3, distributed=dist is not None,
-                                  chained=not args.no_chain and dist is None)
+                                  chained=not args.no_chain)
         total_count = trainer.count
 
         def step():
@@ -492,7 +504,9 @@ def main():
                        'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
                        'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the kernel; loss and dL/dw in one pass over each centre\'s neighbours; the basis rows are rebuilt only when poses or exponents change)'
                                if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
-                       'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else ('native, chained: one launch per step (dc_sequence_step_chained), the last one flushed' if trainer.chained else 'native (dc_sequence_step)'),
+                       'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else ('native, chained: one launch per step (dc_sequence_step_chained), the last one flushed' if trainer.chained else
+                                                     ('native: evaluation (+ the previous Adam update in its launch) -> reduction -> all-reduce'
+                                                      if trainer.update_in_next else 'native (dc_sequence_step)')),
                        'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
                        'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s,

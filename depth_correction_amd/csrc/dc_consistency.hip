@@ -1182,6 +1182,8 @@ struct StepChain {
   int parity, has_prev, n_front, n_out;
   const double* prev;        // the previous launch's rows [(2 + P)][prev_rows]
   int64_t prev_rows;
+  const double* grad_sum;    // or: the previous evaluation's dL/dw already summed (over the ranks: an all-reduce ran in between);
+                             // the leading blocks then only take the Adam update (out_prev is not written)
   double* out_prev;          // [n_out] <- sums of the previous evaluation (slots beyond 2 + P: 0)
   const int32_t* status;
   AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
@@ -1194,10 +1196,18 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch) {
   const int a = blockIdx.x;
   if (a == 0) {
     if (threadIdx.x == 0) __hip_atomic_store(ch.ready + (ch.parity ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ch.has_prev)
+    if (ch.has_prev && !ch.grad_sum)
       for (int z = 2 + P + threadIdx.x; z < ch.n_out; z += kBlock) ch.out_prev[z] = 0.0;
   }
   if (a >= 2 + P) return;
+  if (ch.grad_sum) {                     // the sums exist already: weight a - 2's update, then publish
+    if (a >= 2 && threadIdx.x == 0) {
+      if (ch.has_prev && ch.adam.p) adam_update(ch.adam, a - 2, ch.grad_sum[a - 2]);
+      __threadfence();
+      __hip_atomic_fetch_add(ch.ready + ch.parity, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   const bool step = ch.has_prev && ch.adam.p && a >= 2 && threadIdx.x == 0;
   const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && ch.status && *ch.status != 0;
   double p0 = 0.0, m0 = 0.0, v0 = 0.0;
@@ -2274,6 +2284,8 @@ struct ChainCall {
   int parity, has_prev;
   double* out_prev;
   AdamArgs adam_prev;
+  const double* grad_sum;    // nullptr: the previous evaluation's rows are summed by this launch
+  bool reduce_now;           // also launch the ordinary reduction of THIS evaluation's rows into `out` (no Adam)
 };
 // the two partial-row buffers of a chain: behind the columns ordinary evaluations use, so that an evaluation of the same
 // sequence between two chained steps (a validation pass, a lazily produced loss cloud) cannot overwrite a pending step
@@ -2336,6 +2348,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         ch.ready = chain->ready; ch.parity = chain->parity; ch.has_prev = chain->has_prev; ch.n_front = kChainFront;
         ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
         ch.out_prev = chain->out_prev; ch.status = (const int32_t*)d->status; ch.adam = chain->adam_prev;
+        ch.grad_sum = chain->grad_sum;
       }
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
       {
@@ -2354,6 +2367,11 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
 #undef STEP_LAUNCH
       }
       DC_CHECK_LAUNCH();
+      if (chain && chain->reduce_now) {        // several ranks: this evaluation's sums now (they go through an all-reduce next)
+        hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_terms), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, g_blocks, g_blocks, n_terms,
+                           2 + n_acc, out, AdamArgs{}, (const int32_t*)d->status);
+        DC_CHECK_LAUNCH();
+      }
       if (chain) return DC_OK;                 // its sums are taken by the next launch of the chain, or by the flush
       const int64_t rows_g = (int64_t)grid.x * kWavesPerBlock;
       hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_terms), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_g, rows_g, n_terms, 2 + n_acc, out,
@@ -2463,7 +2481,7 @@ int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e
                              double eps, double weight_decay, int32_t* ready, double* out_prev, hipStream_t stream) {
   if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1) return DC_ERR_ARG;
   if (has_prev && step < 2) return DC_ERR_ARG;
-  ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}};
+  ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}, nullptr, false};
   if (has_prev) {
     int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
     if (rc) return rc;
@@ -2485,6 +2503,19 @@ int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg,
                      n_terms, 2 + n_acc, out, a, (const int32_t*)d->status);
   DC_CHECK_LAUNCH();
   return DC_OK;
+}
+
+int dc_sequence_eval_after_update(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                                  double* exp_avg_sq, int64_t step, const double* grad_sum, double grad_scale, double lr, double beta1,
+                                  double beta2, double eps, double weight_decay, int32_t* ready, double* out, hipStream_t stream) {
+  if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out || step < 1) return DC_ERR_ARG;
+  if (grad_sum && step < 2) return DC_ERR_ARG;
+  ChainCall c{ready, (int)(step & 1), grad_sum ? 1 : 0, out, AdamArgs{}, grad_sum ? grad_sum : w, true};
+  if (grad_sum) {
+    int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
+    if (rc) return rc;
+  }
+  return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out, stream, AdamArgs{}, &c);
 }
 
 }  // extern "C"

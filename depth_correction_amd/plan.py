@@ -308,6 +308,28 @@ class SequencePlan:
         return True
 
     @on_device
+    def eval_after_update(self, w, exponent, poses12, out, exp_avg, exp_avg_sq, t, grad_sum, ready, grad_scale, lr, betas, eps,
+                          weight_decay):
+        """Evaluation number ``t`` whose launch first takes Adam update ``t - 1`` from ``grad_sum`` (the previous evaluation's
+        dL/dw, already summed over sequences / ranks; None for the first call), then the ordinary reduction of this
+        evaluation into ``out`` (dc_sequence_eval_after_update).  Returns False when this plan / model cannot do that."""
+        nt = w.numel()
+        d = self.desc(nt)
+        need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
+        if grad_sum is not None:
+            need(grad_sum, (nt,), dtype=torch.float64, name='grad_sum', device=self.device)
+        self._set_basis(d, w, exponent, poses12, False, False)
+        rc = lib().dc_sequence_eval_after_update(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
+                                                 int(t), ptr(grad_sum), float(grad_scale), float(lr), float(betas[0]),
+                                                 float(betas[1]), float(eps), float(weight_decay), ptr(ready), ptr(out), stream_ptr())
+        if rc in (-4, nv.DC_ERR_BACKWARD_TABLES):
+            return False
+        check(rc, 'dc_sequence_eval_after_update')
+        self.version += 1
+        return True
+
+    @on_device
     def chain_flush(self, w, out, exp_avg, exp_avg_sq, t, grad_scale, lr, betas, eps, weight_decay):
         """Finish evaluation ``t`` of a chain: its sums -> out, its Adam update on ``w`` (dc_sequence_chain_flush)."""
         nt = w.numel()
@@ -593,6 +615,11 @@ class SequenceTrainer:
         # chained steps (single local sequence): every launch also finishes the previous step, so step() returns the sums
         # of the PREVIOUS evaluation and flush() those of the last one; see dc_sequence_step_chained
         self.chained = bool(chained) and self.fused_step
+        # several ranks (or an injected reduction) and one local sequence: the update of step t rides in the launch of step
+        # t + 1 (dc_sequence_eval_after_update), three launches per step instead of four; the returned sums are current, only
+        # the weights lag by the one update flush() applies
+        self.update_in_next = (bool(chained) and not self.fused_step and evaluate is None and adam is None
+                               and len(self.plans) == 1 and self.nt > 0)
         self._pending = False
         self.ready = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
@@ -611,7 +638,10 @@ class SequenceTrainer:
 
     def flush(self):
         """Chained mode: finish the last launched step (its sums and its Adam update); returns them.  No-op otherwise."""
-        if self._pending:
+        if self._pending and self.update_in_next:
+            self.adam(self.outs[0][2:2 + self.nt])                # the last evaluation's (all-reduced) gradient, step self.t
+            self._pending = False
+        elif self._pending:
             self.plans[0].chain_flush(self.w, self.outs[0], self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
                                       self.betas, self.eps, self.weight_decay)
             self._pending = False
@@ -641,6 +671,21 @@ class SequenceTrainer:
                                             self.exp_avg_sq, self.t, self._grad_scale(), self.lr, self.betas, self.eps,
                                             self.weight_decay)
             return out[:2 + self.nt]
+        if self.update_in_next:
+            acc = self.outs[0][:2 + self.nt]
+            # (the launch reads the gradient before the reduction that follows it on the stream overwrites `out`)
+            ok = self.plans[0].eval_after_update(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg, self.exp_avg_sq,
+                                                 self.t + 1, acc[2:] if self._pending else None, self.ready, self._grad_scale(),
+                                                 self.lr, self.betas, self.eps, self.weight_decay)
+            if ok:
+                if self.distributed:
+                    from .distributed import all_reduce_sum
+                    all_reduce_sum(acc, self.group)
+                self.t += 1
+                self._pending = True
+                return acc
+            self.flush()
+            self.update_in_next = False
         for plan, P, out in zip(self.plans, self.poses12, self.outs):
             self.evaluate(plan, self.w, self.exponent, P, out)
         if len(self.outs) == 1:

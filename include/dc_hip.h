@@ -374,6 +374,14 @@ int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e
                              double eps, double weight_decay, int32_t* ready, double* out_prev, dcStream_t stream);
 int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg, double* exp_avg_sq, int64_t step, double grad_scale,
                             double lr, double beta1, double beta2, double eps, double weight_decay, double* out, dcStream_t stream);
+/* The same idea when several sequences / ranks share the weights (an all-reduce of the sums sits between an evaluation and
+ * its update, so a launch cannot sum the previous rows itself): evaluation `step`, whose leading blocks first take Adam update
+ * step - 1 from grad_sum (device fp64 [P]: the previous evaluation's dL/dw summed over all ranks; NULL for the first call),
+ * followed by the ordinary reduction of THIS evaluation into out -- three launches per multi-rank step (evaluation,
+ * reduction, all-reduce) instead of four (+ dc_adam_step).  The last update of a loop is a plain dc_adam_step. */
+int dc_sequence_eval_after_update(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                                  double* exp_avg_sq, int64_t step, const double* grad_sum, double grad_scale, double lr, double beta1,
+                                  double beta2, double eps, double weight_decay, int32_t* ready, double* out, dcStream_t stream);
 
 /* torch.optim.Adam step (train.py:139-149,312) on a device fp64 vector; grad is multiplied by grad_scale first
  * (1 / number of masked points of all sequences = the reference's mean reduction, loss.py:205-213). */

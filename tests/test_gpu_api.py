@@ -247,6 +247,31 @@ def test_chained_steps_equal_ordinary_steps(golden, dtype, ragged):
     assert np.array_equal(npy(a.w), npy(b.w)) and abs(npy(a.w)[0] - g['w'][0]) > 1e-3
 
 
+def test_update_in_next_launch_equals_separate_adam(golden):
+    """The multi-rank form of a step (evaluation -> reduction -> all-reduce -> Adam) with the Adam update moved into the next
+    evaluation's launch (dc_sequence_eval_after_update): the sums of every step are the ordinary ones (current, not lagged),
+    the weights after flush() too.  Run on one rank (the all-reduce is the identity there)."""
+    from depth_correction_amd.plan import SequencePlan, SequenceTrainer
+    g = golden('room_k10')
+    cfg = _cfg(g)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    plan = SequencePlan(clouds, poses, ns[0], mask)
+    plain = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2, distributed=True)
+    moved = SequenceTrainer([plan], g['w'], g['exponent'], [poses], lr=1e-2, distributed=True, chained=True)
+    assert moved.update_in_next and not moved.chained and not plain.update_in_next
+    for it in range(9):
+        a, b = npy(moved.step()).copy(), npy(plain.step()).copy()
+        assert moved.update_in_next and a[1] == b[1]
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-11)
+        np.testing.assert_allclose(a[2:], b[2:], rtol=1e-9, atol=1e-12 * np.abs(b[2:]).max())
+        if it == 4:
+            moved.flush()                                      # a flush in the middle: the chain simply continues
+            np.testing.assert_allclose(npy(moved.w), npy(plain.w), rtol=1e-10)
+    moved.flush()
+    np.testing.assert_allclose(npy(moved.w), npy(plain.w), rtol=1e-10)
+    assert abs(npy(moved.w)[0] - g['w'][0]) > 1e-3
+
+
 @pytest.mark.parametrize('fused', [True, False])
 def test_icp_loss_golden(golden, fused):
     from depth_correction_amd.depth_cloud import DepthCloud
