@@ -89,6 +89,8 @@ class RoomBoxDataset(_Seq):
     half = np.array([10.0, 7.0, 2.0])
 
     def __init__(self, name='room', n_pts=200_000, n_poses=10, seed_base=1000, range_noise=1e-3, dtype=np.float64):
+        if n_poses > 14:
+            raise ValueError('RoomBoxDataset: view point s sits at x = -4.5 + s, inside the 10 m half extent only for s <= 14')
         self.name, self.n_pts, self.n_poses = name, n_pts, n_poses
         self.seed_base, self.range_noise, self.dtype = seed_base, range_noise, dtype
         self.ids = range(n_poses)
