@@ -190,6 +190,22 @@ def cpu_baseline(scans_xyz, poses, k, n_iters, lr, variants):
     return out
 
 
+def launch_ranks(n):
+    """Start `n` ranks of this script (one per GPU, RCCL over xGMI) as a child process and wait for them; returns the
+    children's exit code.  The parent stays off the GPU for its whole life."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def load_profile_table():
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(path):
@@ -203,8 +219,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python3 bench.py --gpus N` on its own: this process has not touched the GPU (importing torch does not), so it
+        # may start the N ranks as a CHILD torch.distributed.run (never exec) and hand back their exit code; rank 0 of the
+        # children prints the one JSON line on the inherited stdout
+        sys.exit(launch_ranks(args.gpus))
+    if args.gpus != world:
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree' % (args.gpus, world))
+    n_visible = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if local_rank >= n_visible:
+        raise SystemExit('bench.py rank %d of %d: needs GPU index %d but this node shows %d GPU(s); --gpus must not exceed '
+                         'the GPUs of the node' % (rank, world, local_rank, n_visible))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -379,6 +404,22 @@ def main():
     elapsed = float(el.item())
     loss = loss.detach().cpu()
     final_loss = float(loss) if loss.numel() == 1 else float(loss[0] / loss[1])
+    rccl = None
+    if dist is not None:
+        # the path's only exchange, measured by itself right after the timed region (all ranks take part): the packed fp64
+        # vector [sum loss, count, dL/dw] every step all-reduces, 100 back-to-back calls between two events
+        buf = torch.zeros((2 + len(w0),), dtype=torch.float64, device=dev)
+        for _ in range(10):
+            dist.all_reduce(buf)
+        ar0, ar1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ar0.record()
+        for _ in range(100):
+            dist.all_reduce(buf)
+        ar1.record()
+        torch.cuda.synchronize()
+        rccl = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+                'allreduce_us_per_step': ar0.elapsed_time(ar1) * 10.0, 'allreduce_bytes': buf.numel() * 8,
+                'what': 'one all-reduce (sum) of [sum loss, count, dL/dw] per step; stand-alone time of that call, stream time'}
 
     # ---- side measurements, after the timed region (the GPU goes idle between their host-synchronised calls; run before
     # the loop they left it at idle clocks for the first timed steps)
@@ -522,6 +563,10 @@ def main():
                 'what': 'untimed dc_sequence_eval calls (loss + dL/dw, no optimiser step) before the W warm-up steps: the GPU reaches '
                         'its clocks only after ~30 ms of sustained load; --device-warmup-ms 0 turns this off'}
         out['config'].update(extras)
+        if rccl:
+            out['config'].update(rccl)
+            out['rccl_ranks'] = rccl['rccl_ranks']
+            out['allreduce_us_per_step'] = rccl['allreduce_us_per_step']
         if world == 1 and args.cpu_scans > 0:
             torch.cuda.empty_cache()
             out['cpu_baseline'] = cpu_baseline(scans_xyz[:args.cpu_scans], poses[:args.cpu_scans], args.k,

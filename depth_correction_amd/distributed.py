@@ -26,22 +26,32 @@ def shard_sequences(n_sequences, rank, world):
 
 
 def all_reduce_sum(vec, group=None):
-    """In-place sum of ``vec`` over the ranks (no-op for a single process)."""
+    """In-place sum of ``vec`` over the ranks (no-op for a single process; with DC_FORCE_DIST=1 in the environment a
+    one-rank group still issues the collective, which is how the RCCL path is exercised on a one-GPU box)."""
+    import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get('DC_FORCE_DIST') == '1'):
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     return vec
 
 
-def gather_objects(obj, group=None):
+def gather_objects(obj, group=None, device=None):
     """List with every rank's ``obj`` (rank order) on every rank; ``[obj]`` for a single process.  Checkpoint-time
-    only (pose corrections of the sequences other ranks own): small pickled tensors, not on the iteration path."""
+    only (pose corrections of the sequences other ranks own): small pickled tensors, not on the iteration path.
+    Under RCCL the pickled bytes are staged on torch's CURRENT device, so ``device`` (this rank's GPU) is made current
+    for the call -- a launcher that passes cfg.device = 'cuda:<local rank>' without torch.cuda.set_device would otherwise
+    stage every rank's buffer on cuda:0."""
     import torch.distributed as dist
     rank, world = world_info(group)
     if world == 1:
         return [obj]
     out = [None] * world
-    dist.all_gather_object(out, obj, group=group)
+    dev = torch.device(device) if device is not None else None
+    if dev is not None and dev.type == 'cuda':
+        with torch.cuda.device(dev):
+            dist.all_gather_object(out, obj, group=group)
+    else:
+        dist.all_gather_object(out, obj, group=group)
     return out
 
 

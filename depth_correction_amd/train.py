@@ -113,6 +113,10 @@ def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     callbacks = callbacks or TrainCallbacks(cfg)
     rank, world = world_info() if getattr(cfg, 'distributed', None) is not False else (0, 1)
     sharded = world > 1
+    if sharded and torch.device(cfg.device).type == 'cuda':
+        # object collectives (the checkpoint gather) and RCCL's own staging use torch's current device: it must be this
+        # rank's GPU, whatever the launcher did
+        torch.cuda.set_device(torch.device(cfg.device))
     os.makedirs(cfg.log_dir, exist_ok=True)
     cfg_path = os.path.join(cfg.log_dir, 'train.yaml')
     if rank == 0 and not os.path.exists(cfg_path):
@@ -224,7 +228,7 @@ def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
             poses_out = [p.detach().cpu().clone() for p in train_poses_upd if p is not None]
             if sharded:
                 # sequence order: rank r owns sequences r, r + world, ...; every rank takes part in the gather
-                by_rank = gather_objects((shard_sequences(n_train, rank, world), deltas, poses_out))
+                by_rank = gather_objects((shard_sequences(n_train, rank, world), deltas, poses_out), device=cfg.device)
                 deltas, poses_out = n_train * [None], n_train * [None]
                 for idx, ds_, ps_ in by_rank:
                     for k, i in enumerate(idx):
