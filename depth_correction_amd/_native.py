@@ -42,6 +42,7 @@ _SIGNATURES = {
     'dc_points_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'dc_partial_rows': (_i64, [_i64]),
     'dc_param_grad_count': (_i32, [_i32, _i32]),
+    'dc_sequence_partials_count': (_i64, [_i64, _i32, _i32]),
     'dc_points_bwd': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32,
                              _i32, _vp, _vp, _vp]),
     'dc_features_fwd': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -115,7 +116,8 @@ class SequenceDesc(ctypes.Structure):
                 ('n_centres', ctypes.c_int64), ('x', _vp), ('rec', _vp),
                 ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp)]
+                ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp),
+                ('partials_count', ctypes.c_int64)]
 
 
 def lib_path():

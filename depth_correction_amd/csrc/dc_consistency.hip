@@ -1185,9 +1185,11 @@ struct StepChain {
   const double* grad_sum;    // or: the previous evaluation's dL/dw already summed (over the ranks: an all-reduce ran in between);
                              // the leading blocks then only take the Adam update (out_prev is not written)
   double* out_prev;          // [n_out] <- sums of the previous evaluation (slots beyond 2 + P: 0)
-  const int32_t* status;
+  int32_t* status;           // bit 0: a point left the q32 extent (read); bit 1: a wait for the weights ran out (raised here)
+  int spin_limit;            // polls a waiting block makes before it gives up (dc_set_option(5, n); 0: gives up at once)
   AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
 };
+constexpr int32_t kStatusChainTimeout = 2;     // (bit 0: q32 overflow, raised by quantize())
 constexpr int kChainFront = 8;             // leading blocks of a chained launch (a multiple of the XCD count)
 
 template <int P>
@@ -1209,7 +1211,8 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch) {
     return;
   }
   const bool step = ch.has_prev && ch.adam.p && a >= 2 && threadIdx.x == 0;
-  const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && ch.status && *ch.status != 0;
+  const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && ch.status &&
+                       __hip_atomic_load(ch.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   double p0 = 0.0, m0 = 0.0, v0 = 0.0;
   if (step) { p0 = ch.adam.p[a - 2]; m0 = ch.adam.m[a - 2]; v0 = ch.adam.v[a - 2]; }
   double s = 0.0;
@@ -1251,12 +1254,14 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch) {
 __device__ __forceinline__ bool chain_wait(const StepChain& ch, int n_weights, int* s_ok) {
   if (threadIdx.x == 0) {
     int ok = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+    for (int spin = 0; spin < ch.spin_limit; ++spin) {
       // relaxed: an agent-scope acquire would invalidate this XCD's L2 on every poll; the weights are read with
       // device-coherent loads afterwards instead
       if (__hip_atomic_load(ch.ready + ch.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_weights) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
+    // a wait that ran out poisons this launch's sums (NaN) AND says so: the status word tells it apart from a q32 overflow
+    if (!ok && ch.status) atomicOr(ch.status, kStatusChainTimeout);
     *s_ok = ok;
   }
   __syncthreads();
@@ -1841,6 +1846,7 @@ static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
 static std::atomic<bool> g_two_pass{false};     // dc_set_option(4, 1): basis form with separate forward and backward kernels
+static std::atomic<int> g_chain_spin{1 << 22};  // dc_set_option(5, n): polls of a chained launch's wait for its weights (tests force 0)
 static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's basis rows (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
 // a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
@@ -1908,6 +1914,13 @@ int dc_version(void) { return 100; }
 int64_t dc_partial_rows(int64_t n) { return xcd_grid(n_blocks(n)) * kWavesPerBlock; }
 
 int dc_param_grad_count(int n_terms, int n_scans) { return 2 * n_terms + 12 * n_scans; }
+
+// ordinary evaluations: rows x (2 + 2 P + 12 S) columns; chained steps: two buffers of (2 + P) columns behind them (chain_buffer)
+int64_t dc_sequence_partials_count(int64_t n, int n_terms, int n_scans) {
+  if (n < 0 || n_terms < 0 || n_scans < 0) return 0;
+  const int64_t rows = xcd_grid(n_blocks(n)) * kWavesPerBlock;
+  return rows * (2 + 2 * (int64_t)n_terms + 12 * (int64_t)n_scans) + 2 * (2 + (int64_t)n_terms) * rows;
+}
 
 static PointInputs make_inputs(const void* vps, const void* dirs, const void* depth, const void* inc,
                                const uint8_t* lmask, const int32_t* scan_id, const double* poses, int n_scans,
@@ -2204,6 +2217,7 @@ int dc_set_option(int option, int value) {
   if (option == 1) { g_fwd_generic.store(value); return DC_OK; }
   if (option == 3) { g_no_basis.store(value != 0); return DC_OK; }
   if (option == 4) { g_two_pass.store(value != 0); return DC_OK; }
+  if (option == 5) { g_chain_spin.store(value < 0 ? (1 << 22) : value); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -2303,6 +2317,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   const int n_terms = d->model_kind == DC_MODEL_NONE ? 0 : d->n_terms;
   const int n_acc = 2 * n_terms + 12 * d->n_scans;
   if (d->n == 0) return (int)hipMemsetAsync(out, 0, (size_t)(2 + n_acc) * sizeof(double), stream);
+  if (d->partials_count < dc_sequence_partials_count(d->n, n_terms, d->n_scans)) return DC_ERR_WORKSPACE;
   const int64_t n_rows = d->centre_idx ? d->n_centres : d->n;      // forward rows (centres); the backward runs over all points
   if (d->centre_idx && (d->n_centres < 0 || d->n_centres > d->n)) return DC_ERR_ARG;
   const int64_t rows = xcd_grid(n_blocks(d->n)) * kWavesPerBlock;      // partial rows: one per wavefront
@@ -2347,7 +2362,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         p_bwd = p_fwd + 2 * g_blocks;
         ch.ready = chain->ready; ch.parity = chain->parity; ch.has_prev = chain->has_prev; ch.n_front = kChainFront;
         ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
-        ch.out_prev = chain->out_prev; ch.status = (const int32_t*)d->status; ch.adam = chain->adam_prev;
+        ch.out_prev = chain->out_prev; ch.status = d->status; ch.spin_limit = g_chain_spin.load(); ch.adam = chain->adam_prev;
         ch.grad_sum = chain->grad_sum;
       }
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
@@ -2496,6 +2511,7 @@ int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg,
   int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step, grad_scale, lr, beta1, beta2, eps, weight_decay, &a);
   if (rc) return rc;
   const int n_terms = d->n_terms, n_acc = 2 * n_terms + 12 * d->n_scans;
+  if (!d->partials || d->partials_count < dc_sequence_partials_count(d->n, n_terms, d->n_scans)) return DC_ERR_WORKSPACE;
   const int64_t n_rows = d->centre_idx ? d->n_centres : d->n;
   const int64_t g_blocks = xcd_grid(n_blocks(n_rows));
   const double* buf = chain_buffer(d, n_terms, (int)(step & 1));

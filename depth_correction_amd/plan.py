@@ -158,9 +158,9 @@ class SequencePlan:
         pdt = torch.int32 if self.qfmt is not None else self.dtype
         self.x = torch.empty((self.n, 4), dtype=pdt, device=dev)
         self.rec = torch.empty((nbr.shape[0], 8), dtype=pdt, device=dev)
-        rows = ops.lib().dc_partial_rows(self.n)
-        nacc = 2 * ops.nv.MAX_MODEL_TERMS + 12 * self.n_scans
-        self.partials = torch.empty((rows * (nacc + 2),), dtype=torch.float64, device=dev)
+        # sized by the library for the largest term count (ordinary columns + the two row buffers of chained steps)
+        self.partials = torch.empty((ops.lib().dc_sequence_partials_count(self.n, ops.nv.MAX_MODEL_TERMS, self.n_scans),),
+                                    dtype=torch.float64, device=dev)
         self.version = 0
         self._desc = None
         self.use_basis = bool(basis)
@@ -205,6 +205,7 @@ class SequencePlan:
             d.bwd_table = None if self._bwd_table is None else self._bwd_table.ref()
             d.centre_idx, d.n_centres = p(self.centre_idx), (0 if self.centre_idx is None else self.centre_idx.shape[0])
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
+            d.partials_count = self.partials.numel()
             d.status = p(self.status)
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
@@ -424,10 +425,25 @@ class SequencePlan:
                                        qfmt=self.qfmt, lane_perm=self.lane_perm, table=self.bwd_table)
         return grads
 
+    STATUS_OVERFLOW, STATUS_CHAIN_TIMEOUT = 1, 2
+
+    def status_bits(self):
+        """The sequence's status word (synchronises): bit 0 = an evaluation produced points outside the q32 format's extent
+        or NaN points, bit 1 = a chained launch's wait for its weights ran out.  Either makes the losses NaN until
+        ``clear_status``."""
+        return int(self.status.item())
+
     def overflowed(self):
         """True when an evaluation produced points outside the q32 format's extent (poses moved far from the initial
         map) or NaN points; the losses of such evaluations are NaN.  Synchronises."""
-        return bool(self.status.item())
+        return bool(self.status_bits() & self.STATUS_OVERFLOW)
+
+    def chain_timed_out(self):
+        """True when a chained step gave up waiting for the weights of its launch (its sums are NaN).  Synchronises."""
+        return bool(self.status_bits() & self.STATUS_CHAIN_TIMEOUT)
+
+    def clear_status(self):
+        self.status.zero_()
 
     def unpermute(self, t):
         """Per-point tensor in plan order -> the caller's scan-major order."""

@@ -324,7 +324,7 @@ int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, con
  * dcSequenceDesc.basis set and no pose / exponent gradient requested, the basis form: no pass over the points, and for up
  * to three weights a single kernel that returns the loss AND dL/dw (second sweep over each centre's own neighbours; no
  * backward record, no transposed table).
- * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_partial_rows(n) * (2 + 2 P + 12 S)] are scratch. */
+ * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_sequence_partials_count(n, P, S)] are scratch. */
 typedef struct dcSequenceDesc {
   int64_t n;
   int32_t k, n_scans, dtype, point_fmt;
@@ -343,10 +343,17 @@ typedef struct dcSequenceDesc {
   const dcBlockTable* fwd_table;   /* block table of nbr, or NULL */
   const dcBlockTable* bwd_table;   /* block table of (csr_ptr, csr_src), or NULL */
   int32_t* status;                 /* device int or NULL: bit 0 raised by dc_points_fwd when a DC_Q32 coordinate overflowed /
-                                      was NaN; while it is set the evaluation's loss (out[0]) is NaN */
+                                      was NaN, bit 1 by a chained launch whose wait for its weights ran out (dc_set_option 5);
+                                      while it is non-zero the evaluation's loss (out[0]) is NaN */
   const void* basis;               /* basis rows of dc_points_basis, valid FOR THE POSES AND EXPONENTS OF THE CALL, or NULL:
                                       x = X0 + (sum_k w_k c_k) u, so an evaluation needs no pass over the points */
+  int64_t partials_count;          /* doubles behind `partials`: at least dc_sequence_partials_count(n, n_terms, n_scans), checked by
+                                      every call (DC_ERR_WORKSPACE) -- the chained steps keep their rows behind the ordinary columns */
 } dcSequenceDesc;
+
+/* Doubles of dcSequenceDesc.partials for a sequence of n points evaluated with up to n_terms weights and n_scans poses:
+ * dc_partial_rows(n) * (2 + 2 n_terms + 12 n_scans) for ordinary evaluations plus the two row buffers of chained steps. */
+int64_t dc_sequence_partials_count(int64_t n, int n_terms, int n_scans);
 
 /* out fp64 [2 + 2 P + 12 S] = {sum of pointwise loss over mask, mask count, d(sum)/dw, /dexponent, /d[R|t]};
  * w, e, poses: device fp64 (model weights [P], exponents [P], poses [S,12]). */
@@ -429,7 +436,10 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
  *           k = 4 / 8 / 10 / 16.
  * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.basis (general path).
  * option 4: value 1 makes basis-form evaluations run the forward and the backward kernel separately instead of the one-pass
- *           loss + dL/dw kernel. */
+ *           loss + dL/dw kernel.
+ * option 5: number of polls a chained launch's blocks make while they wait for the weights its leading blocks publish
+ *           (default 2^22, negative restores it).  A wait that runs out yields NaN sums for that evaluation and raises bit 1 of
+ *           dcSequenceDesc.status (bit 0: DC_Q32 overflow), so the two causes of a NaN loss can be told apart; tests force 0. */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)

@@ -322,3 +322,95 @@ def test_q32_overflow_is_reported_and_large_maps_use_fp64():
     # and a compact map still takes q32
     plan3, _ = build_sequence(scans, poses, k=10, dtype=torch.float32)
     assert plan3.point_format == ('q32' if plan3.qfmt is not None else 'f64')
+
+
+@pytest.mark.timeout(900)
+def test_c2_full_size_chained_steps_equal_ordinary_steps_and_the_oracle_adam_loop(room):
+    """The path bench.py TIMES, at the size it is timed at (N = 2 M: 7 816 + 8 blocks, far more than are resident at once,
+    so blocks of a chained launch really do wait for weights that its leading blocks publish): (a) 25 chained steps
+    (SequenceTrainer(chained=True) = dc_sequence_step_chained, one flush in the middle) equal 25 ordinary steps -- sums to
+    1e-11, weights to 1e-10; (b) the first 3 steps' loss, dL/dw and updated weights equal the oracle's eval_sequence +
+    torch.optim.Adam loop (train.py:300-312) to the north-star 1e-5."""
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import SequenceTrainer
+    scans, poses = room
+    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    w0, e0, lr = [1e-3, 2e-3], [2.0, 4.0], 1e-3
+    plain = SequenceTrainer([plan], w0, e0, [info['poses']], lr=lr)
+    ref, ref_w = [], []
+    for _ in range(25):
+        ref.append(npy(plain.step()).copy())
+        ref_w.append(npy(plain.w).copy())
+    chain = SequenceTrainer([plan], w0, e0, [info['poses']], lr=lr, chained=True)
+    got = []
+    for it in range(25):
+        prev = npy(chain.step()).copy()
+        assert chain.chained
+        if it not in (0, 12):                                  # nothing pending at the start and right after the flush
+            got.append(prev)
+        if it in (11, 24):
+            got.append(npy(chain.flush()).copy())
+            np.testing.assert_allclose(npy(chain.w), ref_w[it], rtol=1e-10)
+    torch.cuda.synchronize()
+    assert len(got) == 25 and chain.t == 25 and not plan.chain_timed_out() and not plan.overflowed()
+    for a, b in zip(got, ref):
+        assert a[1] == b[1] and a[1] > 1.0e6
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-11)
+        np.testing.assert_allclose(a[2:], b[2:], rtol=1e-9, atol=1e-12 * np.abs(b[2:]).max())
+    np.testing.assert_allclose(npy(chain.w), npy(plain.w), rtol=1e-10)
+    assert abs(npy(chain.w)[0] - w0[0]) > 5e-3                 # 25 Adam steps of 1e-3 moved the weights
+
+    # (b) the oracle's loop on the same inputs: 3 iterations of eval_sequence (mean) -> backward -> torch.optim.Adam
+    oc = [dict(vps=c['vps'].double().cpu(), dirs=c['dirs'].double().cpu(), depth=c['depth'].double().cpu(),
+               inc=c['inc_angles'].double().cpu(), mask=c['mask'].cpu()) for c in info['clouds']]
+    wo = torch.nn.Parameter(torch.tensor([w0], dtype=torch.float64))
+    eo = torch.tensor([e0], dtype=torch.float64)
+    opt = torch.optim.Adam([wo], lr=lr)
+    nbr, mask, T = info['neighbors'].long().cpu(), info['mask'].cpu(), info['poses'].cpu()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        for it in range(3):
+            opt.zero_grad()
+            lo, _ = O.eval_sequence(oc, T, wo, eo, nbr, mask, reduction='mean')
+            lo.backward()
+            cnt = got[it][1]
+            np.testing.assert_allclose(got[it][0] / cnt, lo.item(), rtol=1e-5)
+            g = npy(wo.grad).ravel()
+            np.testing.assert_allclose(got[it][2:] / cnt, g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
+            opt.step()
+            # Adam normalises the gradient (lr * m / sqrt(v)): the first updates are +-lr whatever the magnitude, so the bar
+            # on the weights is the bar on the gradient's direction
+            np.testing.assert_allclose(ref_w[it], npy(wo).ravel(), rtol=1e-5)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def test_chained_wait_that_expires_is_reported_not_just_nan(room):
+    """A chained launch whose blocks give up waiting for their weights (forced: zero polls) must not pass as a number and
+    must not look like a q32 overflow: NaN sums AND bit 1 of the status word (SequencePlan.chain_timed_out)."""
+    from depth_correction_amd import _native as nv
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import SequenceTrainer
+    scans, poses = room
+    plan, info = build_sequence([s[:50_000] for s in scans[:3]], poses[:3], k=10, dtype=torch.float32)
+    tr = SequenceTrainer([plan], [1e-3, 2e-3], [2.0, 4.0], [info['poses']], lr=1e-3, chained=True)
+    for _ in range(3):
+        tr.step()
+    ok = npy(tr.flush()).copy()
+    assert np.isfinite(ok).all() and plan.status_bits() == 0
+    nv.check(nv.lib().dc_set_option(5, 0), 'dc_set_option')
+    try:
+        tr.step()
+        bad = npy(tr.flush()).copy()
+    finally:
+        nv.check(nv.lib().dc_set_option(5, -1), 'dc_set_option')
+    torch.cuda.synchronize()
+    assert np.isnan(bad[0]) and plan.chain_timed_out() and not plan.overflowed()
+    assert plan.status_bits() == plan.STATUS_CHAIN_TIMEOUT
+    plan.clear_status()
+    # the sequence is usable again (fresh trainer: the poisoned one carries NaN weights)
+    tr2 = SequenceTrainer([plan], [1e-3, 2e-3], [2.0, 4.0], [info['poses']], lr=1e-3, chained=True)
+    tr2.step()
+    again = npy(tr2.flush()).copy()
+    assert np.isfinite(again).all() and not plan.chain_timed_out()
