@@ -72,6 +72,7 @@ def parse():
                          '(one launch per step: each launch also finishes the previous step; dc_sequence_step_chained)')
     ap.add_argument('--two-pass', action='store_true', help='basis form with separate forward and backward kernels (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
+    ap.add_argument('--step-var', type=int, default=None, help='dc_set_option(6, v): form of the one-pass step kernel (A-B measurements)')
     return ap.parse_args()
 
 
@@ -290,6 +291,8 @@ def main():
         nv.check(nv.lib().dc_set_option(1, 1), 'dc_set_option')
     if args.two_pass:
         nv.check(nv.lib().dc_set_option(4, 1), 'dc_set_option')
+    if args.step_var is not None:
+        nv.check(nv.lib().dc_set_option(6, args.step_var), 'dc_set_option')
     # the k-NN build alone, on the global cloud (reported separately)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()

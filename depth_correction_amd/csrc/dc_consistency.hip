@@ -903,19 +903,21 @@ template <> struct Basis<q32> {
     int32_t q[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) q[c] = r[c];
-    double sc = 0.0;
+    // float32 throughout (one formula for every kernel that forms a point from its basis row, so that all of them form the
+    // same integer): the correction sum is < 2^20 grid steps, its float32 rounding a few hundredths of a step
+    float sc = 0.0f;
     if constexpr (P > 0) {
       float c[P];
 #pragma unroll
       for (int k = 0; k < P; ++k) c[k] = __int_as_float(r[6 + k]);
 #pragma unroll
-      for (int k = 0; k < P; ++k) sc += wq[k] * (double)c[k];
+      for (int k = 0; k < P; ++k) sc = fmaf((float)wq[k], c[k], sc);
     } else {
-      for (int k = 0; k < np; ++k) sc += wq[k] * (double)__int_as_float(r[6 + k]);
+      for (int k = 0; k < np; ++k) sc = fmaf((float)wq[k], __int_as_float(r[6 + k]), sc);
     }
     Pt<q32>::Raw o;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
+    for (int a = 0; a < 3; ++a) o.v[a] = q[a] + (int32_t)rintf(sc * __int_as_float(q[3 + a]));
     return o;
   }
   static __device__ __forceinline__ void stage(int4* tile, int, int t, const Pt<q32>::Raw& r) { tile[t] = make_int4(r.v[0], r.v[1], r.v[2], 0); }
@@ -1193,8 +1195,7 @@ constexpr int32_t kStatusChainTimeout = 2;     // (bit 0: q32 overflow, raised b
 constexpr int kChainFront = 8;             // leading blocks of a chained launch (a multiple of the XCD count)
 
 template <int P>
-__device__ __forceinline__ void chain_front_block(const StepChain& ch) {
-  __shared__ double lds[kBlock / kWave];
+__device__ __forceinline__ void chain_front_block(const StepChain& ch, double* lds /* [kBlock / kWave] in LDS */) {
   const int a = blockIdx.x;
   if (a == 0) {
     if (threadIdx.x == 0) __hip_atomic_store(ch.ready + (ch.parity ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1294,12 +1295,12 @@ template <int P> struct StepRow<q32, P> {
   }
   static __device__ __forceinline__ void place(const Raw& raw, const double* wq, int4* tile, int cap, int t) {
     const int32_t* q = raw.q;
-    double sc = 0.0;
+    float sc = 0.0f;                                      // exactly Basis<q32>::point's arithmetic
 #pragma unroll
-    for (int k = 0; k < P; ++k) sc += wq[k] * (double)__int_as_float(q[6 + k]);
+    for (int k = 0; k < P; ++k) sc = fmaf((float)wq[k], __int_as_float(q[6 + k]), sc);
     int32_t x[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) x[a] = q[a] + (int32_t)rint(sc * (double)__int_as_float(q[3 + a]));
+    for (int a = 0; a < 3; ++a) x[a] = q[a] + (int32_t)rintf(sc * __int_as_float(q[3 + a]));
     tile[t] = make_int4(x[0], x[1], x[2], q[3]);
     tile[cap + t] = make_int4(q[4], q[5], q[6], P > 1 ? q[P > 1 ? 7 : 6] : 0);
     if constexpr (P > 2) tile[2 * cap + t] = make_int4(q[8], 0, 0, 0);
@@ -1399,9 +1400,140 @@ __device__ __forceinline__ void step_point(CovAcc& acc, bool m, const LossParams
   if (!(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
 }
 
+// ---- the slimmer forms of the one-pass kernel's per-centre work (VAR bits of consistency_step_basis_kernel) ----------------
+constexpr int kVarF32Sweep = 1;     // second sweep in float32 (q32 points: differences, u and c are float32-exact already)
+constexpr int kVarSlimTail = 2;     // covariance -> eigenpair -> loss without the intermediate normalisations (eig3_smallest_unit)
+constexpr int kVarDppSums = 4;      // wavefront sums through DPP row operations instead of ds_bpermute shuffles
+constexpr int kStepVar = kVarF32Sweep | kVarSlimTail | kVarDppSums;     // what every instantiation but the A-B baseline (0) uses
+
+// Covariance, smallest eigenpair, loss and the coefficients c1, c2 of a centre from its moments about the centre point.
+// The covariance is only ever needed divided by its trace (eig3_smallest_unit), so the Bessel / unit factor f = unit^2 / D
+// multiplies the trace alone; `full` (wave-uniform): every lane of the wavefront has all NS neighbours, W and D are constants.
+template <typename PT, int NS>
+__device__ __forceinline__ void step_point2(const CovAcc& acc, int n_have, bool full, bool m, const LossParams& lp, const QParams& qp,
+                                            double* acc2, double* cm, double* v0, double* c1, double* c2) {
+  const double u = Pt<PT>::unit(qp);
+  double invW, D, invD;
+  if (full) {
+    invW = 1.0 / NS; D = NS - 1.0; invD = 1.0 / (NS - 1.0);
+  } else {
+    const double W = (double)n_have;
+    invW = recip1_(W);                                  // W = 0: inf * 0 -> NaN mean, like the reference's 0 / 0
+    D = W - 1.0;
+    D = D < 1e-6 ? 1e-6 : D;
+    invD = recip1_(D);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) cm[a] = acc.s[a] * invW;
+  double Cp[6];
+  Cp[0] = fma(-acc.s[0], cm[0], acc.S[0]); Cp[1] = fma(-acc.s[0], cm[1], acc.S[1]); Cp[2] = fma(-acc.s[0], cm[2], acc.S[2]);
+  Cp[3] = fma(-acc.s[1], cm[1], acc.S[3]); Cp[4] = fma(-acc.s[1], cm[2], acc.S[4]); Cp[5] = fma(-acc.s[2], cm[2], acc.S[5]);
+  const double mp = (Cp[0] + Cp[3]) + Cp[5];            // trace in the units of the differences
+  const double f = (u * u) * invD;
+  const double tr = mp * f;
+  double lam_rel, inv_tr;
+  if (!(mp > 0.0) || !(mp < (double)INFINITY)) {
+    const bool zero = (mp == 0.0) && Cp[1] == 0.0 && Cp[2] == 0.0 && Cp[4] == 0.0;
+    lam_rel = zero ? 0.0 : (double)NAN;
+    inv_tr = 1e6;                                       // tr is 0 (or NaN): the clamp of loss.py:253 applies
+    v0[0] = 1.0; v0[1] = 0.0; v0[2] = 0.0;
+  } else {
+    const double inv_m = recip1_(mp);
+    eig3_smallest_unit<!std::is_same<PT, q32>::value>(Cp[0] * inv_m, Cp[1] * inv_m, Cp[2] * inv_m, Cp[3] * inv_m, Cp[4] * inv_m, Cp[5] * inv_m,
+                                                       &lam_rel, v0);
+    const double inv_u2 = std::is_same<PT, q32>::value ? qp.inv_scale * qp.inv_scale : 1.0;
+    inv_tr = inv_m * (D * inv_u2);                      // 1 / tr = 1 / (mp f)
+  }
+  const double lam0 = lam_rel * tr;
+  // loss_and_coeffs with the reciprocals at hand
+  double raw, g_vv = 0.0, g_eye = 0.0;
+  if (lp.kind == DC_LOSS_MIN_EIGVAL) {
+    if (lp.normalization) {
+      const double inv = tr < 1e-6 ? 1e6 : inv_tr;      // 1 / clamp(tr, 1e-6); NaN compares false
+      raw = lam0 * inv;
+      g_vv = inv;
+      g_eye = (tr > 1e-6) ? -raw * inv : 0.0;
+    } else {
+      raw = lam0;
+      g_vv = 1.0;
+    }
+  } else {
+    raw = tr;
+    g_eye = 1.0;
+  }
+  double l = raw;
+  double a = (m && l > 0.0) ? 1.0 : 0.0;
+  l = l > 0.0 ? l : (l != l ? l : 0.0);
+  if (lp.sqrt_) {
+    const double sq = sqrt(l);
+    a = (l > 0.0) ? a * 0.5 / sq : 0.0;
+    l = sq;
+  }
+  const double fd = 2.0 * a * invD;
+  *c1 = fd * g_vv;
+  *c2 = -fd * g_eye;
+  if (m) { acc2[0] = l; acc2[1] = 1.0; }
+  // an empty neighbourhood (NaN mean) must contribute nothing to the second sweep: only possible when slots are missing
+  if (!full && !(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
+}
+
+// One neighbour's share of dL/dw in float32 (q32 rows): the difference to the centre is an exact int32, u and c are float32
+// words already, and the per-centre factors are rounded once; the lane's sums stay float32 over its K neighbours and join the
+// fp64 reduction afterwards.  vs = c1 v0, vu = v0, both float32.
+template <int P>
+__device__ __forceinline__ void chain_term_f32(const int4* tile, int cap, uint32_t off, bool have, const Pt<q32>::Raw& ci, const float* cmf,
+                                               const float* vs, const float* vu, float c2f, float* gw) {
+  const char* row = reinterpret_cast<const char*>(tile) + (have ? off : 0u);
+  const int4 p0 = *reinterpret_cast<const int4*>(row);
+  const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)cap * 16);
+  const float e0 = (float)(p0.x - ci.v[0]) - cmf[0], e1 = (float)(p0.y - ci.v[1]) - cmf[1], e2 = (float)(p0.z - ci.v[2]) - cmf[2];
+  const float u0 = __int_as_float(p0.w), u1 = __int_as_float(p1.x), u2 = __int_as_float(p1.y);
+  const float al = fmaf(vs[2], e2, fmaf(vs[1], e1, vs[0] * e0));
+  const float be = fmaf(vu[2], u2, fmaf(vu[1], u1, vu[0] * u0));
+  const float ga = fmaf(e2, u2, fmaf(e1, u1, e0 * u0));
+  float tj = fmaf(al, be, -(c2f * ga));
+  if (!have) tj = 0.0f;
+  gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
+  if constexpr (P > 1) gw[1] = fmaf(tj, __int_as_float(p1.w), gw[1]);
+  if constexpr (P > 2) gw[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + (size_t)cap * 32)->x), gw[2]);
+}
+
+// ---- wavefront sums through DPP -------------------------------------------------------------------------------------------
+// One 32-bit half of a double moved by a DPP row operation (quad permutes, rotations inside a row of 16 lanes)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  // (every lane has a source under these controls; bound_ctrl only spares the `old` operand its initialisation)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int kDppRor4 = 0x124;     // row_ror:4
+constexpr int kDppRor8 = 0x128;     // row_ror:8
+// Four values per lane -> lane l < 4 of the wavefront holds the total of value bitrev2(l) (as wave_sum_packed<4>): two quad
+// steps that also halve what a lane carries, two rotations inside the rows, two cross-row exchanges.
+__device__ __forceinline__ double wave_sum4_dpp(double* v) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool up1 = (lane & 1) != 0, up2 = (lane & 2) != 0;
+  // bit 0: this lane keeps values {0, 1} (bit clear) or {2, 3} (bit set), the partner the others
+  const double k0 = up1 ? v[2] : v[0], g0 = up1 ? v[0] : v[2];
+  const double k1 = up1 ? v[3] : v[1], g1 = up1 ? v[1] : v[3];
+  const double a0 = k0 + dpp_f64<kDppXor1>(g0);
+  const double a1 = k1 + dpp_f64<kDppXor1>(g1);
+  // bit 1: keeps the first of its two (bit clear) or the second
+  const double kk = up2 ? a1 : a0, gg = up2 ? a0 : a1;
+  double r = kk + dpp_f64<kDppXor2>(gg);
+  r += dpp_f64<kDppRor4>(r);
+  r += dpp_f64<kDppRor8>(r);
+  r += __shfl_xor(r, 16, kWave);
+  r += __shfl_xor(r, 32, kWave);
+  return r;
+}
+
 // {sum loss, count} -> p_fwd columns, dL/dw -> p_bwd columns (same row stride: one row per wavefront), through one packed
 // wavefront reduction of the 2 + P values
-template <int P>
+template <int P, bool DPP = false>
 __device__ __forceinline__ void step_partials(const double* acc2, const double* gw, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
                                               bool per_block = false, int n_front = 0) {
   constexpr int NV = 2 + P, NP2 = NV <= 4 ? 4 : 8;
@@ -1410,7 +1542,9 @@ __device__ __forceinline__ void step_partials(const double* acc2, const double* 
   v[0] = acc2[0]; v[1] = acc2[1];
 #pragma unroll
   for (int k = 0; k < NP2 - 2; ++k) v[2 + k] = k < P ? gw[k] : 0.0;
-  double tot = wave_sum_packed<NP2>(v);
+  double tot;
+  if constexpr (DPP && NP2 == 4) tot = wave_sum4_dpp(v);
+  else tot = wave_sum_packed<NP2>(v);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   int64_t rs = (int64_t)gridDim.x * kWavesPerBlock, row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (per_block) {
@@ -1430,7 +1564,7 @@ __device__ __forceinline__ void step_partials(const double* acc2, const double* 
 }
 
 // partial rows: columns {sum loss, count} at p_fwd (stride gridDim * 4) and [0, P) dL/dw at p_bwd (same stride)
-template <typename PT, int NS, int P>
+template <typename PT, int NS, int P, int VAR = 0>
 __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
@@ -1438,8 +1572,9 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   __shared__ int s_ok;
+  __shared__ double s_front[kBlock / kWave];
   const bool chained = ch.ready != nullptr;
-  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch); return; }
+  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
   double acc2[2] = {0.0, 0.0}, gw[P];
@@ -1496,20 +1631,49 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
       else n_have = gather_fixed<PT, NS, false>(tile, cap, ci, pre, acc);
       acc.W = (double)n_have;
       double cm[3], v0[3], c1, c2;
-      step_point<PT>(acc, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
-      double mean[3];
-      StepRow<PT, P>::mean_of(ci, cm, mean);
-      // second sweep over the same slots (full wavefronts skip the validity selects)
-      if (any_miss) {
-#pragma unroll
-        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
-      } else {
-#pragma unroll
-        for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], true, mean, v0, c1, c2, gw);
-      }
+      const bool in_mask = mask ? mask[i] != 0 : true;
+      if constexpr ((VAR & kVarSlimTail) != 0) step_point2<PT, NS>(acc, n_have, !any_miss, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
+      else step_point<PT>(acc, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
       const double u = Pt<PT>::unit(qp);
+      if constexpr ((VAR & kVarF32Sweep) != 0 && std::is_same<PT, q32>::value) {
+        // second sweep in float32 (see chain_term_f32); the lane's sums join the fp64 reduction
+        float cmf[3], vs[3], vu[3], gwf[P];
 #pragma unroll
-      for (int k = 0; k < P; ++k) gw[k] *= u;            // differences were in grid steps
+        for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
+        const float c2f = (float)c2;
+#pragma unroll
+        for (int k = 0; k < P; ++k) gwf[k] = 0.0f;
+        // (groups of four with a scheduling fence between them: left alone, the compiler requests all 2 NS row pieces up
+        // front -- 80 registers -- and the kernel drops from 6 to 4 wavefronts per SIMD)
+        if (any_miss) {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
+            chain_term_f32<P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cmf, vs, vu, c2f, gwf);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
+            chain_term_f32<P>(tile, cap, pre[q], true, ci, cmf, vs, vu, c2f, gwf);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * u;
+      } else {
+        double mean[3];
+        StepRow<PT, P>::mean_of(ci, cm, mean);
+        // second sweep over the same slots (full wavefronts skip the validity selects)
+        if (any_miss) {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
+        } else {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) chain_term<PT, P>(tile, cap, pre[q], true, mean, v0, c1, c2, gw);
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) gw[k] *= u;            // differences were in grid steps
+      }
     }
   } else {
     if (chained) chain_wait(ch, P, &s_ok);
@@ -1517,7 +1681,169 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
-  step_partials<P>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
+  step_partials<P, (VAR & kVarDppSums) != 0>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
+}
+
+// ---- the one-pass kernel for q32 points and a fixed slot count: what a C2 step runs ----------------------------------------
+// Same table, same basis rows, same staged rows {x0 x1 x2 u0 | u1 u2 c0 c1 | c2} (StepRow<q32, P>) and same sums as
+// consistency_step_basis_kernel<q32, NS, P>; what differs is where the instructions go (the kernel issues VALU instructions
+// ~98 % of its time -- rocprofv3 SQ_ACTIVE_INST_VALU -- so its duration IS its instruction count, at one wave64 VALU instruction
+// per four cycles per SIMD whatever the type: tools/ubench/valu_rates.hip):
+//  * the tile is STATIC LDS of kStepQ32Cap rows: its address and the piece stride are immediates of the ds_read instructions and
+//    the table's 16-bit byte offset is the address register as it stands (dynamic LDS costs a v_add per row piece: 30 per centre);
+//  * the per-centre tail is step_point2 (eig3_smallest_unit: adjugate eigenvector, reciprocals with one Newton step, the
+//    deflation path only for needles);
+//  * the second sweep is float32 (the difference to the centre is an exact int32, u and c are float32 words, the per-centre
+//    factors are rounded once);
+//  * the wavefront sums go through DPP row operations.
+// A fp64-difference row format ({x - ref} as doubles: no int -> fp conversions in the sweeps, 80 instructions fewer) was measured
+// and dropped: 48-B rows make the kernel LDS-bound (SQ_LDS_IDX_ACTIVE 87 % of its duration, 56 % of it bank conflicts of the
+// random row reads: 61 us against 52).
+constexpr int kStepQ32Cap = 512;          // rows of the static LDS tile (16 KB + 8 KB for a third piece: six blocks per CU); tables with
+                                          // more distinct rows per block take consistency_step_basis_kernel
+
+// second sweep, one neighbour (float32): gw[k] += c_kj (c1 (v . e_j)(v . u_j) - c2 (e_j . u_j)); vs = c1 v0, vu = v0
+template <int P, int CAP>
+__device__ __forceinline__ void chain_term_q32(const int4* tile, uint32_t off, bool have, const Pt<q32>::Raw& ci, const float* cmf, const float* vs,
+                                               const float* vu, float c2f, float* gw) {
+  const char* row = reinterpret_cast<const char*>(tile) + (have ? off : 0u);
+  const int4 p0 = *reinterpret_cast<const int4*>(row);
+  const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)CAP * 16);
+  const float e0 = (float)(p0.x - ci.v[0]) - cmf[0], e1 = (float)(p0.y - ci.v[1]) - cmf[1], e2 = (float)(p0.z - ci.v[2]) - cmf[2];
+  const float u0 = __int_as_float(p0.w), u1 = __int_as_float(p1.x), u2 = __int_as_float(p1.y);
+  const float al = fmaf(vs[2], e2, fmaf(vs[1], e1, vs[0] * e0));                       // c1 (v . e_j)
+  const float be = fmaf(vu[2], u2, fmaf(vu[1], u1, vu[0] * u0));                       // v . u_j
+  const float ga = fmaf(e2, u2, fmaf(e1, u1, e0 * u0));                                // e_j . u_j
+  float tj = fmaf(al, be, -(c2f * ga));
+  if (!have) tj = 0.0f;
+  gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
+  if constexpr (P > 1) gw[1] = fmaf(tj, __int_as_float(p1.w), gw[1]);
+  if constexpr (P > 2) gw[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + (size_t)CAP * 32)->x), gw[2]);
+}
+
+template <int NS, int P, int CAP>
+__global__ __launch_bounds__(kBlock) void consistency_step_q32_kernel(
+    PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, const int32_t* __restrict__ centre_idx, int64_t n,
+    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
+    StepChain ch) {
+  constexpr int NV = 2 + P, NP2 = NV <= 4 ? 4 : 8;
+  constexpr int cap = CAP;
+  __shared__ int4 tile[StepRow<q32, P>::kPieces * CAP];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  __shared__ double s_front[kWavesPerBlock];
+  __shared__ double s_comb[kWavesPerBlock * NP2];
+  __shared__ int s_ok[2];
+  const bool chained = ch.ready != nullptr;
+  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  double acc2[2] = {0.0, 0.0}, gw[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) gw[k] = 0.0;
+  const int32_t s0 = blk >= 0 ? tab.slot_ptr[blk] : 0;
+  bool bad = blk >= 0 && tab.slot_ptr[blk + 1] - s0 != NS;
+  if (blk >= 0 && !bad) {
+    const int64_t i = blk * kBlock + threadIdx.x;
+    const bool live = i < n;
+    const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    uint32_t pre[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) pre[q] = (uint32_t)lrow[q * kBlock];
+    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    const int32_t own = (own_base && !centre_idx) ? own_base[blk] : -1;
+    double wq[P];
+    if (chained) {
+      // fetch the rows this lane stages before waiting for the weights of this launch (consistency_step_basis_kernel)
+      typename StepRow<q32, P>::Raw r0, r1;
+      const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
+      if (t0 < nd) r0 = StepRow<q32, P>::fetch(pb, tab.blk_ids[base + t0]);
+      if (t1 < nd) r1 = StepRow<q32, P>::fetch(pb, tab.blk_ids[base + t1]);
+      if (!chain_wait(ch, P, s_ok)) bad = true;
+      stage_weights(pb, s_w, true);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+      if (t0 < nd) StepRow<q32, P>::place(r0, wq, tile, cap, t0);
+      if (t1 < nd) StepRow<q32, P>::place(r1, wq, tile, cap, t1);
+      for (int t = threadIdx.x + 2 * kBlock; t < nd; t += kBlock) StepRow<q32, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    } else {
+      stage_weights(pb, s_w);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+      for (int t = threadIdx.x; t < nd; t += kBlock) StepRow<q32, P>::stage(pb, wq, tab.blk_ids[base + t], tile, cap, t);
+    }
+    Pt<q32>::Raw ci;
+    if (own < 0) ci = Basis<q32>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
+    __syncthreads();
+    if (own >= 0) ci = staged_point<q32>(tile, cap, own + (live ? (int)threadIdx.x : 0));
+    if (live) {
+      CovAcc acc;
+      cov_init(acc);
+      uint32_t mx = pre[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
+      const bool any_miss = __any((int)(mx == kNoLoc)) != 0;
+      int n_have;
+      if (any_miss) n_have = gather_fixed<q32, NS, true>(tile, cap, ci, pre, acc);
+      else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
+      acc.W = (double)n_have;
+      double cm[3], v0[3], c1, c2;
+      step_point2<q32, NS>(acc, n_have, !any_miss, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+      float cmf[3], vs[3], vu[3], gwf[P];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
+      const float c2f = (float)c2;
+#pragma unroll
+      for (int k = 0; k < P; ++k) gwf[k] = 0.0f;
+      // (groups of four with a scheduling fence between them: left alone, the compiler requests every row piece up front
+      // and the kernel loses wavefronts per SIMD to the registers)
+      if (any_miss) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
+          chain_term_q32<P, CAP>(tile, pre[q], pre[q] != kNoLoc, ci, cmf, vs, vu, c2f, gwf);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
+          chain_term_q32<P, CAP>(tile, pre[q], true, ci, cmf, vs, vu, c2f, gwf);
+        }
+      }
+      const double u = qp.scale;
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * u;          // differences were in grid steps
+    }
+  } else {
+    if (chained) chain_wait(ch, P, s_ok);
+    __syncthreads();
+    __syncthreads();
+  }
+  if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
+  // ---- {sum loss, count, dL/dw} of the wavefront (one row per wavefront; chained: per block), as step_partials
+  double v[NP2];
+  v[0] = acc2[0]; v[1] = acc2[1];
+#pragma unroll
+  for (int k = 0; k < NP2 - 2; ++k) v[2 + k] = k < P ? gw[k] : 0.0;
+  double tot;
+  if constexpr (NP2 == 4) tot = wave_sum4_dpp(v);
+  else tot = wave_sum_packed<NP2>(v);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  int64_t rs = (int64_t)gridDim.x * kWavesPerBlock, row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (chained) {
+    if (lane < NP2) s_comb[wave * NP2 + lane] = tot;
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane < NP2) tot = (s_comb[lane] + s_comb[NP2 + lane]) + (s_comb[2 * NP2 + lane] + s_comb[3 * NP2 + lane]);
+    rs = (int64_t)gridDim.x - ch.n_front;
+    row = (int64_t)blockIdx.x - ch.n_front;
+  }
+  if (lane < NP2) {
+    const int q = packed_value_of_lane<NP2>(lane);
+    if (q < 2) p_fwd[q * rs + row] = tot;
+    else if (q < NV) p_bwd[(q - 2) * rs + row] = tot;
+  }
 }
 
 // the same for any slot count (radius neighbourhoods): run-time slot loops, as consistency_fwd_basis_slots_kernel
@@ -1529,8 +1855,9 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   __shared__ int s_ok;
+  __shared__ double s_front[kBlock / kWave];
   const bool chained = ch.ready != nullptr;
-  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch); return; }
+  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
   double acc2[2] = {0.0, 0.0}, gw[P];
@@ -1589,22 +1916,40 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     for (int q = kPreSlots; q < nslots; ++q) n_have += slot_add<PT, true>(tile, cap, ci, lrow[q * kBlock], acc);
     acc.W = (double)n_have;
     double cm[3], v0[3], c1, c2;
-    step_point<PT>(acc, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
-    double mean[3];
-    StepRow<PT, P>::mean_of(ci, cm, mean);
-#pragma unroll
-    for (int q = 0; q < kPreSlots; ++q)
-      if (q < nslots) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
-    for (int q = kPreSlots; q < nslots; ++q) {
-      const uint32_t l = lrow[q * kBlock];
-      chain_term<PT, P>(tile, cap, l, l != kNoLoc, mean, v0, c1, c2, gw);
-    }
+    step_point2<PT, 2>(acc, n_have, false, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
     const double u = Pt<PT>::unit(qp);
+    if constexpr (std::is_same<PT, q32>::value) {
+      float cmf[3], vs[3], vu[3], gwf[P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) gw[k] *= u;
+      for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
+      const float c2f = (float)c2;
+#pragma unroll
+      for (int k = 0; k < P; ++k) gwf[k] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < kPreSlots; ++q)
+        if (q < nslots) chain_term_f32<P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cmf, vs, vu, c2f, gwf);
+      for (int q = kPreSlots; q < nslots; ++q) {
+        const uint32_t l = lrow[q * kBlock];
+        chain_term_f32<P>(tile, cap, l, l != kNoLoc, ci, cmf, vs, vu, c2f, gwf);
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * u;
+    } else {
+      double mean[3];
+      StepRow<PT, P>::mean_of(ci, cm, mean);
+#pragma unroll
+      for (int q = 0; q < kPreSlots; ++q)
+        if (q < nslots) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
+      for (int q = kPreSlots; q < nslots; ++q) {
+        const uint32_t l = lrow[q * kBlock];
+        chain_term<PT, P>(tile, cap, l, l != kNoLoc, mean, v0, c1, c2, gw);
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] *= u;
+    }
   }
   if (timed_out) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
-  step_partials<P>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
+  step_partials<P, true>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
 }
 
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
@@ -1846,6 +2191,8 @@ static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
 static std::atomic<bool> g_two_pass{false};     // dc_set_option(4, 1): basis form with separate forward and backward kernels
+static std::atomic<int> g_step_var{1};          // dc_set_option(6, v): 1 = consistency_step_q32_kernel for float32 clouds with a [rows, K] table (default),
+                                                // 7 = consistency_step_basis_kernel<.., kStepVar> for them too, 0 = its round-2 form (K = 10, P = 2 only: A-B baseline)
 static std::atomic<int> g_chain_spin{1 << 22};  // dc_set_option(5, n): polls of a chained launch's wait for its weights (tests force 0)
 static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's basis rows (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
@@ -2218,6 +2565,7 @@ int dc_set_option(int option, int value) {
   if (option == 3) { g_no_basis.store(value != 0); return DC_OK; }
   if (option == 4) { g_two_pass.store(value != 0); return DC_OK; }
   if (option == 5) { g_chain_spin.store(value < 0 ? (1 << 22) : value); return DC_OK; }
+  if (option == 6) { g_step_var.store(value); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -2366,14 +2714,27 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         ch.grad_sum = chain->grad_sum;
       }
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
-      {
+      const int var = g_step_var.load();
+      // float32 clouds with a [rows, K] table: the kernel with fp64 row differences in LDS (48-B rows + its scratch, all dynamic)
+      const bool q32_step = q32_pts && var == 1 && (fixed_k == 10 || fixed_k == 4 || fixed_k == 8 || fixed_k == 16) && rows_s <= kStepQ32Cap;
+      if (q32_step) {
+        ProfScope prof(1);
+        static_assert(kStepQ32Cap == 512, "the profiler names the instantiation by its literal arguments");
+#define STEPQ_LAUNCH(NS, P) DC_TIMED_LAUNCH((consistency_step_q32_kernel<NS, P, 512>), grid, block, 0, stream, pb, tab, d->fwd_table->own_base, \
+                                            d->centre_idx, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch)
+#define STEPQ_P(NS) do { if (n_terms == 2) STEPQ_LAUNCH(NS, 2); else if (n_terms == 1) STEPQ_LAUNCH(NS, 1); else STEPQ_LAUNCH(NS, 3); } while (0)
+        if (fixed_k == 10) STEPQ_P(10); else if (fixed_k == 4) STEPQ_P(4); else if (fixed_k == 8) STEPQ_P(8); else STEPQ_P(16);
+#undef STEPQ_P
+#undef STEPQ_LAUNCH
+      } else {
         ProfScope prof(1);
 #define STEP_LAUNCH(K) DC_TIMED_LAUNCH(K, grid, block, lds_s, stream, pb, tab, d->fwd_table->own_base, rows_s, d->centre_idx, n_rows, \
                                        d->mask, lp, qp, p_fwd, p_bwd, ch)
-#define STEP_NS(PT, P) do { if (fixed_k == 10) STEP_LAUNCH((consistency_step_basis_kernel<PT, 10, P>)); \
-                            else if (fixed_k == 4) STEP_LAUNCH((consistency_step_basis_kernel<PT, 4, P>)); \
-                            else if (fixed_k == 8) STEP_LAUNCH((consistency_step_basis_kernel<PT, 8, P>)); \
-                            else if (fixed_k == 16) STEP_LAUNCH((consistency_step_basis_kernel<PT, 16, P>)); \
+#define STEP_NS(PT, P) do { if (fixed_k == 10 && P == 2 && var == 0) STEP_LAUNCH((consistency_step_basis_kernel<PT, 10, 2, 0>)); \
+                            else if (fixed_k == 10) STEP_LAUNCH((consistency_step_basis_kernel<PT, 10, P, kStepVar>)); \
+                            else if (fixed_k == 4) STEP_LAUNCH((consistency_step_basis_kernel<PT, 4, P, kStepVar>)); \
+                            else if (fixed_k == 8) STEP_LAUNCH((consistency_step_basis_kernel<PT, 8, P, kStepVar>)); \
+                            else if (fixed_k == 16) STEP_LAUNCH((consistency_step_basis_kernel<PT, 16, P, kStepVar>)); \
                             else STEP_LAUNCH((consistency_step_basis_slots_kernel<PT, P>)); } while (0)
 #define STEP(PT) do { if (n_terms == 2) STEP_NS(PT, 2); else if (n_terms == 1) STEP_NS(PT, 1); else STEP_NS(PT, 3); } while (0)
         if (q32_pts) STEP(q32); else STEP(double);

@@ -26,6 +26,18 @@ DC_HD double recip_(double x) {
   r = fma(fma(-x, r, 1.0), r, r);
   return fma(fma(-x, r, 1.0), r, r);
 }
+// the same with ONE Newton step (v_rcp_f64 is good to ~2^-26, so ~2^-52 afterwards) and the raw instruction (a correction
+// term that is itself ~1e-6 of its sum needs no more); rsqrt likewise
+DC_HD double recip1_(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+DC_HD double rcp_raw_(double x) { return __builtin_amdgcn_rcp(x); }
+DC_HD double rsqrt1_(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);          // 1 - x y^2
+  return fma(0.5 * y, e, y);
+}
 // cos for the root estimate (argument in [0, pi], result only seeds a Newton step): the hardware cosine.  cosf() would
 // drag in the large-argument range reduction (~250 instructions, computed for every lane because it is select-based).
 DC_HD float cos_est_(float x) { return __cosf(x); }
@@ -35,6 +47,9 @@ DC_HD float rcp_est_(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
 template <typename R> DC_HD R rsqrt_(R x) { return R(1) / sqrt(x); }
 DC_HD double recip_(double x) { return 1.0 / x; }
+DC_HD double recip1_(double x) { return 1.0 / x; }
+DC_HD double rcp_raw_(double x) { return 1.0 / x; }
+DC_HD double rsqrt1_(double x) { return 1.0 / sqrt(x); }
 DC_HD float cos_est_(float x) { return cosf(x); }
 DC_HD float sqrt_est_(float x) { return sqrtf(x); }
 DC_HD float rcp_est_(float x) { return 1.0f / x; }
@@ -49,6 +64,10 @@ DC_HD float rcp_est_(float x) { return 1.0f / x; }
 // Planar and generic neighbourhoods therefore never execute the deflation code (it used to run for every wavefront
 // holding one lane with det(B) >= 0).
 constexpr float kDeflateHalf = 0.9f;
+// the slimmer core (eig3_smallest_unit) takes the smallest eigenvalue directly up to here (gap >= 0.05 p), with a second Newton
+// step from kNewton2Half on (gap < 0.52 p): wavefronts holding a few edge-like neighbourhoods then pay ~20 instructions instead of
+// the ~100 of the deflation path, which is left to nearly exact needles
+constexpr float kDeflateHalfUnit = 0.999f, kNewton2Half = 0.9f;
 
 template <typename R>
 DC_HD void cross3(const R* a, const R* b, R* c) {
@@ -179,6 +198,143 @@ DC_HD void eig3_sym(R a00, R a01, R a02, R a11, R a12, R a22, R* lam, R (*V)[3])
     }
   }
   lam[0] *= m; lam[1] *= m; lam[2] *= m;
+}
+
+// Core of the hot path: smallest eigenpair of a symmetric positive semi-definite matrix of TRACE 1 (what a covariance
+// divided by its trace is).  fp32 trigonometric estimate of the isolated root -> one fp64 Newton step on
+// det(A - l I) -> eigenvector = the column of adj(A - l I) with the largest diagonal entry (adj = c v v^T for an
+// eigenvalue, c > 0 for the smallest and for the largest one, so the diagonal is c v_k^2: its largest entry names the
+// best conditioned column and the three columns share their off-diagonal cofactors: 6 products instead of 9 cross-product
+// terms + 3 norms) -> Rayleigh quotient.  The Newton step reuses the adjugate: det = d0 M00 + a01 M01 + a02 M02,
+// d det / dl = -(M00 + M11 + M22).
+// RAYLEIGH = false leaves the eigenvalue at the Newton iterate (error <= ~1e-12 of the spread: below what 32-bit fixed-point
+// coordinates resolve by orders of magnitude; the float32 / q32 kernels take it).
+template <bool RAYLEIGH = true>
+DC_HD void eig3_smallest_unit(double a00, double a01, double a02, double a11, double a12, double a22, double* lam, double* v0) {
+  const double q = 1.0 / 3.0;
+  const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+  const double k01 = a01 * a01, k02 = a02 * a02, k12 = a12 * a12;
+  const double p2 = (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (k01 + k02 + k12)) * (1.0 / 6.0);
+  if (!(p2 > 0.0)) {                      // multiple of the identity
+    *lam = q;
+    v0[0] = 1.0; v0[1] = 0.0; v0[2] = 0.0;
+    return;
+  }
+  // ---- fp32 estimate of the isolated root of det(B - x I) = 0, x in units of p ----
+  const float pf = sqrt_est_((float)p2);
+  const float f00 = (float)b00, f11 = (float)b11, f22 = (float)b22, f01 = (float)a01, f02 = (float)a02, f12 = (float)a12;
+  const float detf = f00 * (f11 * f22 - f12 * f12) - f01 * (f01 * f22 - f12 * f02) + f02 * (f01 * f12 - f11 * f02);
+  float half = 0.5f * detf * rcp_est_(pf * pf * pf);
+  half = fminf(fmaxf(half, -1.0f), 1.0f);
+  const bool iso_is_max = half >= kDeflateHalfUnit;
+  // smallest root beta0 = 2 cos(acos(half) / 3 + 2 pi / 3) without the inverse cosine: in s = sqrt(1 - half) it is analytic on
+  // [0, sqrt 2] (acos(1 - s^2) = 2 asin(s / sqrt 2), and the end half = -1 is even in its own square root), a degree-7 minimax
+  // polynomial is within 5e-8 of it (2.5e-7 evaluated in float32: what the trigonometric form reaches)
+  float beta;
+  {
+    const float sq = sqrt_est_(1.0f - half);
+    float pl = -1.993398076e-04f;
+    pl = fmaf(pl, sq, 1.522336419e-03f); pl = fmaf(pl, sq, -5.673570384e-03f); pl = fmaf(pl, sq, 1.511769878e-02f);
+    pl = fmaf(pl, sq, -3.736451873e-02f); pl = fmaf(pl, sq, 1.110385112e-01f); pl = fmaf(pl, sq, -8.164918407e-01f);
+    beta = fmaf(pl, sq, -1.000000052e+00f);
+  }
+  if (iso_is_max) beta = 2.0f * cos_est_(acosf(half) * (1.0f / 3.0f));          // needles: the largest root starts the deflation
+  double l = q + (double)(pf * beta);
+  const double pa = a02 * a12, pb = a01 * a12, pc = a01 * a02;        // independent of l
+  double d0 = a00 - l, d1 = a11 - l, d2 = a22 - l;
+  double M00 = fma(d1, d2, -k12), M11 = fma(d0, d2, -k02), M22 = fma(d0, d1, -k01);
+  double M01 = fma(-a01, d2, pa), M02 = fma(-a02, d1, pb), M12;
+  {
+    // ---- one Newton step in fp64 ----
+    const double f = fma(a02, M02, fma(a01, M01, d0 * M00));
+    const double s = (M00 + M11) + M22;                                // = -f'(l)
+    if (fabs(s) > 1e-200) l = fma(f, rcp_raw_(s), l);
+  }
+  d0 = a00 - l; d1 = a11 - l; d2 = a22 - l;
+  if (half >= kNewton2Half && !iso_is_max) {
+    // the middle eigenvalue is close (edge-like neighbourhood): a second step
+    M00 = fma(d1, d2, -k12); M11 = fma(d0, d2, -k02); M22 = fma(d0, d1, -k01);
+    M01 = fma(-a01, d2, pa); M02 = fma(-a02, d1, pb);
+    const double f = fma(a02, M02, fma(a01, M01, d0 * M00));
+    const double s = (M00 + M11) + M22;
+    if (fabs(s) > 1e-200) l = fma(f, rcp_raw_(s), l);
+    d0 = a00 - l; d1 = a11 - l; d2 = a22 - l;
+  }
+  M00 = fma(d1, d2, -k12); M11 = fma(d0, d2, -k02); M22 = fma(d0, d1, -k01);
+  M01 = fma(-a01, d2, pa); M02 = fma(-a02, d1, pb); M12 = fma(-a12, d0, pc);
+  const bool s0 = M00 >= M11 && M00 >= M22;
+  const bool s1 = !s0 && M11 >= M22;
+  double iso[3];
+  iso[0] = s0 ? M00 : (s1 ? M01 : M02);
+  iso[1] = s0 ? M01 : (s1 ? M11 : M12);
+  iso[2] = s0 ? M02 : (s1 ? M12 : M22);
+  const double n2 = iso[0] * iso[0] + iso[1] * iso[1] + iso[2] * iso[2];
+  if (n2 > 0.0) {
+    const double inv = rsqrt1_(n2);
+    iso[0] *= inv; iso[1] *= inv; iso[2] *= inv;
+  } else {
+    iso[0] = 1.0; iso[1] = 0.0; iso[2] = 0.0;
+  }
+  double l_iso = l;
+  if (RAYLEIGH || iso_is_max) {
+    // Rayleigh quotient as a correction of l: l + v . (A - l I) v
+    const double w0 = d0 * iso[0] + a01 * iso[1] + a02 * iso[2];
+    const double w1 = a01 * iso[0] + d1 * iso[1] + a12 * iso[2];
+    const double w2 = a02 * iso[0] + a12 * iso[1] + d2 * iso[2];
+    l_iso = l + (iso[0] * w0 + iso[1] * w1 + iso[2] * w2);
+  }
+  if (!iso_is_max) {
+    *lam = l_iso;
+    v0[0] = iso[0]; v0[1] = iso[1]; v0[2] = iso[2];
+    return;
+  }
+  // nearly prolate spectrum: smallest eigenpair of the 2x2 problem in the complement of the (largest) isolated eigenvector
+  double u[3], w[3];
+  if (fabs(iso[0]) > fabs(iso[1])) {
+    const double inv = rsqrt_(iso[0] * iso[0] + iso[2] * iso[2]);
+    u[0] = -iso[2] * inv; u[1] = 0.0; u[2] = iso[0] * inv;
+  } else {
+    const double inv = rsqrt_(iso[1] * iso[1] + iso[2] * iso[2]);
+    u[0] = 0.0; u[1] = iso[2] * inv; u[2] = -iso[1] * inv;
+  }
+  cross3(iso, u, w);
+  const double au0 = a00 * u[0] + a01 * u[1] + a02 * u[2];
+  const double au1 = a01 * u[0] + a11 * u[1] + a12 * u[2];
+  const double au2 = a02 * u[0] + a12 * u[1] + a22 * u[2];
+  const double aw0 = a00 * w[0] + a01 * w[1] + a02 * w[2];
+  const double aw1 = a01 * w[0] + a11 * w[1] + a12 * w[2];
+  const double aw2 = a02 * w[0] + a12 * w[1] + a22 * w[2];
+  const double m00 = u[0] * au0 + u[1] * au1 + u[2] * au2;
+  const double m01 = u[0] * aw0 + u[1] * aw1 + u[2] * aw2;
+  const double m11 = w[0] * aw0 + w[1] * aw1 + w[2] * aw2;
+  const double h = (m00 - m11) * 0.5, mean = (m00 + m11) * 0.5;
+  const double rad = sqrt(h * h + m01 * m01);
+  const double l_lo = mean - rad;
+  const double x1 = m01, y1 = l_lo - m00, x2 = l_lo - m11, y2 = m01;
+  const double n1 = x1 * x1 + y1 * y1, nn2 = x2 * x2 + y2 * y2;
+  double x = n1 >= nn2 ? x1 : x2, y = n1 >= nn2 ? y1 : y2;
+  const double n = n1 >= nn2 ? n1 : nn2;
+  if (n > 0.0) { const double inv = rsqrt_(n); x *= inv; y *= inv; } else { x = 0.0; y = 1.0; }
+  v0[0] = x * u[0] + y * w[0]; v0[1] = x * u[1] + y * w[1]; v0[2] = x * u[2] + y * w[2];
+  *lam = l_lo;
+}
+
+// Smallest eigenpair and trace of any symmetric positive semi-definite matrix through the core above (one reciprocal of
+// the trace, one Newton step on it).
+DC_HD void eig3_smallest_v2(double a00, double a01, double a02, double a11, double a12, double a22, double* lam0,
+                            double* v0, double* tr_out) {
+  const double m = a00 + a11 + a22;
+  *tr_out = m;
+  if (!(m > 0.0) || !(m < (double)INFINITY)) {
+    const bool zero = (m == 0.0) && a01 == 0.0 && a02 == 0.0 && a12 == 0.0;
+    *lam0 = zero ? 0.0 : (double)NAN;
+    v0[0] = 1.0; v0[1] = 0.0; v0[2] = 0.0;
+    return;
+  }
+  const double inv_m = recip1_(m);
+  double lr;
+  eig3_smallest_unit<true>(a00 * inv_m, a01 * inv_m, a02 * inv_m, a11 * inv_m, a12 * inv_m, a22 * inv_m, &lr, v0);
+  *lam0 = lr * m;
 }
 
 // Hot-path variant: only the smallest eigenpair (lam0, v0) and the trace, which is all the min-eigenvalue /

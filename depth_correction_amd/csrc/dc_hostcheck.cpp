@@ -26,6 +26,14 @@ void dc_host_eig3_smallest(const double* cov, long n, double* lam0, double* v0, 
   }
 }
 
+// the slimmer solver of the one-pass step kernel (trace-1 core: adjugate eigenvector, one reciprocal)
+void dc_host_eig3_smallest_v2(const double* cov, long n, double* lam0, double* v0, double* tr) {
+  for (long i = 0; i < n; ++i) {
+    const double* c = cov + i * 6;
+    dc::eig3_smallest_v2(c[0], c[1], c[2], c[3], c[4], c[5], lam0 + i, v0 + i * 3, tr + i);
+  }
+}
+
 // One neighbourhood per row of nbr [n,k]; points [np,3].  Outputs per centre: mean[3], cov6[6], lam[3], v0[3],
 // loss, c1, c2 (loss / backward coefficients for an unmasked point with zero offset).
 void dc_host_neighbourhoods(const double* points, const int* nbr, long n, int k, double scale, int loss_kind,

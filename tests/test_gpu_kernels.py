@@ -539,7 +539,9 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
             if path == 'general':
                 assert 'basis' not in names['consistency_fwd'] and 'basis' not in names['consistency_bwd'] and 'points_fwd' in timed, names
             elif path == 'default' and one_pass_expected:
-                assert names['consistency_fwd'].startswith('consistency_step_basis_slots_kernel' if ragged else 'consistency_step_basis_kernel'), names
+                # (float32 clouds with a [rows, K] table take the kernel with the static LDS tile)
+                assert names['consistency_fwd'].startswith(('consistency_step_basis_slots_kernel',) if ragged else
+                                                           ('consistency_step_basis_kernel', 'consistency_step_q32_kernel')), names
                 assert 'consistency_bwd' not in timed and 'points_fwd' not in timed
             else:
                 want = 'consistency_fwd_basis_slots_kernel' if ragged else 'consistency_fwd_basis_kernel'
@@ -577,8 +579,10 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
             np.testing.assert_allclose(o[2:2 + nt], ref_g, rtol=1e-8 if f64 else 1e-5,
                                        atol=(1e-10 if f64 else (2e-4 if loose else 2e-5)) * np.abs(ref_g).max(), err_msg=path)
     if one_pass_expected:
-        for a, b in zip(outs['default'], outs['two_pass']):        # the same points: the same pointwise losses, summed in another order
-            np.testing.assert_allclose(a[0], b[0], rtol=1e-14)
+        # the same points: the same pointwise losses, summed in another order -- and, for float32 clouds, from another form of the
+        # eigen-solver (the one-pass kernel's eig3_smallest_unit leaves the eigenvalue at its Newton iterate: ~1e-12 of the spread)
+        for a, b in zip(outs['default'], outs['two_pass']):
+            np.testing.assert_allclose(a[0], b[0], rtol=1e-13 if f64 else 1e-10)
     outs = {True: outs['default']}
     assert not np.allclose(outs[True][0][0], outs[True][3][0], rtol=1e-9)          # the moved pose changed the loss
 
@@ -601,7 +605,7 @@ def test_one_pass_step_all_loss_variants_vs_oracle(golden, dev, tag, loss, norm,
     with KernelTimer(every=1) as timer:
         plan.eval_native(w, e, plan.poses12(poses), out)
         names = timer.kernels()
-    assert names['consistency_fwd'].startswith('consistency_step_basis_kernel<%s' % ('double' if dtype == torch.float64 else 'q32'))
+    assert names['consistency_fwd'].startswith('consistency_step_basis_kernel<double' if dtype == torch.float64 else 'consistency_step_q32_kernel')
     sc64 = [dict(vps=s['vps'].double(), dirs=s['dirs'].double(), depth=s['depth'].double().reshape(-1, 1),
                  inc=s['inc'].double().reshape(-1, 1), mask=s['mask']) for s in scans]
     wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)

@@ -63,24 +63,26 @@ def test_eig3_matches_lapack(host, case):
     assert np.abs(np.einsum('nki,nli->nkl', V, V) - np.eye(3)).max() < 1e-14
 
 
-def _eig_smallest(host, C):
+def _eig_smallest(host, C, solver='dc_host_eig3_smallest'):
     c6 = np.ascontiguousarray(np.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1))
     lam0, v0, tr = np.zeros(len(C)), np.zeros((len(C), 3)), np.zeros(len(C))
-    host.dc_host_eig3_smallest(_p(c6), ctypes.c_long(len(C)), _p(lam0), _p(v0), _p(tr))
+    getattr(host, solver)(_p(c6), ctypes.c_long(len(C)), _p(lam0), _p(v0), _p(tr))
     return lam0, v0, tr
 
 
-@pytest.mark.parametrize('case', ['generic', 'planar', 'needle', 'edge', 'threshold', 'double_hi', 'tiny', 'huge'])
-def test_eig3_smallest_matches_lapack(host, case):
+@pytest.mark.parametrize('solver', ['dc_host_eig3_smallest', 'dc_host_eig3_smallest_v2'])
+@pytest.mark.parametrize('case', ['generic', 'planar', 'needle', 'edge', 'threshold', 'threshold_unit', 'double_hi', 'tiny', 'huge'])
+def test_eig3_smallest_matches_lapack(host, case, solver):
     """The hot-path solver (smallest eigenpair + trace only, dc_eig3.h eig3_smallest): eigenvalue within a few
     eps * |C| of LAPACK's for every family, including spectra on either side of the switch between the direct path and
     the isolate-largest-then-deflate path (kDeflateHalf); eigenvector residual small wherever lam0 is separated."""
     rng = np.random.default_rng(1)
     n = 20000
     u = rng.uniform
-    if case == 'threshold':
-        # scaled spectra 2 cos(ang + 2 pi k / 3) with cos(3 ang) swept across the switch at 0.9
-        ang = np.arccos(u(0.85, 0.95, n)) / 3
+    if case in ('threshold', 'threshold_unit'):
+        # scaled spectra 2 cos(ang + 2 pi k / 3) with cos(3 ang) swept across the switch at 0.9 (eig3_smallest: deflation;
+        # eig3_smallest_unit: second Newton step) and across 0.999 (eig3_smallest_unit: deflation)
+        ang = np.arccos(u(0.85, 0.95, n) if case == 'threshold' else u(0.99, 0.99999, n)) / 3
         beta = np.stack([2 * np.cos(ang + 2 * np.pi / 3), 2 * np.cos(ang - 2 * np.pi / 3), 2 * np.cos(ang)], 1)
         lams = 1.0 + 0.3 * beta
     else:
@@ -92,7 +94,7 @@ def test_eig3_smallest_matches_lapack(host, case):
                 'tiny': u(0, 1, (n, 3)) * 1e-14, 'huge': u(0, 1, (n, 3)) * 1e12}[case]
     lams = np.sort(lams, axis=1)
     C = _spd(rng, lams)
-    lam0, v0, tr = _eig_smallest(host, C)
+    lam0, v0, tr = _eig_smallest(host, C, solver)
     ref, refV = np.linalg.eigh(C)
     scale = np.abs(ref).max(1)
     assert (np.abs(lam0 - ref[:, 0]) / scale).max() < 1e-14
@@ -105,6 +107,18 @@ def test_eig3_smallest_matches_lapack(host, case):
         gap = (ref[sep, 1] - ref[sep, 0]) / scale[sep]
         assert (resid[sep] * gap).max() < 1e-13
         assert ((1 - align[sep]) * gap ** 2).max() < 1e-13
+
+
+@pytest.mark.parametrize('solver', ['dc_host_eig3_smallest', 'dc_host_eig3_smallest_v2'])
+def test_eig3_smallest_degenerate_inputs(host, solver):
+    lam0, v0, tr = _eig_smallest(host, np.zeros((2, 3, 3)), solver)
+    assert np.all(lam0 == 0) and np.all(tr == 0) and np.allclose(v0, [[1, 0, 0]] * 2)
+    lam0, _, _ = _eig_smallest(host, np.full((1, 3, 3), np.nan), solver)
+    assert np.all(np.isnan(lam0))
+    lam0, v0, tr = _eig_smallest(host, np.diag([3.0, 1.0, 2.0])[None], solver)
+    assert abs(lam0[0] - 1.0) < 1e-15 and abs(tr[0] - 6.0) < 1e-15 and np.allclose(np.abs(v0), [[0, 1, 0]])
+    lam0, v0, tr = _eig_smallest(host, 0.37 * np.eye(3)[None], solver)          # isotropic: any unit vector
+    assert abs(lam0[0] - 0.37) < 1e-15 and abs(np.linalg.norm(v0) - 1) < 1e-15
 
 
 def test_eig3_degenerate_inputs(host):
