@@ -114,6 +114,12 @@ class Config(object):
         self.show_results = False
         # this build: use the fused per-sequence kernels whenever the configuration allows it
         self.fused = True
+        # train(): iterations between two host synchronisations when nobody watches single iterations (no-op callbacks, one
+        # process); 1 = the reference's per-iteration bookkeeping (train.py _batched_loop); loop_graph: replay the iteration as
+        # one hipGraph
+        self.loop_batch = 64
+        self.loop_graph = True
+        self.loop_native = True        # model-only runs: the library's chained step, one launch per iteration (train._native_loop)
         self.from_dict(kwargs)
 
     # ---- Configurable subset (configurable.py:44-58,166-179) ----

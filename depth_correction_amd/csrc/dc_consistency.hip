@@ -1187,6 +1187,7 @@ struct StepChain {
   const double* grad_sum;    // or: the previous evaluation's dL/dw already summed (over the ranks: an all-reduce ran in between);
                              // the leading blocks then only take the Adam update (out_prev is not written)
   double* out_prev;          // [n_out] <- sums of the previous evaluation (slots beyond 2 + P: 0)
+  double* w_prev_out;        // [P] or nullptr <- the weights the previous evaluation used (a training log records them: train.py)
   int32_t* status;           // bit 0: a point left the q32 extent (read); bit 1: a wait for the weights ran out (raised here)
   int spin_limit;            // polls a waiting block makes before it gives up (dc_set_option(5, n); 0: gives up at once)
   AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
@@ -1215,7 +1216,10 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* l
   const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && ch.status &&
                        __hip_atomic_load(ch.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   double p0 = 0.0, m0 = 0.0, v0 = 0.0;
-  if (step) { p0 = ch.adam.p[a - 2]; m0 = ch.adam.m[a - 2]; v0 = ch.adam.v[a - 2]; }
+  if (step) {
+    p0 = ch.adam.p[a - 2]; m0 = ch.adam.m[a - 2]; v0 = ch.adam.v[a - 2];
+    if (ch.w_prev_out) ch.w_prev_out[a - 2] = p0;
+  }
   double s = 0.0;
   if (ch.has_prev) {
     const double* p = ch.prev + (int64_t)a * ch.prev_rows;
@@ -1780,10 +1784,11 @@ __global__ __launch_bounds__(kBlock) void consistency_step_q32_kernel(
     if (live) {
       CovAcc acc;
       cov_init(acc);
-      uint32_t mx = pre[0];
+      // positions are multiples of 16, the empty-slot mark 0xFFFF is not: bit 0 of the OR of a lane's positions tells
+      uint32_t mo = pre[0];
 #pragma unroll
-      for (int q = 1; q < NS; ++q) mx = max(mx, pre[q]);
-      const bool any_miss = __any((int)(mx == kNoLoc)) != 0;
+      for (int q = 1; q < NS; ++q) mo |= pre[q];
+      const bool any_miss = __any((int)(mo & 1u)) != 0;
       int n_have;
       if (any_miss) n_have = gather_fixed<q32, NS, true>(tile, cap, ci, pre, acc);
       else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
@@ -2648,6 +2653,7 @@ struct ChainCall {
   AdamArgs adam_prev;
   const double* grad_sum;    // nullptr: the previous evaluation's rows are summed by this launch
   bool reduce_now;           // also launch the ordinary reduction of THIS evaluation's rows into `out` (no Adam)
+  double* w_prev_out = nullptr;
 };
 // the two partial-row buffers of a chain: behind the columns ordinary evaluations use, so that an evaluation of the same
 // sequence between two chained steps (a validation pass, a lazily produced loss cloud) cannot overwrite a pending step
@@ -2710,7 +2716,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         p_bwd = p_fwd + 2 * g_blocks;
         ch.ready = chain->ready; ch.parity = chain->parity; ch.has_prev = chain->has_prev; ch.n_front = kChainFront;
         ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
-        ch.out_prev = chain->out_prev; ch.status = d->status; ch.spin_limit = g_chain_spin.load(); ch.adam = chain->adam_prev;
+        ch.out_prev = chain->out_prev; ch.w_prev_out = chain->w_prev_out; ch.status = d->status; ch.spin_limit = g_chain_spin.load(); ch.adam = chain->adam_prev;
         ch.grad_sum = chain->grad_sum;
       }
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
@@ -2858,6 +2864,20 @@ int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e
   if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1) return DC_ERR_ARG;
   if (has_prev && step < 2) return DC_ERR_ARG;
   ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}, nullptr, false};
+  if (has_prev) {
+    int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
+    if (rc) return rc;
+  }
+  return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out_prev, stream, AdamArgs{}, &c);
+}
+
+int dc_sequence_step_chained_rec(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                                 double* exp_avg_sq, int64_t step, int has_prev, double grad_scale, double lr, double beta1, double beta2,
+                                 double eps, double weight_decay, int32_t* ready, double* out_prev, double* w_used_prev,
+                                 hipStream_t stream) {
+  if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1) return DC_ERR_ARG;
+  if (has_prev && step < 2) return DC_ERR_ARG;
+  ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}, nullptr, false, has_prev ? w_used_prev : nullptr};
   if (has_prev) {
     int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
     if (rc) return rc;

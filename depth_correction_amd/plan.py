@@ -288,13 +288,29 @@ class SequencePlan:
 
     @on_device
     def step_chained(self, w, exponent, poses12, out_prev, exp_avg, exp_avg_sq, t, has_prev, ready, grad_scale, lr, betas, eps,
-                     weight_decay):
+                     weight_decay, w_used_prev=None):
         """One step of a CHAIN (dc_sequence_step_chained): evaluation number ``t`` is launched, and the same launch first
-        finishes evaluation ``t - 1`` when ``has_prev`` (its sums -> out_prev, its Adam update on ``w``).  Returns False when
-        this plan / model cannot chain (the caller steps with step_native then)."""
+        finishes evaluation ``t - 1`` when ``has_prev`` (its sums -> out_prev, its Adam update on ``w``; the weights it had
+        used -> ``w_used_prev`` when given).  Returns False when this plan / model cannot chain (the caller steps with
+        step_native then)."""
         nt = w.numel()
         d = self.desc(nt)
         need(out_prev, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out_prev', device=self.device)
+        if w_used_prev is not None:
+            need(w_used_prev, (nt,), dtype=torch.float64, name='w_used_prev', device=self.device)
+            for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
+                need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
+            need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
+            self._set_basis(d, w, exponent, poses12, False, False)
+            rc = lib().dc_sequence_step_chained_rec(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
+                                                    int(t), int(bool(has_prev)), float(grad_scale), float(lr), float(betas[0]),
+                                                    float(betas[1]), float(eps), float(weight_decay), ptr(ready), ptr(out_prev),
+                                                    ptr(w_used_prev), stream_ptr())
+            if rc in (-4, nv.DC_ERR_BACKWARD_TABLES):
+                return False
+            check(rc, 'dc_sequence_step_chained_rec')
+            self.version += 1
+            return True
         need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
         for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
             need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
@@ -652,35 +668,42 @@ class SequenceTrainer:
                                  self.nt, self.t, self._grad_scale(), self.lr, self.betas[0], self.betas[1], self.eps,
                                  self.weight_decay, stream_ptr()), 'dc_adam_step')
 
-    def flush(self):
-        """Chained mode: finish the last launched step (its sums and its Adam update); returns them.  No-op otherwise."""
+    def flush(self, out=None):
+        """Chained mode: finish the last launched step (its sums -> ``out`` or the trainer's own buffer, and its Adam
+        update); returns the sums.  No-op otherwise."""
+        buf = self.outs[0] if out is None else out
         if self._pending and self.update_in_next:
             self.adam(self.outs[0][2:2 + self.nt])                # the last evaluation's (all-reduced) gradient, step self.t
             self._pending = False
         elif self._pending:
-            self.plans[0].chain_flush(self.w, self.outs[0], self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
+            self.plans[0].chain_flush(self.w, buf, self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
                                       self.betas, self.eps, self.weight_decay)
             self._pending = False
-        return self.outs[0][:2 + self.nt] if len(self.outs) == 1 else self.acc
+        return buf[:2 + self.nt] if len(self.outs) == 1 else self.acc
 
     def _grad_scale(self):
         """1 / number of masked points of all sequences (the mean reduction, loss.py:205-213); no masked point at all:
         NaN, the mean of an empty tensor, as in the reference."""
         return 1.0 / self.count if self.count > 0 else float('nan')
 
-    def step(self):
+    def step(self, out_prev=None, w_used_prev=None, require_chain=False):
         """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
-        (mean loss = acc[0] / acc[1]).  No host synchronisation."""
+        (mean loss = acc[0] / acc[1]).  No host synchronisation.  Chained mode only: ``out_prev`` (fp64 [2 + 2P + 12S]) takes
+        the PREVIOUS evaluation's sums instead of the trainer's own buffer and ``w_used_prev`` (fp64 [P]) the weights that
+        evaluation used -- a training log's record of an iteration, written by the launch itself."""
         if self.chained:
-            ok = self.plans[0].step_chained(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg, self.exp_avg_sq,
+            buf = self.outs[0] if out_prev is None else out_prev
+            ok = self.plans[0].step_chained(self.w, self.exponent, self.poses12[0], buf, self.exp_avg, self.exp_avg_sq,
                                             self.t + 1, self._pending, self.ready, self._grad_scale(), self.lr, self.betas, self.eps,
-                                            self.weight_decay)
+                                            self.weight_decay, w_used_prev=w_used_prev)
             if ok:
                 self.t += 1
                 self._pending = True
-                return self.outs[0][:2 + self.nt]
+                return buf[:2 + self.nt]
             self.flush()
             self.chained = False                 # this plan cannot chain: ordinary steps from here on
+            if require_chain:
+                return None                      # (nothing was launched)
         if self.fused_step:
             self.t += 1
             out = self.plans[0].step_native(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg,

@@ -192,6 +192,21 @@ def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     def weighted_of(loss, weight):
         return loss * weight if loss is not None else torch.zeros((), dtype=torch.float64, device=cfg.device)
 
+    batch = int(getattr(cfg, 'loop_batch', 16) or 1)
+    if (batch > 1 and not sharded and type(callbacks) is TrainCallbacks and torch.device(cfg.device).type == 'cuda'
+            and cfg.n_opt_iters > 0):
+        # nobody looks at an iteration while it runs (the callbacks are the no-op base class): the loop runs without a host
+        # synchronisation per iteration -- see _batched_loop
+        native = _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_masks, train_ns, val_clouds, val_poses,
+                                   val_masks, val_ns) if getattr(cfg, 'loop_native', True) else None
+        if native is not None:
+            ran, best = _native_loop(cfg, model, optimizer, native[0], native[1], train_poses, val_poses, batch)
+            if ran:
+                return best
+        return _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch,
+                             lambda: evaluate(train_clouds, train_poses, train_pose_deltas, train_masks, train_ns),
+                             lambda: evaluate(val_clouds, val_poses, val_pose_deltas, val_masks, val_ns))
+
     min_train_loss = min_val_loss = np.inf
     best_cfg = None
     for it in range(cfg.n_opt_iters):
@@ -264,3 +279,236 @@ def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
                 _zero_first_pose(val_pose_deltas)
             val_optimizer.step()
     return best_cfg
+
+
+class _Bookkeeper(object):
+    """The reference's per-iteration bookkeeping (train.py:219-244: improvement rule, progress line, checkpoint files, best
+    config), fed with RECORDED iterations in order.  A batch of records ends with ``end_batch``, which writes the files of the
+    batch's last improvement."""
+
+    def __init__(self, cfg, model):
+        import copy
+        self.cfg, self.min_val, self.best, self._last = cfg, np.inf, None, None
+        self.shadow = copy.deepcopy(model).cpu()                 # formats the progress line from a recorded state, on the host
+        self.shadow_sd = self.shadow.state_dict()
+
+    def record(self, it, tl, vl, sd, deltas, poses):
+        """sd: {name: CPU tensor} of the model at iteration ``it``; deltas / poses: lists of CPU tensors."""
+        saved = tl < np.inf and vl < self.min_val                 # (the reference never lowers its min_train_loss)
+        if saved:
+            self.min_val = vl
+            self._last = (it, vl, sd, deltas, poses)
+        for k, v in sd.items():
+            self.shadow_sd[k].copy_(v)
+        print('It. %03i: train loss: %.9f, val.: %.9f. Model %s %s.' % (it, tl, vl, self.shadow, 'saved' if saved else 'not saved'))
+
+    def end_batch(self):
+        if self._last is None:
+            return
+        it, vl, sd, deltas, poses = self._last
+        self._last = None
+        cfg = self.cfg
+        stem = '%s/%03i_%.6g' % (cfg.log_dir, it, vl)
+        torch.save({k: v.clone() for k, v in sd.items()}, stem + '_state_dict.pth')
+        torch.save([d.clone() for d in deltas], stem + '_pose_deltas.pth')
+        torch.save([p.clone() for p in poses], stem + '_poses_upd.pth')
+        best = cfg.copy()
+        best.model_state_dict = stem + '_state_dict.pth'
+        best.train_pose_deltas = stem + '_pose_deltas.pth'
+        best.to_yaml(os.path.join(cfg.log_dir, 'best.yaml'))
+        self.best = best
+
+
+def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch, eval_train, eval_val):
+    """The loop of train() (train.py:220-322) without a host synchronisation per iteration.
+
+    The reference reads ``train_loss.item()`` / ``val_loss.item()`` in every iteration (checkpoint decision and the progress
+    line) -- a device round trip that costs several times what the GPU needs for the iteration itself.  Here every iteration
+    records {train loss, validation loss, the model's state, the pose corrections, the corrected poses} -- what a checkpoint
+    of that iteration would hold, a few hundred bytes -- into a device ring of ``batch`` slots; after every ``batch``
+    iterations the host synchronises ONCE, replays the reference's bookkeeping over the recorded iterations in order (same
+    progress lines, same improvement rule) and writes the checkpoint files of the LAST improvement of the batch (earlier ones
+    of the same batch would be superseded immediately; ``cfg.loop_batch = 1`` restores one file set per improvement).  After
+    three eager iterations the iteration {losses -> record -> backward -> optimiser steps} is captured once as a hipGraph and
+    replayed (the library launches on torch's current stream, optim.Adam counts its steps on the device), so the host issues
+    one graph launch per iteration; configurations that cannot be captured keep running eagerly, still without the
+    per-iteration round trip.  Losses, weights and pose corrections are those of the plain loop, iteration by iteration."""
+    dev = torch.device(cfg.device)
+    n_it, R = cfg.n_opt_iters, batch
+    sd_items = [(k, v) for k, v in model.state_dict().items()]                   # tensors that alias the live parameters
+    deltas = []
+    for d in train_pose_deltas:
+        if d is not None and all(d is not q for q in deltas):
+            deltas.append(d)
+    # one fp64 record per iteration: [train loss, val loss | model state | pose corrections | corrected poses], written by
+    # three small launches (cat, index_copy, counter) whatever the number of tensors
+    ring, layout = [], []                     # ring[0]: [R, record length]; layout: (kind, key / index, shape, dtype, offset, numel)
+    counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+
+    def body():
+        train_loss, _, train_poses_upd, _ = eval_train()
+        if n_val:
+            val_loss, _, _, _ = eval_val()
+        else:
+            val_loss = train_loss.detach()
+        poses_now = [p for p in train_poses_upd if p is not None]
+        parts = ([train_loss.detach().double().reshape(1), val_loss.detach().double().reshape(1)]
+                 + [v.detach().double().reshape(-1) for _, v in sd_items] + [d.detach().double().reshape(-1) for d in deltas]
+                 + [p.detach().double().reshape(-1) for p in poses_now])
+        if not ring:
+            at = 2
+            for kind, items in (('sd', [v for _, v in sd_items]), ('delta', deltas), ('pose', poses_now)):
+                for i, v in enumerate(items):
+                    layout.append((kind, i, tuple(v.shape), v.dtype, at, v.numel()))
+                    at += v.numel()
+            ring.append(torch.zeros((R, at), dtype=torch.float64, device=dev))
+        ring[0].index_copy_(0, counter.remainder(R), torch.cat(parts).unsqueeze(0))
+        counter.add_(1)
+        if optimizer is not None:
+            optimizer.zero_grad()
+            train_loss.backward()
+        if cfg.pose_correction == PoseCorrection.pose:
+            _zero_first_pose(train_pose_deltas)
+        if optimizer is not None:
+            optimizer.step()
+        if val_optimizer is not None:
+            val_optimizer.zero_grad()
+            val_loss.backward()
+            if cfg.pose_correction == PoseCorrection.pose:
+                _zero_first_pose(val_pose_deltas)
+            val_optimizer.step()
+
+    book = _Bookkeeper(cfg, model)
+    state = dict(done=0)
+
+    def drain(upto):
+        """Bookkeeping of iterations [done, upto) from the ring; ONE synchronisation."""
+        if upto <= state['done']:
+            return
+        h = ring[0].cpu()                                              # synchronises
+        fields = lambda sl, kind: [h[sl, at:at + n].reshape(shape).to(dtype).clone()
+                                   for k_, _, shape, dtype, at, n in layout if k_ == kind]
+        for it in range(state['done'], upto):
+            sl = it % R
+            book.record(it, float(h[sl, 0]), float(h[sl, 1]), {k: v for (k, _), v in zip(sd_items, fields(sl, 'sd'))},
+                        fields(sl, 'delta'), fields(sl, 'pose'))
+        book.end_batch()
+        state['done'] = upto
+
+    graph = None
+    it = 0
+    warm = min(3, n_it)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(warm):                                # real iterations 0 .. warm - 1, off the default stream as captures ask
+            body()
+            it += 1
+    torch.cuda.current_stream(dev).wait_stream(side)
+    if n_it - it >= 4 and getattr(cfg, 'loop_graph', True):
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            graph = g
+        except Exception as ex:                               # something in this configuration synchronises: stay eager
+            print('train(): the iteration could not be captured (%s: %s); running it eagerly' % (type(ex).__name__, str(ex).split('\n')[0]))
+            torch.cuda.synchronize(dev)
+            graph = None
+    while it < n_it:
+        if it - state['done'] >= R:
+            drain(it)
+        if graph is not None:
+            graph.replay()
+        else:
+            body()
+        it += 1
+    drain(n_it)
+    return book.best
+
+
+def _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_masks, train_ns, val_clouds, val_poses, val_masks, val_ns):
+    """(train plan, [validation plans]) when the whole loop can run on plan.SequenceTrainer's chained steps -- only the weights
+    of a polynomial model are optimised, with Adam as train() builds it, over ONE training sequence through the fused
+    min-eigenvalue / trace loss without inlier gating -- else None."""
+    from .eval import _plan_for, fused_supported
+    from .optim import Adam
+    kw = cfg.loss_kwargs
+    w = getattr(model, 'w', None)
+    if not (cfg.pose_correction == PoseCorrection.none and cfg.optimize_model and len(train_clouds) == 1
+            and isinstance(optimizer, Adam) and len(optimizer.param_groups) == 1
+            and fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
+            and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
+            and isinstance(w, torch.nn.Parameter) and [id(p) for p in model.parameters()] == [id(w)]
+            and w.is_cuda and w.dtype == torch.float64 and w.is_contiguous() and 1 <= w.numel() <= 3
+            and model.kernel_params()[0] is w and not model.kernel_params()[1].requires_grad):
+        return None
+    g = optimizer.param_groups[0]
+    if g['weight_decay'] != 0.0 or any(m is None for m in list(train_masks) + list(val_masks)):
+        return None
+    plan = _plan_for(train_clouds[0], train_poses[0], train_ns[0], train_masks[0], model, cfg)
+    vplans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(val_clouds, val_poses, val_ns, val_masks)]
+    return plan, vplans
+
+
+def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, batch):
+    """train()'s loop for the model-only case on the library's own step: ONE launch per iteration (dc_sequence_step_chained_rec:
+    the launch of iteration t evaluates loss and dL/dw with the weights Adam update t - 1 left, and its leading blocks first
+    finish iteration t - 1 -- sums, update, and the record {sums, weights used} of that iteration straight into the log's ring
+    slot), plus one evaluation-only launch pair per validation sequence.  The weights ARE ``model.w`` (the trainer works on
+    the parameter's storage).  Bookkeeping as in _batched_loop: one synchronisation per ``batch`` iterations.  Returns
+    (ran, best config); ran = False, nothing touched, when the plan turns out not to chain."""
+    from .plan import SequenceTrainer
+    dev = torch.device(cfg.device)
+    n_it, R = cfg.n_opt_iters, batch
+    g = optimizer.param_groups[0]
+    w_param = model.w
+    e = model.kernel_params()[1].detach()
+    tr = SequenceTrainer([plan], w_param.detach(), e, [train_poses[0]], lr=g['lr'], betas=g['betas'], eps=g['eps'], chained=True)
+    assert tr.w.data_ptr() == w_param.data_ptr()
+    nt = tr.nt
+    ring = torch.zeros((R, 2 + 2 * nt + 12 * plan.n_scans), dtype=torch.float64, device=dev)
+    ring_w = torch.zeros((R, nt), dtype=torch.float64, device=dev)
+    vrings = [torch.zeros((R, 2 + 2 * nt + 12 * vp.n_scans), dtype=torch.float64, device=dev) for vp in vplans]
+    vP = [vp.poses12(T) for vp, T in zip(vplans, val_poses)]
+    sd_const = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
+    poses_cpu = [train_poses[0].detach().cpu().clone()]
+    book = _Bookkeeper(cfg, model)
+    done = 0
+
+    def drain(upto):
+        nonlocal done
+        if upto <= done:
+            return
+        # iteration upto - 1 is still pending in the chain: its weights are the current ones, its sums come with the flush
+        ring_w[(upto - 1) % R].copy_(tr.w)
+        tr.flush(out=ring[(upto - 1) % R])
+        h, hw = ring.cpu(), ring_w.cpu()                            # synchronises
+        hv = [v.cpu() for v in vrings]
+        for it in range(done, upto):
+            sl = it % R
+            tl = float(h[sl, 0] / h[sl, 1]) if h[sl, 1] > 0 else float('nan')
+            if hv:
+                vs, vc = sum(float(v[sl, 0]) for v in hv), sum(float(v[sl, 1]) for v in hv)
+                vl = vs / vc if vc > 0 else float('nan')
+            else:
+                vl = tl
+            sd = dict(sd_const)
+            sd[w_key] = hw[sl].reshape(w_param.shape).to(w_param.dtype).clone()
+            book.record(it, tl, vl, sd, [], poses_cpu)
+        book.end_batch()
+        done = upto
+
+    for it in range(n_it):
+        if it - done >= R:
+            drain(it)
+        prev = (it - 1) % R
+        if tr.step(out_prev=ring[prev], w_used_prev=ring_w[prev], require_chain=True) is None:
+            assert it == 0
+            return False, None                                 # this plan does not chain; nothing was launched
+        for vp, P, vr in zip(vplans, vP, vrings):                # validation with the weights of THIS iteration
+            vp.eval_native(tr.w, tr.exponent, P, vr[it % R], want_grad=False)
+    drain(n_it)
+    torch.autograd.graph.increment_version(w_param)                # written through its pointer
+    return True, book.best

@@ -379,6 +379,13 @@ int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const 
 int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
                              double* exp_avg_sq, int64_t step, int has_prev, double grad_scale, double lr, double beta1, double beta2,
                              double eps, double weight_decay, int32_t* ready, double* out_prev, dcStream_t stream);
+/* dc_sequence_step_chained that also records, next to the previous evaluation's sums, the weights that evaluation used
+ * (w_used_prev fp64 [n_terms] or NULL; written only when has_prev): what a training log needs per iteration -- loss, gradient
+ * and the parameters they belong to (train.py:219-244) -- without a copy launch between the steps of a chain. */
+int dc_sequence_step_chained_rec(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
+                                 double* exp_avg_sq, int64_t step, int has_prev, double grad_scale, double lr, double beta1, double beta2,
+                                 double eps, double weight_decay, int32_t* ready, double* out_prev, double* w_used_prev,
+                                 dcStream_t stream);
 int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg, double* exp_avg_sq, int64_t step, double grad_scale,
                             double lr, double beta1, double beta2, double eps, double weight_decay, double* out, dcStream_t stream);
 /* The same idea when several sequences / ranks share the weights (an all-reduce of the sums sits between an evaluation and

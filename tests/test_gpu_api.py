@@ -912,3 +912,73 @@ def test_local_clouds_on_several_streams_are_identical():
             for f in ('dirs', 'depth', 'inc_angles', 'mask', 'normals', 'eigvals', 'neighbors'):
                 assert torch.equal(a[f], b[f]), f
         assert torch.equal(info['neighbors'], ref['neighbors']) and torch.equal(info['mask'], ref['mask'])
+
+
+def _train_and_collect(cfg, train_datasets, val_datasets, capsys):
+    import re
+    from depth_correction_amd.train import train
+    capsys.readouterr()
+    best = train(cfg, train_datasets=train_datasets, val_datasets=val_datasets)
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.startswith('It. ')]
+    vals = [tuple(float(x) for x in re.findall(r'(?:train loss|val\.): (-?[0-9]+\.[0-9]+|nan)', ln)) for ln in lines]
+    flags = [ln.rstrip('.').endswith(' saved') and not ln.rstrip('.').endswith('not saved') for ln in lines]
+    return best, lines, vals, flags, out
+
+
+@pytest.mark.parametrize('mode', ['min_eigval_model', 'min_eigval_model_graph', 'icp_pose'])
+def test_train_batched_graph_loop_equals_plain_loop(golden, tmp_path, capsys, mode, monkeypatch):
+    """train() with its default no-op callbacks runs without a host round trip per iteration (train._batched_loop: a device
+    ring of per-iteration records drained every cfg.loop_batch iterations, the iteration replayed as one hipGraph after three
+    eager ones).  Against cfg.loop_batch = 1 (the reference's per-iteration bookkeeping, train.py:220-322): the same
+    progress lines -- losses, model string, saved / not saved -- and the same final checkpoint, for the model-only
+    min-eigenvalue loop (validation sequence included) and for ICP with per-pose corrections."""
+    from depth_correction_amd.config import Config, Loss, PoseCorrection
+    from depth_correction_amd import train as train_mod
+    took = []
+    for name in ('_native_loop', '_batched_loop'):
+        fn = getattr(train_mod, name)
+        monkeypatch.setattr(train_mod, name, (lambda f, n: (lambda *a, **k: (took.append(n), f(*a, **k))[1]))(fn, name))
+    if mode.startswith('min_eigval_model'):
+        # model-only: the library's chained step drives the loop (one launch per iteration, train._native_loop) unless
+        # cfg.loop_native is off, in which case the captured autograd iteration does (train._batched_loop)
+        g = golden('room_k10')
+        mk = lambda d, **kw: _cfg(g, n_opt_iters=13, lr=5e-3, log_dir=str(d), loop_native=mode == 'min_eigval_model',
+                                  model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
+        ds = list(zip(_scan_arrays(g), g['poses']))
+        tr_ds, va_ds = [ds], [ds[:2]]
+    else:
+        from depth_correction_amd.dataset import KittiLikeDataset
+        from depth_correction_amd.preproc import filtered_cloud
+        mk = lambda d, **kw: Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2,
+                                    min_depth=5.0, max_depth=12.0, vp_dispersion_bounds=[], n_opt_iters=13, lr=2e-3,
+                                    log_dir=str(d), model_kwargs={'w': [1e-3, -1e-3], 'exponent': [2.0, 4.0]}).from_dict(kw)
+        c0 = mk(tmp_path)
+        seq = [(filtered_cloud(cloud, c0), pose) for cloud, pose in KittiLikeDataset(n_poses=3, n_rings=96, n_azimuth=384)]
+        tr_ds, va_ds = [seq], []
+    (tmp_path / 'plain').mkdir()
+    (tmp_path / 'fast').mkdir()
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), tr_ds, va_ds, capsys)
+    b1, l1, v1, f1, out1 = _train_and_collect(mk(tmp_path / 'fast', loop_batch=5), tr_ds, va_ds, capsys)
+    assert 'could not be captured' not in out1, out1                 # the iteration replays as a graph
+    assert took == (['_native_loop'] if mode == 'min_eigval_model' else ['_batched_loop']), took
+    assert len(l0) == len(l1) == 13 and f0 == f1 and any(f0)
+    np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-7, atol=1e-12)
+    for a, b in zip(l0, l1):                                           # model string: weights of the iteration, 6 digits
+        ma, mb = a.split('Model ')[1], b.split('Model ')[1]
+        assert ma == mb, (a, b)
+    assert v0[-1][0] != v0[0][0]                                       # the parameters move
+    sa, sb = torch.load(b0.model_state_dict), torch.load(b1.model_state_dict)
+    assert list(sa) == list(sb)
+    for k in sa:
+        np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-9, atol=1e-15)
+    da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
+    assert len(da) == len(db)
+    for x, y in zip(da, db):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-8, atol=1e-14)
+    import os
+    assert os.path.basename(b0.model_state_dict) == os.path.basename(b1.model_state_dict)        # same iteration, same loss
+    # the plain loop writes a file set per improvement, the batched one per drained batch
+    n_plain = len([f for f in os.listdir(tmp_path / 'plain') if f.endswith('_state_dict.pth')])
+    n_fast = len([f for f in os.listdir(tmp_path / 'fast') if f.endswith('_state_dict.pth')])
+    assert n_plain == sum(f0) and 1 <= n_fast <= 3
