@@ -81,6 +81,7 @@ _SIGNATURES = {
     'dc_p2plane_partial_count': (_i64, [_i64]),
     'dc_p2plane_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32,
                                _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'dc_p2plane_sequence_partial_count': (_i64, [_vp, _i32]),
     'dc_p2plane_sequence': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'dc_p2point_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
                                _i64, _vp, _vp, _vp]),

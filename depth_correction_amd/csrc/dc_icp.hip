@@ -78,14 +78,35 @@ __device__ __forceinline__ void scan_point_bwd(const ModelParams& mp, const doub
 
 constexpr int kIcpAcc = 2 + 2 * DC_MAX_MODEL_TERMS + 24;
 
+// kIcpAcc sums of a block through packed wavefront reductions (eight values per butterfly: 10 exchange steps instead of 48),
+// then one LDS row per wavefront; thread q < kIcpAcc ends with the block's total of accumulator q.  Fixed order.
+constexpr int kIcpGroups = (kIcpAcc + 7) / 8;
+__device__ __forceinline__ double icp_block_sums(double* acc, double* lds /* [kWavesPerBlock][kIcpGroups * 8] */) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int g = 0; g < kIcpGroups; ++g) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (g * 8 + q < kIcpAcc) ? acc[g * 8 + q] : 0.0;
+    const double tot = wave_sum_packed<8>(v);
+    if (lane < 8) lds[wave * (kIcpGroups * 8) + g * 8 + packed_value_of_lane<8>(lane)] = tot;
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < kIcpAcc) {
+    const int q = threadIdx.x;
+    r = (lds[q] + lds[kIcpGroups * 8 + q]) + (lds[2 * kIcpGroups * 8 + q] + lds[3 * kIcpGroups * 8 + q]);
+  }
+  return r;
+}
+
+// One block of one scan pair: correspondences [256 blk, 256 blk + 256) of (idxA, idxB) -> row[kIcpAcc] of block sums.
 template <typename T, bool PLANE>
-__global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanView B, const double* __restrict__ poseA,
-                                                              const double* __restrict__ poseB, int model_kind, int n_terms,
-                                                              const double* __restrict__ w, const double* __restrict__ e,
-                                                              const int32_t* __restrict__ idxA,
-                                                              const int32_t* __restrict__ idxB, int64_t m,
-                                                              double* __restrict__ partials) {
-  __shared__ double lds[(kBlock / kWave) * kIcpAcc];
+__device__ __forceinline__ void icp_pair_block(const ScanView& A, const ScanView& B, const double* __restrict__ poseA,
+                                               const double* __restrict__ poseB, int model_kind, int n_terms,
+                                               const double* __restrict__ w, const double* __restrict__ e,
+                                               const int32_t* __restrict__ idxA, const int32_t* __restrict__ idxB, int64_t m,
+                                               int64_t blk, double* __restrict__ row, double* lds) {
   ModelParams mp;
   mp.kind = model_kind; mp.n_terms = n_terms;
 #pragma unroll
@@ -103,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanVi
   double* ge = acc + 2 + DC_MAX_MODEL_TERMS;
   double* gTA = acc + 2 + 2 * DC_MAX_MODEL_TERMS;
   double* gTB = gTA + 12;
-  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t c = blk * kBlock + threadIdx.x;
   if (c < m) {
     ScanPoint<T> a, b;
     load_scan_point<T>(A, mp, TA, idxA[c], a);
@@ -140,12 +161,95 @@ __global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanVi
     scan_point_bwd<T>(mp, TA, a, gxa, gna, gw, ge, gTA);
     scan_point_bwd<T>(mp, TB, b, gxb, gnb, gw, ge, gTB);
   }
-  block_sum<kIcpAcc>(acc, lds);
-  if (threadIdx.x == 0) {
-    double* row = partials + (int64_t)blockIdx.x * kIcpAcc;
-#pragma unroll
-    for (int q = 0; q < kIcpAcc; ++q) row[q] = acc[q];
+  const double tot = icp_block_sums(acc, lds);
+  if (threadIdx.x < kIcpAcc) row[threadIdx.x] = tot;
+}
+
+template <typename T, bool PLANE>
+__global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanView B, const double* __restrict__ poseA,
+                                                              const double* __restrict__ poseB, int model_kind, int n_terms,
+                                                              const double* __restrict__ w, const double* __restrict__ e,
+                                                              const int32_t* __restrict__ idxA,
+                                                              const int32_t* __restrict__ idxB, int64_t m,
+                                                              double* __restrict__ partials) {
+  __shared__ double lds[kWavesPerBlock * kIcpGroups * 8];
+  icp_pair_block<T, PLANE>(A, B, poseA, poseB, model_kind, n_terms, w, e, idxA, idxB, m, blockIdx.x,
+                           partials + (int64_t)blockIdx.x * kIcpAcc, lds);
+}
+
+// All (up to kIcpSeqPairs) scan pairs of a sequence in ONE launch: the pairs' descriptors travel as kernel arguments, block b
+// belongs to the pair whose row range holds it.  (One launch per pair left a C4-shaped iteration -- nine pairs of ~15 k
+// correspondences -- with eighteen dependent launches of ~50 blocks each: 0.22 of its 0.29 ms.)
+constexpr int kIcpSeqPairs = 16;
+struct IcpSeqPair {
+  ScanView A, B;
+  const int32_t* idxA; const int32_t* idxB;
+  int64_t m;
+  double weight;
+  int32_t scan_a, scan_b, row0, rows;
+};
+struct IcpSeqArgs {
+  IcpSeqPair pairs[kIcpSeqPairs];
+  int n_pairs;
+};
+
+template <typename T, bool PLANE>
+__global__ __launch_bounds__(kBlock) void p2plane_seq_kernel(IcpSeqArgs args, const double* __restrict__ poses, int model_kind, int n_terms,
+                                                             const double* __restrict__ w, const double* __restrict__ e,
+                                                             double* __restrict__ partials) {
+  __shared__ double lds[kWavesPerBlock * kIcpGroups * 8];
+  const int b = blockIdx.x;
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < args.n_pairs; ++q)
+    if (b >= args.pairs[q].row0) p = q;
+  const IcpSeqPair& pr = args.pairs[p];
+  icp_pair_block<T, PLANE>(pr.A, pr.B, poses + 12 * pr.scan_a, poses + 12 * pr.scan_b, model_kind, n_terms, w, e, pr.idxA, pr.idxB, pr.m,
+                           b - pr.row0, partials + (int64_t)b * kIcpAcc, lds);
+}
+
+// out = { loss, dw[P], dexponent[P], d[R|t][S,12] } += weight * (sums of every pair), pair after pair in ONE launch.  Block 0:
+// the loss (both directed sums), blocks 1 .. 2 MAX: the model gradients, the last twelve: entry j of BOTH poses of every pair --
+// one block per destination, so the additions to a scan's slot happen in the order consecutive launches would make them.
+struct IcpSeqReduce {
+  double weight[kIcpSeqPairs];
+  int32_t scan_a[kIcpSeqPairs], scan_b[kIcpSeqPairs], row0[kIcpSeqPairs], rows[kIcpSeqPairs];
+  int n_pairs;
+};
+__global__ __launch_bounds__(kBlock) void p2plane_reduce_all_kernel(const double* __restrict__ partials, IcpSeqReduce rq, int n_terms,
+                                                                    double* __restrict__ out) {
+  __shared__ double lds[2 * (kBlock / kWave)];
+  const int a = blockIdx.x;
+  const int pw = 2, pe = 2 + DC_MAX_MODEL_TERMS, pa = 2 + 2 * DC_MAX_MODEL_TERMS, pb = pa + 12;
+  const bool pose = a >= 1 + 2 * DC_MAX_MODEL_TERMS;
+  const int j = a - (1 + 2 * DC_MAX_MODEL_TERMS);                       // pose entry
+  const int col0 = a == 0 ? 0 : (pose ? pa + j : a + 1), col1 = a == 0 ? 1 : (pose ? pb + j : -1);
+  if (!pose && a >= 1) {                                                // model gradient slots beyond n_terms: nothing to do
+    const int k = (a - 1) % DC_MAX_MODEL_TERMS;
+    if (k >= n_terms) return;
   }
+  for (int p = 0; p < rq.n_pairs; ++p) {
+    double v[2] = {0.0, 0.0};
+    const double* rows = partials + (int64_t)rq.row0[p] * kIcpAcc;
+    for (int r = threadIdx.x; r < rq.rows[p]; r += kBlock) {
+      v[0] += rows[(int64_t)r * kIcpAcc + col0];
+      if (col1 >= 0) v[1] += rows[(int64_t)r * kIcpAcc + col1];
+    }
+    block_sum<2>(v, lds);
+    if (threadIdx.x == 0) {
+      const double wt = rq.weight[p];
+      if (a == 0) out[0] += wt * (v[0] + v[1]);
+      else if (!pose) {
+        const int k = (a - 1) % DC_MAX_MODEL_TERMS;
+        out[1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + k] += wt * v[0];
+      } else {
+        out[1 + 2 * n_terms + 12 * rq.scan_a[p] + j] += wt * v[0];
+        out[1 + 2 * n_terms + 12 * rq.scan_b[p] + j] += wt * v[1];
+      }
+    }
+    __syncthreads();
+  }
+  (void)pw; (void)pe;
 }
 
 // Sum rows [n_rows, kIcpAcc] and compact to out = {sum12, sum21, gw[P], ge[P], gTA[12], gTB[12]}.
@@ -273,20 +377,53 @@ static int icp_sequence_impl(bool plane, const dcIcpScan* scans, int n_scans, co
   }
   hipError_t err = hipMemsetAsync(out, 0, (size_t)(1 + 2 * n_terms + 12 * n_scans) * sizeof(double), stream);
   if (err != hipSuccess) return (int)err;
-  for (int p = 0; p < n_pairs; ++p) {
-    const dcIcpPair& q = pairs[p];
-    if (q.m == 0) continue;
-    const dcIcpScan &a = scans[q.scan_a], &b = scans[q.scan_b];
-    ScanView A{a.vps, a.dirs, a.depth, a.inc, a.lmask, plane ? a.normals : nullptr},
-        B{b.vps, b.dirs, b.depth, b.inc, b.lmask, plane ? b.normals : nullptr};
-    const double *poseA = poses + 12 * q.scan_a, *poseB = poses + 12 * q.scan_b;
-    const int64_t rows = (q.m + kBlock - 1) / kBlock;
-    launch_pair(plane, dtype, rows, stream, A, B, poseA, poseB, model_kind, n_terms, w, e, q.idx_a, q.idx_b, q.m, partials_ws);
-    hipLaunchKernelGGL(p2plane_reduce_seq_kernel, dim3(kIcpAcc), dim3(kBlock), 0, stream, partials_ws, rows, n_terms,
-                       q.weight, q.scan_a, q.scan_b, out);
+  // chunks of up to kIcpSeqPairs pairs: one pair launch + one reduction launch per chunk (the workspace holds the rows of the
+  // largest chunk: dc_p2plane_sequence_partial_count)
+  int p = 0;
+  while (p < n_pairs) {
+    IcpSeqArgs args{};
+    IcpSeqReduce rq{};
+    int64_t row0 = 0;
+    int np = 0;
+    for (; p < n_pairs && np < kIcpSeqPairs; ++p) {
+      const dcIcpPair& q = pairs[p];
+      if (q.m == 0) continue;
+      const dcIcpScan &a = scans[q.scan_a], &b = scans[q.scan_b];
+      IcpSeqPair& t = args.pairs[np];
+      t.A = ScanView{a.vps, a.dirs, a.depth, a.inc, a.lmask, plane ? a.normals : nullptr};
+      t.B = ScanView{b.vps, b.dirs, b.depth, b.inc, b.lmask, plane ? b.normals : nullptr};
+      t.idxA = q.idx_a; t.idxB = q.idx_b; t.m = q.m; t.weight = q.weight; t.scan_a = q.scan_a; t.scan_b = q.scan_b;
+      const int64_t rows = (q.m + kBlock - 1) / kBlock;
+      if (row0 + rows > INT32_MAX) return DC_ERR_UNSUPPORTED;
+      t.row0 = (int32_t)row0; t.rows = (int32_t)rows;
+      rq.weight[np] = q.weight; rq.scan_a[np] = q.scan_a; rq.scan_b[np] = q.scan_b; rq.row0[np] = t.row0; rq.rows[np] = t.rows;
+      row0 += rows;
+      ++np;
+    }
+    if (np == 0) continue;
+    args.n_pairs = rq.n_pairs = np;
+    const dim3 grid((unsigned)row0), block(kBlock);
+#define ICP_SEQ(T, PLANE) hipLaunchKernelGGL((p2plane_seq_kernel<T, PLANE>), grid, block, 0, stream, args, poses, model_kind, n_terms, w, e, partials_ws)
+    if (dtype == DC_F32) { if (plane) ICP_SEQ(float, true); else ICP_SEQ(float, false); }
+    else { if (plane) ICP_SEQ(double, true); else ICP_SEQ(double, false); }
+#undef ICP_SEQ
+    hipLaunchKernelGGL(p2plane_reduce_all_kernel, dim3(1 + 2 * DC_MAX_MODEL_TERMS + 12), dim3(kBlock), 0, stream, partials_ws, rq, n_terms, out);
   }
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int64_t dc_p2plane_sequence_partial_count(const dcIcpPair* pairs, int n_pairs) {
+  int64_t best = 1, rows = 0;
+  int np = 0;
+  for (int p = 0; pairs && p < n_pairs; ++p) {
+    if (pairs[p].m <= 0) continue;
+    if (np == kIcpSeqPairs) { rows = 0; np = 0; }
+    rows += (pairs[p].m + kBlock - 1) / kBlock;
+    ++np;
+    best = rows > best ? rows : best;
+  }
+  return best * kIcpAcc;
 }
 
 int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,

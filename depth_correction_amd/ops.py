@@ -726,7 +726,8 @@ class IcpSequence:
             d.scan_a, d.scan_b, d.idx_a, d.idx_b, d.m = int(a), int(b), ptr(idx_a), ptr(idx_b), m
             d.weight = (0.5 if plane else 1.0) / (max(m, 1) * len(pairs))
             max_m = max(max_m, m)
-        self.part = torch.empty((lib().dc_p2plane_partial_count(max_m),), dtype=torch.float64, device=self.device)
+        self.part = torch.empty((lib().dc_p2plane_sequence_partial_count(ctypes.cast(self.pair_desc, ctypes.c_void_p), self.n_pairs),),
+                                dtype=torch.float64, device=self.device)
 
     @on_device
     def eval(self, poses12, model_kind=None, w=None, e=None, out=None):

@@ -276,7 +276,9 @@ int dc_p2plane_pair(const void* vpsA, const void* dirsA, const void* depthA, con
  *   scans / pairs: HOST arrays of descriptors holding device pointers (idx_a / idx_b index the local points of
  *                  scans scan_a / scan_b, scan_a != scan_b); poses fp64 [n_scans, 12] device;
  *   out fp64 [1 + 2 P + 12 n_scans] = { loss, dloss/dw [P], /dexponent [P], /d[R|t] [n_scans, 12] };
- *   partials_ws fp64 [dc_p2plane_partial_count(max_p m_p)] (pairs run one after the other on the stream). */
+ *   partials_ws fp64 [dc_p2plane_sequence_partial_count(pairs, n_pairs)]: the pairs run 16 to a launch (their descriptors
+ *                  travel as kernel arguments; one pair launch and one reduction launch per 16 pairs), the workspace holds the
+ *                  block rows of the largest such group. */
 typedef struct dcIcpScan {
   const void* vps;            /* [n,3] or NULL (sensor at the origin) */
   const void* dirs;           /* [n,3] */
@@ -292,6 +294,7 @@ typedef struct dcIcpPair {
   int64_t m;
   double weight;
 } dcIcpPair;
+int64_t dc_p2plane_sequence_partial_count(const dcIcpPair* pairs, int n_pairs);
 int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
                         const double* poses, int model_kind, int n_terms, const double* w, const double* e,
                         double* partials_ws, double* out, dcStream_t stream);
