@@ -16,6 +16,7 @@
 // few cells (L1/L2 hits) and the sorted coordinates they stream are contiguous.
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
 #include "dc_common.h"
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
                                                            const int32_t* __restrict__ qids, int64_t n_query,
                                                            const Grid* __restrict__ gp, CellTable tab, int k, double r_max,
                                                            int64_t n_points, int r_exhaust,
-                                                           int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                           int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                           int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= n_query) return;
   const Grid g = *gp;
@@ -379,6 +381,13 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
   };
   bool exhaustive = false;
   for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+    // A query that r_budget shells do not settle sits in a sparse region (lidar density falls with the square of the range) and
+    // would walk hundreds of mostly empty cells alone while the 63 other lanes of its wavefront idle: it goes on the pending
+    // list, and knn_tail_kernel finishes it with a whole wavefront (64 cells probed per trip).
+    if (pending && r > r_budget) {
+      pending[atomicAdd(n_pending, 1)] = (int32_t)t;
+      return;
+    }
     if (r > r_exhaust) { exhaustive = true; break; }
     // the cube of cells at Chebyshev distance <= r minus its interior (visited by the earlier shells), as one loop
     // nest with ONE inlined copy of the candidate code: for_shell's three call sites tripled it, and with it the
@@ -476,7 +485,183 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
   }
 }
 
+// ---- the pending queries of knn_query_kernel: ONE WAVEFRONT PER QUERY --------------------------------------------------------
+// Lane l probes cell l, l + 64, ... of the current shell (hash probe -> its points -> squared distances, cKDTree's arithmetic);
+// candidates that beat the current k-th best are appended to a per-wavefront LDS buffer (ballot + prefix count), and after every
+// shell (or when the buffer fills) the k smallest of {current best, buffer} by (distance, index) are extracted by k rounds of a
+// wave-wide lexicographic minimum -- the order knn_query_kernel's sorted insertion produces, so indices and distances are
+// bit-identical.  Same termination rule, same fall-back to a scan of all points beyond r_exhaust shells.
+constexpr int kTailCap = 320;            // candidate entries per wavefront behind the KMAX best ones
+__device__ __forceinline__ int udiv_small(int a, int d, float inv_d) {      // a / d for 0 <= a < 2^22, d > 0
+  int q = (int)((float)a * inv_d);
+  q -= (q * d > a) ? 1 : 0;
+  q += ((q + 1) * d <= a) ? 1 : 0;
+  return q;
+}
+// cell j of the cube shell at Chebyshev distance r (side = 2 r + 1): the two z faces first, then the perimeters of the slices between
+__device__ __forceinline__ void shell_cell(int r, int side, float inv_side, float inv_ring, int j, int* dx, int* dy, int* dz) {
+  if (r == 0) { *dx = *dy = *dz = 0; return; }
+  const int face = side * side, ring = 4 * side - 4;
+  if (j < 2 * face) {
+    const int f = j >= face ? 1 : 0, jj = j - f * face;
+    const int y = udiv_small(jj, side, inv_side);
+    *dx = jj - y * side - r; *dy = y - r; *dz = f ? r : -r;
+    return;
+  }
+  const int jj = j - 2 * face;
+  const int sl = udiv_small(jj, ring, inv_ring), pos = jj - sl * ring;
+  *dz = sl + 1 - r;
+  if (pos < side) { *dx = pos - r; *dy = -r; }
+  else if (pos < 2 * side) { *dx = pos - side - r; *dy = r; }
+  else if (pos < 3 * side - 2) { *dx = -r; *dy = pos - 2 * side + 1 - r; }
+  else { *dx = r; *dy = pos - (3 * side - 2) + 1 - r; }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                          const double* __restrict__ queries, const int32_t* __restrict__ qids,
+                                                          const int32_t* __restrict__ pending, const int32_t* __restrict__ n_pending,
+                                                          const Grid* __restrict__ gp, CellTable tab, int k, double r_max, int64_t n_points,
+                                                          int r_exhaust, int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+  __shared__ double s_d[kWavesPerBlock][KMAX + kTailCap];
+  __shared__ int32_t s_i[kWavesPerBlock][KMAX + kTailCap];
+  __shared__ double s_nd[kWavesPerBlock][KMAX];
+  __shared__ int32_t s_ni[kWavesPerBlock][KMAX];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  double* pd = s_d[wave];
+  int32_t* pi = s_i[wave];
+  const Grid g = *gp;
+  const int total_waves = gridDim.x * kWavesPerBlock;
+  const int n_pend = *n_pending;
+  const double ub2 = r_max > 0.0 ? r_max * r_max : INFINITY;
+  for (int wq = blockIdx.x * kWavesPerBlock + wave; wq < n_pend; wq += total_waves) {
+    const int64_t t = pending[wq];
+    const double q[3] = {queries[t * 3], queries[t * 3 + 1], queries[t * 3 + 2]};
+    const int64_t row = qids ? qids[t] : t;
+    int32_t c[3];
+    cell_of(g, q, c);
+    for (int s = lane; s < k; s += kWave) { pd[s] = INFINITY; pi[s] = 0x7fffffff; }
+    int nc = 0;                                   // candidates behind the k best (wave-uniform)
+    double worst_d = INFINITY;
+    int32_t worst_i = 0x7fffffff;
+    // the k smallest of pool [0, k + nc) by (distance, index) -> pool [0, k)
+    auto select = [&]() {
+      const int np = k + nc;
+      double last_d = -1.0;
+      int32_t last_i = -1;
+      for (int s = 0; s < k; ++s) {
+        double md = INFINITY;
+        int32_t mi = 0x7fffffff;
+        for (int e = lane; e < np; e += kWave) {
+          const double d = pd[e];
+          const int32_t i = pi[e];
+          const bool gt = d > last_d || (d == last_d && i > last_i);
+          const bool lt = d < md || (d == md && i < mi);
+          if (gt && lt) { md = d; mi = i; }
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+          const double od = __shfl_xor(md, off, kWave);
+          const int32_t oi = __shfl_xor(mi, off, kWave);
+          if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+        }
+        if (lane == 0) { s_nd[wave][s] = md; s_ni[wave][s] = mi; }
+        last_d = md; last_i = mi;
+        if (!(md < INFINITY)) {                    // nothing finite is left: the remaining slots are empty
+          for (int s2 = s + 1 + lane; s2 < k; s2 += kWave) { s_nd[wave][s2] = INFINITY; s_ni[wave][s2] = 0x7fffffff; }
+          break;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int s = lane; s < k; s += kWave) { pd[s] = s_nd[wave][s]; pi[s] = s_ni[wave][s]; }
+      __builtin_amdgcn_wave_barrier();
+      worst_d = pd[k - 1]; worst_i = pi[k - 1];
+      nc = 0;
+    };
+    // one candidate per lane (has = false: none): filter, wave-aggregated append, selection when the buffer runs full
+    auto offer = [&](bool has, double d, int32_t id) {
+      const bool acc = has && d < ub2 && (d < worst_d || (d == worst_d && id < worst_i));
+      const unsigned long long m = __ballot(acc);
+      if (m == 0ull) return;
+      const int pos = k + nc + __popcll(m & ((1ull << lane) - 1ull));
+      if (acc) { pd[pos] = d; pi[pos] = id; }
+      nc += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (nc > kTailCap - kWave) select();
+    };
+    const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+    bool exhaustive = false;
+    for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+      if (r > r_exhaust) { exhaustive = true; break; }
+      const int side = 2 * r + 1, ring = 4 * side - 4;
+      const int n_cells = r == 0 ? 1 : 2 * side * side + (side - 2) * ring;
+      const float inv_side = 1.0f / (float)side, inv_ring = r == 0 ? 1.0f : 1.0f / (float)ring;
+      for (int j0 = 0; j0 < n_cells; j0 += kWave) {
+        const int j = j0 + lane;
+        int32_t b = 0, e = 0;
+        if (j < n_cells) {
+          int dx, dy, dz;
+          shell_cell(r, side, inv_side, inv_ring, j, &dx, &dy, &dz);
+          const int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
+          if (x >= 0 && y >= 0 && z >= 0 && x < g.dim[0] && y < g.dim[1] && z < g.dim[2]) {
+            if (!find_cell(tab, morton3(x, y, z), &b, &e)) { b = 0; e = 0; }
+          }
+        }
+        for (int32_t p = b; __any((int)(p < e)); ++p) {
+          const bool has = p < e;
+          const int32_t pc = has ? p : 0;
+          const double pp[3] = {sp[(int64_t)pc * 3], sp[(int64_t)pc * 3 + 1], sp[(int64_t)pc * 3 + 2]};
+          offer(has, sqdist(pp, q), sids[pc]);
+        }
+      }
+      if (nc > 0) select();
+      const double bound = shell_bound(g, q, c, r);
+      const double b2 = bound * bound;
+      if (worst_d < b2) break;
+      if (b2 >= ub2) break;
+    }
+    if (exhaustive) {
+      for (int s = lane; s < k; s += kWave) { pd[s] = INFINITY; pi[s] = 0x7fffffff; }
+      nc = 0; worst_d = INFINITY; worst_i = 0x7fffffff;
+      __builtin_amdgcn_wave_barrier();
+      for (int64_t p0 = 0; p0 < n_points; p0 += kWave) {
+        const int64_t p = p0 + lane;
+        const bool has = p < n_points;
+        const int64_t pc = has ? p : 0;
+        const double pp[3] = {sp[pc * 3], sp[pc * 3 + 1], sp[pc * 3 + 2]};
+        offer(has, sqdist(pp, q), sids[pc]);
+      }
+      if (nc > 0) select();
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < k; s += kWave) {
+      const bool ok = pi[s] != 0x7fffffff;
+      idx_out[row * k + s] = ok ? pi[s] : -1;
+      if (dist_out) dist_out[row * k + s] = ok ? sqrt(pd[s]) : INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- radius search: count, then fill (ascending index, -1 padded) ------------------------------------
+constexpr int kRadiusSortMax = 192;      // longest row radius_sort_rows_kernel sorts in LDS (64 rows x 192 entries = 48 KB per block)
+// one lane per row: row -> LDS (entry s of lane l at s * 64 + l: conflict-free), insertion sort up to the first -1, row back
+__global__ __launch_bounds__(kWave) void radius_sort_rows_kernel(int32_t* __restrict__ idx, int64_t n, int kmax) {
+  extern __shared__ int32_t s_rows[];
+  const int64_t rowi = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (rowi >= n) return;
+  int32_t* row = idx + rowi * kmax;
+  int cnt = 0;
+  for (int s = 0; s < kmax; ++s) {
+    const int32_t id = row[s];
+    if (id < 0) break;
+    int t = cnt;
+    while (t > 0 && s_rows[(t - 1) * kWave + threadIdx.x] > id) { s_rows[t * kWave + threadIdx.x] = s_rows[(t - 1) * kWave + threadIdx.x]; --t; }
+    s_rows[t * kWave + threadIdx.x] = id;
+    ++cnt;
+  }
+  for (int s = 0; s < cnt; ++s) row[s] = s_rows[s * kWave + threadIdx.x];
+}
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
                                                         int64_t n, const Grid* __restrict__ gp, CellTable tab, double rad,
@@ -491,6 +676,10 @@ __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict
   int32_t c[3];
   cell_of(g, q, c);
   int32_t cnt = 0;
+  // FILL: hits are appended to the row in the order the cells are visited; radius_sort_rows_kernel then puts every row into
+  // ascending order inside LDS (the shifting insertion straight into the global row cost 0.42 ms per 200 k-point scan, three
+  // times the counting pass).  Rows longer than kRadiusSortMax are still built by insertion in place.
+  const bool in_lds = FILL && kmax <= kRadiusSortMax;      // append now, rows sorted by radius_sort_rows_kernel afterwards
   int32_t* out = FILL ? idx_out + row * kmax : nullptr;
   const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
   for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
@@ -501,11 +690,14 @@ __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict
         const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
         if (sqdist(pp, q) <= r2) {
           if (FILL) {
-            // insertion into the ascending row (rows are short)
             const int32_t id = sids[p];
             int32_t s = cnt;
-            while (s > 0 && out[s - 1] > id) { out[s] = out[s - 1]; --s; }
-            out[s] = id;
+            if (in_lds) {
+              out[s] = id;
+            } else {
+              while (s > 0 && out[s - 1] > id) { out[s] = out[s - 1]; --s; }
+              out[s] = id;
+            }
           }
           ++cnt;
         }
@@ -572,7 +764,7 @@ static uint32_t table_size(int64_t n) {
 struct GridWs {
   double* part; Grid* grid; uint64_t* keys; uint64_t* skeys; int32_t* ids; int32_t* sids; double* sp;
   uint64_t* tab_key; int32_t* tab_beg; int32_t* tab_end; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
-  double* qf64; size_t total;
+  double* qf64; int32_t* pending; int32_t* n_pending; size_t total;
 };
 
 static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
@@ -590,6 +782,8 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   g.tab_beg = c.take<int32_t>(g.tab_n);
   g.tab_end = c.take<int32_t>(g.tab_n);
   g.qf64 = c.take<double>(3 * n_query_extra);
+  g.pending = c.take<int32_t>(n > n_query_extra ? n : n_query_extra);      // queries knn_query_kernel hands to knn_tail_kernel
+  g.n_pending = c.take<int32_t>(16);
   g.sort_bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr,
                             (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0, 63, (hipStream_t)0);
@@ -614,17 +808,32 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   return DC_OK;
 }
 
+static std::atomic<int> g_knn_budget{2};        // dc_knn_set_shell_budget: shells a lane walks alone before its query goes to the tail kernel
+
 static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, const double* q, const int32_t* qids, int64_t nq,
-                      const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, hipStream_t st) {
+                      const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, int32_t* pending, int32_t* n_pending,
+                      hipStream_t st) {
   const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
   // shells 0..R hold (2R+1)^3 cells at ~4 candidates' worth of work each; a scan of all n points costs n candidates
   int r_exhaust = (int)(cbrt((double)n * 0.25) * 0.5);
   r_exhaust = r_exhaust < 4 ? 4 : (r_exhaust > 64 ? 64 : r_exhaust);
-#define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, n, r_exhaust, idx, dist)
+  const int budget = g_knn_budget.load();
+  if (budget < 0) pending = nullptr;               // one lane per query to the end (the round-2 behaviour)
+  if (pending) DC_HIP(hipMemsetAsync(n_pending, 0, sizeof(int32_t), st));
+#define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, n, r_exhaust, idx, dist, \
+                                  budget, pending, n_pending)
   // the sorted insertion costs ~12 instructions per slot and runs for a whole wavefront whenever one lane accepts a
   // candidate, so the slot count follows k closely (10 = the reference's default nn_k)
   if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 10) LK(10); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
 #undef LK
+  if (pending) {
+    // one wavefront per pending query; their number stays on the device (the grid is fixed, wavefronts stride over the list)
+    const int64_t want = (nq + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 tgrid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048));
+#define LT(KM) hipLaunchKernelGGL((knn_tail_kernel<KM>), tgrid, block, 0, st, sp, sids, q, qids, pending, n_pending, g, tab, k, r, n, r_exhaust, idx, dist)
+    if (k <= 16) LT(16); else LT(64);
+#undef LT
+  }
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
@@ -634,6 +843,8 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
 using namespace dc;
 
 extern "C" {
+
+int dc_knn_set_shell_budget(int shells) { g_knn_budget.store(shells); return DC_OK; }
 
 size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
   if (n < 0 || n_query < 0) return 0;
@@ -664,12 +875,12 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
   else return DC_ERR_DTYPE;
   if (rc) return rc;
   CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
-  if (!query) return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, stream);
+  if (!query) return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, stream);
   if (n_query == 0) return DC_OK;
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
   if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
   else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
-  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, stream);
+  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, stream);
 }
 
 // Radius search, pass 1: per-point neighbour counts and their maximum (device scalars).
@@ -703,6 +914,9 @@ int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, si
   CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, nullptr, idx_out, kmax);
+  if (kmax <= kRadiusSortMax && kmax > 1)
+    hipLaunchKernelGGL(radius_sort_rows_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), (size_t)kmax * kWave * sizeof(int32_t),
+                       stream, idx_out, n, kmax);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
