@@ -9,7 +9,7 @@ oracle's restatement of the published algorithm (recorded in each fixture's ``me
 Before a fixture is written, the oracle restatement (oracle/dc_oracle.py) is run on the same inputs
 and asserted equal to the reference's outputs, so a committed fixture certifies both.
 
-Usage:  python oracle/gen_golden.py [names]    (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid,shadow,models}.npz, about 10 MB)
+Usage:  python oracle/gen_golden.py [names]    (writes tests/golden/{c0_plane,room_k10,icp_pairs,knn,grid,shadow,models,inliers,io,online}.npz, about 12 MB)
 """
 import os
 import sys
@@ -469,10 +469,161 @@ def gen_knn():
     np.savez_compressed(os.path.join(GOLD, 'knn.npz'), **out)
 
 
+def gen_io():
+    """Scan and pose files read by the LIVE reference readers: KITTI-360 ``.bin`` with the ego-box crop
+    (datasets/kitti360.py:96-109), ASL-laser point CSV / ``.npz`` (asl_laser.py:33-45), pose CSV read and written
+    (asl_laser.py:48-66), FEE-corridor structured ``.npz`` (fee_corridor.py:35-45).  The fixture holds the FILES (as bytes)
+    and what the reference's readers and DepthCloud.from_structured_array / from_points + filter_depth make of them."""
+    for m in ['kitti360scripts', 'kitti360scripts.helpers', 'kitti360scripts.helpers.annotation', 'kitti360scripts.helpers.labels',
+              'kitti360scripts.helpers.ply', 'kitti360scripts.devkits', 'kitti360scripts.devkits.commons',
+              'kitti360scripts.devkits.commons.loadCalibration', 'matplotlib', 'matplotlib.cm', 'matplotlib.pyplot']:
+        sys.modules.setdefault(m, MagicMock())
+    from depth_correction.datasets import asl_laser, fee_corridor, kitti360
+    from depth_correction.filters import filter_depth
+    from numpy.lib.recfunctions import structured_to_unstructured, unstructured_to_structured
+    rng = np.random.default_rng(5)
+    tmp = tempfile.mkdtemp()
+    out = dict(meta=np.array(META))
+    rd = lambda path: np.frombuffer(open(path, 'rb').read(), dtype=np.uint8).copy()
+
+    # ---- KITTI-360 .bin: rays around the car, a fifth of them inside the 1 m ego box
+    n = 3000
+    xyz = rng.normal(size=(n, 3)) * [12.0, 9.0, 1.5]
+    xyz[::5] = rng.uniform(-0.99, 0.99, size=(len(xyz[::5]), 3))
+    xyz[7] = [1.0, 0.5, 0.2]                                   # exactly on the box: |x| <= d is dropped
+    raw = np.concatenate([xyz, rng.uniform(0, 1, size=(n, 1))], axis=1).astype(np.float32)
+    os.makedirs(os.path.join(tmp, 'velo'))
+    path = os.path.join(tmp, 'velo', '%010d.bin' % 3)
+    raw.tofile(path)
+    ds = object.__new__(kitti360.Dataset)                      # the reader alone: no sequence folder to open
+    ds.cloud_dir = os.path.join(tmp, 'velo')
+    cloud = ds.local_cloud(3)
+    assert cloud.dtype.names == ('x', 'y', 'z', 'i') and 0 < len(cloud) < n
+    out['kitti_bin'] = rd(path)
+    out['kitti_xyzi'] = structured_to_unstructured(cloud)
+    for tag, dtype in (('f32', np.float32), ('f64', np.float64)):
+        dc = DepthCloud.from_structured_array(cloud, dtype=dtype)
+        keep = filter_depth(dc, min=2.0, max=25.0, only_mask=True)
+        out['kitti_%s_dirs' % tag], out['kitti_%s_depth' % tag], out['kitti_%s_keep' % tag] = npy(dc.dirs), npy(dc.depth), npy(keep)
+        assert bool((dc.vps == 0).all())
+
+    # ---- ASL-laser point CSV (header; id, x, y, z, intensity) and its .npz twin
+    pts = rng.normal(size=(500, 3)) * [6.0, 5.0, 2.0]
+    path = os.path.join(tmp, 'PointCloud7.csv')
+    with open(path, 'w') as f:
+        f.write('timestamp,x,y,z,intensity\n')
+        for i, q in enumerate(pts):
+            f.write('%d,%.9g,%.9g,%.9g,%.4f\n' % (1000 + i, q[0], q[1], q[2], rng.uniform()))
+    got = asl_laser.read_points(path)
+    assert got.shape == (500, 3)
+    out['asl_csv'], out['asl_csv_points'] = rd(path), got
+    dc = DepthCloud.from_points(torch.as_tensor(got), dtype=torch.float64)      # (with a numpy array and a numpy dtype the reference raises)
+    out['asl_f64_dirs'], out['asl_f64_depth'] = npy(dc.dirs), npy(dc.depth)
+    path = os.path.join(tmp, 'cloud7.npz')
+    np.savez(path, got)
+    assert np.array_equal(asl_laser.read_points_npz(path), got)
+    out['asl_npz'] = rd(path)
+
+    # ---- pose CSV: written by the reference, read back by it
+    ids = [3, 4, 7]
+    poses = []
+    for k in ids:
+        T = np.eye(4)
+        T[:3, :3] = npy(O.axis_angle_to_matrix(torch.tensor([[0.1 * k, -0.05 * k, 0.2]], dtype=torch.float64)))[0]
+        T[:3, 3] = [1.5 * k, -0.25 * k, 0.1]
+        poses.append(T)
+    path = os.path.join(tmp, 'poses.csv')
+    asl_laser.write_poses(ids, poses, path, ts=[10.5, 11.5, 12.5])
+    rids, rposes = asl_laser.read_poses(path)
+    assert rids == ids
+    out['poses_csv'], out['poses_ids'], out['poses_T'] = rd(path), np.array(rids), np.stack(rposes)
+    close(np.stack(rposes), np.stack(poses), rtol=0, atol=1e-9, what='pose csv round trip')
+
+    # ---- FEE corridor: structured array with viewpoints under the key 'cloud', string pose ids
+    m = 400
+    vp = rng.normal(size=(m, 3)) * 0.05 + [0.2, -0.1, 0.4]
+    xyz = vp + rng.normal(size=(m, 3)) * [5.0, 4.0, 1.0]
+    arr = unstructured_to_structured(np.concatenate([xyz, vp], axis=1).astype(np.float32),
+                                     names=['x', 'y', 'z', 'vp_x', 'vp_y', 'vp_z'])
+    path = os.path.join(tmp, 'scan.npz')
+    np.savez(path, cloud=arr)
+    got = fee_corridor.read_points_npz(path)
+    assert got.dtype.names == arr.dtype.names
+    out['fee_npz'] = rd(path)
+    dc = DepthCloud.from_structured_array(got, dtype=np.float64)
+    out['fee_f64_vps'], out['fee_f64_dirs'], out['fee_f64_depth'] = npy(dc.vps), npy(dc.dirs), npy(dc.depth)
+    path = os.path.join(tmp, 'fee_poses.csv')
+    with open(path, 'w') as f:
+        f.write('poseId, timestamp, ' + ', '.join('T%d%d' % (r, c) for r in range(4) for c in range(4)) + '\n')
+        for k, T in zip(ids, poses):
+            f.write('%s, %.9f, %s\n' % ('1669300%03d' % k, 0.5 * k, ', '.join('%.9f' % x for x in T.flatten())))
+    fids, fposes = fee_corridor.read_poses(path)
+    out['fee_poses_csv'], out['fee_poses_ids'], out['fee_poses_T'] = rd(path), np.array([int(i) for i in fids]), np.asarray(fposes)
+    print('io: kitti %d -> %d rows, asl csv %d, fee npz %d, %d poses' % (n, len(cloud), len(pts), m, len(ids)))
+    np.savez_compressed(os.path.join(GOLD, 'io.npz'), **out)
+
+
+def gen_online():
+    """The online correction node's per-scan statements (scripts/depth_correction:31-58) on the LIVE reference:
+        dc = local_feature_cloud(input_cloud, cfg); dc = model(dc); dc.update_points(); out = dc.to_structured_array()
+    for a ring scan with range steps (shadow points at their edges), with the shadow filter on, k-NN neighbourhoods, the
+    default planarity mask and a ScaledPolynomial model; input with and without viewpoint fields."""
+    ds = KittiLikeDataset(n_poses=1, n_rings=32, n_azimuth=1024)
+    cloud, _ = ds[0]
+    xyz = xyz_of(cloud)
+    d = np.linalg.norm(xyz, axis=1)
+    az = np.arange(len(xyz)) % 1024
+    xyz[(az % 40) < 3] *= 0.6                                     # occluding poles
+    keep = (np.linalg.norm(xyz, axis=1) > 1.0) & (np.linalg.norm(xyz, axis=1) < 25.0)   # "depth and grid filters are run earlier"
+    xyz = xyz[keep].astype(np.float32)
+    from numpy.lib.recfunctions import unstructured_to_structured
+    out = dict(meta=np.array(META), xyz=xyz)
+    w, e = [2e-3, -1e-3], [2.0, 4.0]
+    out['w'], out['exponent'] = np.array(w), np.array(e)
+    # (float64 clouds only: on a float32 cloud with a mask the reference's model raises -- its weights are always float64 and
+    # index_put refuses the mixed dtypes, model.py:260)
+    for tag, dtype, with_vp in (('f64', 'float64', False), ('f64vp', 'float64', True)):
+        cfg = Config()
+        cfg.log_dir = tempfile.mkdtemp()
+        cfg.log_filters = False
+        cfg.float_type = dtype
+        cfg.nn_k, cfg.nn_r = 10, None
+        cfg.shadow_neighborhood_angle = 0.017453 * 1.5
+        cfg.shadow_angle_bounds = [float(np.radians(5.0)), float('inf')]
+        if with_vp:
+            vp = np.tile(np.array([[0.05, -0.02, 0.1]], dtype=np.float32), (len(xyz), 1))
+            arr = unstructured_to_structured(np.concatenate([xyz + vp, vp], axis=1), names=['x', 'y', 'z', 'vp_x', 'vp_y', 'vp_z'])
+        else:
+            arr = unstructured_to_structured(xyz, names=['x', 'y', 'z'])
+        model = ScaledPolynomial(w=w, exponent=e)
+        with torch.no_grad():
+            dc = local_feature_cloud(arr, cfg)
+            n_after_shadow = len(dc)
+            dc = model(dc)
+            dc.update_points()
+        # the fields to_structured_array publishes (depth_cloud.py:508-533), cast as it casts them; the call itself fails under
+        # numpy >= 2 (merge_arrays' default fill value -1 does not fit the uint8 mask), which is not the path's arithmetic
+        out[tag + '_points'] = npy(dc.get_points()).astype(np.float32)
+        out[tag + '_vps'] = npy(dc.vps).astype(np.float32)
+        out[tag + '_mask'] = npy(dc.mask).astype(np.uint8)
+        out[tag + '_inc'] = npy(dc.inc_angles).astype(np.float32)[:, 0]
+        out[tag + '_normals'] = npy(dc.normals).astype(np.float32)
+        out[tag + '_depth'] = npy(dc.depth)
+        out[tag + '_neighbors'] = compact(dc.neighbors)
+        assert 0 < n_after_shadow < len(xyz) and bool(dc.mask.any()) and not bool(dc.mask.all())
+        print('online %s: %d rays -> %d after the shadow filter, %d in the planarity mask' % (tag, len(xyz), n_after_shadow, int(dc.mask.sum())))
+    out['shadow_neighborhood_angle'], out['shadow_bound_deg'], out['nn_k'] = 0.017453 * 1.5, 5.0, 10
+    np.savez_compressed(os.path.join(GOLD, 'online.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models', 'inliers']
+    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models', 'inliers', 'io', 'online']
+    if 'io' in which:
+        gen_io()
+    if 'online' in which:
+        gen_online()
     if 'grid' in which:
         gen_grid()
     if 'knn' in which:

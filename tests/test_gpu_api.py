@@ -982,3 +982,79 @@ def test_train_batched_graph_loop_equals_plain_loop(golden, tmp_path, capsys, mo
     n_plain = len([f for f in os.listdir(tmp_path / 'plain') if f.endswith('_state_dict.pth')])
     n_fast = len([f for f in os.listdir(tmp_path / 'fast') if f.endswith('_state_dict.pth')])
     assert n_plain == sum(f0) and 1 <= n_fast <= 3
+
+
+def test_device_scan_loaders_match_the_reference_readers(golden, tmp_path):
+    """scan_io.load_*_device on the files of tests/golden/io.npz against what the LIVE reference made of them: its readers
+    (datasets/kitti360.py:96-109 with the ego-box crop, asl_laser.py:33-45, fee_corridor.py:35-38) followed by
+    DepthCloud.from_structured_array / from_points (depth_cloud.py:577-638) and filter_depth (filters.py:116-141)."""
+    from depth_correction_amd import scan_io
+    g = golden('io')
+
+    def wr(name, key):
+        p = tmp_path / name
+        p.write_bytes(g[key].tobytes())
+        return str(p)
+    path = wr('0000000003.bin', 'kitti_bin')
+    for tag, dtype, rtol in (('f32', torch.float32, 2e-7), ('f64', torch.float64, 1e-15)):
+        dc = scan_io.load_kitti_bin_device(path, dtype=dtype)
+        assert dc.dirs.dtype == dtype and len(dc) == len(g['kitti_%s_depth' % tag])                # same rows survive the crop
+        np.testing.assert_allclose(npy(dc.depth), g['kitti_%s_depth' % tag], rtol=rtol)
+        np.testing.assert_allclose(npy(dc.dirs), g['kitti_%s_dirs' % tag], rtol=0, atol=rtol)
+        assert bool((dc.vps == 0).all())
+        keep = g['kitti_%s_keep' % tag]
+        dcf = scan_io.load_kitti_bin_device(path, dtype=dtype, min_depth=2.0, max_depth=25.0)      # crop + depth filter fused
+        assert len(dcf) == int(keep.sum()) and 0 < len(dcf) < len(dc)
+        np.testing.assert_allclose(npy(dcf.depth), g['kitti_%s_depth' % tag][keep], rtol=rtol)
+    dc = scan_io.load_points_csv_device(wr('PointCloud7.csv', 'asl_csv'), dtype=torch.float64)
+    np.testing.assert_allclose(npy(dc.depth), g['asl_f64_depth'], rtol=1e-15)
+    np.testing.assert_allclose(npy(dc.dirs), g['asl_f64_dirs'], rtol=0, atol=1e-15)
+    dc = scan_io.load_points_npz_device(wr('cloud7.npz', 'asl_npz'), dtype=torch.float64)
+    np.testing.assert_allclose(npy(dc.depth), g['asl_f64_depth'], rtol=1e-15)
+    dc = scan_io.load_points_npz_device(wr('scan.npz', 'fee_npz'), dtype=torch.float64)            # structured, with viewpoints
+    np.testing.assert_allclose(npy(dc.vps), g['fee_f64_vps'], rtol=1e-15)
+    np.testing.assert_allclose(npy(dc.depth), g['fee_f64_depth'], rtol=1e-14)
+    np.testing.assert_allclose(npy(dc.dirs), g['fee_f64_dirs'], rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize('tag', ['f64', 'f64vp'])
+def test_online_correction_sequence_golden(golden, tag):
+    """online.correct_cloud = the correction node's per-scan statements (scripts/depth_correction:31-58: local_feature_cloud
+    with the shadow filter -> model -> update_points) against the LIVE reference run on the same scan (tests/golden/
+    online.npz, oracle/gen_golden.py:gen_online): the surviving points, their neighbourhoods (bit-exact), planarity mask,
+    incidence angles, oriented normals, corrected depths and published points -- from a structured array without and
+    with viewpoint fields, and from a cloud already on the device."""
+    from numpy.lib.recfunctions import unstructured_to_structured
+    from depth_correction_amd.config import Config
+    from depth_correction_amd.model import ScaledPolynomial
+    from depth_correction_amd.online import correct_cloud
+    from depth_correction_amd.scan_io import cloud_on_device
+    g = golden('online')
+    cfg = Config(nn_k=int(g['nn_k']), nn_r=None, float_type='float64', device='cuda:0', log_filters=False,
+                 shadow_neighborhood_angle=float(g['shadow_neighborhood_angle']),
+                 shadow_angle_bounds=[float(np.radians(float(g['shadow_bound_deg']))), float('inf')])
+    model = ScaledPolynomial(w=g['w'].tolist(), exponent=g['exponent'].tolist(), device='cuda:0')
+    xyz = g['xyz']
+    if tag == 'f64vp':
+        vp = np.tile(np.array([[0.05, -0.02, 0.1]], dtype=np.float32), (len(xyz), 1))
+        arr = unstructured_to_structured(np.concatenate([xyz + vp, vp], axis=1), names=['x', 'y', 'z', 'vp_x', 'vp_y', 'vp_z'])
+        inputs = [arr]
+    else:
+        inputs = [unstructured_to_structured(xyz, names=['x', 'y', 'z']),
+                  cloud_on_device(torch.as_tensor(xyz, device='cuda:0'), dtype=torch.float64)]
+    for inp in inputs:
+        dc = correct_cloud(inp, model, cfg)
+        assert len(dc) == len(g[tag + '_depth']) < len(xyz)                                   # the shadow filter removed the same rays
+        assert np.array_equal(npy(dc.neighbors), g[tag + '_neighbors'])
+        assert np.array_equal(npy(dc.mask).astype(np.uint8), g[tag + '_mask'])
+        np.testing.assert_allclose(npy(dc.depth), g[tag + '_depth'], rtol=1e-12)
+        np.testing.assert_allclose(npy(dc.inc_angles)[:, 0], g[tag + '_inc'], rtol=0, atol=2e-6)       # float32 in the fixture
+        pts = npy(dc.get_points()).astype(np.float32)
+        np.testing.assert_allclose(pts, g[tag + '_points'], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(npy(dc.vps).astype(np.float32), g[tag + '_vps'], rtol=0, atol=1e-7)
+        # normals: eigenvectors of well separated smallest eigenvalues, oriented towards the sensor (depth_cloud.py:401-415)
+        cos = np.abs(np.einsum('ni,ni->n', npy(dc.normals), g[tag + '_normals'].astype(np.float64)))
+        planar = g[tag + '_mask'].astype(bool)
+        assert cos[planar].min() > 1 - 1e-6
+        same_side = np.einsum('ni,ni->n', npy(dc.normals), g[tag + '_normals'].astype(np.float64))[planar] > 0
+        assert same_side.all()

@@ -280,3 +280,36 @@ def test_quantile_fallback_beyond_torch_limit_is_the_same_arithmetic():
                 got = torch.lerp(s[lo], s[hi], rank - lo.to(dtype))
                 assert torch.equal(got, want), (dtype, n, q)
                 assert torch.equal(plan._quantile(v, q), want)
+
+
+def _write(tmp_path, name, data):
+    p = tmp_path / name
+    p.write_bytes(bytes(bytearray(data.tolist())) if not isinstance(data, (bytes, bytearray)) else data)
+    return str(p)
+
+
+def test_scan_and_pose_readers_match_the_reference_readers(golden, tmp_path):
+    """scan_io's host readers on the very files the LIVE reference read when tests/golden/io.npz was generated
+    (oracle/gen_golden.py:gen_io): KITTI-360 .bin with the ego-box crop (datasets/kitti360.py:96-109), ASL-laser CSV and
+    .npz (asl_laser.py:33-45), FEE-corridor structured .npz (fee_corridor.py:35-38), pose CSVs read (asl_laser.py:48-66,
+    fee_corridor.py:41-49) and written (asl_laser.py:59-66: byte for byte)."""
+    from numpy.lib.recfunctions import structured_to_unstructured
+    from depth_correction_amd import scan_io
+    g = golden('io')
+    cloud = scan_io.read_kitti_bin(_write(tmp_path, '0000000003.bin', g['kitti_bin'].tobytes()))
+    assert cloud.dtype.names == ('x', 'y', 'z', 'i')
+    assert np.array_equal(structured_to_unstructured(cloud), g['kitti_xyzi'])
+    pts = scan_io.read_points_csv(_write(tmp_path, 'PointCloud7.csv', g['asl_csv'].tobytes()))
+    assert np.array_equal(pts, g['asl_csv_points'])
+    assert np.array_equal(scan_io.read_points_npz(_write(tmp_path, 'cloud7.npz', g['asl_npz'].tobytes())), g['asl_csv_points'])
+    fee = scan_io.read_points_npz(_write(tmp_path, 'scan.npz', g['fee_npz'].tobytes()))
+    assert fee.dtype.names == ('x', 'y', 'z', 'vp_x', 'vp_y', 'vp_z') and len(fee) == len(g['fee_f64_depth'])
+    ids, poses = scan_io.read_poses_csv(_write(tmp_path, 'poses.csv', g['poses_csv'].tobytes()))
+    assert ids == g['poses_ids'].tolist() and np.array_equal(np.stack(poses), g['poses_T'])
+    ids, poses = scan_io.read_poses_csv(_write(tmp_path, 'fee_poses.csv', g['fee_poses_csv'].tobytes()))
+    assert ids == g['fee_poses_ids'].tolist() and np.array_equal(np.stack(poses), g['fee_poses_T'])
+    out = str(tmp_path / 'written.csv')
+    scan_io.write_poses_csv(g['poses_ids'].tolist(), list(g['poses_T']), out, ts=[10.5, 11.5, 12.5])
+    # the reference wrote the fixture's file from the unrounded poses; what it READ BACK is what we are given, so the bytes
+    # agree wherever nine decimals survive the round trip -- which is everywhere
+    assert open(out, 'rb').read() == g['poses_csv'].tobytes()
