@@ -15,7 +15,7 @@ def install_as(alias='depth_correction'):
     import sys
     pkg = sys.modules[__name__]
     sys.modules[alias] = pkg
-    for name in ('config', 'dataset', 'depth_cloud', 'eval', 'filters', 'loss', 'model', 'nearest_neighbors', 'preproc',
-                 'train', 'transform', 'utils'):
+    for name in ('config', 'dataset', 'depth_cloud', 'eval', 'filters', 'io', 'loss', 'metrics', 'model', 'nearest_neighbors',
+                 'preproc', 'train', 'transform', 'utils'):
         sys.modules['%s.%s' % (alias, name)] = importlib.import_module('%s.%s' % (__name__, name))
     return pkg

@@ -33,6 +33,8 @@ _SIGNATURES = {
     'dc_knn_build': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_count': (_i32, [_vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_fill': (_i32, [_i64, _f64, _i32, _vp, _vp, _sz, _vp]),
+    'dc_radius_count_query': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
+    'dc_radius_fill_query': (_i32, [_i64, _i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     'dc_knn_transpose_workspace_bytes': (_sz, [_i64, _i32]),
     'dc_knn_transpose': (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     'dc_spatial_order_workspace_bytes': (_sz, [_i64]),

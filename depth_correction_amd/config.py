@@ -113,6 +113,9 @@ class Config(object):
         self.log_filters = False
         self.show_results = False
         # this build: use the fused per-sequence kernels whenever the configuration allows it
+        self.depth_noise = 0.0           # dataset.noisy_dataset (config.py:242-244)
+        self.pose_noise = 0.0
+        self.pose_noise_mode = None
         self.fused = True
         # train(): iterations between two host synchronisations when nobody watches single iterations (no-op callbacks, one
         # process); 1 = the reference's per-iteration bookkeeping (train.py _batched_loop); loop_graph: replay the iteration as

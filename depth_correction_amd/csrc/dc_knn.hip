@@ -662,16 +662,19 @@ __global__ __launch_bounds__(kWave) void radius_sort_rows_kernel(int32_t* __rest
   }
   for (int s = 0; s < cnt; ++s) row[s] = s_rows[s * kWave + threadIdx.x];
 }
+// queries / qids: the query points and their output rows (self search: the sorted points and their original indices; another
+// cloud: its points in fp64, qids == nullptr -> row t)
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                        const double* __restrict__ queries, const int32_t* __restrict__ qids,
                                                         int64_t n, const Grid* __restrict__ gp, CellTable tab, double rad,
                                                         int32_t* __restrict__ count, int32_t* __restrict__ idx_out,
                                                         int kmax) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= n) return;
   const Grid g = *gp;
-  const double q[3] = {sp[t * 3], sp[t * 3 + 1], sp[t * 3 + 2]};
-  const int64_t row = sids[t];
+  const double q[3] = {queries[t * 3], queries[t * 3 + 1], queries[t * 3 + 2]};
+  const int64_t row = qids ? qids[t] : t;
   const double r2 = rad * rad;
   int32_t c[3];
   cell_of(g, q, c);
@@ -899,8 +902,53 @@ int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double
   if (rc) return rc;
   CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, count_out, nullptr, 0);
+  hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, count_out, nullptr, 0);
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), block, 0, stream, count_out, n, kmax_out);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+// The same for the points of ANOTHER cloud as queries (nearest_neighbors.py:50-51 accepts any query): counts per query row.
+int dc_radius_count_query(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride, int64_t n_query,
+                          double r, int32_t* count_out, int32_t* kmax_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!points || n < 0 || n_query < 0 || !(r > 0.0) || !kmax_out || !ws || stride < 3 || q_stride < 3) return DC_ERR_ARG;
+  if (n_query > 0 && (!query || !count_out)) return DC_ERR_ARG;
+  if (n >= (int64_t)0x7fffffff || n_query >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  GridWs w = carve_grid(ws, n, n_query);
+  if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
+  DC_HIP(hipMemsetAsync(kmax_out, 0, sizeof(int32_t), stream));
+  if (n_query == 0) return DC_OK;
+  if (n == 0) return (int)hipMemsetAsync(count_out, 0, (size_t)n_query * sizeof(int32_t), stream);
+  int rc;
+  if (dtype == DC_F32) rc = build_grid((const float*)points, stride, n, 0, r, w, stream);
+  else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, 0, r, w, stream);
+  else return DC_ERR_DTYPE;
+  if (rc) return rc;
+  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
+  else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
+  hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, w.qf64, (const int32_t*)nullptr, n_query, w.grid, tab, r,
+                     count_out, nullptr, 0);
+  hipLaunchKernelGGL(max_i32_kernel, dim3(256), block, 0, stream, count_out, n_query, kmax_out);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+// pass 2 of dc_radius_count_query (grid and fp64 queries still in `ws`)
+int dc_radius_fill_query(int64_t n, int64_t n_query, double r, int kmax, int32_t* idx_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || n_query < 0 || !(r > 0.0) || kmax < 1 || !idx_out || !ws) return DC_ERR_ARG;
+  GridWs w = carve_grid(ws, n, n_query);
+  if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
+  if (n_query == 0) return DC_OK;
+  if (n == 0) return (int)hipMemsetAsync(idx_out, 0xff, (size_t)n_query * kmax * sizeof(int32_t), stream);
+  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
+  hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, w.qf64, (const int32_t*)nullptr, n_query, w.grid, tab, r,
+                     nullptr, idx_out, kmax);
+  if (kmax <= kRadiusSortMax && kmax > 1)
+    hipLaunchKernelGGL(radius_sort_rows_kernel, dim3((unsigned)((n_query + kWave - 1) / kWave)), dim3(kWave), (size_t)kmax * kWave * sizeof(int32_t),
+                       stream, idx_out, n_query, kmax);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
@@ -913,7 +961,7 @@ int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, si
   if (n == 0) return DC_OK;
   CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, nullptr, idx_out, kmax);
+  hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, nullptr, idx_out, kmax);
   if (kmax <= kRadiusSortMax && kmax > 1)
     hipLaunchKernelGGL(radius_sort_rows_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), (size_t)kmax * kWave * sizeof(int32_t),
                        stream, idx_out, n, kmax);

@@ -16,7 +16,8 @@ from __future__ import annotations
 import numpy as np
 from numpy.lib.recfunctions import unstructured_to_structured, merge_arrays
 
-__all__ = ['PlaneDataset', 'RoomBoxDataset', 'KittiLikeDataset', 'create_dataset', 'add_depth_noise']
+__all__ = ['PlaneDataset', 'RoomBoxDataset', 'KittiLikeDataset', 'create_dataset', 'add_depth_noise', 'Forwarding',
+           'TransformingDataset', 'FilteredDataset', 'NoisyPoseDataset', 'NoisyDepthDataset', 'noisy_dataset', 'euler_matrix']
 
 
 def _structured(xyz, normals=None):
@@ -176,3 +177,148 @@ def create_dataset(name, cfg=None, **kwargs):
     if name.startswith('kitti_like'):
         return KittiLikeDataset(**kwargs)
     raise ValueError('Unsupported dataset: %s (real-data readers are out of scope).' % name)
+
+
+# ---- dataset wrappers of the caller scripts (dataset.py:718-873, :933-950) ------------------------------------------------
+class Forwarding(object):
+    """Everything not overridden goes to ``target``."""
+
+    def __init__(self, target):
+        self.target = target
+
+    def __getattr__(self, item):
+        return getattr(self.target, item)
+
+    def __getitem__(self, item):
+        return self.target[item]
+
+    def __iter__(self):
+        return iter(self.target)
+
+    def __len__(self):
+        return len(self.target)
+
+    def __str__(self):
+        return str(self.target)
+
+
+class TransformingDataset(Forwarding):
+    """(cloud, pose) items of ``target`` passed through ``transform_cloud`` / ``transform_pose`` (item index as a keyword)."""
+
+    def transform_cloud(self, cloud, **kwargs):
+        return cloud
+
+    def transform_pose(self, pose, **kwargs):
+        return pose
+
+    def __getitem__(self, item):
+        assert isinstance(item, int), item
+        cloud, pose = self.target[item]
+        return self.transform_cloud(cloud, item=item), self.transform_pose(pose, item=item)
+
+    def __iter__(self):
+        for item, (cloud, pose) in enumerate(self.target):
+            yield self.transform_cloud(cloud, item=item), self.transform_pose(pose, item=item)
+
+    def local_cloud(self, id):
+        return self.transform_cloud(self.target.local_cloud(id))
+
+    def cloud_pose(self, id):
+        return self.transform_pose(self.target.cloud_pose(id))
+
+
+class FilteredDataset(TransformingDataset):
+    """Clouds through preproc.filtered_cloud (depth + voxel-grid pre-filters of ``cfg``; dataset.py:765-773)."""
+
+    def __init__(self, dataset, cfg):
+        super().__init__(dataset)
+        self.cfg = cfg
+
+    def transform_cloud(self, cloud, **kwargs):
+        from .preproc import filtered_cloud
+        return filtered_cloud(cloud, self.cfg)
+
+
+def euler_matrix(ai, aj, ak):
+    """tf.transformations.euler_matrix(ai, aj, ak) with its default axes 'sxyz' (rotations about the static x, y, z axes in
+    that order: R = Rz(ak) Ry(aj) Rx(ai)), 4x4.  tf is a ROS package and absent here: restated from its published
+    definition, not pinned against it."""
+    ci, cj, ck = np.cos(ai), np.cos(aj), np.cos(ak)
+    si, sj, sk = np.sin(ai), np.sin(aj), np.sin(ak)
+    M = np.eye(4)
+    M[0, 0], M[0, 1], M[0, 2] = cj * ck, sj * si * ck - ci * sk, sj * ci * ck + si * sk
+    M[1, 0], M[1, 1], M[1, 2] = cj * sk, sj * si * sk + ci * ck, sj * ci * sk - si * ck
+    M[2, 0], M[2, 1], M[2, 2] = -sj, cj * si, cj * ci
+    return M
+
+
+class NoisyPoseDataset(TransformingDataset):
+    """Poses right-multiplied by a random rigid transform: Euler angles and translation ~ noise * N(0, 1), seeded by the pose
+    itself (mode 'pose': every pose its own perturbation, the first one left alone unless ``first_noisy``) or by the
+    configuration's seed (mode 'common': one perturbation for all) -- dataset.py:776-812."""
+
+    class Mode(object):
+        pose = 'pose'
+        common = 'common'
+        values = ('pose', 'common')
+
+    def __init__(self, dataset, noise=0.0, mode=None, first_noisy=False):
+        assert isinstance(noise, float) or len(noise) == 6
+        assert mode is not None and mode in NoisyPoseDataset.Mode.values
+        super().__init__(dataset)
+        self.noise, self.mode, self.first_noisy = np.asarray(noise), mode, first_noisy
+
+    def random_transform(self, seed):
+        vec = self.noise * np.random.default_rng(seed).normal(size=(6,))
+        T = euler_matrix(*vec[:3])
+        T[:3, 3] = vec[3:]
+        return T
+
+    def transform_pose(self, pose, item=None):
+        from .config import Config
+        from .utils import hashable
+        if self.mode == NoisyPoseDataset.Mode.pose:
+            if not self.first_noisy and item == 0:
+                print('No noise for first pose')
+                return pose
+            seed = abs(hash(hashable(pose)))
+        else:
+            seed = Config().random_seed
+        if (self.noise != 0.0).any():
+            pose = np.matmul(pose, self.random_transform(seed))
+        return pose
+
+
+class NoisyDepthDataset(TransformingDataset):
+    """Points moved along their rays by noise * N(0, 1), seeded by the depths themselves (dataset.py:815-846)."""
+
+    def __init__(self, dataset, noise=None):
+        super().__init__(dataset)
+        self.noise = noise
+
+    def transform_cloud(self, cloud, **kwargs):
+        from numpy.lib.recfunctions import structured_to_unstructured
+        from .utils import hashable
+        if self.noise:
+            pts = structured_to_unstructured(cloud[['x', 'y', 'z']])
+            dirs = pts - (structured_to_unstructured(cloud[['vp_x', 'vp_y', 'vp_z']]) if 'vp_x' in cloud.dtype.names else 0.0)
+            depth = np.linalg.norm(dirs, axis=1)
+            valid = depth > 0.0
+            depth = depth[valid]
+            dirs = dirs[valid] / depth[:, None]
+            rng = np.random.default_rng(abs(hash(hashable(depth))))
+            pts[valid] += dirs * self.noise * rng.normal(size=depth.shape)[:, None]
+            cloud[['x', 'y', 'z']] = unstructured_to_structured(pts, names=['x', 'y', 'z'])
+        return cloud
+
+
+def noisy_dataset(ds, cfg):
+    """Depth noise and pose noise of the configuration on top of ``ds`` (dataset.py:933-950; the depth-bias wrapper needs a
+    mesh-free inverse model and is applied by the caller where wanted)."""
+    if getattr(cfg, 'depth_noise', 0.0):
+        print('Adding depth noise %.3g.' % cfg.depth_noise)
+        ds = NoisyDepthDataset(ds, noise=cfg.depth_noise)
+    if getattr(cfg, 'pose_noise_mode', None) is not None and np.any(np.asarray(getattr(cfg, 'pose_noise', 0.0)) != 0.0):
+        print('Adding pose noise %s, %s.' % (cfg.pose_noise, cfg.pose_noise_mode))
+        ds = NoisyPoseDataset(ds, noise=cfg.pose_noise, mode=cfg.pose_noise_mode)
+    return ds

@@ -38,6 +38,4 @@ def nearest_neighbors(points, query, k=None, r=None, n_jobs=-1):
     if k:
         dist, ind = ops.knn(pts, int(k), r=r, query=None if same else qry.to(pts.dtype))
         return dist, ind.long()
-    if not same:
-        raise NotImplementedError('radius search is implemented for self queries (the only use in the reference)')
-    return None, ops.radius_neighbors(pts, float(r)).long()
+    return None, ops.radius_neighbors(pts, float(r), query=None if same else qry.to(pts.dtype)).long()

@@ -59,10 +59,28 @@ def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
 
 
 @on_device
-def radius_neighbors(points, r):
-    """All neighbours within ``r`` (inclusive), ascending index, padded with -1: idx i32 [N, Kmax]."""
+def radius_neighbors(points, r, query=None):
+    """All neighbours within ``r`` (inclusive) of every point -- or of every row of ``query``, another cloud -- ascending
+    index, padded with -1: idx i32 [N | M, Kmax]."""
     need(points, (None, 3), name='points')
     n = points.shape[0]
+    if query is not None:
+        need(query, (None, 3), dtype=points.dtype, name='query', device=points.device)
+        m = query.shape[0]
+        if m == 0:
+            return torch.empty((0, 0), dtype=torch.int32, device=points.device)
+        nbytes = lib().dc_knn_workspace_bytes(n, m)
+        ws = _ws(nbytes, points.device)
+        count = torch.empty((m,), dtype=torch.int32, device=points.device)
+        kmax = torch.zeros((1,), dtype=torch.int32, device=points.device)
+        check(lib().dc_radius_count_query(ptr(points), 3, dtype_code(points), n, ptr(query), 3, m, float(r), ptr(count), ptr(kmax),
+                                          ptr(ws), nbytes, stream_ptr()), 'dc_radius_count_query')
+        km = max(int(kmax.item()), 1)
+        if m * km * 4 > (16 << 30):
+            raise MemoryError('radius neighbourhoods too dense for a padded [M, Kmax] table (%d x %d)' % (m, km))
+        idx = torch.empty((m, km), dtype=torch.int32, device=points.device)
+        check(lib().dc_radius_fill_query(n, m, float(r), km, ptr(idx), ptr(ws), nbytes, stream_ptr()), 'dc_radius_fill_query')
+        return idx
     if n == 0:
         return torch.empty((0, 0), dtype=torch.int32, device=points.device)
     nbytes = lib().dc_knn_workspace_bytes(n, 0)

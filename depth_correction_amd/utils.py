@@ -12,7 +12,7 @@ import time
 
 import torch
 
-__all__ = ['covs', 'trace', 'timing']
+__all__ = ['covs', 'trace', 'timing', 'rotation_angle', 'translation_norm', 'transform_inv', 'delta_transform', 'hashable']
 
 
 def timing(f):
@@ -61,3 +61,47 @@ def covs(x, obs_axis=-2, var_axis=-1, center=True, correction=True, weights=None
 
 def trace(x, dim1=-2, dim2=-1):
     return x.diagonal(dim1=dim1, dim2=dim2).sum(dim=-1)
+
+
+# ---- pose helpers the caller scripts report with (scripts/train_demo:10; utils.py:174-205), numpy 4x4 matrices --------------
+def rotation_angle(T):
+    """Angle of the rotation part, from its trace (clipped into arccos' domain)."""
+    import numpy as np
+    c = (np.trace(np.asarray(T)[:-1, :-1]) - 1.0) / 2.0
+    return float(np.arccos(np.clip(c, -1.0, 1.0)))
+
+
+def translation_norm(T):
+    import numpy as np
+    return float(np.linalg.norm(np.asarray(T)[:-1, -1]))
+
+
+def transform_inv(T):
+    """Inverse of a rigid transform [R t; 0 1] as [R^T  -R^T t; 0 1]."""
+    import numpy as np
+    T = np.asarray(T)
+    out = np.eye(T.shape[0])
+    R = T[:-1, :-1]
+    out[:-1, :-1] = R.T
+    out[:-1, -1:] = -R.T @ T[:-1, -1:]
+    return out
+
+
+def delta_transform(T_0, T_1):
+    """D with T_1 = T_0 D (a linear solve, as the reference does it: no orthonormality assumed)."""
+    import numpy as np
+    return np.linalg.solve(T_0, T_1)
+
+
+def hashable(obj):
+    """Nested lists / dicts / slices / arrays as tuples, so that they can seed a generator (utils.py:67-76)."""
+    import numpy as np
+    if isinstance(obj, (list, tuple)):
+        return tuple(hashable(o) for o in obj)
+    if isinstance(obj, dict):
+        return hashable(sorted(obj.items()))
+    if isinstance(obj, slice):
+        return obj.start, obj.stop, obj.step
+    if isinstance(obj, np.ndarray):
+        return hashable(obj.tolist())
+    return obj

@@ -68,6 +68,13 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
 int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double r, int32_t* count_out,
                     int32_t* kmax_out, void* ws, size_t ws_bytes, dcStream_t stream);
 int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, size_t ws_bytes, dcStream_t stream);
+/* Radius search of the points of ANOTHER cloud (nearest_neighbors.py:50-51: query_ball_point takes any query): the same two
+ * passes, rows = queries; pass 2 needs the workspace of pass 1 untouched (grid of `points` + the queries in fp64).
+ * ws: dc_knn_workspace_bytes(n, n_query). */
+int dc_radius_count_query(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride, int64_t n_query,
+                          double r, int32_t* count_out, int32_t* kmax_out, void* ws, size_t ws_bytes, dcStream_t stream);
+int dc_radius_fill_query(int64_t n, int64_t n_query, double r, int kmax, int32_t* idx_out, void* ws, size_t ws_bytes,
+                         dcStream_t stream);
 
 /* Transposed neighbour list for the backward (replaces autograd's index_put scatter of depth_cloud.py:303-304):
  * nbr int32 [n,k] with values in [0, n_dst) (n_dst <= 0: n_dst = n); csr_ptr int32 [n_dst+1], csr_src int32 [n*k]

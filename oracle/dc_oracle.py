@@ -475,3 +475,16 @@ def closed_form_backward(points, neighbors, mask, kind='min_eigval_loss', normal
     np.add.at(g, nb.reshape(-1), contrib.reshape(-1, 3))
     loss = (ell * msk).sum() / M
     return dict(loss=loss, grad_points=g, pointwise=ell, eigvals=lam, mean=m, v0=v0)
+
+
+def euler_matrix(ai, aj, ak):
+    """tf.transformations.euler_matrix for its default axes 'sxyz' (published definition: static-frame rotations about x, y, z
+    in that order, R = Rz(ak) Ry(aj) Rx(ai)); tf is a ROS package that is absent here, so the fixture generator substitutes
+    this restatement into the reference (dataset.py:25,801) and records that in the fixture's meta."""
+    import numpy as np
+    Rx = np.array([[1, 0, 0], [0, np.cos(ai), -np.sin(ai)], [0, np.sin(ai), np.cos(ai)]])
+    Ry = np.array([[np.cos(aj), 0, np.sin(aj)], [0, 1, 0], [-np.sin(aj), 0, np.cos(aj)]])
+    Rz = np.array([[np.cos(ak), -np.sin(ak), 0], [np.sin(ak), np.cos(ak), 0], [0, 0, 1]])
+    M = np.eye(4)
+    M[:3, :3] = Rz @ Ry @ Rx
+    return M

@@ -563,6 +563,43 @@ def gen_io():
     np.savez_compressed(os.path.join(GOLD, 'io.npz'), **out)
 
 
+def gen_helpers():
+    """Host helpers the caller scripts import (scripts/train_demo:4,10, model_poses_learning_icp:16): utils.delta_transform /
+    rotation_angle / translation_norm / transform_inv (utils.py:174-205) and the dataset wrappers NoisyPoseDataset /
+    NoisyDepthDataset (dataset.py:776-846) from the LIVE reference.  tf.transformations.euler_matrix (ROS) is substituted by
+    the oracle's restatement, like pytorch3d's axis_angle_to_matrix."""
+    import depth_correction.dataset as RD
+    from depth_correction import utils as RU
+    from numpy.lib.recfunctions import unstructured_to_structured, structured_to_unstructured
+    RD.euler_matrix = O.euler_matrix
+    rng = np.random.default_rng(11)
+    out = dict(meta=np.array(META + '; tf.transformations.euler_matrix substituted by oracle restatement (unpinned)'))
+    Ts = []
+    for k in range(4):
+        T = O.euler_matrix(*rng.normal(size=3) * 0.4)
+        T[:3, 3] = rng.normal(size=3) * 2.0
+        Ts.append(T)
+    Ts = np.stack(Ts)
+    out['poses'] = Ts
+    out['delta'] = np.stack([RU.delta_transform(Ts[0], T) for T in Ts])
+    out['rotation_angle'] = np.array([RU.rotation_angle(T) for T in Ts])
+    out['translation_norm'] = np.array([RU.translation_norm(T) for T in Ts])
+    out['transform_inv'] = np.stack([RU.transform_inv(T) for T in Ts])
+    pts = rng.normal(size=(50, 3)) * [4.0, 3.0, 1.0]
+    cloud = unstructured_to_structured(pts, names=['x', 'y', 'z'])
+    base = [(cloud.copy(), T) for T in Ts]
+    noise = [0.01, 0.02, 0.03, 0.1, 0.2, 0.3]
+    out['pose_noise'] = np.array(noise)
+    for mode in ('pose', 'common'):
+        ds = RD.NoisyPoseDataset(base, noise=noise, mode=mode)
+        out['noisy_pose_' + mode] = np.stack([p for _, p in ds])
+    ds = RD.NoisyDepthDataset([(cloud.copy(), Ts[0])], noise=0.05)
+    out['cloud_xyz'] = pts
+    out['noisy_depth_xyz'] = structured_to_unstructured(next(iter(ds))[0][['x', 'y', 'z']])
+    print('helpers: %d poses, pose noise modes pose / common, depth noise' % len(Ts))
+    np.savez_compressed(os.path.join(GOLD, 'helpers.npz'), **out)
+
+
 def gen_online():
     """The online correction node's per-scan statements (scripts/depth_correction:31-58) on the LIVE reference:
         dc = local_feature_cloud(input_cloud, cfg); dc = model(dc); dc.update_points(); out = dc.to_structured_array()
@@ -619,11 +656,13 @@ def gen_online():
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models', 'inliers', 'io', 'online']
+    which = sys.argv[1:] or ['knn', 'grid', 'c0', 'room', 'icp', 'shadow', 'models', 'inliers', 'io', 'online', 'helpers']
     if 'io' in which:
         gen_io()
     if 'online' in which:
         gen_online()
+    if 'helpers' in which:
+        gen_helpers()
     if 'grid' in which:
         gen_grid()
     if 'knn' in which:

@@ -409,6 +409,16 @@ def test_nearest_neighbors_api(golden):
     assert np.array_equal(npy(i), g['k8_r015_ind'])
     d, i = nearest_neighbors(p, p, r=0.12)
     assert d is None and np.array_equal(npy(i), g['r012_ind'])
+    # radius search of ANOTHER cloud's points (nearest_neighbors.py:50-51: query_ball_point takes any query) against cKDTree
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(12)
+    qn = (g['points'][rng.choice(len(g['points']), 700, replace=False)] + rng.normal(size=(700, 3)) * 0.05).astype(np.float32).astype(np.float64)
+    qn[5] = [50.0, 50.0, 50.0]                                  # a query with no neighbour at all
+    d, i = nearest_neighbors(p, t(qn, 'cuda:0'), r=0.2)
+    lists = cKDTree(g['points']).query_ball_point(qn, 0.2)
+    kmax = max(len(x) for x in lists)
+    ref = np.array([sorted(x) + (kmax - len(x)) * [-1] for x in lists])
+    assert d is None and i.dtype == torch.int64 and np.array_equal(npy(i), ref) and (ref[5] == -1).all() and kmax > 20
     dc_r = t(g['points'][:500], 'cuda:0')
     from depth_correction_amd.depth_cloud import DepthCloud
     cloud = DepthCloud.from_points(dc_r)

@@ -313,3 +313,77 @@ def test_scan_and_pose_readers_match_the_reference_readers(golden, tmp_path):
     # the reference wrote the fixture's file from the unrounded poses; what it READ BACK is what we are given, so the bytes
     # agree wherever nine decimals survive the round trip -- which is everywhere
     assert open(out, 'rb').read() == g['poses_csv'].tobytes()
+
+
+def test_caller_script_helpers_match_the_reference(golden, capsys):
+    """utils.delta_transform / rotation_angle / translation_norm / transform_inv and the NoisyPoseDataset / NoisyDepthDataset
+    wrappers against the LIVE reference (tests/golden/helpers.npz; euler_matrix of ROS' tf substituted on both sides)."""
+    from numpy.lib.recfunctions import structured_to_unstructured, unstructured_to_structured
+    from depth_correction_amd import dataset as D, utils as U
+    g = golden('helpers')
+    Ts = g['poses']
+    for k, T in enumerate(Ts):
+        np.testing.assert_allclose(U.delta_transform(Ts[0], T), g['delta'][k], rtol=1e-12, atol=1e-14)
+        assert abs(U.rotation_angle(T) - g['rotation_angle'][k]) < 1e-14
+        assert abs(U.translation_norm(T) - g['translation_norm'][k]) < 1e-14
+        np.testing.assert_allclose(U.transform_inv(T), g['transform_inv'][k], rtol=1e-14, atol=1e-16)
+    cloud = unstructured_to_structured(g['cloud_xyz'], names=['x', 'y', 'z'])
+    base = [(cloud.copy(), T) for T in Ts]
+    for mode in ('pose', 'common'):
+        ds = D.NoisyPoseDataset(base, noise=g['pose_noise'].tolist(), mode=mode)
+        np.testing.assert_allclose(np.stack([p for _, p in ds]), g['noisy_pose_' + mode], rtol=1e-13, atol=1e-15)
+    assert np.array_equal(g['noisy_pose_pose'][0], Ts[0]) and not np.allclose(g['noisy_pose_common'][0], Ts[0])
+    ds = D.NoisyDepthDataset([(cloud.copy(), Ts[0])], noise=0.05)
+    np.testing.assert_allclose(structured_to_unstructured(next(iter(ds))[0][['x', 'y', 'z']]), g['noisy_depth_xyz'], rtol=1e-13)
+    capsys.readouterr()
+
+
+CALLER_IMPORTS = {
+    # the import lines of the reference's caller scripts that this package answers under install_as('depth_correction'):
+    'scripts/train_demo': {'config': ['Config', 'Loss', 'Model', 'NeighborhoodType', 'PoseCorrection'],
+                           'dataset': ['create_dataset', 'noisy_dataset', 'NoisyPoseDataset'], 'depth_cloud': ['DepthCloud'],
+                           'model': ['load_model', 'model_by_name'], 'preproc': ['filtered_cloud', 'global_cloud', 'local_feature_cloud'],
+                           'train': ['train', 'TrainCallbacks'], 'utils': ['delta_transform', 'rotation_angle', 'timing', 'translation_norm']},
+    'scripts/model_poses_learning': {'depth_cloud': ['DepthCloud'], 'model': ['ScaledPolynomial'],
+                                     'preproc': ['filtered_cloud', 'local_feature_cloud', 'establish_neighborhoods', 'compute_neighborhood_features'],
+                                     'config': ['Config', 'PoseCorrection', 'Loss', 'NeighborhoodType'], 'loss': ['icp_loss', 'create_loss'],
+                                     'eval': ['create_corrected_poses', 'global_cloud']},
+    'scripts/model_poses_learning_icp': {'depth_cloud': ['DepthCloud'], 'model': ['ScaledPolynomial'], 'preproc': ['local_feature_cloud'],
+                                         'config': ['Config', 'PoseCorrection'], 'loss': ['icp_loss'], 'eval': ['create_corrected_poses', 'global_cloud'],
+                                         'io': ['write', 'append'], 'dataset': ['NoisyPoseDataset', 'FilteredDataset'],
+                                         'transform': ['matrix_to_xyz_axis_angle', 'xyz_axis_angle_to_matrix']},
+    'scripts/depth_correction': {'config': ['Config'], 'model': ['load_model'], 'preproc': ['local_feature_cloud']},
+    'examples/optimization': {'dataset': ['create_dataset'], 'depth_cloud': ['DepthCloud'], 'model': ['ScaledPolynomial'],
+                              'preproc': ['filtered_cloud', 'local_feature_cloud', 'establish_neighborhoods', 'compute_neighborhood_features'],
+                              'config': ['Config', 'PoseCorrection', 'Loss', 'NeighborhoodType'], 'loss': ['create_loss'],
+                              'eval': ['create_corrected_poses', 'global_cloud']},
+    'examples/optimization_icp': {'dataset': ['create_dataset'], 'depth_cloud': ['DepthCloud'], 'model': ['ScaledPolynomial'],
+                                  'preproc': ['filtered_cloud'], 'config': ['Config'], 'loss': ['point_to_plane_dist']},
+}
+# what those scripts import beyond it -- ROS / data-set / viewer glue that stays outside (INTEGRATION.md A)
+NOT_PROVIDED = {'scripts/train_demo': ['point_cloud.PointCloud'],
+                'scripts/model_poses_learning': ['datasets.fee_corridor.Dataset', 'datasets.fee_corridor.dataset_names'],
+                'scripts/model_poses_learning_icp': ['datasets.fee_corridor.Dataset', 'datasets.fee_corridor.dataset_names',
+                                                     'datasets.fee_corridor.seq_names'],
+                'examples/optimization': ['visualization.visualize_dataset']}
+
+
+def test_caller_script_imports_resolve_under_install_as():
+    import importlib
+    import sys
+    import depth_correction_amd
+    depth_correction_amd.install_as('depth_correction')
+    try:
+        for script, mods in CALLER_IMPORTS.items():
+            for mod, names in mods.items():
+                m = importlib.import_module('depth_correction.' + mod)
+                for n in names:
+                    assert hasattr(m, n), '%s: depth_correction.%s.%s does not resolve' % (script, mod, n)
+        for script, names in NOT_PROVIDED.items():                    # stated as absent: make sure the statement stays true
+            for dotted in names:
+                mod = dotted.rsplit('.', 1)[0]
+                with pytest.raises(ImportError):
+                    importlib.import_module('depth_correction.' + mod)
+    finally:
+        for k in [k for k in sys.modules if k == 'depth_correction' or k.startswith('depth_correction.')]:
+            del sys.modules[k]
