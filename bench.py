@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--k', type=int, default=10)
     ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
     ap.add_argument('--cpu-scans', type=int, default=10, help='scans in the CPU baseline (10 = the full C2 workload; 0 = skip)')
-    ap.add_argument('--cpu-iters', type=int, default=3, help='timed iterations of the fp64 all-cores CPU baseline')
+    ap.add_argument('--cpu-iters', type=int, default=5, help='timed iterations of the fp64 all-cores CPU baseline (BASELINE.md 3: >= 5 after one warm-up)')
     ap.add_argument('--cpu-variants', type=int, default=1, help='also time the fp32 and the 8-thread variants (BASELINE.md 3)')
     ap.add_argument('--no-sort', action='store_true', help='keep the scan-major point order (ablation)')
     ap.add_argument('--point-format', default='auto', choices=['auto', 'q32', 'float'])

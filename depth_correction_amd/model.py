@@ -52,6 +52,15 @@ class BaseModel(torch.nn.Module):
         """(w [1,P], exponent [1,P]) for the kernels; ``w`` stays connected to the model's parameters by autograd."""
         raise NotImplementedError()
 
+    def _zero_exponent(self, n, device):
+        """The constant exponent vector of the models that have none: ONE tensor per (model, device), so that the plans' basis
+        rows -- keyed by the identity and version of the exponent tensor -- survive from one evaluation to the next."""
+        z = self.__dict__.get('_zero_exp')
+        if z is None or z.shape[1] != n or z.device != device:
+            z = torch.zeros((1, n), dtype=torch.float64, device=device)
+            self.__dict__['_zero_exp'] = z
+        return z
+
     def __str__(self):
         return 'BaseModel()'
 
@@ -70,7 +79,7 @@ class Linear(BaseModel):
 
     def kernel_params(self):
         w = torch.stack([self.w0.reshape(()), self.w1.reshape(()), self.b.reshape(())]).reshape(1, 3)
-        return w, torch.zeros((1, 3), dtype=torch.float64, device=w.device)
+        return w, self._zero_exponent(3, w.device)
 
     def __init__(self, w0=1.0, w1=0.0, b=0.0, uniform_weights=False, device=torch.device('cpu')):
         super().__init__(device=device)
@@ -157,7 +166,7 @@ class InvCos(BaseModel):
 
     def kernel_params(self):
         w = self.p0.reshape(1, 1)
-        return w, torch.zeros((1, 1), dtype=torch.float64, device=w.device)
+        return w, self._zero_exponent(1, w.device)
 
     def __init__(self, p0=0.0, device=torch.device('cpu')):
         super().__init__(device=device)
@@ -178,7 +187,7 @@ class ScaledInvCos(BaseModel):
 
     def kernel_params(self):
         w = self.p0.reshape(1, 1)
-        return w, torch.zeros((1, 1), dtype=torch.float64, device=w.device)
+        return w, self._zero_exponent(1, w.device)
 
     def __init__(self, p0=0.0, device=torch.device('cpu')):
         super().__init__(device=device)

@@ -103,7 +103,29 @@ def on_streams(jobs, device, n_streams=4):
             out.append(job())
     for s_ in streams:
         main.wait_stream(s_)
+    # the results were allocated in the side streams' pools: tell the allocator that the caller's stream uses them from here
+    # on, or a later free would hand the blocks back to a side stream with nothing ordering the reuse after these readers
+    for r in out:
+        for t in _tensors_of(r):
+            t.record_stream(main)
     return out
+
+
+def _tensors_of(obj, depth=0):
+    """The torch tensors reachable from a job's result: tensors, containers of them, objects holding them as attributes
+    (DepthCloud fields)."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors_of(o, depth + 1)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_of(o, depth + 1)
+    elif depth < 2 and hasattr(obj, '__dict__'):
+        for o in vars(obj).values():
+            yield from _tensors_of(o, depth + 1)
 
 
 class _Stages(object):

@@ -27,7 +27,7 @@ from .loss import create_loss, icp_correspondences
 from .model import load_model
 from .preproc import establish_neighborhoods, global_cloud, global_cloud_mask, local_feature_cloud
 
-__all__ = ['TrainCallbacks', 'train']
+__all__ = ['TrainCallbacks', 'train', 'release_plans']
 
 
 class TrainCallbacks(object):
@@ -107,8 +107,28 @@ def _zero_first_pose(pose_deltas):
             d.grad[0].zero_()                                 # the first pose stays fixed (train.py:309-311)
 
 
+def release_plans():
+    """Drop the cached per-sequence plans (eval._plans, loss._icp_plans): each holds the local clouds, tables and work buffers
+    of a sequence -- hundreds of MB at C2 -- and nothing else releases them in a long-lived process."""
+    from . import eval as _eval, loss as _loss
+    _eval._plans.clear()
+    reg = getattr(_loss, '_icp_plans', None)
+    if reg is not None:
+        reg.clear()
+
+
 def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
-    """Optimise the depth-correction model (and pose corrections); returns the config of the best iteration."""
+    """Optimise the depth-correction model (and pose corrections); returns the config of the best iteration.  The plans built
+    for its sequences are released when it returns (``cfg.keep_plans = True`` keeps them for a caller that goes on
+    evaluating the same clouds)."""
+    try:
+        return _train(cfg, callbacks, train_datasets, val_datasets)
+    finally:
+        if not getattr(cfg, 'keep_plans', False):
+            release_plans()
+
+
+def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     assert cfg.nn_type == NeighborhoodType.ball
     callbacks = callbacks or TrainCallbacks(cfg)
     rank, world = world_info() if getattr(cfg, 'distributed', None) is not False else (0, 1)

@@ -243,7 +243,22 @@ def test_consistency_f32_vs_oracle(golden, dev, name, tag, loss, norm, sqrt):
             # (b) end to end against the fp64 oracle: 1e-5 relative plus the first-order effect of moving a
             # coordinate by one resolution step, d(lambda) = 2 sqrt(lambda) step  (3e-8 m here)
             lam, ref = npy(r['fw']['eigvals']).astype(np.float64), npy(ref_f['eigvals'])
-            assert np.all(np.abs(lam - ref) <= RTOL * np.abs(ref) + 2 * np.sqrt(np.abs(ref)) * step)
+            err = np.abs(lam - ref)
+            assert np.all(err <= RTOL * np.abs(ref) + 2 * np.sqrt(np.abs(ref)) * step)
+            # how much of that allowance is used.  One grid step of a coordinate moves an eigenvalue by ~2 sqrt(lambda) step, which IS
+            # more than 1e-5 of it wherever sqrt(lambda) < 2e5 step = 6 mm: the thin direction of this fixture's surfaces (range noise
+            # 1e-3 of 1..10 m).  Measured: 13.7 % of the eigenvalues are in that regime (fp32-rounded points, the reference's own fp32
+            # mode, put all of them there: their step is 20x coarser at 10 m), none uses more than 0.6 of the quantisation term, and
+            # the quantities the path returns -- loss and gradients, sums over the cloud -- keep the bare 1e-5 (asserted above)
+            rel = err / np.maximum(np.abs(ref), 1e-300)
+            need_slack = err > RTOL * np.abs(ref)
+            frac, worst = float(need_slack.mean()), float(rel.max())
+            used = float((err[need_slack] / (2 * np.sqrt(np.abs(ref[need_slack])) * step)).max()) if need_slack.any() else 0.0
+            print('q32 eigenvalues vs fp64 oracle: worst relative error %.3g; %.4f %% of the eigenvalues need the quantisation term, '
+                  'which they use to at most %.2f' % (worst, 100 * frac, used))
+            assert frac <= 0.2 and used <= 0.75, (frac, used)
+            gw_slack = gw_err > RTOL * np.abs(ref_gw)
+            print('q32 dL/dw: %d of %d components beyond the bare 1e-5 (allowance: 2e-7 of the sum of |terms|)' % (int(gw_slack.sum()), gw_slack.size))
         else:
             # float32 points (API layout): x is rounded to fp32 once (half an ulp), which bounds what dL/dw can
             # agree to on a 10 000-point cloud; eigenvalues are checked on exactly the device's fp32 points
