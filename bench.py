@@ -448,6 +448,31 @@ def main():
                     nv.check(nv.lib().dc_set_option(opt, 0), 'dc_set_option')
             extras['same_step_other_forms'] = abl
 
+        # the reference-API loop itself: train() (train.py:220-322) with its default callbacks on this very workload, wall clock
+        # per iteration from two runs of different length (set-up cancels); see tools/train_bench.py for the C4 shape
+        if args.scans * args.points <= 4_000_000:
+            import contextlib
+            import io
+            import tempfile
+            from depth_correction_amd.config import Config as _Cfg
+            from depth_correction_amd.train import train as _train
+            tcfg = _Cfg(nn_k=args.k, nn_r=None, min_depth=0.0, max_depth=float('inf'), grid_res=0.0, vp_dispersion_bounds=[], lr=1e-3,
+                        float_type=args.dtype, device=str(dev), model_kwargs={'w': w0, 'exponent': e0})
+            seq = [(c, p) for c, p in ds]
+            wall = {}
+            for n_it in (40, 40, 440):
+                c = tcfg.copy()
+                c.n_opt_iters, c.log_dir = n_it, tempfile.mkdtemp()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    _train(c, train_datasets=[seq], val_datasets=[])
+                torch.cuda.synchronize()
+                wall[n_it] = time.perf_counter() - t0            # (the first 40-iteration run pays the process's one-time costs)
+            extras['train_iteration_ms'] = (wall[440] - wall[40]) / 400 * 1e3
+            extras['train_iteration_note'] = ('depth_correction_amd.train.train() itself, default callbacks, cfg.loop_batch = %d: model-only runs '
+                                              'go to the chained native step, one launch per iteration' % tcfg.loop_batch)
+
         # BASELINE config 1 (one 200k-point scan, nn_k = 10, covariance + eig forward only, all DepthCloud features written)
         c0 = info['clouds'][0]
         x1, n1 = c0['points'], c0['points'].shape[0]
@@ -545,7 +570,7 @@ def main():
                                    'ScaledPolynomial, min_eigval_loss(normalization) fwd+bwd + Adam; one sequence per GPU'
                                    % (args.scans, args.points // 1000, n_local, args.k),
                        'storage': args.dtype + ('+q32 points' if plan.qfmt is not None else ''),
-                       'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); fp32 per-edge terms in the backward for q32 records',
+                       'arithmetic': 'fp64 on chip (moments, eigen-solve, loss, accumulators); float32 second sweep (dL/dw terms from exact int32 differences and float32 u, c)',
                        'form': 'basis (x = X0 + (sum_k w_k c_k) u formed inside the kernel; loss and dL/dw in one pass over each centre\'s neighbours; the basis rows are rebuilt only when poses or exponents change)'
                                if getattr(plan, '_basis', None) else 'general (dc_points_fwd every evaluation)',
                        'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else ('native, chained: one launch per step (dc_sequence_step_chained), the last one flushed' if trainer.chained else
