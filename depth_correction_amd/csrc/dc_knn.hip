@@ -53,9 +53,24 @@ __device__ __forceinline__ void cell_of(const Grid& g, const double* p, int32_t*
     c[a] = ci;
   }
 }
-__device__ __forceinline__ uint32_t hash_key(uint64_t k) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-  return (uint32_t)k;
+__device__ __forceinline__ uint32_t compact21(uint64_t x) {            // inverse of spread21
+  x &= 0x1249249249249249ull;
+  x = (x | x >> 2) & 0x10c30c30c30c30c3ull;
+  x = (x | x >> 4) & 0x100f00f00f00f00full;
+  x = (x | x >> 8) & 0x1f0000ff0000ffull;
+  x = (x | x >> 16) & 0x1f00000000ffffull;
+  x = (x | x >> 32) & 0x1fffffull;
+  return (uint32_t)x;
+}
+// The hash table of the cells is keyed by the PACKED cell coordinates (21 bits each) and hashed by a three-multiply mix of
+// them; the Morton code only orders the sorted array.  A query probes ~27-125 cells, and interleaving three coordinates
+// (~45 instructions) plus a 64-bit finaliser (~20) per probe was a quarter of knn_query_kernel's instructions.
+__device__ __forceinline__ uint64_t cell_key(int32_t x, int32_t y, int32_t z) {
+  return (uint64_t)(uint32_t)x | ((uint64_t)(uint32_t)y << 21) | ((uint64_t)(uint32_t)z << 42);
+}
+__device__ __forceinline__ uint32_t cell_hash(int32_t x, int32_t y, int32_t z) {
+  uint32_t h = (uint32_t)x * 0x9E3779B1u ^ (uint32_t)y * 0x85EBCA77u ^ (uint32_t)z * 0xC2B2AE3Du;
+  return h ^ (h >> 15);
 }
 
 template <typename T>
@@ -247,9 +262,11 @@ __global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restri
   double x[3];
   load_xyz(xyz, sids[p], stride, x);
   sp[p * 3] = x[0]; sp[p * 3 + 1] = x[1]; sp[p * 3 + 2] = x[2];
-  const uint64_t key = skeys[p];
-  if (p == 0 || skeys[p - 1] != key) {
-    uint32_t slot = hash_key(key) & tab_mask;
+  const uint64_t mk = skeys[p];
+  if (p == 0 || skeys[p - 1] != mk) {
+    const int32_t cx = (int32_t)compact21(mk), cy = (int32_t)compact21(mk >> 1), cz = (int32_t)compact21(mk >> 2);
+    const uint64_t key = cell_key(cx, cy, cz);
+    uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
     while (true) {
       const unsigned long long prev = atomicCAS((unsigned long long*)&tab_key[slot], (unsigned long long)kEmptyKey,
                                                 (unsigned long long)key);
@@ -264,9 +281,11 @@ __global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const uint6
                                                           int32_t* __restrict__ tab_end, uint32_t tab_mask) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  const uint64_t key = skeys[p];
-  if (p == n - 1 || skeys[p + 1] != key) {
-    uint32_t slot = hash_key(key) & tab_mask;
+  const uint64_t mk = skeys[p];
+  if (p == n - 1 || skeys[p + 1] != mk) {
+    const int32_t cx = (int32_t)compact21(mk), cy = (int32_t)compact21(mk >> 1), cz = (int32_t)compact21(mk >> 2);
+    const uint64_t key = cell_key(cx, cy, cz);
+    uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
     while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
     tab_end[slot] = (int32_t)(p + 1);
   }
@@ -279,8 +298,9 @@ struct CellTable {
   uint32_t mask;
 };
 
-__device__ __forceinline__ bool find_cell(const CellTable& t, uint64_t key, int32_t* b, int32_t* e) {
-  uint32_t slot = hash_key(key) & t.mask;
+__device__ __forceinline__ bool find_cell(const CellTable& t, int32_t x, int32_t y, int32_t z, int32_t* b, int32_t* e) {
+  const uint64_t key = cell_key(x, y, z);
+  uint32_t slot = cell_hash(x, y, z) & t.mask;
   while (true) {
     const uint64_t k = t.key[slot];
     if (k == key) { *b = t.beg[slot]; *e = t.end[slot]; return true; }
@@ -337,8 +357,9 @@ __device__ __forceinline__ double shell_bound(const Grid& g, const double* q, co
 }
 
 // ---- k nearest neighbours ---------------------------------------------------------------------------
+constexpr int kKnnQueue = 3;             // accepted candidates a lane holds before the wavefront merges its queues
 template <int KMAX>
-__global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+__global__ __launch_bounds__(kBlock, KMAX <= 16 ? 4 : 1) void knn_query_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
                                                            const double* __restrict__ queries,
                                                            const int32_t* __restrict__ qids, int64_t n_query,
                                                            const Grid* __restrict__ gp, CellTable tab, int k, double r_max,
@@ -360,10 +381,18 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
   int32_t c[3];
   cell_of(g, q, c);
   const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
-  // one candidate: sorted insertion by (distance, index), cKDTree's order
-  auto offer = [&](double d, int32_t id) {
-    if (!(d < ub2)) return;
-    if (!(d < worst_d || (d == worst_d && id < worst_i))) return;
+  // The sorted insertion by (distance, index) -- cKDTree's order -- costs ~10 instructions per slot and runs for the whole
+  // wavefront whenever ONE lane accepts a candidate, i.e. at nearly every step.  So an accepted candidate first goes into a small
+  // per-lane queue (a shift register of kKnnQueue entries), and the queues are merged into the sorted lists only when some lane's
+  // queue is full -- every lane then merges whatever it holds -- or a shell ends: the number of insertion passes a wavefront
+  // executes falls from (steps at which any lane accepts) to about (accepts of its busiest lane).  The acceptance test uses
+  // the k-th best as of the last merge, which is never smaller than the current one: nothing is rejected wrongly.
+  double qd[kKnnQueue];
+  int32_t qi[kKnnQueue];
+  int qn = 0;
+#pragma unroll
+  for (int s = 0; s < kKnnQueue; ++s) { qd[s] = INFINITY; qi[s] = 0x7fffffff; }
+  auto insert = [&](double d, int32_t id) {
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
       const bool lt = (d < bd[s]) || (d == bd[s] && id < bi[s]);
@@ -372,12 +401,38 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
       bd[s] = lt ? d : td; bi[s] = lt ? id : ti;
       d = lt ? td : d; id = lt ? ti : id;
     }
+  };
+  auto merge = [&]() {                      // (every lane that reaches this: queue slots beyond qn hold +inf and fall through)
+#pragma unroll
+    for (int s = 0; s < kKnnQueue; ++s) {
+      if (__any((int)(s < qn))) insert(qd[s], qi[s]);
+      qd[s] = INFINITY; qi[s] = 0x7fffffff;
+    }
+    qn = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) if (s == k - 1) { worst_d = bd[s]; worst_i = bi[s]; }
+  };
+  auto offer = [&](double d, int32_t id) {
+    const bool acc = d < ub2 && (d < worst_d || (d == worst_d && id < worst_i));
+    if (acc) {
+#pragma unroll
+      for (int s = kKnnQueue - 1; s > 0; --s) { qd[s] = qd[s - 1]; qi[s] = qi[s - 1]; }
+      qd[0] = d; qi[0] = id;
+      ++qn;
+    }
+    if (__any((int)(qn == kKnnQueue))) merge();
+  };
+  // (the scan of all points, a rare path, inserts directly: another inlined copy of the queue logic would cost registers)
+  auto offer_direct = [&](double d, int32_t id) {
+    if (!(d < ub2)) return;
+    if (!(d < worst_d || (d == worst_d && id < worst_i))) return;
+    insert(d, id);
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) if (s == k - 1) { worst_d = bd[s]; worst_i = bi[s]; }
   };
   auto consider = [&](int32_t p) {
     const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
-    offer(sqdist(pp, q), sids[p]);
+    offer_direct(sqdist(pp, q), sids[p]);
   };
   bool exhaustive = false;
   for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
@@ -415,8 +470,8 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
           uint32_t slot[4];
 #pragma unroll
           for (int u_ = 0; u_ < 4; ++u_) {
-            key[u_] = morton3(xs + (j0 + u_) * step, y, z);
-            slot[u_] = hash_key(key[u_]) & tab.mask;
+            key[u_] = cell_key(xs + (j0 + u_) * step, y, z);
+            slot[u_] = cell_hash(xs + (j0 + u_) * step, y, z) & tab.mask;
             got[u_] = (j0 + u_ < cnt) ? tab.key[slot[u_]] : kEmptyKey;
           }
           int32_t bb[4], ee[4];
@@ -449,6 +504,7 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
           }
         }
       }
+    if (qn > 0) merge();
     const double bound = shell_bound(g, q, c, r);
     const double b2 = bound * bound;
     if (worst_d < b2) break;              // k-th best is closer than anything unvisited
@@ -460,6 +516,9 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
     // scan sees every point once.
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+#pragma unroll
+    for (int s = 0; s < kKnnQueue; ++s) { qd[s] = INFINITY; qi[s] = 0x7fffffff; }
+    qn = 0;
     worst_d = INFINITY; worst_i = 0x7fffffff;
     int64_t p = 0;
     for (; p + 4 <= n_points; p += 4) {                     // four points' loads in flight per trip
@@ -470,8 +529,8 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const double* __restr
         pp[u_][0] = sp[(p + u_) * 3]; pp[u_][1] = sp[(p + u_) * 3 + 1]; pp[u_][2] = sp[(p + u_) * 3 + 2];
         id[u_] = sids[p + u_];
       }
-#pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) offer(sqdist(pp[u_], q), id[u_]);
+#pragma unroll 1
+      for (int u_ = 0; u_ < 4; ++u_) offer_direct(sqdist(pp[u_], q), id[u_]);
     }
     for (; p < n_points; ++p) consider((int32_t)p);
   }
@@ -604,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
           shell_cell(r, side, inv_side, inv_ring, j, &dx, &dy, &dz);
           const int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
           if (x >= 0 && y >= 0 && z >= 0 && x < g.dim[0] && y < g.dim[1] && z < g.dim[2]) {
-            if (!find_cell(tab, morton3(x, y, z), &b, &e)) { b = 0; e = 0; }
+            if (!find_cell(tab, x, y, z, &b, &e)) { b = 0; e = 0; }
           }
         }
         for (int32_t p = b; __any((int)(p < e)); ++p) {
@@ -688,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict
   for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
     for_shell(g, c, r, [&](int x, int y, int z) {
       int32_t b, e;
-      if (!find_cell(tab, morton3(x, y, z), &b, &e)) return;
+      if (!find_cell(tab, x, y, z, &b, &e)) return;
       for (int32_t p = b; p < e; ++p) {
         const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
         if (sqdist(pp, q) <= r2) {
