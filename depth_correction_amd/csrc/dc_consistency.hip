@@ -1398,7 +1398,7 @@ __device__ __forceinline__ void step_point(CovAcc& acc, bool m, const LossParams
   const double u = Pt<PT>::unit(qp);
   double moff[3], C[6], D, omega, lam0, tr;
   cov_finish(acc, 0.0, moff, cm, C, &D, &omega, u * u);
-  eig3_smallest(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);
+  eig3_smallest_r2(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);      // (the A-B baseline form, dc_set_option(6, 0))
   const double l = loss_and_coeffs(lp, lam0, tr, D, 0.0, m, c1, c2);
   if (m) { acc2[0] = l; acc2[1] = 1.0; }
   if (!(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }

@@ -343,8 +343,8 @@ DC_HD void eig3_smallest_v2(double a00, double a01, double a02, double a11, doub
 // and is polished by one fp64 Newton step on the characteristic polynomial (isolated root: quadratic
 // convergence to ~1e-12), then by the Rayleigh quotient of its fp64 eigenvector.  Roughly half the fp64
 // instructions of the full solver; accuracy identical (checked against LAPACK in tests/test_hostcheck.py).
-DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22, double* lam0,
-                         double* v0, double* tr_out) {
+DC_HD void eig3_smallest_r2(double a00, double a01, double a02, double a11, double a12, double a22, double* lam0,
+                            double* v0, double* tr_out) {
   // covariance matrices are positive semi-definite: the trace bounds every entry, one add instead of a max tree
   const double m = a00 + a11 + a22;
   *tr_out = m;
@@ -426,4 +426,13 @@ DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double 
   *lam0 = l_lo * m;
 }
 
+}  // namespace dc
+
+namespace dc {
+// What the kernels call: the round-3 solver (eig3_smallest_v2: trace-1 core, adjugate eigenvector, polynomial root estimate);
+// eig3_smallest_r2 above is round 2's, kept for the A-B baseline form of the step kernel and pinned by the same host checks.
+DC_HD void eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22, double* lam0, double* v0,
+                         double* tr_out) {
+  eig3_smallest_v2(a00, a01, a02, a11, a12, a22, lam0, v0, tr_out);
+}
 }  // namespace dc

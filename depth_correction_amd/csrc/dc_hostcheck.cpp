@@ -26,6 +26,14 @@ void dc_host_eig3_smallest(const double* cov, long n, double* lam0, double* v0, 
   }
 }
 
+// round 2's solver (isolate-then-deflate with three cross products), still the A-B baseline of the step kernel
+void dc_host_eig3_smallest_r2(const double* cov, long n, double* lam0, double* v0, double* tr) {
+  for (long i = 0; i < n; ++i) {
+    const double* c = cov + i * 6;
+    dc::eig3_smallest_r2(c[0], c[1], c[2], c[3], c[4], c[5], lam0 + i, v0 + i * 3, tr + i);
+  }
+}
+
 // the slimmer solver of the one-pass step kernel (trace-1 core: adjugate eigenvector, one reciprocal)
 void dc_host_eig3_smallest_v2(const double* cov, long n, double* lam0, double* v0, double* tr) {
   for (long i = 0; i < n; ++i) {

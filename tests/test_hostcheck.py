@@ -70,7 +70,7 @@ def _eig_smallest(host, C, solver='dc_host_eig3_smallest'):
     return lam0, v0, tr
 
 
-@pytest.mark.parametrize('solver', ['dc_host_eig3_smallest', 'dc_host_eig3_smallest_v2'])
+@pytest.mark.parametrize('solver', ['dc_host_eig3_smallest', 'dc_host_eig3_smallest_r2', 'dc_host_eig3_smallest_v2'])
 @pytest.mark.parametrize('case', ['generic', 'planar', 'needle', 'edge', 'threshold', 'threshold_unit', 'double_hi', 'tiny', 'huge'])
 def test_eig3_smallest_matches_lapack(host, case, solver):
     """The hot-path solver (smallest eigenpair + trace only, dc_eig3.h eig3_smallest): eigenvalue within a few
@@ -109,7 +109,7 @@ def test_eig3_smallest_matches_lapack(host, case, solver):
         assert ((1 - align[sep]) * gap ** 2).max() < 1e-13
 
 
-@pytest.mark.parametrize('solver', ['dc_host_eig3_smallest', 'dc_host_eig3_smallest_v2'])
+@pytest.mark.parametrize('solver', ['dc_host_eig3_smallest', 'dc_host_eig3_smallest_r2', 'dc_host_eig3_smallest_v2'])
 def test_eig3_smallest_degenerate_inputs(host, solver):
     lam0, v0, tr = _eig_smallest(host, np.zeros((2, 3, 3)), solver)
     assert np.all(lam0 == 0) and np.all(tr == 0) and np.allclose(v0, [[1, 0, 0]] * 2)
