@@ -92,6 +92,8 @@ _SIGNATURES = {
     'dc_pose_correct_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     'dc_pose_correct_bwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     'dc_shadow_mask': (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp]),
+    'dc_correct_depth': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    'dc_shadow_filter': (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _f64, _f64, _f64, _vp, _vp, _sz, _vp]),
 }
 
 

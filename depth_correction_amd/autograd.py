@@ -18,9 +18,9 @@ __all__ = ['neighborhood_features', 'NeighborhoodGraph']
 class NeighborhoodGraph:
     """int32 neighbour table + its transpose, built once per neighbourhood set and cached on the cloud."""
 
-    def __init__(self, neighbors):
+    def __init__(self, neighbors, nbr=None):
         self.version = neighbors._version
-        self.nbr = ops.as_index32(neighbors)
+        self.nbr = ops.as_index32(neighbors) if nbr is None else nbr        # nbr: the int32 table `neighbors` was made from
         self._csr = None
 
     @staticmethod

@@ -775,6 +775,62 @@ __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict
   }
 }
 
+// ---- scan-shadow filter straight off the direction grid (filters.py:257-309 after depth_cloud.py:352-360) ---------------
+// The reference builds the padded table of every point's direction-neighbours (all rays within `rad` chord length of its own)
+// and then takes min / max over the table's rows of the angle between the ray back to the viewpoint and the vector to the
+// neighbour.  The mask only depends on the SET of neighbours (the fill value of short rows, the mean of the bounds, never
+// violates them), so the walk over the grid cells evaluates the angles as it meets the neighbours and no table is written:
+// one pass instead of count + fill + row sort + mask.  The inclusion test is radius_kernel's (fp64, on the fp64 copies of the
+// directions), the angle arithmetic is shadow_mask_kernel's (dc_filters.hip), in the cloud's precision.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void shadow_walk_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                             int64_t n, const Grid* __restrict__ gp, CellTable tab, double rad,
+                                                             const T* __restrict__ x, const T* __restrict__ vps, int vps_rows,
+                                                             T lo, T hi, uint8_t* __restrict__ mask) {
+#pragma clang fp contract(off)
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n) return;
+  const Grid g = *gp;
+  const double q[3] = {sp[t * 3], sp[t * 3 + 1], sp[t * 3 + 2]};
+  const int64_t i = sids[t];
+  const double r2 = rad * rad;
+  const T eps = (T)1e-8;
+  const T xi0 = x[i * 3], xi1 = x[i * 3 + 1], xi2 = x[i * 3 + 2];
+  const T* o = vps + (vps_rows == 1 ? 0 : i * 3);
+  T a0 = o[0] - xi0, a1 = o[1] - xi1, a2 = o[2] - xi2;
+  const T na = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const T da = na > eps ? na : eps;
+  a0 /= da; a1 /= da; a2 /= da;
+  T amin = (T)INFINITY, amax = -(T)INFINITY;
+  bool bad = false;
+  int32_t c[3];
+  cell_of(g, q, c);
+  const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+  for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+    for_shell(g, c, r, [&](int cx, int cy, int cz) {
+      int32_t b, e;
+      if (!find_cell(tab, cx, cy, cz, &b, &e)) return;
+      for (int32_t p = b; p < e; ++p) {
+        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
+        if (!(sqdist(pp, q) <= r2)) continue;
+        const int64_t j = sids[p];
+        T b0 = x[j * 3] - xi0, b1 = x[j * 3 + 1] - xi1, b2 = x[j * 3 + 2] - xi2;
+        const T nb = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+        const T db = nb > eps ? nb : eps;
+        b0 /= db; b1 /= db; b2 /= db;
+        const T cs = a0 * b0 + a1 * b1 + a2 * b2;
+        const T ang = acos(cs);
+        bad = bad || (ang != ang);
+        amin = ang < amin ? ang : amin;
+        amax = ang > amax ? ang : amax;
+      }
+    });
+    if (shell_bound(g, q, c, r) > rad) break;
+  }
+  // a ray with no neighbour at all (not even itself: non-finite direction) has an all-fill row in the reference: kept
+  mask[i] = (!bad && (amin > amax ? lo <= hi : (amin >= lo && amax <= hi))) ? 1 : 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void to_f64_kernel(const T* __restrict__ xyz, int stride, int64_t n,
                                                         double* __restrict__ out) {
@@ -963,6 +1019,31 @@ int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, count_out, nullptr, 0);
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), block, 0, stream, count_out, n, kmax_out);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+// Scan-shadow mask without the direction-neighbour table: grid over `dirs` (cell edge r), one walk.  mask_out uint8 [n].
+int dc_shadow_filter(const void* points, const void* vps, int vps_rows, const void* dirs, int dtype, int64_t n, double r, double lo,
+                     double hi, uint8_t* mask_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return DC_OK;
+  if (!points || !vps || !dirs || n < 0 || !(r > 0.0) || !mask_out || !ws || (vps_rows != 1 && vps_rows != n)) return DC_ERR_ARG;
+  if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
+  GridWs w = carve_grid(ws, n, 0);
+  if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
+  int rc;
+  if (dtype == DC_F32) rc = build_grid((const float*)dirs, 3, n, 0, r, w, stream);
+  else if (dtype == DC_F64) rc = build_grid((const double*)dirs, 3, n, 0, r, w, stream);
+  else return DC_ERR_DTYPE;
+  if (rc) return rc;
+  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((shadow_walk_kernel<float>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const float*)points,
+                       (const float*)vps, vps_rows, (float)lo, (float)hi, mask_out);
+  else
+    hipLaunchKernelGGL((shadow_walk_kernel<double>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const double*)points,
+                       (const double*)vps, vps_rows, lo, hi, mask_out);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

@@ -92,6 +92,11 @@ class DepthCloud(object):
     def __getitem__(self, item):
         if isinstance(item, list) and len(item) > 0 and isinstance(item[0], str):
             return DepthCloud(**{f: getattr(self, f) for f in item})
+        if isinstance(item, torch.Tensor) and item.dtype == torch.bool and item.dim() == 1 and item.is_cuda:
+            # x[mask] runs a count + a partition + a gather per FIELD; the surviving rows are found once here
+            item = item.nonzero().squeeze(1)
+            return DepthCloud(**{f: getattr(self, f).index_select(0, item) for f in DepthCloud.sliced_fields
+                                 if getattr(self, f) is not None})
         return DepthCloud(**{f: getattr(self, f)[item] for f in DepthCloud.sliced_fields if getattr(self, f) is not None})
 
     def __add__(self, other):
@@ -245,7 +250,7 @@ class DepthCloud(object):
     def update_neighbors(self, k=None, r=None):
         assert self.points is not None
         self._distances, self.neighbors = nearest_neighbors(self.get_points(), self.get_points(), k=k, r=r)
-        self.weights = self.valid_neighbor_mask().float()[..., None]
+        self.weights = (self.graph().nbr >= 0).float()[..., None]          # valid_neighbor_mask() read off the int32 table
         self.weights._dc_validity = True
         self.neighbor_points = None
         self._feat = None

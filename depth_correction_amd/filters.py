@@ -13,10 +13,12 @@ import torch
 from numpy.lib.recfunctions import structured_to_unstructured
 
 from . import ops
+from .autograd import NeighborhoodGraph
 from .depth_cloud import DepthCloud
 
 __all__ = ['filter_depth', 'filter_eigenvalue', 'filter_eigenvalue_ratio', 'filter_eigenvalue_ratios',
-           'filter_eigenvalues', 'filter_grid', 'filter_shadow_points', 'filter_valid_neighbors', 'within_bounds']
+           'filter_eigenvalues', 'filter_grid', 'filter_shadow_points', 'filter_valid_neighbors', 'shadow_points_mask',
+           'within_bounds']
 
 default_rng = np.random.default_rng(135)
 
@@ -184,24 +186,45 @@ def filter_eigenvalue_ratios(cloud: DepthCloud, bounds: list, only_mask: bool = 
                    'eigenvalue ratios', only_mask, log)
 
 
-def filter_shadow_points(cloud: DepthCloud, angle_bounds: list, only_mask: bool = False, log: bool = False):
-    """Scan-shadow filter (filters.py:257-309): keep a point when the angles between the ray back to its viewpoint
-    and the vectors to its direction-neighbours all lie within ``angle_bounds``.  Needs ``update_dir_neighbors``
-    (radius search on the unit directions, on the GPU).  ``only_mask=True`` returns the mask (the reference returns
-    the flag itself there, an obvious slip)."""
-    assert cloud.vps is not None and cloud.dir_neighbors is not None
+def _shadow_bounds(angle_bounds):
     lo = 0.0 if (angle_bounds[0] is None or not (angle_bounds[0] >= 0.0)) else float(angle_bounds[0])
     hi = torch.pi if (angle_bounds[1] is None or not (angle_bounds[1] <= torch.pi)) else float(angle_bounds[1])
     # the reference holds the bounds in a float32 tensor (torch.as_tensor of Python floats) and fills the angles of
     # missing neighbours with its mean
     lo, hi = float(np.float32(lo)), float(np.float32(hi))
     fill = float((np.float32(lo) + np.float32(hi)) / np.float32(2.0))
+    return lo, hi, fill
+
+
+def shadow_points_mask(cloud: DepthCloud, neighborhood_angle: float, angle_bounds: list, log: bool = False):
+    """``update_dir_neighbors(angle=neighborhood_angle)`` + ``filter_shadow_points(only_mask=True)`` in one walk over the
+    direction grid (dc_shadow_filter): the table of direction neighbours, which the reference's callers drop right after the
+    filter (preproc.py:44-47: ``cloud[mask]`` keeps the per-point fields only), is never written.  Device clouds only."""
+    from .nearest_neighbors import ball_angle_to_distance
+    lo, hi, _ = _shadow_bounds(angle_bounds)
+    r = float(ball_angle_to_distance(torch.as_tensor(neighborhood_angle)))
+    x = cloud.get_points()
+    with torch.no_grad():
+        mask = ops.shadow_filter(x.detach().contiguous(), cloud.vps.detach().to(x.dtype).contiguous(),
+                                 cloud.dirs.detach().contiguous(), r, lo, hi)
+    if log:
+        print('%.3f = %i / %i points kept (shadow points removed).' % (mask.double().mean(), mask.sum(), mask.numel()))
+    return mask
+
+
+def filter_shadow_points(cloud: DepthCloud, angle_bounds: list, only_mask: bool = False, log: bool = False):
+    """Scan-shadow filter (filters.py:257-309): keep a point when the angles between the ray back to its viewpoint
+    and the vectors to its direction-neighbours all lie within ``angle_bounds``.  Needs ``update_dir_neighbors``
+    (radius search on the unit directions, on the GPU).  ``only_mask=True`` returns the mask (the reference returns
+    the flag itself there, an obvious slip)."""
+    assert cloud.vps is not None and cloud.dir_neighbors is not None
+    lo, hi, fill = _shadow_bounds(angle_bounds)
     x = cloud.get_points()
     if x.is_cuda:
         # one kernel over the direction-neighbour rows (dc_shadow_mask): no [N, K, 3] tensors
         with torch.no_grad():
             mask = ops.shadow_mask(x.detach().contiguous(), cloud.vps.detach().to(x.dtype).contiguous(),
-                                   ops.as_index32(cloud.dir_neighbors), lo, hi, fill)
+                                   NeighborhoodGraph.of(cloud.dir_neighbors).nbr, lo, hi, fill)
     else:
         # host tensors (data preparation on a CPU-only machine): the reference's tensor expressions
         to_vp = (cloud.vps.expand_as(x) - x).unsqueeze(dim=1)

@@ -11,6 +11,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import ops
 from .depth_cloud import DepthCloud
 
 __all__ = ['BaseModel', 'InvCos', 'Linear', 'load_model', 'model_by_name', 'Polynomial', 'ScaledPolynomial',
@@ -31,10 +32,16 @@ class BaseModel(torch.nn.Module):
     def inverse(self, dc: DepthCloud, mask=None) -> DepthCloud:
         return dc
 
-    def _apply_to_depth(self, dc, mask, fun):
-        """New cloud whose depth is fun(depth, inc_angles) on the masked points (never in place)."""
+    def _apply_to_depth(self, dc, mask, fun, op=None):
+        """New cloud whose depth is fun(depth, inc_angles) on the masked points (never in place).  ``op``: the same function as
+        a dc_correct_depth code, used when nothing here needs a gradient (the online node, evaluation under no_grad) -- one
+        kernel instead of the boolean gather, pow, GEMM, elementwise passes and index_put of the tensor expression."""
         assert dc.inc_angles is not None
         out = dc.copy()
+        if op is not None and self._no_grad_on_device(dc, mask):
+            w, e = self.kernel_params()
+            out.depth = ops.correct_depth(dc.depth.contiguous(), dc.inc_angles.contiguous(), mask, w, e, op)
+            return out
         if mask is None:
             out.depth = fun(dc.depth, dc.inc_angles)
         else:
@@ -44,6 +51,18 @@ class BaseModel(torch.nn.Module):
             depth[mask] = fun(dc.depth[mask], dc.inc_angles[mask]).to(depth.dtype)
             out.depth = depth
         return out
+
+    def _no_grad_on_device(self, dc, mask):
+        d, g = dc.depth, dc.inc_angles
+        if not (d.is_cuda and d.dtype in (torch.float32, torch.float64) and g.dtype == d.dtype and g.device == d.device
+                and d.dim() == 2 and d.shape[1] == 1 and g.shape == d.shape):
+            return False
+        if mask is not None and not (mask.dtype == torch.bool and mask.shape == d.shape[:1] and mask.device == d.device):
+            return False
+        w, e = self.kernel_params()
+        if w.device != d.device or w.dtype != torch.float64 or e.dtype != torch.float64:
+            return False
+        return not (torch.is_grad_enabled() and any(t.requires_grad for t in (d, g, w, e)))
 
     # ---- the fused HIP kernels' view of a model: its kind and its parameters as one [1, P] tensor + exponents ------
     kernel_kind = None        # name understood by the point kernels (_native.MODEL_KINDS); None: tensor path only
@@ -142,12 +161,12 @@ class Polynomial(_PolynomialBase):
     kernel_kind = 'Polynomial'
 
     def correct_depth(self, dc, mask=None):
-        return self._apply_to_depth(dc, mask, lambda d, g: d - self.bias(g))
+        return self._apply_to_depth(dc, mask, lambda d, g: d - self.bias(g), op=0)
 
     def inverse(self, dc, mask=None):
         if mask is None:       # the reference's two branches differ (model.py:201-213); kept as is
-            return self._apply_to_depth(dc, None, lambda d, g: d / (1. - self.bias(g)))
-        return self._apply_to_depth(dc, mask, lambda d, g: d + self.bias(g))
+            return self._apply_to_depth(dc, None, lambda d, g: d / (1. - self.bias(g)), op=3)
+        return self._apply_to_depth(dc, mask, lambda d, g: d + self.bias(g), op=1)
 
 
 class ScaledPolynomial(_PolynomialBase):
@@ -155,10 +174,10 @@ class ScaledPolynomial(_PolynomialBase):
     kernel_kind = 'ScaledPolynomial'
 
     def correct_depth(self, dc, mask=None):
-        return self._apply_to_depth(dc, mask, lambda d, g: d * (1. - self.bias(g)))
+        return self._apply_to_depth(dc, mask, lambda d, g: d * (1. - self.bias(g)), op=2)
 
     def inverse(self, dc, mask=None):
-        return self._apply_to_depth(dc, mask, lambda d, g: d / (1. - self.bias(g)))
+        return self._apply_to_depth(dc, mask, lambda d, g: d / (1. - self.bias(g)), op=3)
 
 
 class InvCos(BaseModel):

@@ -37,5 +37,14 @@ def nearest_neighbors(points, query, k=None, r=None, n_jobs=-1):
     same = qry.data_ptr() == pts.data_ptr() and qry.shape == pts.shape
     if k:
         dist, ind = ops.knn(pts, int(k), r=r, query=None if same else qry.to(pts.dtype))
-        return dist, ind.long()
-    return None, ops.radius_neighbors(pts, float(r), query=None if same else qry.to(pts.dtype)).long()
+        return dist, _as_reference_index(ind)
+    return None, _as_reference_index(ops.radius_neighbors(pts, float(r), query=None if same else qry.to(pts.dtype)))
+
+
+def _as_reference_index(ind32):
+    """int64 copy of the builder's int32 table (the reference's index dtype, nearest_neighbors.py:78) that REMEMBERS the int32
+    table it came from: the kernels behind DepthCloud take int32, and converting back cost a pass per consumer."""
+    from .autograd import NeighborhoodGraph
+    ind = ind32.long()
+    ind._dc_graph = NeighborhoodGraph(ind, nbr=ind32)
+    return ind

@@ -15,7 +15,7 @@ from ._native import lib, check, need, ptr, stream_ptr, dtype_code, on_device
 __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
-    'IcpSequence', 'shadow_mask', 'cloud_from_points',
+    'IcpSequence', 'shadow_mask', 'shadow_filter', 'correct_depth', 'cloud_from_points',
     'as_index32',
 ]
 
@@ -611,6 +611,46 @@ def cloud_from_points(points, vps=None, dtype=None, ego_box=None, min_depth=None
                                      ptr(index), ptr(count), ptr(ws), nbytes, stream_ptr()), 'dc_cloud_from_points')
     m = int(count.item()) if filtered else n
     return (None if vps_out is None else vps_out[:m], dirs[:m], depth[:m], None if index is None else index[:m].long())
+
+
+@on_device
+def correct_depth(depth, gamma, mask, w, exponent, op):
+    """depth' [N,1]: the polynomial models outside the training loop (dc_correct_depth; op 0 d-b, 1 d+b, 2 d(1-b), 3 d/(1-b));
+    ``mask`` bool [N] or None; ``w`` / ``exponent`` fp64 [1,P] on the device.  No autograd."""
+    n = depth.shape[0]
+    dev = depth.device
+    need(depth, (n, 1), name='depth')
+    need(gamma, (n, 1), dtype=depth.dtype, name='inc_angles', device=dev)
+    w1, e1 = w.detach().reshape(-1).contiguous(), exponent.detach().reshape(-1).contiguous()
+    need(w1, (None,), dtype=torch.float64, name='w', device=dev)
+    need(e1, (w1.shape[0],), dtype=torch.float64, name='exponent', device=dev)
+    if mask is not None:
+        need(mask, (n,), dtype=torch.bool, name='mask', device=dev)
+    out = torch.empty_like(depth)
+    check(lib().dc_correct_depth(ptr(depth), ptr(gamma), ptr(mask), ptr(w1), ptr(e1), w1.shape[0], int(op), dtype_code(depth), n,
+                                 ptr(out), stream_ptr()), 'dc_correct_depth')
+    return out
+
+
+@on_device
+def shadow_filter(points, vps, dirs, r, lo, hi):
+    """bool [N]: ``shadow_mask`` over the direction neighbourhoods of radius ``r`` (chord length) WITHOUT building their table
+    (dc_shadow_filter: grid over ``dirs`` + one walk); the same mask as radius_neighbors(dirs, r) -> shadow_mask."""
+    need(points, (None, 3), name='points')
+    n = points.shape[0]
+    dev, dt = points.device, points.dtype
+    vps = vps.reshape(-1, 3)
+    need(vps, (None, 3), dtype=dt, name='vps', device=dev)
+    need(dirs, (n, 3), dtype=dt, name='dirs', device=dev)
+    if vps.shape[0] not in (1, n):
+        raise ValueError('vps must have 1 or %d rows' % n)
+    mask = torch.empty((n,), dtype=torch.bool, device=dev)
+    if n:
+        nbytes = lib().dc_knn_workspace_bytes(n, 0)
+        ws = _ws(nbytes, dev)
+        check(lib().dc_shadow_filter(ptr(points), ptr(vps), vps.shape[0], ptr(dirs), dtype_code(points), n, float(r), float(lo), float(hi),
+                                     ptr(mask), ptr(ws), nbytes, stream_ptr()), 'dc_shadow_filter')
+    return mask
 
 
 @on_device

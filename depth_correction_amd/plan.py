@@ -71,7 +71,8 @@ class SequencePlan:
         self._poses_key = self._poses12 = self._poses_ref = None
         self.sizes = sizes
         self.model_kind, self.loss, self.normalization, self.sqrt = model_kind, loss, bool(normalization), bool(sqrt)
-        nbr = ops.as_index32(neighbors)
+        g = getattr(neighbors, '_dc_graph', None)          # the int32 table the reference-typed indices were made from
+        nbr = g.nbr if g is not None and g.version == neighbors._version else ops.as_index32(neighbors)
         need(nbr, (self.n, None), dtype=torch.int32, name='neighbors', device=dev)
         self.k = nbr.shape[1]
         if mask is not None:

@@ -9,7 +9,7 @@ import torch
 
 from .config import Config, NeighborhoodType
 from .depth_cloud import DepthCloud
-from .filters import (filter_depth, filter_eigenvalue_ratios, filter_eigenvalues, filter_grid, filter_shadow_points,
+from .filters import (filter_depth, filter_eigenvalue_ratios, filter_eigenvalues, filter_grid, filter_shadow_points, shadow_points_mask,
                       filter_valid_neighbors, within_bounds)
 from .transform import xyz_axis_angle_to_matrix
 
@@ -45,9 +45,24 @@ def local_feature_cloud(cloud, cfg: Config):
         cloud = make(cloud, dtype=cfg.numpy_float_type(), device=cfg.device)
     assert isinstance(cloud, DepthCloud)
     if cfg.shadow_angle_bounds:                      # preproc.py:44-47
-        cloud.update_dir_neighbors(angle=cfg.shadow_neighborhood_angle)
-        cloud = filter_shadow_points(cloud, cfg.shadow_angle_bounds, log=cfg.log_filters)
+        if cloud.dirs.is_cuda:
+            # the direction-neighbour table would be dropped by cloud[mask] right away: the mask comes from one grid walk
+            cloud = cloud[shadow_points_mask(cloud, cfg.shadow_neighborhood_angle, cfg.shadow_angle_bounds, log=cfg.log_filters)]
+        else:
+            cloud.update_dir_neighbors(angle=cfg.shadow_neighborhood_angle)
+            cloud = filter_shadow_points(cloud, cfg.shadow_angle_bounds, log=cfg.log_filters)
     cloud.update_all(k=cfg.nn_k, r=cfg.nn_r)
+    if cloud.eigvals.is_cuda and not cfg.log_filters and (cfg.eigenvalue_bounds or cfg.eigenvalue_ratio_bounds):
+        # the same masks ANDed in place, one kernel per bound (dc_mask_bounds): no ones / and passes between them
+        from . import ops
+        mask = torch.ones((len(cloud),), dtype=torch.bool, device=cloud.device()) if cloud.mask is None else cloud.mask.clone()
+        ev = cloud.eigvals.detach().contiguous()
+        for e, lo, hi in (cfg.eigenvalue_bounds or []):
+            ops.mask_bounds(mask, ev, int(e), lo=lo, hi=hi)
+        for i, j, lo, hi in (cfg.eigenvalue_ratio_bounds or []):
+            ops.mask_bounds(mask, ev, int(i), ev, int(j), lo, hi)
+        cloud.mask = mask
+        return cloud
     if cfg.eigenvalue_bounds:
         _and_mask(cloud, filter_eigenvalues(cloud, cfg.eigenvalue_bounds, only_mask=True, log=cfg.log_filters))
     if cfg.eigenvalue_ratio_bounds:

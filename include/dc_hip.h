@@ -264,6 +264,21 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
 int dc_shadow_mask(const void* points, const void* vps, int vps_rows, int dtype, const int32_t* dir_nbr, int64_t n, int k,
                    double lo, double hi, double fill, uint8_t* mask_out, dcStream_t stream);
 
+/* The same mask WITHOUT the direction-neighbour table (the online call pattern, scripts/depth_correction:44-47 ->
+ * preproc.local_feature_cloud preproc.py:44-47: update_dir_neighbors + filter_shadow_points, after which the table is dropped):
+ * grid over `dirs` with cell edge r (the chord length of the neighbourhood angle, nearest_neighbors.py:13-19) and one walk
+ * that evaluates the angles as it meets the neighbours.  Identical mask: it depends on the set of neighbours only.
+ * ws: dc_knn_workspace_bytes(n, 0). */
+int dc_shadow_filter(const void* points, const void* vps, int vps_rows, const void* dirs, int dtype, int64_t n, double r,
+                     double lo, double hi, uint8_t* mask_out, void* ws, size_t ws_bytes, dcStream_t stream);
+
+/* The polynomial models applied to a cloud OUTSIDE the training loop (no gradients): Polynomial.correct_depth / inverse
+ * model.py:181-215, ScaledPolynomial.correct_depth / inverse model.py:250-274, as the node calls them
+ * (scripts/depth_correction:52).  depth_out[i] = mask[i] ? f(depth[i], sum_k w_k gamma[i]^e_k) : depth[i] with
+ * op 0: d - b, 1: d + b, 2: d (1 - b), 3: d / (1 - b); fp64 arithmetic in torch's order, rounded to `dtype` at the end. */
+int dc_correct_depth(const void* depth, const void* gamma, const uint8_t* mask, const double* w, const double* exponent,
+                     int n_terms, int op, int dtype, int64_t n, void* depth_out, dcStream_t stream);
+
 /* ---- point-to-plane ICP loss: loss.point_to_plane_dist loss.py:406-488 inside icp_loss :373-403 (model(c),
  *      c.transform(pose) :381-386) with precomputed correspondences (train.py:178-210) ------------------------------
  * One scan pair (A, B): idxA / idxB int32 [m] index the local points of scan A / B; poseA / poseB fp64 [12]

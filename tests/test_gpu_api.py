@@ -1097,3 +1097,86 @@ def test_basis_rows_are_built_once_over_iterations(golden, name):
         assert plan is not None and plan._basis is not None
         rows.append(plan._basis[1].data_ptr())
     assert len(set(rows)) == 1, rows
+
+
+@pytest.mark.parametrize('tag,dtype', [('f64', torch.float64), ('f32', torch.float32)])
+def test_shadow_mask_without_the_neighbour_table(golden, tag, dtype):
+    """dc_shadow_filter (grid over the directions + one walk evaluating the angles, what local_feature_cloud runs on device
+    clouds) gives the mask of update_dir_neighbors + filter_shadow_points bit for bit: the mask depends on the set of
+    direction neighbours only (preproc.py:44-47 drops the table right after)."""
+    from depth_correction_amd.depth_cloud import DepthCloud
+    from depth_correction_amd.filters import filter_shadow_points, shadow_points_mask
+    g = golden('shadow')
+    dev = 'cuda:0'
+    dc = DepthCloud(t(g[tag + '_vps'], dev), t(g[tag + '_dirs'], dev), t(g[tag + '_depth'], dev))
+    dc.update_points()
+    removed = 0
+    for angle, lo_deg, hi in ((float(g['angle']), float(g['bounds_deg']), float('inf')), (0.03, 10.0, 2.5), (0.004, 0.0, 3.0)):
+        bounds = [float(np.radians(lo_deg)), hi]
+        fused = shadow_points_mask(dc, angle, list(bounds))
+        two = dc.copy()
+        two.update_dir_neighbors(angle=angle)
+        want = filter_shadow_points(two, list(bounds), only_mask=True)
+        assert torch.equal(fused, want)
+        assert 0.05 < float(fused.double().mean()) <= 1.0
+        removed = removed + int((~fused).sum())
+    assert removed > 0
+    # the mask of a device cloud through local_feature_cloud is the same as the reference's statement sequence
+    from depth_correction_amd.config import Config
+    from depth_correction_amd.preproc import local_feature_cloud
+    cfg = Config(nn_k=8, nn_r=None, device=dev, log_filters=False, shadow_neighborhood_angle=float(g['angle']),
+                 shadow_angle_bounds=[float(np.radians(float(g['bounds_deg']))), float('inf')])
+    out = local_feature_cloud(dc.copy(), cfg)
+    two = dc.copy()
+    two.update_dir_neighbors(angle=float(g['angle']))
+    kept = filter_shadow_points(two, cfg.shadow_angle_bounds)
+    assert torch.equal(out.depth, kept.depth) and torch.equal(out.dirs, kept.dirs) and torch.equal(out.vps, kept.vps)
+
+
+def test_cloud_slicing_with_a_device_mask_finds_the_rows_once(golden):
+    """cloud[mask] with a bool mask on the device: every per-point field gathered through ONE nonzero(); same tensors as
+    field[mask], neighbourhood fields dropped (depth_cloud.py:75-82)."""
+    from depth_correction_amd.depth_cloud import DepthCloud
+    g = golden('room_k10')
+    x = t(g['scan0_xyz'], 'cuda:0')
+    dc = DepthCloud.from_points(x)
+    dc.update_all(k=6)
+    mask = dc.eigvals[:, 0] < dc.eigvals[:, 0].median()
+    cut = dc[mask]
+    for f in DepthCloud.sliced_fields:
+        a, b = getattr(dc, f), getattr(cut, f)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a[mask], b)
+    assert cut.neighbors is None and cut.weights is None and len(cut) == int(mask.sum())
+    w = torch.ones((len(dc), 1), dtype=dc.depth.dtype, device='cuda:0', requires_grad=True)
+    dd = DepthCloud(dc.vps, dc.dirs, dc.depth * w)[mask]
+    dd.depth.sum().backward()
+    assert torch.equal(w.grad[:, 0] != 0, mask)
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('name', ['Polynomial', 'ScaledPolynomial'])
+def test_polynomial_models_without_gradients_run_one_kernel(golden, name, dtype):
+    """model(dc) / model.inverse(dc) outside the training loop (the node, evaluation under no_grad): dc_correct_depth against
+    the tensor expression the same classes evaluate when a gradient is needed (model.py:181-215, 250-274) -- fp64 clouds to
+    2 ulp (the product of the [n,P] x [P,1] GEMM is accumulated in a library-chosen order), float32 clouds to 1 float32 ulp;
+    unmasked points keep their depth bit for bit."""
+    from depth_correction_amd import model as M
+    from depth_correction_amd.depth_cloud import DepthCloud
+    g = golden('room_k10')
+    dc = DepthCloud.from_points(t(g['scan0_xyz'], 'cuda:0').to(dtype))
+    dc.update_all(k=8)
+    model = getattr(M, name)(w=[1.5e-3, -2e-3, 4e-4], exponent=[2.0, 4.0, 0.5], device='cuda:0')
+    masks = [None, dc.eigvals[:, 0] < dc.eigvals[:, 0].median()]
+    eps = torch.finfo(dtype).eps
+    for mask in masks:
+        for fun in (model.correct_depth, model.inverse):
+            with torch.no_grad():
+                fast = fun(dc, mask).depth
+            slow = fun(dc, mask).depth                      # w requires grad and grad mode is on: the tensor expression
+            assert slow.requires_grad and not fast.requires_grad and fast.dtype == dtype and fast.shape == dc.depth.shape
+            rel = ((fast - slow.detach()).abs() / slow.detach().abs()).max().item()
+            assert rel <= 2 * eps, rel
+            if mask is not None:
+                assert torch.equal(fast[~mask], dc.depth[~mask]) and not torch.equal(fast[mask], dc.depth[mask])
