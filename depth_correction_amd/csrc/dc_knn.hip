@@ -45,6 +45,30 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) {
 __device__ __forceinline__ uint64_t morton3(int32_t x, int32_t y, int32_t z) {
   return spread21((uint32_t)x) | (spread21((uint32_t)y) << 1) | (spread21((uint32_t)z) << 2);
 }
+// The search grids are ordered by a 30-bit Morton code (10 bits per axis, grid_setup_kernel keeps every axis below 1024 cells):
+// a 32-bit key halves the bytes the sort moves and lets it finish in radix passes over 30 bits.
+typedef uint32_t GridKey;
+constexpr int kGridKeyBits = 30;
+constexpr int kGridAxisCells = 1023;             // most cells per axis of a search grid
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+  uint32_t x = v & 0x3ffu;
+  x = (x | x << 16) & 0x030000ffu;
+  x = (x | x << 8) & 0x0300f00fu;
+  x = (x | x << 4) & 0x030c30c3u;
+  x = (x | x << 2) & 0x09249249u;
+  return x;
+}
+__device__ __forceinline__ uint32_t compact10(uint32_t x) {             // inverse of spread10
+  x &= 0x09249249u;
+  x = (x | x >> 2) & 0x030c30c3u;
+  x = (x | x >> 4) & 0x0300f00fu;
+  x = (x | x >> 8) & 0x030000ffu;
+  x = (x | x >> 16) & 0x3ffu;
+  return x;
+}
+__device__ __forceinline__ GridKey grid_key(int32_t x, int32_t y, int32_t z) {
+  return spread10((uint32_t)x) | (spread10((uint32_t)y) << 1) | (spread10((uint32_t)z) << 2);
+}
 __device__ __forceinline__ void cell_of(const Grid& g, const double* p, int32_t* c) {
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -52,15 +76,6 @@ __device__ __forceinline__ void cell_of(const Grid& g, const double* p, int32_t*
     int32_t ci = (f > 0.0) ? ((f < (double)(g.dim[a] - 1)) ? (int32_t)f : g.dim[a] - 1) : 0;   // NaN -> 0
     c[a] = ci;
   }
-}
-__device__ __forceinline__ uint32_t compact21(uint64_t x) {            // inverse of spread21
-  x &= 0x1249249249249249ull;
-  x = (x | x >> 2) & 0x10c30c30c30c30c3ull;
-  x = (x | x >> 4) & 0x100f00f00f00f00full;
-  x = (x | x >> 8) & 0x1f0000ff0000ffull;
-  x = (x | x >> 16) & 0x1f00000000ffffull;
-  x = (x | x >> 32) & 0x1fffffull;
-  return (uint32_t)x;
 }
 // The hash table of the cells is keyed by the PACKED cell coordinates (21 bits each) and hashed by a three-multiply mix of
 // them; the Morton code only orders the sorted array.  A query probes ~27-125 cells, and interleaving three coordinates
@@ -194,20 +209,20 @@ __global__ void grid_setup_kernel(const double* __restrict__ part, int n_part, i
     h = area > 0.0 ? sqrt(area * kk / (2.0 * (double)(n > 0 ? n : 1))) : Lmax / 16.0;
     if (!(h > 0.0)) h = 1.0;
   }
-  const double hmin = Lmax / 2097150.0;          // at most 2^21 - 1 cells per axis
+  const double hmin = Lmax / (double)(kGridAxisCells - 1);          // at most kGridAxisCells cells per axis (30-bit cell order key)
   if (h < hmin) h = hmin;
   g->h = h;
   g->inv_h = 1.0 / h;
   for (int a = 0; a < 3; ++a) {
     g->origin[a] = lo[a];
     double d = floor(L[a] / h) + 1.0;
-    g->dim[a] = d < 2097151.0 ? (int32_t)d : 2097151;
+    g->dim[a] = d < (double)kGridAxisCells ? (int32_t)d : kGridAxisCells;
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__ xyz, int stride, int64_t n,
-                                                           const Grid* __restrict__ gp, uint64_t* __restrict__ keys,
+                                                           const Grid* __restrict__ gp, GridKey* __restrict__ keys,
                                                            int32_t* __restrict__ ids) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__
   int32_t c[3];
   load_xyz(xyz, i, stride, p);
   cell_of(g, p, c);
-  keys[i] = morton3(c[0], c[1], c[2]);
+  keys[i] = grid_key(c[0], c[1], c[2]);
   ids[i] = (int32_t)i;
 }
 
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void fine_keys_kernel(const T* __restrict__
 // Gather the sorted fp64 coordinates and insert every cell's first position into the hash table.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restrict__ xyz, int stride, int64_t n,
-                                                               const uint64_t* __restrict__ skeys,
+                                                               const GridKey* __restrict__ skeys,
                                                                const int32_t* __restrict__ sids,
                                                                double* __restrict__ sp, uint64_t* __restrict__ tab_key,
                                                                int32_t* __restrict__ tab_beg, uint32_t tab_mask) {
@@ -262,9 +277,9 @@ __global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restri
   double x[3];
   load_xyz(xyz, sids[p], stride, x);
   sp[p * 3] = x[0]; sp[p * 3 + 1] = x[1]; sp[p * 3 + 2] = x[2];
-  const uint64_t mk = skeys[p];
+  const GridKey mk = skeys[p];
   if (p == 0 || skeys[p - 1] != mk) {
-    const int32_t cx = (int32_t)compact21(mk), cy = (int32_t)compact21(mk >> 1), cz = (int32_t)compact21(mk >> 2);
+    const int32_t cx = (int32_t)compact10(mk), cy = (int32_t)compact10(mk >> 1), cz = (int32_t)compact10(mk >> 2);
     const uint64_t key = cell_key(cx, cy, cz);
     uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
     while (true) {
@@ -276,14 +291,14 @@ __global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restri
   }
 }
 
-__global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const uint64_t* __restrict__ skeys,
+__global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const GridKey* __restrict__ skeys,
                                                           const uint64_t* __restrict__ tab_key,
                                                           int32_t* __restrict__ tab_end, uint32_t tab_mask) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  const uint64_t mk = skeys[p];
+  const GridKey mk = skeys[p];
   if (p == n - 1 || skeys[p + 1] != mk) {
-    const int32_t cx = (int32_t)compact21(mk), cy = (int32_t)compact21(mk >> 1), cz = (int32_t)compact21(mk >> 2);
+    const int32_t cx = (int32_t)compact10(mk), cy = (int32_t)compact10(mk >> 1), cz = (int32_t)compact10(mk >> 2);
     const uint64_t key = cell_key(cx, cy, cz);
     uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
     while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
@@ -880,7 +895,7 @@ static uint32_t table_size(int64_t n) {
 }
 
 struct GridWs {
-  double* part; Grid* grid; uint64_t* keys; uint64_t* skeys; int32_t* ids; int32_t* sids; double* sp;
+  double* part; Grid* grid; GridKey* keys; GridKey* skeys; int32_t* ids; int32_t* sids; double* sp;
   uint64_t* tab_key; int32_t* tab_beg; int32_t* tab_end; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
   double* qf64; int32_t* pending; int32_t* n_pending; size_t total;
 };
@@ -890,8 +905,8 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   Carver c(ws);
   g.part = c.take<double>(kBoxBlocks * kBoxVals);
   g.grid = c.take<Grid>(1);
-  g.keys = c.take<uint64_t>(n);
-  g.skeys = c.take<uint64_t>(n);
+  g.keys = c.take<GridKey>(n);
+  g.skeys = c.take<GridKey>(n);
   g.ids = c.take<int32_t>(n);
   g.sids = c.take<int32_t>(n);
   g.sp = c.take<double>(3 * n);
@@ -903,8 +918,8 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   g.pending = c.take<int32_t>(n > n_query_extra ? n : n_query_extra);      // queries knn_query_kernel hands to knn_tail_kernel
   g.n_pending = c.take<int32_t>(16);
   g.sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr,
-                            (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0, 63, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (GridKey*)nullptr, (GridKey*)nullptr, (int32_t*)nullptr,
+                            (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0, kGridKeyBits, (hipStream_t)0);
   g.sort_tmp = c.take<char>(g.sort_bytes);
   g.total = c.off + 256;
   return g;
@@ -917,7 +932,7 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   hipLaunchKernelGGL((bbox_partial_kernel<T>), dim3(kBoxBlocks), dim3(kBlock), 0, st, xyz, stride, n, w.part);
   hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(kBlock), 0, st, w.part, kBoxBlocks, n, k, cell_hint, w.grid);
   hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.grid, w.keys, w.ids);
-  DC_HIP(rocprim::radix_sort_pairs(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, 63, st));
+  DC_HIP(rocprim::radix_sort_pairs(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, kGridKeyBits, st));
   DC_HIP(hipMemsetAsync(w.tab_key, 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
   hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp,
                      w.tab_key, w.tab_beg, w.tab_n - 1);
