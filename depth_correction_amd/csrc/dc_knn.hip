@@ -455,7 +455,14 @@ __global__ __launch_bounds__(kBlock, KMAX <= 16 ? 4 : 1) void knn_query_kernel(c
     // would walk hundreds of mostly empty cells alone while the 63 other lanes of its wavefront idle: it goes on the pending
     // list, and knn_tail_kernel finishes it with a whole wavefront (64 cells probed per trip).
     if (pending && r > r_budget) {
-      pending[atomicAdd(n_pending, 1)] = (int32_t)t;
+      // one atomic per wavefront; its unsettled queries stay next to each other on the list (they are neighbours in space)
+      const uint64_t m = __ballot(1);
+      const int lane = threadIdx.x & (kWave - 1);
+      const int leader = __ffsll((long long)m) - 1;
+      int32_t base = 0;
+      if (lane == leader) base = atomicAdd(n_pending, (int32_t)__popcll(m));
+      base = __shfl(base, leader, kWave);
+      pending[base + (int32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)t;
       return;
     }
     if (r > r_exhaust) { exhaustive = true; break; }
@@ -717,6 +724,271 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
   }
 }
 
+// ---- k nearest neighbours, SIXTEEN LANES PER QUERY (k <= 16) ----------------------------------------------------------------
+// knn_query_kernel gives every query one lane: a wavefront then walks 27 (+98) cells one after the other and each cell's points
+// one after the other -- some 250 dependent memory round trips per wavefront, with the trip count of every loop set by the
+// busiest of 64 lanes -- and one unsettled query in 64 sends all of them through the next shell.  A 200 k-point scan is less
+// than one wavefront per SIMD: its build time WAS that chain of round trips.  Here a query owns one DPP row:
+//   * its 16 lanes probe 16 cells of the current stage at once (stage 1: the 27 cells around the query's own; stage r >= 2: the
+//     shell at Chebyshev distance r);
+//   * the points of those 16 cells are numbered through and taken 16 per step: candidate jj lies in the cell of lane
+//     L = #{lanes whose inclusive point count <= jj}, found without a search -- every lane drops a one into bin
+//     (inclusive count - step base) of a 16-bin LDS histogram and the running sum of the bins up to a lane's own is its L --
+//     so the trip count is the row's candidate count / 16, not the sum over cells of the fullest cell;
+//   * candidates that beat the current k-th best go to the row's LDS pool (ballot + prefix count); the k best of {best list,
+//     pool} by (distance, index) -- cKDTree's order -- are then found by a float32 threshold (every lane sorts its five rounded
+//     distances once, k rounds of a row-wide minimum over the heads pop at least k entries: at least k keys are <= the last
+//     minimum, and rounding is monotone, so nothing at or below the k-th distance is lost), after which the ~k finalists are
+//     ranked, one per lane, by 15 row rotations of their rounded distances -- of (fp64 distance, index) when two share one.
+//     More than 16 finalists (points repeated many times) take k rounds of an exact row-wide lexicographic minimum instead.
+// The best list lives one slot per lane (lane s of the row = the s-th neighbour).  Same distances (sqdist), same order, same
+// termination rule as knn_query_kernel: bit-identical tables.  Queries not settled after r_budget stages go to knn_tail_kernel.
+// Measured (k = 10): 200 k-point scan 0.47 -> 0.38 ms, 2 M-point cloud 1.95 -> 1.89 ms per build.
+constexpr int kGrp = 16;                           // lanes per query: one DPP row
+constexpr int kGrpPerBlock = kBlock / kGrp;
+constexpr int kGrpPool = 64;                       // pool entries per query: four per lane in the selection
+
+// LDS hand-over between the lanes of one wavefront: the wavefront's LDS operations execute in program order, so no hardware
+// barrier is needed, but the compiler must not move memory operations across the hand-over (wave_barrier alone is IntrNoMem)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
+__device__ __forceinline__ float row_all_min(float m) {
+  m = fminf(m, dpp_f32<0xB1>(m));                  // quad_perm [1,0,3,2]
+  m = fminf(m, dpp_f32<0x4E>(m));                  // quad_perm [2,3,0,1]
+  m = fminf(m, dpp_f32<0x124>(m));                 // row_ror:4
+  m = fminf(m, dpp_f32<0x128>(m));                 // row_ror:8
+  return m;
+}
+__device__ __forceinline__ int row_incl_scan(int v) {          // inclusive prefix sum along the row (row_shr shifts zeros in)
+  v += dpp_i32<0x111>(v);
+  v += dpp_i32<0x112>(v);
+  v += dpp_i32<0x114>(v);
+  v += dpp_i32<0x118>(v);
+  return v;
+}
+__device__ __forceinline__ bool lex_less(double ad, int32_t ai, double bd, int32_t bi) { return ad < bd || (ad == bd && ai < bi); }
+template <int CTRL>
+__device__ __forceinline__ int rot_less(double md, int32_t mi) {          // 1 when the entry CTRL lanes away sorts before mine
+  const double od = __hiloint2double(dpp_i32<CTRL>(__double2hiint(md)), dpp_i32<CTRL>(__double2loint(md)));
+  const int32_t oi = dpp_i32<CTRL>(mi);
+  return lex_less(od, oi, md, mi) ? 1 : 0;
+}
+template <int CTRL>
+__device__ __forceinline__ void row_lex_min_step(double& md, int32_t& mi) {
+  const double od = __hiloint2double(dpp_i32<CTRL>(__double2hiint(md)), dpp_i32<CTRL>(__double2loint(md)));
+  const int32_t oi = dpp_i32<CTRL>(mi);
+  if (lex_less(od, oi, md, mi)) { md = od; mi = oi; }
+}
+
+// (six wavefronts per SIMD: 79 VGPRs and 60 B of scratch; five -- 96 VGPRs, no scratch -- and seven were both slower)
+__global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                           const double* __restrict__ queries, const int32_t* __restrict__ qids,
+                                                           int64_t n_query, const Grid* __restrict__ gp, CellTable tab, int k,
+                                                           double r_max, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                           int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending) {
+  __shared__ int32_t s_hist[kGrpPerBlock][kGrp];
+  __shared__ double s_pd[kGrpPerBlock][kGrpPool];
+  __shared__ int32_t s_pi[kGrpPerBlock][kGrpPool];
+  __shared__ double s_fd[kGrpPerBlock][kGrp];
+  __shared__ int32_t s_fi[kGrpPerBlock][kGrp];
+  constexpr int32_t kNone = 0x7fffffff;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane & (kGrp - 1), grp = threadIdx.x / kGrp;
+  const int64_t t = (int64_t)blockIdx.x * kGrpPerBlock + grp;
+  const bool valid = t < n_query;
+  const int64_t tc = valid ? t : 0;
+  const Grid g = *gp;
+  const double q[3] = {queries[tc * 3], queries[tc * 3 + 1], queries[tc * 3 + 2]};
+  const int64_t row = qids ? qids[tc] : tc;
+  int32_t c[3];
+  cell_of(g, q, c);
+  const double ub2 = r_max > 0.0 ? r_max * r_max : INFINITY;
+  const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+  bool done = !(valid && finite_q && shell_in_grid(g, c, 0));      // (all of these are uniform over the row)
+  bool unsettled = false;                          // done without an answer: the tail kernel's
+  double bd = INFINITY;                            // lane s: the s-th best so far
+  int32_t bi = kNone;
+  double worst_d = INFINITY;
+  int32_t worst_i = kNone;
+  int nc = 0;                                      // pool entries (uniform over the row)
+  const int row_lane0 = lane & ~(kGrp - 1);
+
+  // ---- the k best of {best list, pool} -> best list ----
+  auto select = [&]() {
+    double ed[5];
+    int32_t ei[5];
+    float k0[5], kf[5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = sub + kGrp * i;
+      const bool ok = e < nc;
+      ed[i] = ok ? s_pd[grp][e] : INFINITY;
+      ei[i] = ok ? s_pi[grp][e] : kNone;
+    }
+    ed[4] = bd; ei[4] = bi;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { k0[i] = ei[i] != kNone ? (float)ed[i] : INFINITY; kf[i] = k0[i]; }
+    // every lane sorts its five keys once (nine compare-exchanges); a round then looks at the heads only
+#define DC_CE(a, b) { const float lo_ = fminf(kf[a], kf[b]), hi_ = fmaxf(kf[a], kf[b]); kf[a] = lo_; kf[b] = hi_; }
+    DC_CE(0, 1) DC_CE(3, 4) DC_CE(2, 4) DC_CE(2, 3) DC_CE(1, 4) DC_CE(0, 3) DC_CE(0, 2) DC_CE(1, 3) DC_CE(1, 2)
+#undef DC_CE
+    float tau = INFINITY;                    // bound on the k-th smallest rounded distance
+    for (int s = 0; s < k; ++s) {
+      const float mm = row_all_min(kf[0]);
+      tau = mm;
+      // lanes whose head is the minimum pop it: every round removes at least one entry, all of them <= the last minimum,
+      // so after k rounds at least k keys are <= tau (and tau is at most the k-th distinct key)
+      const bool pop = kf[0] == mm;
+      kf[0] = pop ? kf[1] : kf[0]; kf[1] = pop ? kf[2] : kf[1]; kf[2] = pop ? kf[3] : kf[2]; kf[3] = pop ? kf[4] : kf[3];
+      kf[4] = pop ? INFINITY : kf[4];
+    }
+    bool fin[5];
+    int cf = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { fin[i] = ei[i] != kNone && k0[i] <= tau; cf += fin[i] ? 1 : 0; }
+    const int fincl = row_incl_scan(cf);
+    const int nf = __shfl(fincl, row_lane0 + kGrp - 1, kWave);
+    if (!__any((int)(nf > kGrp))) {
+      int off = fincl - cf;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) if (fin[i]) { s_fd[grp][off] = ed[i]; s_fi[grp][off] = ei[i]; ++off; }
+      wave_sync();
+      const bool mine = sub < nf;
+      const double md = mine ? s_fd[grp][sub] : INFINITY;
+      const int32_t mi = mine ? s_fi[grp][sub] : kNone;
+      // rank among the finalists: by the rounded distance (one register per rotation); the exact (fp64, index) comparison
+      // only when two finalists of some row share a rounded distance
+      const float mk = mine ? (float)md : INFINITY;
+      int rank = 0;
+      bool tie = false;
+#define DC_ROT(C) { const float ok_ = dpp_f32<C>(mk); rank += ok_ < mk ? 1 : 0; tie = tie || (ok_ == mk && mine); }
+      DC_ROT(0x121) DC_ROT(0x122) DC_ROT(0x123) DC_ROT(0x124) DC_ROT(0x125) DC_ROT(0x126) DC_ROT(0x127) DC_ROT(0x128)
+      DC_ROT(0x129) DC_ROT(0x12A) DC_ROT(0x12B) DC_ROT(0x12C) DC_ROT(0x12D) DC_ROT(0x12E) DC_ROT(0x12F)
+#undef DC_ROT
+      if (__any((int)tie)) {
+        rank = 0;
+        rank += rot_less<0x121>(md, mi); rank += rot_less<0x122>(md, mi); rank += rot_less<0x123>(md, mi);
+        rank += rot_less<0x124>(md, mi); rank += rot_less<0x125>(md, mi); rank += rot_less<0x126>(md, mi);
+        rank += rot_less<0x127>(md, mi); rank += rot_less<0x128>(md, mi); rank += rot_less<0x129>(md, mi);
+        rank += rot_less<0x12A>(md, mi); rank += rot_less<0x12B>(md, mi); rank += rot_less<0x12C>(md, mi);
+        rank += rot_less<0x12D>(md, mi); rank += rot_less<0x12E>(md, mi); rank += rot_less<0x12F>(md, mi);
+      }
+      wave_sync();
+      if (mine) { s_fd[grp][rank] = md; s_fi[grp][rank] = mi; }
+      wave_sync();
+      const bool take = mine && sub < k;
+      bd = take ? s_fd[grp][sub] : INFINITY;
+      bi = take ? s_fi[grp][sub] : kNone;
+      wave_sync();
+    } else {
+      // more finalists than lanes (points repeated many times): k rounds of an exact row-wide minimum
+      double last_d = -1.0, nbd = INFINITY;
+      int32_t last_i = -1, nbi = kNone;
+      for (int s = 0; s < k; ++s) {
+        double md = INFINITY;
+        int32_t mi = kNone;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const bool gt = ed[i] > last_d || (ed[i] == last_d && ei[i] > last_i);
+          if (ei[i] != kNone && gt && lex_less(ed[i], ei[i], md, mi)) { md = ed[i]; mi = ei[i]; }
+        }
+        row_lex_min_step<0xB1>(md, mi);
+        row_lex_min_step<0x4E>(md, mi);
+        row_lex_min_step<0x124>(md, mi);
+        row_lex_min_step<0x128>(md, mi);
+        if (sub == s) { nbd = md; nbi = mi; }
+        last_d = md; last_i = mi;
+        if (mi == kNone) last_d = INFINITY;                   // nothing is left: the remaining slots stay empty
+      }
+      bd = nbd; bi = nbi;
+    }
+    worst_d = __shfl(bd, row_lane0 + k - 1, kWave);
+    worst_i = __shfl(bi, row_lane0 + k - 1, kWave);
+    nc = 0;
+  };
+
+  for (int r = 1; __any((int)!done); ++r) {
+    const int side = 2 * r + 1, ring = 4 * side - 4;
+    const int n_cells = r == 1 ? 27 : 2 * side * side + (side - 2) * ring;
+    const float inv_side = 1.0f / (float)side, inv_ring = 1.0f / (float)ring;
+    for (int j0 = 0; j0 < n_cells; j0 += kGrp) {
+      // sixteen cells of the stage: one hash probe per lane
+      const int j = j0 + sub;
+      int32_t b = 0, e = 0;
+      if (!done && j < n_cells) {
+        int dx, dy, dz;
+        if (r == 1) { dz = j / 9; const int jj = j - dz * 9; dy = jj / 3; dx = jj - dy * 3; dx -= 1; dy -= 1; dz -= 1; }
+        else shell_cell(r, side, inv_side, inv_ring, j, &dx, &dy, &dz);
+        const int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
+        if (x >= 0 && y >= 0 && z >= 0 && x < g.dim[0] && y < g.dim[1] && z < g.dim[2]) {
+          if (!find_cell(tab, x, y, z, &b, &e)) { b = 0; e = 0; }
+        }
+      }
+      const int cnt = e - b;
+      const int incl = row_incl_scan(cnt);
+      const int excl = incl - cnt;
+      const int T = __shfl(incl, row_lane0 + kGrp - 1, kWave);       // points in the row's sixteen cells
+      // their points numbered through, sixteen per step: candidate jj lies in the cell of lane L = #{lanes: incl <= jj}.  Every
+      // lane drops a one into the bin min(incl - s0, .) of a 16-bin LDS histogram; the running sum of the bins up to `sub` is
+      // that count for candidate s0 + sub (a load-balanced search without a search).
+      for (int s0 = 0; __any((int)(s0 < T)); s0 += kGrp) {
+        s_hist[grp][sub] = 0;
+        wave_sync();
+        const int v = incl - s0;
+        if (v < kGrp) atomicAdd(&s_hist[grp][v > 0 ? v : 0], 1);
+        wave_sync();
+        const int L = row_incl_scan(s_hist[grp][sub]);
+        wave_sync();
+        const int jj = s0 + sub;
+        const bool has = jj < T;
+        const int src = row_lane0 + (L & (kGrp - 1));
+        // (the shuffles outside the conditional: ds_bpermute returns 0 from lanes that are masked off, and the cell of an active
+        //  lane's candidate is often held by a lane with no candidate of its own in this step)
+        const int32_t b_src = __shfl(b, src, kWave), excl_src = __shfl(excl, src, kWave);
+        const int32_t p = has ? b_src + (jj - excl_src) : 0;
+        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
+        const int32_t id = sids[p];
+        const double d = sqdist(pp, q);
+        const bool acc = has && d < ub2 && lex_less(d, id, worst_d, worst_i);
+        const unsigned long long m = __ballot(acc);
+        const unsigned m16 = (unsigned)(m >> row_lane0) & 0xffffu;
+        const int pos = nc + __popc(m16 & ((1u << sub) - 1u));
+        if (acc) { s_pd[grp][pos] = d; s_pi[grp][pos] = id; }
+        nc += __popc(m16);
+        wave_sync();
+        if (__any((int)(nc > kGrpPool - kGrp))) select();
+      }
+    }
+    if (__any((int)(nc > 0))) select();
+    if (!done) {
+      const double bound = shell_bound(g, q, c, r);
+      const double b2 = bound * bound;
+      if (worst_d < b2 || b2 >= ub2 || !shell_in_grid(g, c, r + 1)) done = true;       // settled
+      else if (r >= r_budget) { done = true; unsettled = true; }
+    }
+  }
+  // unsettled queries: one entry per row, one atomic per wavefront
+  const bool pend = unsettled && sub == 0;
+  const unsigned long long pm = __ballot(pend);
+  if (pm != 0ull) {
+    const int leader = __ffsll((long long)pm) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(n_pending, (int32_t)__popcll(pm));
+    base = __shfl(base, leader, kWave);
+    if (pend) pending[base + (int32_t)__popcll(pm & ((1ull << lane) - 1ull))] = (int32_t)t;
+  }
+  if (valid && !unsettled && sub < k) {
+    const bool ok = bi != kNone;
+    idx_out[row * k + sub] = ok ? bi : -1;
+    if (dist_out) dist_out[row * k + sub] = ok ? sqrt(bd) : INFINITY;
+  }
+}
+
 // ---- radius search: count, then fill (ascending index, -1 padded) ------------------------------------
 constexpr int kRadiusSortMax = 192;      // longest row radius_sort_rows_kernel sorts in LDS (64 rows x 192 entries = 48 KB per block)
 // one lane per row: row -> LDS (entry s of lane l at s * 64 + l: conflict-free), insertion sort up to the first -1, row back
@@ -915,7 +1187,7 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   g.tab_beg = c.take<int32_t>(g.tab_n);
   g.tab_end = c.take<int32_t>(g.tab_n);
   g.qf64 = c.take<double>(3 * n_query_extra);
-  g.pending = c.take<int32_t>(n > n_query_extra ? n : n_query_extra);      // queries knn_query_kernel hands to knn_tail_kernel
+  g.pending = c.take<int32_t>(n > n_query_extra ? n : n_query_extra);      // queries the query kernels hand to knn_tail_kernel
   g.n_pending = c.take<int32_t>(16);
   g.sort_bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (GridKey*)nullptr, (GridKey*)nullptr, (int32_t*)nullptr,
@@ -950,15 +1222,23 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
   // shells 0..R hold (2R+1)^3 cells at ~4 candidates' worth of work each; a scan of all n points costs n candidates
   int r_exhaust = (int)(cbrt((double)n * 0.25) * 0.5);
   r_exhaust = r_exhaust < 4 ? 4 : (r_exhaust > 64 ? 64 : r_exhaust);
-  const int budget = g_knn_budget.load();
-  if (budget < 0) pending = nullptr;               // one lane per query to the end (the round-2 behaviour)
+  // dc_knn_set_shell_budget(b): b < 0 one lane per query to the end (round 2); 0 <= b < 100: stages before the tail kernel,
+  // sixteen lanes per query when k <= 16 (knn_group_kernel); b >= 100: the same with b - 100 and ONE lane per query (A-B).
+  const int raw = g_knn_budget.load();
+  const int budget = raw >= 100 ? raw - 100 : raw;
+  if (budget < 0) pending = nullptr;
   if (pending) DC_HIP(hipMemsetAsync(n_pending, 0, sizeof(int32_t), st));
+  if (pending && raw < 100 && budget >= 1 && k <= kGrp) {
+    const dim3 ggrid((unsigned)((nq + kGrpPerBlock - 1) / kGrpPerBlock));
+    hipLaunchKernelGGL(knn_group_kernel, ggrid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist, budget, pending, n_pending);
+  } else {
 #define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, n, r_exhaust, idx, dist, \
                                   budget, pending, n_pending)
-  // the sorted insertion costs ~12 instructions per slot and runs for a whole wavefront whenever one lane accepts a
-  // candidate, so the slot count follows k closely (10 = the reference's default nn_k)
-  if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 10) LK(10); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
+    // the sorted insertion costs ~12 instructions per slot and runs for a whole wavefront whenever one lane accepts a
+    // candidate, so the slot count follows k closely (10 = the reference's default nn_k)
+    if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 10) LK(10); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
 #undef LK
+  }
   if (pending) {
     // one wavefront per pending query; their number stays on the device (the grid is fixed, wavefronts stride over the list)
     const int64_t want = (nq + kWavesPerBlock - 1) / kWavesPerBlock;

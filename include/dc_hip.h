@@ -56,8 +56,10 @@ int dc_version(void);
  * r > 0: keep only d < r (cKDTree distance_upper_bound), missing -> idx -1 / dist inf.  cell_hint <= 0: auto.
  * idx_out int32 [rows, k], dist_out fp64 [rows, k] or NULL.  Ordering: ascending fp64 distance, self first. */
 size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query);
-/* Shells of cells a lane of the k-NN query kernel walks by itself before its query is handed to the wavefront-per-query tail
- * kernel (default 2: 125 cells; negative: never -- one lane per query to the end).  Results do not depend on it. */
+/* Stages of cells a query walks (stage 1: the 27 cells around its own, stage r: the shell at Chebyshev distance r) before it is
+ * handed to the wavefront-per-query tail kernel: default 2 (125 cells).  0 <= shells < 100: sixteen lanes per query for
+ * k <= 16 (knn_group_kernel), one lane per query above; shells + 100: one lane per query for every k (the round-2/3 kernel,
+ * kept for A-B runs); negative: one lane per query to the end, no tail kernel.  Results do not depend on it. */
 int dc_knn_set_shell_budget(int shells);
 int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride,
                  int64_t n_query, int k, double r, double cell_hint, int32_t* idx_out, double* dist_out, void* ws,

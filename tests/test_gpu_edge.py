@@ -305,3 +305,70 @@ def test_sequence_plan_small_and_odd_sizes(sizes, k, dtype):
         f64 = dtype == torch.float64
         np.testing.assert_allclose(a[0], b[0], rtol=1e-11 if f64 else 1e-5)
         np.testing.assert_allclose(a[2:4], b[2:4], rtol=1e-8 if f64 else 1e-3, atol=(1e-11 if f64 else 1e-5) * np.abs(b[2:4]).max())
+
+
+@pytest.mark.timeout(180)
+def test_knn_row_per_query_kernel_corner_cases():
+    """knn_group_kernel (16 lanes per query, the default for k <= 16) against cKDTree and against the two lane-per-query builds
+    (dc_knn_set_shell_budget(102): with the tail kernel, (-1): to the end) where its special paths run:
+      * points repeated 40 times -- more than 16 finalists share the k-th rounded distance: the exact row-wide selection;
+      * a regular lattice -- many EQUAL distances: finalists ranked by (fp64 distance, index), cKDTree's tie order by index;
+      * k = 1, 4, 10, 16, a radius limit that leaves rows short, a cloud smaller than k, one dense cell with 600 points
+        (pool refilled many times), NaN rows."""
+    from depth_correction_amd import ops, _native as nv
+    rng = np.random.default_rng(3)
+
+    def three_ways(x, k, r=None, query=None):
+        out = []
+        for budget in (2, 102, -1):
+            nv.check(nv.lib().dc_knn_set_shell_budget(budget), 'budget')
+            try:
+                d, i = ops.knn(x, k, r=r, query=query)
+            finally:
+                nv.check(nv.lib().dc_knn_set_shell_budget(2), 'budget')
+            out.append((npy(d), npy(i)))
+        for d, i in out[1:]:
+            assert np.array_equal(out[0][1], i) and np.array_equal(out[0][0], d)
+        return out[0]
+
+    # repeated points: every query has 40 candidates at distance 0 and 40 more at each next distance
+    base = rng.uniform(-1, 1, size=(300, 3)) * [1, 1, 0.02]
+    rep = np.repeat(base, 40, axis=0)[rng.permutation(300 * 40)]
+    d, i = three_ways(t(rep, DEV), 10)
+    dref, iref = O.knn_ckdtree(rep, 10)
+    assert np.array_equal(d, dref)                                       # distances are unique as a multiset
+    assert (d == 0).all()                                                # ten of the 40 copies
+    same = (rep[i] == rep[:, None, :]).all(axis=2)
+    assert same.all()
+    assert (np.diff(i, axis=1) > 0).all()                                # equal distances: ascending index, the builders' order
+    # lattice: equal distances everywhere
+    ax = np.arange(24, dtype=np.float64) * 0.25
+    lat = np.stack(np.meshgrid(ax, ax, ax[:6], indexing='ij'), axis=-1).reshape(-1, 3)[rng.permutation(24 * 24 * 6)]
+    for k in (1, 4, 10, 16):
+        d, i = three_ways(t(lat, DEV), k)
+        dref, _ = O.knn_ckdtree(lat, k)
+        assert np.array_equal(d, dref.reshape(d.shape))
+        dd = np.linalg.norm(lat[i] - lat[:, None, :], axis=2)
+        assert np.allclose(dd, d, rtol=0, atol=1e-12)
+        tie = np.diff(d, axis=1) == 0
+        assert (np.diff(i, axis=1)[tie] > 0).all()
+    # radius limit + short rows, float32 input
+    pts = (rng.uniform(-2, 2, size=(6000, 3)) * [1, 1, 0.05]).astype(np.float32)
+    d, i = three_ways(t(pts, DEV), 8, r=0.08)
+    dref, iref = O.knn_ckdtree(pts.astype(np.float64), 8, r=0.08)
+    assert np.array_equal(i, iref) and np.array_equal(d, dref) and (i == -1).any()
+    # fewer points than k; cross-cloud queries
+    tiny = rng.uniform(-1, 1, size=(7, 3))
+    d, i = three_ways(t(tiny, DEV), 10)
+    assert (i[:, 7:] == -1).all() and np.isinf(d[:, 7:]).all() and (np.sort(i[:, :7], axis=1) == np.arange(7)).all()
+    d, i = three_ways(t(pts.astype(np.float64), DEV), 16, query=t(rng.uniform(-2.5, 2.5, size=(999, 3)) * [1, 1, 0.1], DEV))
+    # one very dense cell: the pool runs full over and over
+    dense = np.concatenate([rng.normal(scale=1e-3, size=(600, 3)), rng.uniform(-1, 1, size=(4000, 3)) * [1, 1, 0.02]])
+    d, i = three_ways(t(dense, DEV), 10)
+    dref, iref = O.knn_ckdtree(dense, 10)
+    assert np.array_equal(i, iref) and np.array_equal(d, dref)
+    # NaN rows neither find nor are found
+    bad = pts.astype(np.float64).copy()
+    bad[::97] = np.nan
+    d, i = three_ways(t(bad, DEV), 5)
+    assert (i[::97] == -1).all() and not np.isin(i, np.arange(0, len(bad), 97)).any()
