@@ -989,6 +989,114 @@ __global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __re
   }
 }
 
+// ---- scan-shadow filter straight off the direction grid (filters.py:257-309 after depth_cloud.py:352-360) ---------------
+// The reference builds the padded table of every point's direction-neighbours (all rays within `rad` chord length of its own)
+// and then takes min / max over the table's rows of the angle between the ray back to the viewpoint and the vector to the
+// neighbour.  The mask only depends on the SET of neighbours (the fill value of short rows, the mean of the bounds, never
+// violates them), so the walk over the grid cells evaluates the angles as it meets the neighbours and no table is written:
+// one pass instead of count + fill + row sort + mask.  The inclusion test is radius_kernel's (fp64, on the fp64 copies of the
+// directions), the angle arithmetic is shadow_mask_kernel's (dc_filters.hip), in the cloud's precision.
+// SIXTEEN LANES PER RAY, knn_group_kernel's division of labour (a lane-per-ray walk of a 200 k-point scan is one wavefront per
+// SIMD following ~100 dependent loads: 0.23 ms): 16 cells probed at once, their points dealt 16 per step.
+template <int CTRL> __device__ __forceinline__ float dpp_val_f(float v) { return dpp_f32<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ double dpp_val_d(double v) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL> __device__ __forceinline__ float dpp_any(float v) { return dpp_val_f<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ double dpp_any(double v) { return dpp_val_d<CTRL>(v); }
+template <typename T>
+__device__ __forceinline__ void row_min_max(T& lo, T& hi) {          // all lanes of the row end up with the row's min / max
+#define DC_STEP(C) { const T ol = dpp_any<C>(lo), oh = dpp_any<C>(hi); lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi; }
+  DC_STEP(0xB1) DC_STEP(0x4E) DC_STEP(0x124) DC_STEP(0x128)
+#undef DC_STEP
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void shadow_group_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+                                                              int64_t n, const Grid* __restrict__ gp, CellTable tab, double rad,
+                                                              const T* __restrict__ x, const T* __restrict__ vps, int vps_rows,
+                                                              T lo, T hi, uint8_t* __restrict__ mask) {
+#pragma clang fp contract(off)
+  __shared__ int32_t s_hist[kGrpPerBlock][kGrp];
+  const int lane = threadIdx.x & (kWave - 1), sub = lane & (kGrp - 1), grp = threadIdx.x / kGrp;
+  const int row_lane0 = lane & ~(kGrp - 1);
+  const int64_t t = (int64_t)blockIdx.x * kGrpPerBlock + grp;
+  const bool valid = t < n;
+  const int64_t tc = valid ? t : 0;
+  const Grid g = *gp;
+  const double q[3] = {sp[tc * 3], sp[tc * 3 + 1], sp[tc * 3 + 2]};
+  const int64_t i = sids[tc];
+  const double r2 = rad * rad;
+  const T eps = (T)1e-8;
+  const T xi0 = x[i * 3], xi1 = x[i * 3 + 1], xi2 = x[i * 3 + 2];
+  const T* o = vps + (vps_rows == 1 ? 0 : i * 3);
+  T a0 = o[0] - xi0, a1 = o[1] - xi1, a2 = o[2] - xi2;
+  const T na = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+  const T da = na > eps ? na : eps;
+  a0 /= da; a1 /= da; a2 /= da;
+  T amin = (T)INFINITY, amax = -(T)INFINITY;
+  bool bad = false;
+  int32_t c[3];
+  cell_of(g, q, c);
+  const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
+  bool done = !(valid && finite_q && shell_in_grid(g, c, 0));
+  for (int r = 1; __any((int)!done); ++r) {
+    const int side = 2 * r + 1, ring = 4 * side - 4;
+    const int n_cells = r == 1 ? 27 : 2 * side * side + (side - 2) * ring;
+    const float inv_side = 1.0f / (float)side, inv_ring = 1.0f / (float)ring;
+    for (int j0 = 0; j0 < n_cells; j0 += kGrp) {
+      const int j = j0 + sub;
+      int32_t b = 0, e = 0;
+      if (!done && j < n_cells) {
+        int dx, dy, dz;
+        if (r == 1) { dz = j / 9; const int jj = j - dz * 9; dy = jj / 3; dx = jj - dy * 3; dx -= 1; dy -= 1; dz -= 1; }
+        else shell_cell(r, side, inv_side, inv_ring, j, &dx, &dy, &dz);
+        const int cx = c[0] + dx, cy = c[1] + dy, cz = c[2] + dz;
+        if (cx >= 0 && cy >= 0 && cz >= 0 && cx < g.dim[0] && cy < g.dim[1] && cz < g.dim[2]) {
+          if (!find_cell(tab, cx, cy, cz, &b, &e)) { b = 0; e = 0; }
+        }
+      }
+      const int cnt = e - b;
+      const int incl = row_incl_scan(cnt);
+      const int excl = incl - cnt;
+      const int Tn = __shfl(incl, row_lane0 + kGrp - 1, kWave);
+      for (int s0 = 0; __any((int)(s0 < Tn)); s0 += kGrp) {        // (see knn_group_kernel)
+        s_hist[grp][sub] = 0;
+        wave_sync();
+        const int v = incl - s0;
+        if (v < kGrp) atomicAdd(&s_hist[grp][v > 0 ? v : 0], 1);
+        wave_sync();
+        const int L = row_incl_scan(s_hist[grp][sub]);
+        wave_sync();
+        const int jj = s0 + sub;
+        const bool has = jj < Tn;
+        const int src = row_lane0 + (L & (kGrp - 1));
+        const int32_t b_src = __shfl(b, src, kWave), excl_src = __shfl(excl, src, kWave);
+        const int32_t p = has ? b_src + (jj - excl_src) : 0;
+        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
+        const int64_t jn = sids[p];
+        if (has && sqdist(pp, q) <= r2) {
+          T b0 = x[jn * 3] - xi0, b1 = x[jn * 3 + 1] - xi1, b2 = x[jn * 3 + 2] - xi2;
+          const T nb = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+          const T db = nb > eps ? nb : eps;
+          b0 /= db; b1 /= db; b2 /= db;
+          const T cs = a0 * b0 + a1 * b1 + a2 * b2;
+          const T ang = acos(cs);
+          bad = bad || (ang != ang);
+          amin = ang < amin ? ang : amin;
+          amax = ang > amax ? ang : amax;
+        }
+      }
+    }
+    if (!done && (shell_bound(g, q, c, r) > rad || !shell_in_grid(g, c, r + 1))) done = true;
+  }
+  row_min_max(amin, amax);
+  const unsigned long long bm = __ballot(bad);
+  const bool row_bad = ((unsigned)(bm >> row_lane0) & 0xffffu) != 0u;
+  // a ray with no neighbour at all (not even itself: non-finite direction) has an all-fill row in the reference: kept
+  if (valid && sub == 0) mask[i] = (!row_bad && (amin > amax ? lo <= hi : (amin >= lo && amax <= hi))) ? 1 : 0;
+}
+
 // ---- radius search: count, then fill (ascending index, -1 padded) ------------------------------------
 constexpr int kRadiusSortMax = 192;      // longest row radius_sort_rows_kernel sorts in LDS (64 rows x 192 entries = 48 KB per block)
 // one lane per row: row -> LDS (entry s of lane l at s * 64 + l: conflict-free), insertion sort up to the first -1, row back
@@ -1060,62 +1168,6 @@ __global__ __launch_bounds__(kBlock) void radius_kernel(const double* __restrict
   } else {
     count[row] = cnt;
   }
-}
-
-// ---- scan-shadow filter straight off the direction grid (filters.py:257-309 after depth_cloud.py:352-360) ---------------
-// The reference builds the padded table of every point's direction-neighbours (all rays within `rad` chord length of its own)
-// and then takes min / max over the table's rows of the angle between the ray back to the viewpoint and the vector to the
-// neighbour.  The mask only depends on the SET of neighbours (the fill value of short rows, the mean of the bounds, never
-// violates them), so the walk over the grid cells evaluates the angles as it meets the neighbours and no table is written:
-// one pass instead of count + fill + row sort + mask.  The inclusion test is radius_kernel's (fp64, on the fp64 copies of the
-// directions), the angle arithmetic is shadow_mask_kernel's (dc_filters.hip), in the cloud's precision.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void shadow_walk_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
-                                                             int64_t n, const Grid* __restrict__ gp, CellTable tab, double rad,
-                                                             const T* __restrict__ x, const T* __restrict__ vps, int vps_rows,
-                                                             T lo, T hi, uint8_t* __restrict__ mask) {
-#pragma clang fp contract(off)
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n) return;
-  const Grid g = *gp;
-  const double q[3] = {sp[t * 3], sp[t * 3 + 1], sp[t * 3 + 2]};
-  const int64_t i = sids[t];
-  const double r2 = rad * rad;
-  const T eps = (T)1e-8;
-  const T xi0 = x[i * 3], xi1 = x[i * 3 + 1], xi2 = x[i * 3 + 2];
-  const T* o = vps + (vps_rows == 1 ? 0 : i * 3);
-  T a0 = o[0] - xi0, a1 = o[1] - xi1, a2 = o[2] - xi2;
-  const T na = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-  const T da = na > eps ? na : eps;
-  a0 /= da; a1 /= da; a2 /= da;
-  T amin = (T)INFINITY, amax = -(T)INFINITY;
-  bool bad = false;
-  int32_t c[3];
-  cell_of(g, q, c);
-  const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
-  for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
-    for_shell(g, c, r, [&](int cx, int cy, int cz) {
-      int32_t b, e;
-      if (!find_cell(tab, cx, cy, cz, &b, &e)) return;
-      for (int32_t p = b; p < e; ++p) {
-        const double pp[3] = {sp[(int64_t)p * 3], sp[(int64_t)p * 3 + 1], sp[(int64_t)p * 3 + 2]};
-        if (!(sqdist(pp, q) <= r2)) continue;
-        const int64_t j = sids[p];
-        T b0 = x[j * 3] - xi0, b1 = x[j * 3 + 1] - xi1, b2 = x[j * 3 + 2] - xi2;
-        const T nb = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
-        const T db = nb > eps ? nb : eps;
-        b0 /= db; b1 /= db; b2 /= db;
-        const T cs = a0 * b0 + a1 * b1 + a2 * b2;
-        const T ang = acos(cs);
-        bad = bad || (ang != ang);
-        amin = ang < amin ? ang : amin;
-        amax = ang > amax ? ang : amax;
-      }
-    });
-    if (shell_bound(g, q, c, r) > rad) break;
-  }
-  // a ray with no neighbour at all (not even itself: non-finite direction) has an all-fill row in the reference: kept
-  mask[i] = (!bad && (amin > amax ? lo <= hi : (amin >= lo && amax <= hi))) ? 1 : 0;
 }
 
 template <typename T>
@@ -1332,12 +1384,12 @@ int dc_shadow_filter(const void* points, const void* vps, int vps_rows, const vo
   else return DC_ERR_DTYPE;
   if (rc) return rc;
   CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  const dim3 grid((unsigned)((n + kGrpPerBlock - 1) / kGrpPerBlock)), block(kBlock);
   if (dtype == DC_F32)
-    hipLaunchKernelGGL((shadow_walk_kernel<float>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const float*)points,
+    hipLaunchKernelGGL((shadow_group_kernel<float>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const float*)points,
                        (const float*)vps, vps_rows, (float)lo, (float)hi, mask_out);
   else
-    hipLaunchKernelGGL((shadow_walk_kernel<double>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const double*)points,
+    hipLaunchKernelGGL((shadow_group_kernel<double>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const double*)points,
                        (const double*)vps, vps_rows, lo, hi, mask_out);
   DC_HIP(hipGetLastError());
   return DC_OK;
