@@ -1707,22 +1707,32 @@ constexpr int kStepQ32Cap = 512;          // rows of the static LDS tile (16 KB 
                                           // more distinct rows per block take consistency_step_basis_kernel
 
 // second sweep, one neighbour (float32): gw[k] += c_kj (c1 (v . e_j)(v . u_j) - c2 (e_j . u_j)); vs = c1 v0, vu = v0
+typedef float float2v __attribute__((ext_vector_type(2)));
 template <int P, int CAP>
 __device__ __forceinline__ void chain_term_q32(const int4* tile, uint32_t off, bool have, const Pt<q32>::Raw& ci, const float* cmf, const float* vs,
                                                const float* vu, float c2f, float* gw) {
   const char* row = reinterpret_cast<const char*>(tile) + (have ? off : 0u);
   const int4 p0 = *reinterpret_cast<const int4*>(row);
   const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)CAP * 16);
-  const float e0 = (float)(p0.x - ci.v[0]) - cmf[0], e1 = (float)(p0.y - ci.v[1]) - cmf[1], e2 = (float)(p0.z - ci.v[2]) - cmf[2];
+  // (two-wide float operations where the operands already sit in neighbouring registers: v_pk_add_f32 / v_pk_fma_f32 issue two
+  //  operations in one slot)
+  const float2v e01 = float2v{(float)(p0.x - ci.v[0]), (float)(p0.y - ci.v[1])} - float2v{cmf[0], cmf[1]};
+  const float e0 = e01.x, e1 = e01.y, e2 = (float)(p0.z - ci.v[2]) - cmf[2];
   const float u0 = __int_as_float(p0.w), u1 = __int_as_float(p1.x), u2 = __int_as_float(p1.y);
   const float al = fmaf(vs[2], e2, fmaf(vs[1], e1, vs[0] * e0));                       // c1 (v . e_j)
   const float be = fmaf(vu[2], u2, fmaf(vu[1], u1, vu[0] * u0));                       // v . u_j
   const float ga = fmaf(e2, u2, fmaf(e1, u1, e0 * u0));                                // e_j . u_j
   float tj = fmaf(al, be, -(c2f * ga));
   if (!have) tj = 0.0f;
-  gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
-  if constexpr (P > 1) gw[1] = fmaf(tj, __int_as_float(p1.w), gw[1]);
-  if constexpr (P > 2) gw[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + (size_t)CAP * 32)->x), gw[2]);
+  if constexpr (P == 2) {
+    float2v g = float2v{gw[0], gw[1]};
+    g = __builtin_elementwise_fma(float2v{tj, tj}, float2v{__int_as_float(p1.z), __int_as_float(p1.w)}, g);
+    gw[0] = g.x; gw[1] = g.y;
+  } else {
+    gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
+    if constexpr (P > 1) gw[1] = fmaf(tj, __int_as_float(p1.w), gw[1]);
+    if constexpr (P > 2) gw[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + (size_t)CAP * 32)->x), gw[2]);
+  }
 }
 
 template <int NS, int P, int CAP>
