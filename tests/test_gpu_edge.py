@@ -372,3 +372,36 @@ def test_knn_row_per_query_kernel_corner_cases():
     bad[::97] = np.nan
     d, i = three_ways(t(bad, DEV), 5)
     assert (i[::97] == -1).all() and not np.isin(i, np.arange(0, len(bad), 97)).any()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('shape', ['volume', 'plane', 'line', 'clusters'])
+def test_knn_row_per_query_kernel_shapes_and_sizes(shape):
+    """knn_group_kernel over cloud shapes (volumetric, planar, a line, tight clusters with empty space between them: every
+    stage-count and tail hand-over) x sizes that are not multiples of 16 x k = 2..15: indices and distances equal cKDTree's and
+    the lane-per-query build's."""
+    from depth_correction_amd import ops, _native as nv
+    rng = np.random.default_rng({'volume': 1, 'plane': 2, 'line': 3, 'clusters': 4}[shape])
+    for n in (1, 15, 17, 1000, 30011):
+        if shape == 'volume':
+            pts = rng.uniform(-1, 1, size=(n, 3))
+        elif shape == 'plane':
+            pts = rng.uniform(-5, 5, size=(n, 3)) * [1, 1, 1e-3]
+        elif shape == 'line':
+            pts = np.outer(rng.uniform(0, 100, size=n), [1.0, 0.5, 0.25]) + 1e-4 * rng.normal(size=(n, 3))
+        else:
+            centres = rng.uniform(-50, 50, size=(7, 3))
+            pts = centres[rng.integers(0, 7, size=n)] + 0.01 * rng.normal(size=(n, 3))
+        x = t(pts, DEV)
+        for k in (2, 5, 9, 15):
+            d, i = ops.knn(x, k)
+            dref, iref = O.knn_ckdtree(pts, k)
+            assert np.array_equal(npy(i), iref.reshape(npy(i).shape)), (shape, n, k)
+            assert np.array_equal(npy(d), dref.reshape(npy(d).shape)), (shape, n, k)
+        nv.check(nv.lib().dc_knn_set_shell_budget(102), 'budget')
+        try:
+            d2, i2 = ops.knn(x, 9)
+        finally:
+            nv.check(nv.lib().dc_knn_set_shell_budget(2), 'budget')
+        d1, i1 = ops.knn(x, 9)
+        assert torch.equal(i1, i2) and torch.equal(d1, d2)
