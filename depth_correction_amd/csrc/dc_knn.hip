@@ -1265,7 +1265,8 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   return DC_OK;
 }
 
-static std::atomic<int> g_knn_budget{2};        // dc_knn_set_shell_budget: shells a lane walks alone before its query goes to the tail kernel
+constexpr int kKnnBudgetAuto = 1000;   // dc_knn_set_shell_budget value for "by size": 2 stages below a million queries, 4 above
+static std::atomic<int> g_knn_budget{kKnnBudgetAuto};        // dc_knn_set_shell_budget
 
 static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, const double* q, const int32_t* qids, int64_t nq,
                       const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, int32_t* pending, int32_t* n_pending,
@@ -1276,7 +1277,10 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
   r_exhaust = r_exhaust < 4 ? 4 : (r_exhaust > 64 ? 64 : r_exhaust);
   // dc_knn_set_shell_budget(b): b < 0 one lane per query to the end (round 2); 0 <= b < 100: stages before the tail kernel,
   // sixteen lanes per query when k <= 16 (knn_group_kernel); b >= 100: the same with b - 100 and ONE lane per query (A-B).
-  const int raw = g_knn_budget.load();
+  int raw = g_knn_budget.load();
+  // measured (k = 10): one 200 k-point scan 0.39 / 0.40 / 0.41 ms with 2 / 3 / 4 stages before the tail kernel, the 2 M-point cloud
+  // 1.90 / 1.87 / 1.84 ms (its tail queries are few and each costs the tail kernel a wavefront's restart)
+  if (raw == kKnnBudgetAuto) raw = nq >= 1000000 ? 4 : 2;
   const int budget = raw >= 100 ? raw - 100 : raw;
   if (budget < 0) pending = nullptr;
   if (pending) DC_HIP(hipMemsetAsync(n_pending, 0, sizeof(int32_t), st));

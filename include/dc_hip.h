@@ -57,7 +57,7 @@ int dc_version(void);
  * idx_out int32 [rows, k], dist_out fp64 [rows, k] or NULL.  Ordering: ascending fp64 distance, self first. */
 size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query);
 /* Stages of cells a query walks (stage 1: the 27 cells around its own, stage r: the shell at Chebyshev distance r) before it is
- * handed to the wavefront-per-query tail kernel: default 2 (125 cells).  0 <= shells < 100: sixteen lanes per query for
+ * handed to the wavefront-per-query tail kernel: default (the value 1000) 2 below a million queries, 4 above.  0 <= shells < 100: sixteen lanes per query for
  * k <= 16 (knn_group_kernel), one lane per query above; shells + 100: one lane per query for every k (the round-2/3 kernel,
  * kept for A-B runs); negative: one lane per query to the end, no tail kernel.  Results do not depend on it. */
 int dc_knn_set_shell_budget(int shells);

@@ -325,7 +325,7 @@ def test_knn_row_per_query_kernel_corner_cases():
             try:
                 d, i = ops.knn(x, k, r=r, query=query)
             finally:
-                nv.check(nv.lib().dc_knn_set_shell_budget(2), 'budget')
+                nv.check(nv.lib().dc_knn_set_shell_budget(1000), 'budget')
             out.append((npy(d), npy(i)))
         for d, i in out[1:]:
             assert np.array_equal(out[0][1], i) and np.array_equal(out[0][0], d)
@@ -402,6 +402,6 @@ def test_knn_row_per_query_kernel_shapes_and_sizes(shape):
         try:
             d2, i2 = ops.knn(x, 9)
         finally:
-            nv.check(nv.lib().dc_knn_set_shell_budget(2), 'budget')
+            nv.check(nv.lib().dc_knn_set_shell_budget(1000), 'budget')
         d1, i1 = ops.knn(x, 9)
         assert torch.equal(i1, i2) and torch.equal(d1, d2)

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--budget', type=int, nargs='+', default=[2])
+    ap.add_argument('--budget', type=int, nargs='+', default=[1000])
     ap.add_argument('--k', type=int, default=10)
     args = ap.parse_args()
     from depth_correction_amd import ops, _native as nv
@@ -37,7 +37,7 @@ def main():
                 ref[name] = (d.clone(), i.clone())
             res[name + '_same'] = bool(torch.equal(ref[name][0], d) and torch.equal(ref[name][1], i))
         print(json.dumps(res))
-    nv.check(nv.lib().dc_knn_set_shell_budget(2), 'budget')
+    nv.check(nv.lib().dc_knn_set_shell_budget(1000), 'budget')
 
 
 if __name__ == '__main__':
