@@ -30,6 +30,7 @@ _SIGNATURES = {
     'dc_version': (ctypes.c_int, []),
     'dc_knn_workspace_bytes': (_sz, [_i64, _i64]),
     'dc_knn_set_shell_budget': (_i32, [_i32]),
+    'dc_knn_set_fine_cell_count': (_i32, [_i32]),
     'dc_knn_build': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_count': (_i32, [_vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_fill': (_i32, [_i64, _f64, _i32, _vp, _vp, _sz, _vp]),

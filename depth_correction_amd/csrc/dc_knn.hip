@@ -45,11 +45,16 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) {
 __device__ __forceinline__ uint64_t morton3(int32_t x, int32_t y, int32_t z) {
   return spread21((uint32_t)x) | (spread21((uint32_t)y) << 1) | (spread21((uint32_t)z) << 2);
 }
-// The search grids are ordered by a 30-bit Morton code (10 bits per axis, grid_setup_kernel keeps every axis below 1024 cells):
-// a 32-bit key halves the bytes the sort moves and lets it finish in radix passes over 30 bits.
+// TWO LEVELS.  The cell edge h is chosen from the cloud's AVERAGE areal density, but lidar density is anything but uniform: weighted
+// by query, the 27 cells around a query hold 110 points on the 2 M-point test cloud (median 77, 90th percentile 245) for k = 10.  So
+// the grid has a second, fine level of edge h / 2: the points are ordered by the 30-bit Morton code of their FINE cell (10 bits per
+// axis; grid_setup_kernel keeps the coarse level below 512 cells per axis), a coarse cell is then eight consecutive fine cells --
+// one sorted array serves both levels -- and the hash table's entry of a coarse cell carries the starts of its eight fine cells.
+// knn_group_kernel searches at the fine level where the query's own coarse cell holds at least g_knn_fine_min points (mean
+// candidates 110 -> 53 at 16, 11.6 % instead of 11.2 % of the queries need a second stage); every other kernel uses the coarse level.
 typedef uint32_t GridKey;
 constexpr int kGridKeyBits = 30;
-constexpr int kGridAxisCells = 1023;             // most cells per axis of a search grid
+constexpr int kGridAxisCells = 511;              // most cells per axis of a search grid (its fine level has twice as many: 10 bits)
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {
   uint32_t x = v & 0x3ffu;
   x = (x | x << 16) & 0x030000ffu;
@@ -68,6 +73,17 @@ __device__ __forceinline__ uint32_t compact10(uint32_t x) {             // inver
 }
 __device__ __forceinline__ GridKey grid_key(int32_t x, int32_t y, int32_t z) {
   return spread10((uint32_t)x) | (spread10((uint32_t)y) << 1) | (spread10((uint32_t)z) << 2);
+}
+// cell of p at `level` (0: edge h, 1: edge h / 2); the coarse cell of a point is its fine cell >> 1 exactly (2 x is exact)
+__device__ __forceinline__ void cell_of_level(const Grid& g, const double* p, int level, int32_t* c) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double t = (p[a] - g.origin[a]) * g.inv_h;
+    if (level) t *= 2.0;
+    const double f = floor(t);
+    const int32_t top = (g.dim[a] << level) - 1;
+    c[a] = (f > 0.0) ? ((f < (double)top) ? (int32_t)f : top) : 0;   // NaN -> 0
+  }
 }
 __device__ __forceinline__ void cell_of(const Grid& g, const double* p, int32_t* c) {
 #pragma unroll
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__
   double p[3];
   int32_t c[3];
   load_xyz(xyz, i, stride, p);
-  cell_of(g, p, c);
+  cell_of_level(g, p, 1, c);                      // the order key is the FINE cell's; coarse cell = fine >> 1 per axis
   keys[i] = grid_key(c[0], c[1], c[2]);
   ids[i] = (int32_t)i;
 }
@@ -265,63 +281,117 @@ __global__ __launch_bounds__(kBlock) void fine_keys_kernel(const T* __restrict__
   ids[i] = (int32_t)i;
 }
 
-// Gather the sorted fp64 coordinates and insert every cell's first position into the hash table.
+// One hash table, keyed by the COARSE cell (open addressing, linear probing; empty key = all ones); its payload is the nine
+// sorted positions s[0..8] at which the cell's eight fine cells start (s[8] = the cell's end; Morton sub-index
+// i = fx&1 | (fy&1) << 1 | (fz&1) << 2, an empty fine cell has s[i] == s[i+1]).  A coarse lookup reads s[0], s[8]; a fine lookup
+// hashes the coarse cell it lies in and reads s[i], s[i+1]: no second table, and the 27 fine cells around a query lie in only
+// 8 coarse cells, so their probes share cache lines.  The payload is requested TOGETHER with the key (its address only needs the
+// slot): a probe is one memory round trip unless the slot holds another cell's key.  Keys (8 B) and payloads (48 B) are separate arrays: most probes of a
+// neighbourhood hit empty cells and only ever touch the key array (16-byte {key, begin, end} entries doubled the bytes those
+// probes pull in and made the 2 M-point build memory-bound).
+constexpr int kCellStride = 12;                  // ints per payload: s[0..8], pad, then (begin, end) again as one aligned pair
+struct CellTable {
+  const uint64_t* key;
+  const int32_t* s;
+  uint32_t mask;
+};
+
+// Gather the sorted fp64 coordinates and insert the key of every coarse cell (at its first point) into the hash table.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restrict__ xyz, int stride, int64_t n,
                                                                const GridKey* __restrict__ skeys,
                                                                const int32_t* __restrict__ sids,
-                                                               double* __restrict__ sp, uint64_t* __restrict__ tab_key,
-                                                               int32_t* __restrict__ tab_beg, uint32_t tab_mask) {
+                                                               double* __restrict__ sp, uint64_t* __restrict__ tab_key, uint32_t tab_mask) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   double x[3];
   load_xyz(xyz, sids[p], stride, x);
   sp[p * 3] = x[0]; sp[p * 3 + 1] = x[1]; sp[p * 3 + 2] = x[2];
   const GridKey mk = skeys[p];
-  if (p == 0 || skeys[p - 1] != mk) {
-    const int32_t cx = (int32_t)compact10(mk), cy = (int32_t)compact10(mk >> 1), cz = (int32_t)compact10(mk >> 2);
+  if (p == 0 || (skeys[p - 1] >> 3) != (mk >> 3)) {
+    const int32_t cx = (int32_t)compact10(mk) >> 1, cy = (int32_t)compact10(mk >> 1) >> 1, cz = (int32_t)compact10(mk >> 2) >> 1;
     const uint64_t key = cell_key(cx, cy, cz);
     uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
     while (true) {
       const unsigned long long prev = atomicCAS((unsigned long long*)&tab_key[slot], (unsigned long long)kEmptyKey,
                                                 (unsigned long long)key);
-      if (prev == kEmptyKey || prev == key) { tab_beg[slot] = (int32_t)p; break; }
+      if (prev == kEmptyKey || prev == key) break;
       slot = (slot + 1) & tab_mask;
     }
   }
 }
 
+// The fine-cell starts of every coarse cell (second pass: all keys are in the table).  The first point of a fine cell writes its
+// position into s[i] of its coarse cell and into the entries of the empty fine cells before it (back to the previous point's
+// fine cell, or to 0 at the coarse cell's first point); the last point of the coarse cell writes the end into the rest.
 __global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const GridKey* __restrict__ skeys,
-                                                          const uint64_t* __restrict__ tab_key,
-                                                          int32_t* __restrict__ tab_end, uint32_t tab_mask) {
+                                                          const uint64_t* __restrict__ tab_key, int32_t* __restrict__ tab_s,
+                                                          uint32_t tab_mask) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   const GridKey mk = skeys[p];
-  if (p == n - 1 || skeys[p + 1] != mk) {
-    const int32_t cx = (int32_t)compact10(mk), cy = (int32_t)compact10(mk >> 1), cz = (int32_t)compact10(mk >> 2);
-    const uint64_t key = cell_key(cx, cy, cz);
-    uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
-    while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
-    tab_end[slot] = (int32_t)(p + 1);
+  const bool c_head = p == 0 || (skeys[p - 1] >> 3) != (mk >> 3);
+  const bool f_head = p == 0 || skeys[p - 1] != mk;
+  const bool c_tail = p == n - 1 || (skeys[p + 1] >> 3) != (mk >> 3);
+  if (!f_head && !c_tail) return;
+  const int32_t fx = (int32_t)compact10(mk), fy = (int32_t)compact10(mk >> 1), fz = (int32_t)compact10(mk >> 2);
+  const int32_t cx = fx >> 1, cy = fy >> 1, cz = fz >> 1;
+  const uint64_t key = cell_key(cx, cy, cz);
+  uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
+  while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
+  int32_t* s = tab_s + (int64_t)slot * kCellStride;
+  const int i = (int)(mk & 7u);                    // Morton sub-index of the fine cell: x | y << 1 | z << 2
+  if (f_head) {
+    const int from = c_head ? 0 : (int)(skeys[p - 1] & 7u) + 1;
+    for (int j = from; j <= i; ++j) s[j] = (int32_t)p;
   }
+  if (c_tail) {
+    for (int j = i + 1; j <= 8; ++j) s[j] = (int32_t)(p + 1);
+    s[11] = (int32_t)(p + 1);
+  }
+  if (c_head) s[10] = (int32_t)p;
 }
 
-struct CellTable {
-  const uint64_t* key;
-  const int32_t* beg;
-  const int32_t* end;
-  uint32_t mask;
-};
+// fine[p] = 1 when the coarse cell of sorted point p holds at least fine_min points: the level knn_group_kernel searches for it
+__global__ __launch_bounds__(kBlock) void cell_level_kernel(int64_t n, const GridKey* __restrict__ skeys, const uint64_t* __restrict__ tab_key,
+                                                            const int32_t* __restrict__ tab_s, uint32_t tab_mask, int fine_min,
+                                                            uint8_t* __restrict__ fine) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const GridKey mk = skeys[p];
+  const int32_t cx = (int32_t)compact10(mk) >> 1, cy = (int32_t)compact10(mk >> 1) >> 1, cz = (int32_t)compact10(mk >> 2) >> 1;
+  const uint64_t key = cell_key(cx, cy, cz);
+  uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
+  while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
+  const int2 be = *reinterpret_cast<const int2*>(tab_s + (int64_t)slot * kCellStride + 10);
+  fine[p] = be.y - be.x >= fine_min ? 1 : 0;
+}
 
-__device__ __forceinline__ bool find_cell(const CellTable& t, int32_t x, int32_t y, int32_t z, int32_t* b, int32_t* e) {
-  const uint64_t key = cell_key(x, y, z);
-  uint32_t slot = cell_hash(x, y, z) & t.mask;
-  while (true) {
-    const uint64_t k = t.key[slot];
-    if (k == key) { *b = t.beg[slot]; *e = t.end[slot]; return true; }
+static uint32_t table_size(int64_t n) {
+  uint64_t s = 1024;
+  while (s < (uint64_t)(2 * n + 2)) s <<= 1;             // at most n coarse cells: load factor <= 1/2
+  return (uint32_t)s;
+}
+
+// [b, e) of sorted positions of cell (x, y, z) of `level` (0: coarse, 1: fine); false when its coarse cell is empty
+__device__ __forceinline__ bool find_cell(const CellTable& t, int32_t x, int32_t y, int32_t z, int32_t* b, int32_t* e, int level = 0) {
+  const int32_t cx = x >> level, cy = y >> level, cz = z >> level;
+  const uint64_t key = cell_key(cx, cy, cz);
+  uint32_t slot = cell_hash(cx, cy, cz) & t.mask;
+  const int i = level ? ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2)) : 10;       // the payload pair wanted: s[i], s[i+1]
+  // key and payload of the first slot are requested together
+  uint64_t k = t.key[slot];
+  const int32_t* s = t.s + (int64_t)slot * kCellStride + i;
+  int32_t vb = s[0], ve = s[1];
+  while (k != key) {
     if (k == kEmptyKey) return false;
-    slot = (slot + 1) & t.mask;
+    slot = (slot + 1) & t.mask;                    // another cell's key: linear probing (rare at load factor <= 1/2)
+    k = t.key[slot];
+    s = t.s + (int64_t)slot * kCellStride + i;
+    vb = s[0]; ve = s[1];
   }
+  *b = vb; *e = ve;
+  return true;
 }
 
 // cKDTree's squared distance: products and sums individually rounded, in axis order.
@@ -504,8 +574,8 @@ __global__ __launch_bounds__(kBlock, KMAX <= 16 ? 4 : 1) void knn_query_kernel(c
               got[u_] = tab.key[slot[u_]];
             }
             const bool hit = got[u_] == key[u_];
-            bb[u_] = hit ? tab.beg[slot[u_]] : 0;
-            ee[u_] = hit ? tab.end[slot[u_]] : 0;
+            bb[u_] = hit ? tab.s[(int64_t)slot[u_] * kCellStride + 10] : 0;
+            ee[u_] = hit ? tab.s[(int64_t)slot[u_] * kCellStride + 11] : 0;
           }
 #pragma unroll 1
           for (int u_ = 0; u_ < 4; ++u_) {
@@ -791,7 +861,8 @@ __global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __re
                                                            const double* __restrict__ queries, const int32_t* __restrict__ qids,
                                                            int64_t n_query, const Grid* __restrict__ gp, CellTable tab, int k,
                                                            double r_max, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                           int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending) {
+                                                           int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending,
+                                                           int fine_min, const uint8_t* __restrict__ fine_flag) {
   __shared__ int32_t s_hist[kGrpPerBlock][kGrp];
   __shared__ double s_pd[kGrpPerBlock][kGrpPool];
   __shared__ int32_t s_pi[kGrpPerBlock][kGrpPool];
@@ -799,17 +870,44 @@ __global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __re
   __shared__ int32_t s_fi[kGrpPerBlock][kGrp];
   constexpr int32_t kNone = 0x7fffffff;
   const int lane = threadIdx.x & (kWave - 1), sub = lane & (kGrp - 1), grp = threadIdx.x / kGrp;
+  // (blocks stay in launch order: giving every XCD one contiguous stretch of the Morton-ordered queries -- xcd_block -- made the
+  //  2 M-point build 12 % slower: the stretches differ in density, and the XCD with the crowded one finishes last)
   const int64_t t = (int64_t)blockIdx.x * kGrpPerBlock + grp;
   const bool valid = t < n_query;
   const int64_t tc = valid ? t : 0;
   const Grid g = *gp;
   const double q[3] = {queries[tc * 3], queries[tc * 3 + 1], queries[tc * 3 + 2]};
   const int64_t row = qids ? qids[tc] : tc;
+  // the level of the search: fine (cell edge h / 2) where the query's own coarse cell is crowded
   int32_t c[3];
-  cell_of(g, q, c);
+  cell_of_level(g, q, 0, c);
+  int lv = 0;
+  if (fine_flag) lv = valid ? (int)fine_flag[tc] : 0;          // self search: decided per sorted point by cell_level_kernel
+  else if (fine_min != 0x7fffffff && valid) {                   // another cloud's queries: one more probe
+    int32_t b0 = 0, e0 = 0;
+    if (find_cell(tab, c[0], c[1], c[2], &b0, &e0) && e0 - b0 >= fine_min) lv = 1;
+  }
+  if (lv) cell_of_level(g, q, 1, c);
+  const double h_lv = lv ? 0.5 * g.h : g.h;
+  const int32_t dim_lv[3] = {g.dim[0] << lv, g.dim[1] << lv, g.dim[2] << lv};
+  // (shell_in_grid / shell_bound at the row's level)
+  auto stage_in_grid = [&](int r) {
+    return c[0] - r >= 0 || c[1] - r >= 0 || c[2] - r >= 0 || c[0] + r < dim_lv[0] || c[1] + r < dim_lv[1] || c[2] + r < dim_lv[2];
+  };
+  auto stage_bound = [&](int r) {
+    double fmin_ = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double lo = g.origin[a] + (double)c[a] * h_lv, hi = lo + h_lv;
+      fmin_ = fmin(fmin_, fmin(q[a] - lo, hi - q[a]));
+    }
+    if (!(fmin_ > 0.0)) fmin_ = 0.0;
+    const double bnd = (double)r * h_lv + fmin_ - 1e-7 * h_lv;      // guard against cell-assignment rounding
+    return bnd > 0.0 ? bnd : 0.0;
+  };
   const double ub2 = r_max > 0.0 ? r_max * r_max : INFINITY;
   const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
-  bool done = !(valid && finite_q && shell_in_grid(g, c, 0));      // (all of these are uniform over the row)
+  bool done = !(valid && finite_q);                // (all of these are uniform over the row)
   bool unsettled = false;                          // done without an answer: the tail kernel's
   double bd = INFINITY;                            // lane s: the s-th best so far
   int32_t bi = kNone;
@@ -917,7 +1015,7 @@ __global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __re
     const int n_cells = r == 1 ? 27 : 2 * side * side + (side - 2) * ring;
     const float inv_side = 1.0f / (float)side, inv_ring = 1.0f / (float)ring;
     for (int j0 = 0; j0 < n_cells; j0 += kGrp) {
-      // sixteen cells of the stage: one hash probe per lane
+      // sixteen cells of the stage: one hash probe per lane (a single memory round trip, find_cell)
       const int j = j0 + sub;
       int32_t b = 0, e = 0;
       if (!done && j < n_cells) {
@@ -925,8 +1023,8 @@ __global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __re
         if (r == 1) { dz = j / 9; const int jj = j - dz * 9; dy = jj / 3; dx = jj - dy * 3; dx -= 1; dy -= 1; dz -= 1; }
         else shell_cell(r, side, inv_side, inv_ring, j, &dx, &dy, &dz);
         const int x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
-        if (x >= 0 && y >= 0 && z >= 0 && x < g.dim[0] && y < g.dim[1] && z < g.dim[2]) {
-          if (!find_cell(tab, x, y, z, &b, &e)) { b = 0; e = 0; }
+        if (x >= 0 && y >= 0 && z >= 0 && x < dim_lv[0] && y < dim_lv[1] && z < dim_lv[2]) {
+          if (!find_cell(tab, x, y, z, &b, &e, lv)) { b = 0; e = 0; }
         }
       }
       const int cnt = e - b;
@@ -966,9 +1064,9 @@ __global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __re
     }
     if (__any((int)(nc > 0))) select();
     if (!done) {
-      const double bound = shell_bound(g, q, c, r);
+      const double bound = stage_bound(r);
       const double b2 = bound * bound;
-      if (worst_d < b2 || b2 >= ub2 || !shell_in_grid(g, c, r + 1)) done = true;       // settled
+      if (worst_d < b2 || b2 >= ub2 || !stage_in_grid(r + 1)) done = true;       // settled
       else if (r >= r_budget) { done = true; unsettled = true; }
     }
   }
@@ -1212,15 +1310,9 @@ __global__ __launch_bounds__(kBlock) void max_i32_kernel(const int32_t* __restri
 
 constexpr int kBoxBlocks = 256;
 
-static uint32_t table_size(int64_t n) {
-  uint64_t s = 1024;
-  while (s < (uint64_t)(2 * n + 2)) s <<= 1;
-  return (uint32_t)s;
-}
-
 struct GridWs {
   double* part; Grid* grid; GridKey* keys; GridKey* skeys; int32_t* ids; int32_t* sids; double* sp;
-  uint64_t* tab_key; int32_t* tab_beg; int32_t* tab_end; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
+  uint64_t* tab_key; int32_t* tab_s; uint8_t* fine; void* sort_tmp; size_t sort_bytes; uint32_t tab_n;
   double* qf64; int32_t* pending; int32_t* n_pending; size_t total;
 };
 
@@ -1236,8 +1328,8 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   g.sp = c.take<double>(3 * n);
   g.tab_n = table_size(n);
   g.tab_key = c.take<uint64_t>(g.tab_n);
-  g.tab_beg = c.take<int32_t>(g.tab_n);
-  g.tab_end = c.take<int32_t>(g.tab_n);
+  g.tab_s = c.take<int32_t>((size_t)g.tab_n * kCellStride);
+  g.fine = c.take<uint8_t>(n);
   g.qf64 = c.take<double>(3 * n_query_extra);
   g.pending = c.take<int32_t>(n > n_query_extra ? n : n_query_extra);      // queries the query kernels hand to knn_tail_kernel
   g.n_pending = c.take<int32_t>(16);
@@ -1258,19 +1350,25 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.grid, w.keys, w.ids);
   DC_HIP(rocprim::radix_sort_pairs(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, kGridKeyBits, st));
   DC_HIP(hipMemsetAsync(w.tab_key, 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
-  hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp,
-                     w.tab_key, w.tab_beg, w.tab_n - 1);
-  hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, w.tab_key, w.tab_end, w.tab_n - 1);
+  hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp, w.tab_key, w.tab_n - 1);
+  hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, w.tab_key, w.tab_s, w.tab_n - 1);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
 
+static std::atomic<int> g_knn_fine_min{16};      // dc_knn_set_fine_cell_count: points in a query's coarse cell from which it searches the fine level
 constexpr int kKnnBudgetAuto = 1000;   // dc_knn_set_shell_budget value for "by size": 2 stages below a million queries, 4 above
 static std::atomic<int> g_knn_budget{kKnnBudgetAuto};        // dc_knn_set_shell_budget
 
+// sixteen lanes per query (knn_group_kernel, both grid levels) or one (knn_query_kernel, coarse level)?
+static bool knn_rows_per_query(int k) {
+  const int raw = g_knn_budget.load();
+  return k <= 16 && (raw == kKnnBudgetAuto || (raw >= 1 && raw < 100));
+}
+
 static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, const double* q, const int32_t* qids, int64_t nq,
                       const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, int32_t* pending, int32_t* n_pending,
-                      hipStream_t st) {
+                      const uint8_t* fine_flag, hipStream_t st) {
   const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
   // shells 0..R hold (2R+1)^3 cells at ~4 candidates' worth of work each; a scan of all n points costs n candidates
   int r_exhaust = (int)(cbrt((double)n * 0.25) * 0.5);
@@ -1284,9 +1382,10 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
   const int budget = raw >= 100 ? raw - 100 : raw;
   if (budget < 0) pending = nullptr;
   if (pending) DC_HIP(hipMemsetAsync(n_pending, 0, sizeof(int32_t), st));
-  if (pending && raw < 100 && budget >= 1 && k <= kGrp) {
+  if (pending && knn_rows_per_query(k)) {
     const dim3 ggrid((unsigned)((nq + kGrpPerBlock - 1) / kGrpPerBlock));
-    hipLaunchKernelGGL(knn_group_kernel, ggrid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist, budget, pending, n_pending);
+    hipLaunchKernelGGL(knn_group_kernel, ggrid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist, budget, pending, n_pending,
+                       g_knn_fine_min.load(), fine_flag);
   } else {
 #define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, n, r_exhaust, idx, dist, \
                                   budget, pending, n_pending)
@@ -1314,6 +1413,7 @@ using namespace dc;
 extern "C" {
 
 int dc_knn_set_shell_budget(int shells) { g_knn_budget.store(shells); return DC_OK; }
+int dc_knn_set_fine_cell_count(int points) { g_knn_fine_min.store(points < 1 ? 0x7fffffff : points); return DC_OK; }
 
 size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
   if (n < 0 || n_query < 0) return 0;
@@ -1343,13 +1443,22 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
   else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, k, cell_hint, w, stream);
   else return DC_ERR_DTYPE;
   if (rc) return rc;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
-  if (!query) return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, stream);
+  CellTable tab{w.tab_key, w.tab_s, w.tab_n - 1};
+  if (!query) {
+    const uint8_t* flags = nullptr;
+    const int fine_min = g_knn_fine_min.load();
+    if (knn_rows_per_query(k) && fine_min != 0x7fffffff) {          // the level every sorted point searches at (it is its own query)
+      hipLaunchKernelGGL(cell_level_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, w.skeys, w.tab_key, w.tab_s,
+                         w.tab_n - 1, fine_min, w.fine);
+      flags = w.fine;
+    }
+    return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, flags, stream);
+  }
   if (n_query == 0) return DC_OK;
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
   if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
   else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
-  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, stream);
+  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, nullptr, stream);
 }
 
 // Radius search, pass 1: per-point neighbour counts and their maximum (device scalars).
@@ -1366,7 +1475,7 @@ int dc_radius_count(const void* points, int stride, int dtype, int64_t n, double
   else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, 0, r, w, stream);
   else return DC_ERR_DTYPE;
   if (rc) return rc;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key, w.tab_s, w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<false>), grid, block, 0, stream, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, count_out, nullptr, 0);
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), block, 0, stream, count_out, n, kmax_out);
@@ -1387,7 +1496,7 @@ int dc_shadow_filter(const void* points, const void* vps, int vps_rows, const vo
   else if (dtype == DC_F64) rc = build_grid((const double*)dirs, 3, n, 0, r, w, stream);
   else return DC_ERR_DTYPE;
   if (rc) return rc;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key, w.tab_s, w.tab_n - 1};
   const dim3 grid((unsigned)((n + kGrpPerBlock - 1) / kGrpPerBlock)), block(kBlock);
   if (dtype == DC_F32)
     hipLaunchKernelGGL((shadow_group_kernel<float>), grid, block, 0, stream, w.sp, w.sids, n, w.grid, tab, r, (const float*)points,
@@ -1415,7 +1524,7 @@ int dc_radius_count_query(const void* points, int stride, int dtype, int64_t n, 
   else if (dtype == DC_F64) rc = build_grid((const double*)points, stride, n, 0, r, w, stream);
   else return DC_ERR_DTYPE;
   if (rc) return rc;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key, w.tab_s, w.tab_n - 1};
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
   if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
   else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
@@ -1433,7 +1542,7 @@ int dc_radius_fill_query(int64_t n, int64_t n_query, double r, int kmax, int32_t
   if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
   if (n_query == 0) return DC_OK;
   if (n == 0) return (int)hipMemsetAsync(idx_out, 0xff, (size_t)n_query * kmax * sizeof(int32_t), stream);
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key, w.tab_s, w.tab_n - 1};
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, w.qf64, (const int32_t*)nullptr, n_query, w.grid, tab, r,
                      nullptr, idx_out, kmax);
@@ -1450,7 +1559,7 @@ int dc_radius_fill(int64_t n, double r, int kmax, int32_t* idx_out, void* ws, si
   GridWs w = carve_grid(ws, n, 0);
   if (ws_bytes < w.total) return DC_ERR_WORKSPACE;
   if (n == 0) return DC_OK;
-  CellTable tab{w.tab_key, w.tab_beg, w.tab_end, w.tab_n - 1};
+  CellTable tab{w.tab_key, w.tab_s, w.tab_n - 1};
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   hipLaunchKernelGGL((radius_kernel<true>), grid, block, 0, stream, w.sp, w.sids, w.sp, w.sids, n, w.grid, tab, r, nullptr, idx_out, kmax);
   if (kmax <= kRadiusSortMax && kmax > 1)

@@ -367,6 +367,22 @@ def test_knn_row_per_query_kernel_corner_cases():
     d, i = three_ways(t(dense, DEV), 10)
     dref, iref = O.knn_ckdtree(dense, 10)
     assert np.array_equal(i, iref) and np.array_equal(d, dref)
+    # the grid level a query searches at (fine where its own coarse cell is crowded) never changes the answer
+    mixed = np.concatenate([rng.normal(scale=0.02, size=(3000, 3)) + [0.5, 0.5, 0.0], rng.uniform(-2, 2, size=(5000, 3)) * [1, 1, 0.03]])
+    want = None
+    for fine_min in (0, 1, 4, 16, 64):
+        nv.check(nv.lib().dc_knn_set_fine_cell_count(fine_min), 'fine')
+        try:
+            d, i = ops.knn(t(mixed, DEV), 10)
+            dq, iq = ops.knn(t(mixed, DEV), 7, query=t(mixed[::3] + 1e-3, DEV))
+        finally:
+            nv.check(nv.lib().dc_knn_set_fine_cell_count(16), 'fine')
+        got = (npy(d), npy(i), npy(dq), npy(iq))
+        if want is None:
+            want = got
+            dref, iref = O.knn_ckdtree(mixed, 10)
+            assert np.array_equal(got[1], iref) and np.array_equal(got[0], dref)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
     # NaN rows neither find nor are found
     bad = pts.astype(np.float64).copy()
     bad[::97] = np.nan
