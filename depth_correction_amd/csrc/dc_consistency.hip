@@ -1735,8 +1735,10 @@ __device__ __forceinline__ void chain_term_q32(const int4* tile, uint32_t off, b
   }
 }
 
+// (six wavefronts per SIMD: left alone the kernel takes 81 VGPRs -- one allocation granule over the 80 of six wavefronts, i.e. FIVE per SIMD;
+//  at 79 + 12 B of scratch a step takes 44.4 instead of 47.2 us.  Seven -- 71 VGPRs, 44 B of scratch -- take 50.9 us.)
 template <int NS, int P, int CAP>
-__global__ __launch_bounds__(kBlock) void consistency_step_q32_kernel(
+__global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
     StepChain ch) {
