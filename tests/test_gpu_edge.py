@@ -391,13 +391,13 @@ def test_knn_row_per_query_kernel_corner_cases():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('shape', ['volume', 'plane', 'line', 'clusters'])
+@pytest.mark.parametrize('shape', ['volume', 'plane', 'line', 'clusters', 'offset', 'tiny', 'identical'])
 def test_knn_row_per_query_kernel_shapes_and_sizes(shape):
     """knn_group_kernel over cloud shapes (volumetric, planar, a line, tight clusters with empty space between them: every
     stage-count and tail hand-over) x sizes that are not multiples of 16 x k = 2..15: indices and distances equal cKDTree's and
     the lane-per-query build's."""
     from depth_correction_amd import ops, _native as nv
-    rng = np.random.default_rng({'volume': 1, 'plane': 2, 'line': 3, 'clusters': 4}[shape])
+    rng = np.random.default_rng({'volume': 1, 'plane': 2, 'line': 3, 'clusters': 4, 'offset': 5, 'tiny': 6, 'identical': 7}[shape])
     for n in (1, 15, 17, 1000, 30011):
         if shape == 'volume':
             pts = rng.uniform(-1, 1, size=(n, 3))
@@ -405,15 +405,27 @@ def test_knn_row_per_query_kernel_shapes_and_sizes(shape):
             pts = rng.uniform(-5, 5, size=(n, 3)) * [1, 1, 1e-3]
         elif shape == 'line':
             pts = np.outer(rng.uniform(0, 100, size=n), [1.0, 0.5, 0.25]) + 1e-4 * rng.normal(size=(n, 3))
-        else:
+        elif shape == 'clusters':
             centres = rng.uniform(-50, 50, size=(7, 3))
             pts = centres[rng.integers(0, 7, size=n)] + 0.01 * rng.normal(size=(n, 3))
+        elif shape == 'offset':                      # a cloud far from the origin: absolute coordinates ~1e6, extent a few metres
+            pts = rng.uniform(-3, 3, size=(n, 3)) * [1, 1, 0.05] + [1.0e6, -2.0e6, 5.0e5]
+        elif shape == 'tiny':                        # extent 1e-7: every distance is a handful of ulps of the coordinates
+            pts = 1.0 + 1e-7 * rng.uniform(size=(n, 3))
+        else:                                        # one point repeated (one cell holds everything)
+            if n > 1000:
+                continue
+            pts = np.tile(np.array([[0.25, -1.5, 3.0]]), (n, 1))
         x = t(pts, DEV)
         for k in (2, 5, 9, 15):
             d, i = ops.knn(x, k)
             dref, iref = O.knn_ckdtree(pts, k)
-            assert np.array_equal(npy(i), iref.reshape(npy(i).shape)), (shape, n, k)
             assert np.array_equal(npy(d), dref.reshape(npy(d).shape)), (shape, n, k)
+            if shape == 'identical':                 # equal distances: cKDTree's order is its traversal's, the builders' is by index
+                ii = npy(i)
+                assert (ii[:, :min(k, n)] == np.arange(min(k, n))).all() and (ii[:, n:] == -1).all()
+            else:
+                assert np.array_equal(npy(i), iref.reshape(npy(i).shape)), (shape, n, k)
         nv.check(nv.lib().dc_knn_set_shell_budget(102), 'budget')
         try:
             d2, i2 = ops.knn(x, 9)
