@@ -856,8 +856,9 @@ __device__ __forceinline__ void row_lex_min_step(double& md, int32_t& mi) {
   if (lex_less(od, oi, md, mi)) { md = od; mi = oi; }
 }
 
-// (six wavefronts per SIMD: 79 VGPRs and 60 B of scratch; five -- 96 VGPRs, no scratch -- and seven were both slower)
-__global__ __launch_bounds__(kBlock, 6) void knn_group_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
+// (five wavefronts per SIMD: 96 VGPRs, 8 B of scratch.  Six -- 80 VGPRs, 96 B of scratch -- cost the two-level kernel 10 % at 2 M points,
+//  four 14 %)
+__global__ __launch_bounds__(kBlock, 5) void knn_group_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
                                                            const double* __restrict__ queries, const int32_t* __restrict__ qids,
                                                            int64_t n_query, const Grid* __restrict__ gp, CellTable tab, int k,
                                                            double r_max, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
@@ -1356,7 +1357,7 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   return DC_OK;
 }
 
-static std::atomic<int> g_knn_fine_min{16};      // dc_knn_set_fine_cell_count: points in a query's coarse cell from which it searches the fine level
+static std::atomic<int> g_knn_fine_min{14};      // dc_knn_set_fine_cell_count: points in a query's coarse cell from which it searches the fine level
 constexpr int kKnnBudgetAuto = 1000;   // dc_knn_set_shell_budget value for "by size": 2 stages below a million queries, 4 above
 static std::atomic<int> g_knn_budget{kKnnBudgetAuto};        // dc_knn_set_shell_budget
 
@@ -1413,7 +1414,7 @@ using namespace dc;
 extern "C" {
 
 int dc_knn_set_shell_budget(int shells) { g_knn_budget.store(shells); return DC_OK; }
-int dc_knn_set_fine_cell_count(int points) { g_knn_fine_min.store(points < 1 ? 0x7fffffff : points); return DC_OK; }
+int dc_knn_set_fine_cell_count(int points) { g_knn_fine_min.store(points < 1 ? 0x7fffffff : points); return DC_OK; }      // default 14
 
 size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
   if (n < 0 || n_query < 0) return 0;

@@ -62,7 +62,7 @@ size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query);
  * kept for A-B runs); negative: one lane per query to the end, no tail kernel.  Results do not depend on it. */
 int dc_knn_set_shell_budget(int shells);
 /* The search grid has two levels (cell edge h from the cloud's average density, and h / 2): a query of the sixteen-lanes-per-query
- * kernel searches the fine level when its own coarse cell holds at least `points` points (default 16; < 1: never).  Lidar density
+ * kernel searches the fine level when its own coarse cell holds at least `points` points (default 14; < 1: never).  Lidar density
  * is far from uniform: weighted by query the 27 coarse cells around a query hold ~110 points for k = 10.  Results do not depend on it. */
 int dc_knn_set_fine_cell_count(int points);
 int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride,

@@ -376,7 +376,7 @@ def test_knn_row_per_query_kernel_corner_cases():
             d, i = ops.knn(t(mixed, DEV), 10)
             dq, iq = ops.knn(t(mixed, DEV), 7, query=t(mixed[::3] + 1e-3, DEV))
         finally:
-            nv.check(nv.lib().dc_knn_set_fine_cell_count(16), 'fine')
+            nv.check(nv.lib().dc_knn_set_fine_cell_count(14), 'fine')
         got = (npy(d), npy(i), npy(dq), npy(iq))
         if want is None:
             want = got
