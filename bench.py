@@ -473,23 +473,52 @@ def main():
             extras['train_iteration_note'] = ('depth_correction_amd.train.train() itself, default callbacks, cfg.loop_batch = %d: model-only runs '
                                               'go to the chained native step, one launch per iteration' % tcfg.loop_batch)
 
-        # BASELINE config 1 (one 200k-point scan, nn_k = 10, covariance + eig forward only, all DepthCloud features written)
+        # BASELINE config 1 (one 200k-point scan, nn_k = 10, covariance + eig forward only, all DepthCloud features written):
+        # 220 launches, each timed by the library's dispatch stamps (the host call takes longer than the kernel, so stream events
+        # around a loop of calls would time the host)
         c0 = info['clouds'][0]
         x1, n1 = c0['points'], c0['points'].shape[0]
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        for it in range(21):
-            if it == 1:
-                evs[0].record()
+        for _ in range(20):
             ops.features_fwd(x1, c0['neighbors'], dirs=c0['dirs'])
-        evs[1].record()
-        torch.cuda.synchronize()
-        c1_ms = evs[0].elapsed_time(evs[1]) / 20
+        with KernelTimer(every=1) as ft:
+            for _ in range(220):
+                ops.features_fwd(x1, c0['neighbors'], dirs=c0['dirs'])
+            torch.cuda.synchronize()
+            c1_ms, c1_launches = ft.read()['features_fwd']
+            c1_kernel = ft.kernels()['features_fwd']
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         evs[0].record()
         ops.knn(x1, args.k, want_dist=False)
         evs[1].record()
         torch.cuda.synchronize()
-        extras['c1_forward_only'] = {'points': n1, 'features_fwd_ms': c1_ms, 'points_per_s': n1 / (c1_ms * 1e-3),
-                                     'algorithmic_GBps': 284 * n1 / (c1_ms * 1e-3) / 1e9, 'knn_build_ms': evs[0].elapsed_time(evs[1])}
+        c1 = {'points': n1, 'features_fwd_ms': c1_ms, 'timed_launches': c1_launches, 'kernel': c1_kernel,
+              'points_per_s': n1 / (c1_ms * 1e-3), 'algorithmic_GBps': 284 * n1 / (c1_ms * 1e-3) / 1e9,
+              'knn_build_ms': evs[0].elapsed_time(evs[1])}
+        prof = (load_profile_table().get('_paths') or {}).get('kernels', {}).get('%s @ c1' % c1_kernel.replace('dc::', '')) \
+            if n1 == 200_000 and args.k == 10 else None
+        comp1 = n1 * (4 * args.k + (12 + 12) + (12 + 36 + 12 + 36 + 12 + 4))           # index rows, centre + direction, six outputs
+        traffic = prof['hbm_bytes'] if prof and 'hbm_bytes' in prof else None
+        insts = prof.get('valu_insts_per_wave') if prof else None
+        waves = (n1 + 63) // 64
+        t_s = c1_ms * 1e-3
+        hbm_frac = (traffic or comp1) / t_s / 1e9 / HBM_PEAK_GBPS
+        valu_frac = None if insts is None else insts * waves / (t_s * N_SIMD * CLOCK_GHZ * 1e9 / 4)
+        # the gathers: N K rows of 12 B, each its own cache line when the scan's points are in no spatial order (these rays are
+        # drawn at random) -- the kernel is bound by the CUs' vector-memory address pipelines (one line look-up per lane and
+        # gather), neither by bytes nor by instructions: tools/ubench/gather_rows.hip measures that floor by itself
+        c1['roofline'] = {'bound': 'L1 line look-ups of the random row gathers (neither roofline: see note)',
+                          'achieved': (traffic or comp1) / t_s / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': hbm_frac,
+                          'traffic': traffic, 'compulsory_bytes': comp1,
+                          'traffic_source': (load_profile_table().get('_paths') or {}).get('source') if prof else
+                          'no committed PMC profile of this instantiation: achieved uses compulsory_bytes',
+                          'valu': {'insts_per_wave': insts, 'frac_of_issue_peak': valu_frac},
+                          'gather_lookups_per_launch': n1 * (args.k - 1),
+                          'note': 'SURVEY 8d prices C1 at 284 B/pt (algorithmic_GBps above); measured bytes and instructions put '
+                                  'the kernel far below both rooflines because its %d x (K - 1) = %d random 12-B gathers from an L2-resident '
+                                  '2.4 MB table cost ~7 us by themselves on this chip whatever the cache policy '
+                                  '(profiles/r04_ubench_gather_rows.txt); the same kernel on the same points in Morton order: '
+                                  'tools/features_bench.py' % (n1, n1 * (args.k - 1))}
+        extras['c1_forward_only'] = c1
         # the online correction node's per-scan work (scripts/depth_correction:31-58): local_feature_cloud (shadow filter,
         # neighbourhoods, features, mask) -> model -> update_points, on an already uploaded 200k-point scan
         from depth_correction_amd.config import Config

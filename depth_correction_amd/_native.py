@@ -51,6 +51,7 @@ _SIGNATURES = {
                              _i32, _vp, _vp, _vp]),
     'dc_features_fwd': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
+    'dc_features_set_tiled': (_i32, [_i32]),
     'dc_features_bwd': (_i32, [_vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dc_block_table_slots': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_workspace_bytes': (_sz, [_i64]),

@@ -22,6 +22,7 @@
 #include "dc_common.h"
 #include "dc_device.h"
 #include "dc_pointmath.h"
+#include "dc_prof.h"
 #include "dc_points_dev.h"
 #include "../../include/dc_hip.h"
 
@@ -2227,50 +2228,6 @@ static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t ro
   return true;
 }
 
-// ---- in-library kernel timer: HIP events recorded on the launch stream right around the main kernels ------
-namespace {
-constexpr int kProfKinds = 3;            // 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd
-constexpr int kProfCap = 4096;
-// Process-wide state behind a mutex: launches from different host threads (distinct streams) may time concurrently;
-// the events of one ProfScope are only touched by the thread that owns it until its destructor publishes them.
-struct ProfState {
-  std::mutex mu;
-  int every = 0;                           // 0 = off, N = time every N-th launch of each kind
-  int64_t seen[kProfKinds] = {0, 0, 0};
-  int count[kProfKinds] = {0, 0, 0};
-  hipEvent_t start[kProfKinds][kProfCap];
-  hipEvent_t stop[kProfKinds][kProfCap];
-  int created[kProfKinds] = {0, 0, 0};
-  const char* last_kernel[kProfKinds] = {nullptr, nullptr, nullptr};     // instantiation launched last, per kind
-} g_prof;
-
-// One timed launch: the kernel is launched through hipExtLaunchKernelGGL, which stamps the two events with the
-// dispatch's own start / end times (what rocprofv3 reports) instead of bracketing it with event packets.
-struct ProfScope {
-  int kind, slot;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  explicit ProfScope(int kind_) : kind(kind_), slot(-1) {
-    std::lock_guard<std::mutex> lock(g_prof.mu);
-    if (g_prof.every <= 0 || g_prof.count[kind] >= kProfCap) return;
-    if ((g_prof.seen[kind]++ % g_prof.every) != 0) return;
-    slot = g_prof.count[kind];
-    if (slot >= g_prof.created[kind]) {
-      if (hipEventCreate(&g_prof.start[kind][slot]) != hipSuccess || hipEventCreate(&g_prof.stop[kind][slot]) != hipSuccess) { slot = -1; return; }
-      g_prof.created[kind] = slot + 1;
-    }
-    g_prof.count[kind] = slot + 1;         // reserved now, so that a concurrent scope takes the next slot
-    ev0 = g_prof.start[kind][slot];
-    ev1 = g_prof.stop[kind][slot];
-  }
-  hipEvent_t start() const { return ev0; }
-  hipEvent_t stop() const { return ev1; }
-  void name(const char* kernel) const { g_prof.last_kernel[kind] = kernel; }
-};
-// launch of a hot kernel inside a `ProfScope prof` block
-#define DC_TIMED_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-  (prof.name(#kernel), hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, prof.start(), prof.stop(), 0, __VA_ARGS__))
-}  // namespace
-
 extern "C" {
 
 int dc_version(void) { return 100; }
@@ -2605,7 +2562,7 @@ int dc_profiler_kernel(int kind, char* buf, int len) {
   snprintf(buf, (size_t)len, "%s", nm ? nm : "");
   return DC_OK;
 }
-// kind: 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd.  Waits for the recorded launches to finish.
+// kind: 0 points_fwd, 1 consistency_fwd, 2 consistency_bwd, 3 features_fwd.  Waits for the recorded launches to finish.
 int dc_profiler_read(int kind, double* total_ms, int64_t* launches) {
   if (kind < 0 || kind >= kProfKinds || !total_ms || !launches) return DC_ERR_ARG;
   double tot = 0.0;

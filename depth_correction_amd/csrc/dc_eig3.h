@@ -33,6 +33,7 @@ DC_HD double recip1_(double x) {
   return fma(fma(-x, r, 1.0), r, r);
 }
 DC_HD double rcp_raw_(double x) { return __builtin_amdgcn_rcp(x); }
+DC_HD double rsq_raw_(double x) { return __builtin_amdgcn_rsq(x); }              // v_rsq_f64 as it stands (~2^-26)
 DC_HD double rsqrt1_(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   const double e = fma(-x * y, y, 1.0);          // 1 - x y^2
@@ -49,6 +50,7 @@ template <typename R> DC_HD R rsqrt_(R x) { return R(1) / sqrt(x); }
 DC_HD double recip_(double x) { return 1.0 / x; }
 DC_HD double recip1_(double x) { return 1.0 / x; }
 DC_HD double rcp_raw_(double x) { return 1.0 / x; }
+DC_HD double rsq_raw_(double x) { return 1.0 / sqrt(x); }
 DC_HD double rsqrt1_(double x) { return 1.0 / sqrt(x); }
 DC_HD float cos_est_(float x) { return cosf(x); }
 DC_HD float sqrt_est_(float x) { return sqrtf(x); }
@@ -317,6 +319,140 @@ DC_HD void eig3_smallest_unit(double a00, double a01, double a02, double a11, do
   if (n > 0.0) { const double inv = rsqrt_(n); x *= inv; y *= inv; } else { x = 0.0; y = 1.0; }
   v0[0] = x * u[0] + y * w[0]; v0[1] = x * u[1] + y * w[1]; v0[2] = x * u[2] + y * w[2];
   *lam = l_lo;
+}
+
+// The full decomposition at the cost of the hot path's solver (round 4; what features_fwd_tile_kernel calls).  eig3_sym above
+// spends ~700 instructions per matrix, two thirds of them in fp64 acos / cos, IEEE divisions and square roots.  Same scheme --
+// isolate the eigenvalue on the side of the sign of det(B), deflate, solve the exact 2x2 problem in the complement -- built
+// from the pieces of eig3_smallest_unit: exact power-of-two scaling (frexp / ldexp: no reciprocal, no rounding), the root
+// estimate in float32 on B / p (the degree-7 polynomial in sqrt(1 - |half|): the isolated root always sits on the
+// well-conditioned side, and the largest root of B is minus the smallest root of -B), one fp64 Halley step on det(A - l I)
+// from the adjugate, the adjugate's best column as eigenvector, a Rayleigh correction, v_rsq_f64 + one Newton step for every
+// normalisation.  ~270 instructions; pinned against LAPACK by the same host families as eig3_sym (tests/test_hostcheck.py).
+DC_HD void eig3_sym_v2(double a00, double a01, double a02, double a11, double a12, double a22, double* lam, double (*V)[3]) {
+  double m = fmax(fmax(fabs(a00), fabs(a11)), fabs(a22));
+  m = fmax(m, fmax(fabs(a01), fmax(fabs(a02), fabs(a12))));
+  if (!(m > 0.0) || !(m < (double)INFINITY)) {   // zero matrix, or NaN/inf input
+    const double z = (m == 0.0) ? 0.0 : (double)NAN;
+    lam[0] = lam[1] = lam[2] = z;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    return;
+  }
+  int ex;
+  (void)frexp(m, &ex);                           // m = f 2^ex, f in [0.5, 1): the scaling below is exact
+  a00 = ldexp(a00, -ex); a01 = ldexp(a01, -ex); a02 = ldexp(a02, -ex);
+  a11 = ldexp(a11, -ex); a12 = ldexp(a12, -ex); a22 = ldexp(a22, -ex);
+  const double q = ((a00 + a11) + a22) * (1.0 / 3.0);
+  const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+  const double k01 = a01 * a01, k02 = a02 * a02, k12 = a12 * a12;
+  const double p2 = (b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * (k01 + k02 + k12)) * (1.0 / 6.0);
+  if (!(p2 > 0.0)) {                             // multiple of the identity
+    lam[0] = lam[1] = lam[2] = ldexp(q, ex);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    return;
+  }
+  // ---- float32 estimate of the isolated root of det(B - x I) = 0 on B / p (entries of order one whatever p is) ----
+  const double rp = rsq_raw_(p2);
+  const float rpf = (float)rp;
+  const float f00 = (float)b00 * rpf, f11 = (float)b11 * rpf, f22 = (float)b22 * rpf;
+  const float f01 = (float)a01 * rpf, f02 = (float)a02 * rpf, f12 = (float)a12 * rpf;
+  const float detf = f00 * (f11 * f22 - f12 * f12) - f01 * (f01 * f22 - f12 * f02) + f02 * (f01 * f12 - f11 * f02);
+  float half = fminf(fmaxf(0.5f * detf, -1.0f), 1.0f);
+  if (!(half == half)) half = 0.0f;              // (an overflowing p2 / rp pair: any start inside the spectrum will do)
+  const bool iso_is_max = half >= 0.0f;          // det(B) >= 0: the largest eigenvalue is the isolated one (gap >= sqrt(3) p)
+  float beta;
+  {
+    const float sq = sqrt_est_(1.0f + fabsf(half));       // smallest root of B for -|half|: in [1, sqrt 2]
+    float pl = -1.993398076e-04f;
+    pl = fmaf(pl, sq, 1.522336419e-03f); pl = fmaf(pl, sq, -5.673570384e-03f); pl = fmaf(pl, sq, 1.511769878e-02f);
+    pl = fmaf(pl, sq, -3.736451873e-02f); pl = fmaf(pl, sq, 1.110385112e-01f); pl = fmaf(pl, sq, -8.164918407e-01f);
+    beta = fmaf(pl, sq, -1.000000052e+00f);
+    beta = iso_is_max ? -beta : beta;
+  }
+  double l = fma(p2 * rp, (double)beta, q);      // q + p beta
+  const double pa = a02 * a12, pb = a01 * a12, pc = a01 * a02;
+  double d0 = a00 - l, d1 = a11 - l, d2 = a22 - l;
+  double M00 = fma(d1, d2, -k12), M11 = fma(d0, d2, -k02), M22 = fma(d0, d1, -k01);
+  double M01 = fma(-a01, d2, pa), M02 = fma(-a02, d1, pb), M12;
+  {
+    // ---- one Halley step in fp64 on f(l) = det(A - l I): f' = -(M00 + M11 + M22), f'' = 2 (d0 + d1 + d2).  Cubic
+    // convergence from the 2.5e-7 p estimate lands at the rounding level (a Newton step leaves ~1e-13 p, which shows as an
+    // eigenvector residual of 1e-14: five instructions more buy LAPACK's accuracy) ----
+    const double f = fma(a02, M02, fma(a01, M01, d0 * M00));
+    const double s = (M00 + M11) + M22;
+    const double den = fma(2.0 * s, s, -f * (2.0 * ((d0 + d1) + d2)));
+    if (fabs(den) > 1e-300) l = fma(2.0 * f * s, rcp_raw_(den), l);
+  }
+  d0 = a00 - l; d1 = a11 - l; d2 = a22 - l;
+  M00 = fma(d1, d2, -k12); M11 = fma(d0, d2, -k02); M22 = fma(d0, d1, -k01);
+  M01 = fma(-a01, d2, pa); M02 = fma(-a02, d1, pb); M12 = fma(-a12, d0, pc);
+  // adj(A - l I) = c v v^T with c > 0 for the smallest and for the largest eigenvalue: the largest diagonal entry names the
+  // best conditioned column
+  const bool s0 = M00 >= M11 && M00 >= M22;
+  const bool s1 = !s0 && M11 >= M22;
+  double iso[3];
+  iso[0] = s0 ? M00 : (s1 ? M01 : M02);
+  iso[1] = s0 ? M01 : (s1 ? M11 : M12);
+  iso[2] = s0 ? M02 : (s1 ? M12 : M22);
+  const double n2 = iso[0] * iso[0] + iso[1] * iso[1] + iso[2] * iso[2];
+  if (n2 > 0.0) {
+    const double inv = rsqrt1_(n2);
+    iso[0] *= inv; iso[1] *= inv; iso[2] *= inv;
+  } else {
+    iso[0] = 1.0; iso[1] = 0.0; iso[2] = 0.0;
+  }
+  // Rayleigh quotient as a correction of l: l + v . (A - l I) v
+  double l_iso;
+  {
+    const double w0 = d0 * iso[0] + a01 * iso[1] + a02 * iso[2];
+    const double w1 = a01 * iso[0] + d1 * iso[1] + a12 * iso[2];
+    const double w2 = a02 * iso[0] + a12 * iso[1] + d2 * iso[2];
+    l_iso = l + (iso[0] * w0 + iso[1] * w1 + iso[2] * w2);
+  }
+  // orthonormal basis (u, w) of the complement, the exact 2x2 problem there
+  double u[3], w[3];
+  if (fabs(iso[0]) > fabs(iso[1])) {
+    const double inv = rsqrt1_(iso[0] * iso[0] + iso[2] * iso[2]);
+    u[0] = -iso[2] * inv; u[1] = 0.0; u[2] = iso[0] * inv;
+  } else {
+    const double inv = rsqrt1_(iso[1] * iso[1] + iso[2] * iso[2]);
+    u[0] = 0.0; u[1] = iso[2] * inv; u[2] = -iso[1] * inv;
+  }
+  cross3(iso, u, w);
+  const double au0 = a00 * u[0] + a01 * u[1] + a02 * u[2];
+  const double au1 = a01 * u[0] + a11 * u[1] + a12 * u[2];
+  const double au2 = a02 * u[0] + a12 * u[1] + a22 * u[2];
+  const double aw0 = a00 * w[0] + a01 * w[1] + a02 * w[2];
+  const double aw1 = a01 * w[0] + a11 * w[1] + a12 * w[2];
+  const double aw2 = a02 * w[0] + a12 * w[1] + a22 * w[2];
+  const double m00 = u[0] * au0 + u[1] * au1 + u[2] * au2;
+  const double m01 = u[0] * aw0 + u[1] * aw1 + u[2] * aw2;
+  const double m11 = w[0] * aw0 + w[1] * aw1 + w[2] * aw2;
+  const double h = (m00 - m11) * 0.5, mean = (m00 + m11) * 0.5;
+  const double r2 = h * h + m01 * m01;
+  const double rad = r2 > 0.0 ? r2 * rsqrt1_(r2) : 0.0;
+  double l_hi = mean + rad, l_lo = mean - rad;
+  double ca, cb;
+  {
+    // eigenvector of l_hi in (u, w) coordinates: the better conditioned of the two row null vectors
+    const double x1 = m01, y1 = l_hi - m00, x2 = l_hi - m11, y2 = m01;
+    const double n1 = x1 * x1 + y1 * y1, nn2 = x2 * x2 + y2 * y2;
+    const double x = n1 >= nn2 ? x1 : x2, y = n1 >= nn2 ? y1 : y2, n = n1 >= nn2 ? n1 : nn2;
+    if (n > 0.0) { const double inv = rsqrt1_(n); ca = x * inv; cb = y * inv; } else { ca = 1.0; cb = 0.0; }
+  }
+  const double vhi[3] = {ca * u[0] + cb * w[0], ca * u[1] + cb * w[1], ca * u[2] + cb * w[2]};
+  const double vlo[3] = {ca * w[0] - cb * u[0], ca * w[1] - cb * u[1], ca * w[2] - cb * u[2]};
+  // ascending order: the pair is ordered by construction; the isolated eigenvalue can only cross it by round-off
+  // (spectra isotropic to machine precision), where moving it onto its neighbour changes nothing that can be resolved
+  if (iso_is_max) {
+    l_iso = fmax(l_iso, l_hi);
+    lam[0] = ldexp(l_lo, ex); lam[1] = ldexp(l_hi, ex); lam[2] = ldexp(l_iso, ex);
+    for (int j = 0; j < 3; ++j) { V[0][j] = vlo[j]; V[1][j] = vhi[j]; V[2][j] = iso[j]; }
+  } else {
+    l_iso = fmin(l_iso, l_lo);
+    lam[0] = ldexp(l_iso, ex); lam[1] = ldexp(l_lo, ex); lam[2] = ldexp(l_hi, ex);
+    for (int j = 0; j < 3; ++j) { V[0][j] = iso[j]; V[1][j] = vlo[j]; V[2][j] = vhi[j]; }
+  }
 }
 
 // Smallest eigenpair and trace of any symmetric positive semi-definite matrix through the core above (one reciprocal of

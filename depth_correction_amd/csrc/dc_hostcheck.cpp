@@ -18,6 +18,17 @@ void dc_host_eig3(const double* cov, long n, double* lam, double* vec) {
   }
 }
 
+// round 4's full solver (what features_fwd_tile_kernel calls)
+void dc_host_eig3_v2(const double* cov, long n, double* lam, double* vec) {
+  for (long i = 0; i < n; ++i) {
+    const double* c = cov + i * 6;
+    double V[3][3];
+    dc::eig3_sym_v2(c[0], c[1], c[2], c[3], c[4], c[5], lam + i * 3, V);
+    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 3; ++j) vec[i * 9 + k * 3 + j] = V[k][j];
+  }
+}
+
 // Hot-path variant: smallest eigenpair + trace only.
 void dc_host_eig3_smallest(const double* cov, long n, double* lam0, double* v0, double* tr) {
   for (long i = 0; i < n; ++i) {

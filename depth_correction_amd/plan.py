@@ -587,8 +587,9 @@ def consistency_loss(plan, w, exponent, poses, inlier_ratio=1.0, inlier_max_loss
 
 
 class KernelTimer:
-    """HIP-event timing of the three hot kernels, recorded inside the library on the launch stream."""
-    KINDS = ('points_fwd', 'consistency_fwd', 'consistency_bwd')
+    """HIP-event timing of the hot kernels (the three of the fused step and dc_features_fwd's), recorded inside the library on
+    the launch stream."""
+    KINDS = ('points_fwd', 'consistency_fwd', 'consistency_bwd', 'features_fwd')
 
     def __init__(self, every=1):
         """every: time every N-th launch of each kernel (an event pair idles the GPU for a few microseconds)."""

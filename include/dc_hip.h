@@ -148,6 +148,12 @@ int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nb
                     void* eigvecs, void* normals, void* inc_angles, int32_t* nvalid, void* weights_out,
                     void* cmean_out, void* invd_out, dcStream_t stream);
 
+/* A-B switch for measurements (process-wide atomic, read once per launch, NOT synchronised with concurrent dc_features_fwd calls
+ * of other threads): 0 sends every dc_features_fwd call to the general run-time-k kernel, 1 (default) lets calls with
+ * k = 4 / 8 / 10 / 16, validity weights and 16-B aligned arrays take the tiled kernel (features_fwd_tile_kernel: coalesced index
+ * tile, k gathers in flight, outputs through LDS).  Same reference lines as dc_features_fwd; results agree to round-off. */
+int dc_features_set_tiled(int on);   /* returns the previous setting */
+
 /* dL/dpoints from dL/d(mean, cov, eigvals) (any may be NULL); grec_ws: dtype [n,12] scratch. */
 int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* csr_ptr, const int32_t* csr_src,
                     int64_t n, const void* cmean, const void* invd, const int32_t* nvalid, const void* eigvecs,
@@ -484,7 +490,7 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)
- * bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them.
+ * and dc_features_fwd (kind 3) bracket their main kernel with HIP events on the launch stream; dc_profiler_read waits and sums them.
  * every: 0 = off, N >= 1 = time every N-th launch of each kind (an event pair costs a few microseconds of idle GPU
  * around the kernel, so a timed production loop samples); `launches` counts the timed launches.  The timer state is
  * one per process behind a mutex: entry points may be called from several host threads on distinct streams. */

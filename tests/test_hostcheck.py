@@ -26,10 +26,10 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def _eig(host, C):
+def _eig(host, C, solver='dc_host_eig3'):
     c6 = np.ascontiguousarray(np.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1))
     lam, vec = np.zeros((len(C), 3)), np.zeros((len(C), 9))
-    host.dc_host_eig3(_p(c6), ctypes.c_long(len(C)), _p(lam), _p(vec))
+    getattr(host, solver)(_p(c6), ctypes.c_long(len(C)), _p(lam), _p(vec))
     return lam, vec.reshape(-1, 3, 3)
 
 
@@ -39,8 +39,10 @@ def _spd(rng, lams):
     return 0.5 * (C + C.transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize('case', ['generic', 'planar', 'needle', 'double_lo', 'double_hi', 'isotropic', 'tiny', 'huge'])
-def test_eig3_matches_lapack(host, case):
+@pytest.mark.parametrize('solver', ['dc_host_eig3', 'dc_host_eig3_v2'])
+@pytest.mark.parametrize('case', ['generic', 'planar', 'needle', 'double_lo', 'double_hi', 'isotropic', 'near_isotropic', 'edge',
+                                  'sign_switch', 'tiny', 'huge'])
+def test_eig3_matches_lapack(host, case, solver):
     """Every eigenvalue within LAPACK's own absolute accuracy (a few eps * |C|), for clustered small eigenvalues too;
     the reference's known-answer test asks for 1e-6 / 1e-5 (loss.py:731-735)."""
     rng = np.random.default_rng(0)
@@ -51,9 +53,18 @@ def test_eig3_matches_lapack(host, case):
             'needle': np.stack([10 ** u(-10, -4, n), 10 ** u(-10, -4, n), u(0.3, 1, n)], 1),
             'double_lo': np.stack([np.full(n, 0.2), np.full(n, 0.2), u(0.3, 1, n)], 1),
             'double_hi': np.stack([u(0.01, 0.2, n), np.full(n, 0.5), np.full(n, 0.5)], 1),
-            'isotropic': np.full((n, 3), 0.37), 'tiny': u(0, 1, (n, 3)) * 1e-14, 'huge': u(0, 1, (n, 3)) * 1e12}[case]
+            'isotropic': np.full((n, 3), 0.37),
+            # anisotropy from round-off level up to 1e-6 of the scale; spectra with det(B) on either side of zero (where the
+            # solvers switch the eigenvalue they isolate); edge-like spectra
+            'near_isotropic': 0.37 * (1.0 + 10 ** u(-16, -6, (n, 1)) * u(-1, 1, (n, 3))),
+            'edge': np.stack([10 ** u(-8, -3, n), 10 ** u(-3, -0.5, n), u(0.3, 1, n)], 1),
+            'sign_switch': np.stack([0.5 - u(0.1, 0.4, n), 0.5 + u(-1e-7, 1e-7, n), 0.5 + u(0.1, 0.4, n)], 1),
+            'tiny': u(0, 1, (n, 3)) * 1e-14, 'huge': u(0, 1, (n, 3)) * 1e12}[case]
+    if case == 'sign_switch':
+        lams[:, 2] = 1.0 - lams[:, 0]                                  # symmetric about the middle one: det(B) ~ 0
+    lams = np.sort(lams, axis=1)
     C = _spd(rng, lams)
-    lam, V = _eig(host, C)
+    lam, V = _eig(host, C, solver)
     ref = np.linalg.eigh(C)[0]
     scale = np.abs(ref).max(1, keepdims=True)
     assert np.all(np.diff(lam, axis=1) >= 0)
@@ -121,13 +132,17 @@ def test_eig3_smallest_degenerate_inputs(host, solver):
     assert abs(lam0[0] - 0.37) < 1e-15 and abs(np.linalg.norm(v0) - 1) < 1e-15
 
 
-def test_eig3_degenerate_inputs(host):
-    lam, V = _eig(host, np.zeros((2, 3, 3)))
+@pytest.mark.parametrize('solver', ['dc_host_eig3', 'dc_host_eig3_v2'])
+def test_eig3_degenerate_inputs(host, solver):
+    lam, V = _eig(host, np.zeros((2, 3, 3)), solver)
     assert np.all(lam == 0) and np.allclose(V, np.eye(3))
-    lam, _ = _eig(host, np.full((1, 3, 3), np.nan))
+    lam, _ = _eig(host, np.full((1, 3, 3), np.nan), solver)
     assert np.all(np.isnan(lam))
-    lam, _ = _eig(host, np.diag([3.0, 1.0, 2.0])[None])
+    lam, V = _eig(host, np.diag([3.0, 1.0, 2.0])[None], solver)
     assert np.allclose(lam, [[1.0, 2.0, 3.0]])
+    assert np.allclose(np.abs(V[0]), [[0, 1, 0], [0, 0, 1], [1, 0, 0]])
+    lam, V = _eig(host, np.diag([0.0, 0.0, 2.0])[None], solver)         # rank one
+    assert np.allclose(lam, [[0.0, 0.0, 2.0]]) and np.allclose(np.abs(V[0, 2]), [0, 0, 1])
 
 
 @pytest.mark.parametrize('kind,norm,sqrt', [(0, 1, 0), (0, 0, 0), (0, 1, 1), (1, 0, 0), (1, 0, 1)])

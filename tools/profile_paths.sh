@@ -1,13 +1,14 @@
 #!/bin/bash
 # Kernel-trace + PMC passes (separately, as MI355X_MICROARCH.md prescribes) over tools/profile_paths.py, one workload at a time.
-#   tools/profile_paths.sh <out_dir> <workload> [<workload> ...]      -> <out_dir>/<workload>/{kernel_stats.csv, pmc_summary.json}
+#   [REPS=220] tools/profile_paths.sh <out_dir> <workload> [<workload> ...]      -> <out_dir>/<workload>/{kernel_stats.csv, pmc_summary.json}
+# REPS: launches of the kernel-trace pass (default 20; the counter passes always take 6)
 set -o pipefail
 OUT=${1:?out dir}; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"; export TMPDIR=/tmp
 for w in "$@"; do
   D="$OUT/$w"; mkdir -p "$D/raw"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$D/raw/kt" -o p -- python3 tools/profile_paths.py --what $w > "$D/raw/kt.log" 2>&1 || { echo "$w: trace failed"; tail -5 "$D/raw/kt.log"; continue; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$D/raw/kt" -o p -- python3 tools/profile_paths.py --what $w --reps ${REPS:-20} > "$D/raw/kt.log" 2>&1 || { echo "$w: trace failed"; tail -5 "$D/raw/kt.log"; continue; }
   cp "$(find "$D/raw/kt" -name 'p_kernel_stats.csv' | head -1)" "$D/kernel_stats.csv"
   i=0
   for counters in "FETCH_SIZE" "WRITE_SIZE" \
