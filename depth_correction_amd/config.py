@@ -123,6 +123,7 @@ class Config(object):
         self.loop_batch = 64
         self.loop_graph = True
         self.loop_native = True        # model-only runs: the library's chained step, one launch per iteration (train._native_loop)
+        self.keep_plans = False        # train() releases the per-sequence plans it built when it returns; True keeps them cached
         self.from_dict(kwargs)
 
     # ---- Configurable subset (configurable.py:44-58,166-179) ----

@@ -668,6 +668,13 @@ __device__ __forceinline__ void shell_cell(int r, int side, float inv_side, floa
   else { *dx = r; *dy = pos - (3 * side - 2) + 1 - r; }
 }
 
+// LDS hand-over between the lanes of one wavefront: the wavefront's LDS operations execute in program order, so no hardware
+// barrier is needed, but the compiler must not move memory operations across the hand-over (wave_barrier alone is IntrNoMem)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restrict__ sp, const int32_t* __restrict__ sids,
                                                           const double* __restrict__ queries, const int32_t* __restrict__ qids,
@@ -723,9 +730,9 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
           break;
         }
       }
-      __builtin_amdgcn_wave_barrier();
+      wave_sync();
       for (int s = lane; s < k; s += kWave) { pd[s] = s_nd[wave][s]; pi[s] = s_ni[wave][s]; }
-      __builtin_amdgcn_wave_barrier();
+      wave_sync();
       worst_d = pd[k - 1]; worst_i = pi[k - 1];
       nc = 0;
     };
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
       const int pos = k + nc + __popcll(m & ((1ull << lane) - 1ull));
       if (acc) { pd[pos] = d; pi[pos] = id; }
       nc += __popcll(m);
-      __builtin_amdgcn_wave_barrier();
+      wave_sync();
       if (nc > kTailCap - kWave) select();
     };
     const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
     if (exhaustive) {
       for (int s = lane; s < k; s += kWave) { pd[s] = INFINITY; pi[s] = 0x7fffffff; }
       nc = 0; worst_d = INFINITY; worst_i = 0x7fffffff;
-      __builtin_amdgcn_wave_barrier();
+      wave_sync();
       for (int64_t p0 = 0; p0 < n_points; p0 += kWave) {
         const int64_t p = p0 + lane;
         const bool has = p < n_points;
@@ -784,13 +791,13 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
       }
       if (nc > 0) select();
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     for (int s = lane; s < k; s += kWave) {
       const bool ok = pi[s] != 0x7fffffff;
       idx_out[row * k + s] = ok ? pi[s] : -1;
       if (dist_out) dist_out[row * k + s] = ok ? sqrt(pd[s]) : INFINITY;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
   }
 }
 
@@ -818,12 +825,6 @@ constexpr int kGrp = 16;                           // lanes per query: one DPP r
 constexpr int kGrpPerBlock = kBlock / kGrp;
 constexpr int kGrpPool = 64;                       // pool entries per query: four per lane in the selection
 
-// LDS hand-over between the lanes of one wavefront: the wavefront's LDS operations execute in program order, so no hardware
-// barrier is needed, but the compiler must not move memory operations across the hand-over (wave_barrier alone is IntrNoMem)
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 template <int CTRL>

@@ -180,30 +180,28 @@ def create_dataset(name, cfg=None, **kwargs):
 
 
 # ---- dataset wrappers of the caller scripts (dataset.py:718-873, :933-950) ------------------------------------------------
-class Forwarding(object):
-    """Everything not overridden goes to ``target``."""
+class Forwarding:
+    """A stand-in for ``target``: attribute look-ups that fail here, indexing, iteration, ``len`` and ``str`` all reach the
+    wrapped object (contract of the reference's wrapper base, dataset.py:718-735)."""
 
     def __init__(self, target):
         self.target = target
 
-    def __getattr__(self, item):
-        return getattr(self.target, item)
+    def __getattr__(self, name):                 # only consulted when normal look-up fails
+        if name == 'target':                     # (not yet set: unpickling / copy) -- no recursion
+            raise AttributeError(name)
+        return getattr(self.target, name)
 
-    def __getitem__(self, item):
-        return self.target[item]
-
-    def __iter__(self):
-        return iter(self.target)
-
-    def __len__(self):
-        return len(self.target)
-
-    def __str__(self):
-        return str(self.target)
+    __getitem__ = lambda self, key: self.target[key]
+    __iter__ = lambda self: iter(self.target)
+    __len__ = lambda self: len(self.target)
+    __str__ = lambda self: str(self.target)
 
 
 class TransformingDataset(Forwarding):
-    """(cloud, pose) items of ``target`` passed through ``transform_cloud`` / ``transform_pose`` (item index as a keyword)."""
+    """``target``'s (cloud, pose) items with both members passed through the hooks ``transform_cloud`` / ``transform_pose``
+    (identity here; the hooks get the item's index as keyword ``item``).  Integer indexing, iteration and the by-id accessors
+    ``local_cloud`` / ``cloud_pose`` all go through the same hooks (contract: dataset.py:738-762)."""
 
     def transform_cloud(self, cloud, **kwargs):
         return cloud
@@ -211,14 +209,16 @@ class TransformingDataset(Forwarding):
     def transform_pose(self, pose, **kwargs):
         return pose
 
+    def _hooked(self, index, pair):
+        cloud, pose = pair
+        return self.transform_cloud(cloud, item=index), self.transform_pose(pose, item=index)
+
     def __getitem__(self, item):
         assert isinstance(item, int), item
-        cloud, pose = self.target[item]
-        return self.transform_cloud(cloud, item=item), self.transform_pose(pose, item=item)
+        return self._hooked(item, self.target[item])
 
     def __iter__(self):
-        for item, (cloud, pose) in enumerate(self.target):
-            yield self.transform_cloud(cloud, item=item), self.transform_pose(pose, item=item)
+        return (self._hooked(index, pair) for index, pair in enumerate(self.target))
 
     def local_cloud(self, id):
         return self.transform_cloud(self.target.local_cloud(id))

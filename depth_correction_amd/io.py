@@ -1,7 +1,13 @@
-"""Text files shared between processes (io.py:7-65): ``write`` / ``append`` under an exclusive ``<path>.lock`` file, which
-the experiment scripts use to collect result tables from parallel runs (scripts/model_poses_learning_icp:15)."""
+"""Text files shared between processes: ``write`` / ``append`` serialised through an exclusive ``<path>.lock`` file.  The
+experiment scripts collect result tables from parallel runs this way (scripts/model_poses_learning_icp:15; contract of the
+reference's io.py:7-65: ``PathLock(path, interval, repeat)`` with ``lock`` / ``unlock`` / context-manager use, waiting a random
+share of ``interval`` between attempts, ``repeat`` < 0 meaning for ever, ``PathLockException`` once the attempts are used up).
+
+Written from that contract: the lock is taken with ``os.open(O_CREAT | O_EXCL)`` -- atomic on POSIX file systems -- and holds
+the owner's pid, which makes a stale lock identifiable by a person looking at the directory."""
 from __future__ import annotations
 
+import itertools
 import os
 import random
 import time
@@ -10,53 +16,63 @@ __all__ = ['write', 'append', 'PathLock', 'PathLockException']
 
 
 class PathLockException(Exception):
-    pass
+    """The lock file stayed taken for all permitted attempts."""
 
 
-class PathLock(object):
-    """Context manager holding ``<path>.lock`` (created with mode 'x'); waits a random fraction of ``interval`` between
-    attempts, ``repeat`` < 0: for ever."""
-
+class PathLock:
     lock_template = '%s.lock'
 
     def __init__(self, path, interval=1.0, repeat=-1):
-        self.path, self.lock_path = path, PathLock.lock_template % path
-        self.locked, self.interval, self.repeat = False, interval, repeat
+        self.path = path
+        self.lock_path = self.lock_template % path
+        self.interval = interval
+        self.repeat = repeat
+        self.locked = False
+
+    def _try_once(self):
+        try:
+            fd = os.open(self.lock_path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644)
+        except FileExistsError:
+            return False
+        with os.fdopen(fd, 'w') as f:
+            f.write('%d\n' % os.getpid())
+        return True
 
     def lock(self):
-        assert not self.locked
-        attempt = 0
-        while self.repeat < 0 or attempt <= self.repeat:
-            attempt += 1
-            try:
-                with open(self.lock_path, 'x'):
-                    pass
+        assert not self.locked, 'lock() on a lock this object already holds'
+        attempts = itertools.count() if self.repeat < 0 else range(self.repeat + 1)
+        for _ in attempts:
+            if self._try_once():
                 self.locked = True
                 return self
-            except FileExistsError:
-                time.sleep(random.random() * self.interval)
-        raise PathLockException()
+            time.sleep(self.interval * random.random())
+        raise PathLockException('could not take %s' % self.lock_path)
 
     def unlock(self):
         assert self.locked and os.path.exists(self.lock_path)
-        os.remove(self.lock_path)
+        os.unlink(self.lock_path)
         self.locked = False
 
     def __enter__(self):
         return self.lock()
 
-    def __exit__(self, exc_type, exc_val, exc_tb):
+    def __exit__(self, *exc):
         if self.locked:
             self.unlock()
+        return False
+
+
+def _put(path, text, mode, create_dirs):
+    folder = os.path.dirname(path)
+    if create_dirs and folder:
+        os.makedirs(folder, exist_ok=True)
+    with PathLock(path), open(path, mode) as f:
+        f.write(text)
 
 
 def write(path, text, append=False, create_dirs=True):
-    if create_dirs:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-    with PathLock(path):
-        with open(path, 'a' if append else 'w') as f:
-            f.write(text)
+    _put(path, text, 'a' if append else 'w', create_dirs)
 
 
 def append(path, text, create_dirs=True):
-    write(path, text, append=True, create_dirs=create_dirs)
+    _put(path, text, 'a', create_dirs)

@@ -504,6 +504,13 @@ class PlanRegistry(object):
     def clear(self):
         self.entries = []
 
+    def keys(self):
+        return [k for k, _, _ in self.entries]
+
+    def discard_except(self, keep):
+        """Drop every entry whose key is not in ``keep`` (train() releases what it added and nothing else)."""
+        self.entries = [e for e in self.entries if e[0] in keep]
+
 
 class _ConsistencyLoss(torch.autograd.Function):
     """sum over the mask of the pointwise loss of one sequence, differentiable w.r.t. w, exponent, poses.

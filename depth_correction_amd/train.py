@@ -15,6 +15,7 @@ TensorBoard / ROS publishing are out of scope; ``TrainCallbacks`` is the hook fo
 from __future__ import annotations
 
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -107,25 +108,33 @@ def _zero_first_pose(pose_deltas):
             d.grad[0].zero_()                                 # the first pose stays fixed (train.py:309-311)
 
 
-def release_plans():
-    """Drop the cached per-sequence plans (eval._plans, loss._icp_plans): each holds the local clouds, tables and work buffers
-    of a sequence -- hundreds of MB at C2 -- and nothing else releases them in a long-lived process."""
+def _plan_registries():
     from . import eval as _eval, loss as _loss
-    _eval._plans.clear()
-    reg = getattr(_loss, '_icp_plans', None)
-    if reg is not None:
-        reg.clear()
+    return [r for r in (_eval._plans, getattr(_loss, '_icp_plans', None)) if r is not None]
+
+
+def release_plans(keep=None):
+    """Drop the cached per-sequence plans (eval._plans, loss._icp_plans): each holds the local clouds, tables and work buffers
+    of a sequence -- hundreds of MB at C2 -- and nothing else releases them in a long-lived process.  ``keep``: per registry
+    the set of keys to leave alone (train() passes the keys that existed before it started, so that plans another caller
+    built -- an evaluation loop around train(), a train() inside a callback -- survive it)."""
+    for i, reg in enumerate(_plan_registries()):
+        if keep is None:
+            reg.clear()
+        else:
+            reg.discard_except(keep[i])
 
 
 def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     """Optimise the depth-correction model (and pose corrections); returns the config of the best iteration.  The plans built
     for its sequences are released when it returns (``cfg.keep_plans = True`` keeps them for a caller that goes on
     evaluating the same clouds)."""
+    before = [set(reg.keys()) for reg in _plan_registries()]
     try:
         return _train(cfg, callbacks, train_datasets, val_datasets)
     finally:
         if not getattr(cfg, 'keep_plans', False):
-            release_plans()
+            release_plans(keep=before)                        # only what this call added
 
 
 def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
@@ -133,9 +142,10 @@ def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     callbacks = callbacks or TrainCallbacks(cfg)
     rank, world = world_info() if getattr(cfg, 'distributed', None) is not False else (0, 1)
     sharded = world > 1
-    if sharded and torch.device(cfg.device).type == 'cuda':
+    if sharded and torch.device(cfg.device).type == 'cuda' and torch.device(cfg.device).index is not None:
         # object collectives (the checkpoint gather) and RCCL's own staging use torch's current device: it must be this
-        # rank's GPU, whatever the launcher did
+        # rank's GPU, whatever the launcher did.  An index-less 'cuda' means "the current device" (the launcher has already
+        # called set_device(local_rank)): nothing to change, and set_device would refuse a device without an index
         torch.cuda.set_device(torch.device(cfg.device))
     os.makedirs(cfg.log_dir, exist_ok=True)
     cfg_path = os.path.join(cfg.log_dir, 'train.yaml')
@@ -212,7 +222,7 @@ def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     def weighted_of(loss, weight):
         return loss * weight if loss is not None else torch.zeros((), dtype=torch.float64, device=cfg.device)
 
-    batch = int(getattr(cfg, 'loop_batch', 16) or 1)
+    batch = int(getattr(cfg, 'loop_batch', 64) or 1)
     if (batch > 1 and not sharded and type(callbacks) is TrainCallbacks and torch.device(cfg.device).type == 'cuda'
             and cfg.n_opt_iters > 0):
         # nobody looks at an iteration while it runs (the callbacks are the no-op base class): the loop runs without a host
@@ -435,14 +445,23 @@ def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_p
             print('train(): the iteration could not be captured (%s: %s); running it eagerly' % (type(ex).__name__, str(ex).split('\n')[0]))
             torch.cuda.synchronize(dev)
             graph = None
-    while it < n_it:
-        if it - state['done'] >= R:
+    try:
+        while it < n_it:
+            if it - state['done'] >= R:
+                drain(it)
+            if graph is not None:
+                graph.replay()
+            else:
+                body()
+            it += 1
+    except BaseException:
+        # an interrupted run (Ctrl-C, an exception in an iteration) keeps what it finished: the ring holds the records of the
+        # completed iterations since the last drain, so best.yaml and the checkpoint files of the best of them get written
+        try:
             drain(it)
-        if graph is not None:
-            graph.replay()
-        else:
-            body()
-        it += 1
+        except Exception:
+            pass
+        raise
     drain(n_it)
     return book.best
 
@@ -496,39 +515,87 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
     poses_cpu = [train_poses[0].detach().cpu().clone()]
     book = _Bookkeeper(cfg, model)
     done = 0
+    snap = None                      # optimiser state after iteration done - 1: where a batch can be started again
+
+    def snapshot():
+        return tr.w.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.t
+
+    def record(it, sums, w_used, vsums):
+        tl = float(sums[0] / sums[1]) if sums[1] > 0 else float('nan')
+        if vsums:
+            vs, vc = sum(float(v[0]) for v in vsums), sum(float(v[1]) for v in vsums)
+            vl = vs / vc if vc > 0 else float('nan')
+        else:
+            vl = tl
+        sd = dict(sd_const)
+        sd[w_key] = w_used.reshape(w_param.shape).to(w_param.dtype).clone()
+        book.record(it, tl, vl, sd, [], poses_cpu)
+
+    def plain_iterations(first):
+        """Iterations first .. n_it - 1 with ordinary (two-launch) steps and one synchronisation each: where the loop goes on
+        after a chained launch gave up waiting for its weights (status bit 1: its sums are NaN, and so is every weight the
+        Adam updates after it produced)."""
+        tr.chained = False
+        for it in range(first, n_it):
+            w_used = tr.w.clone()
+            vs = [vp.eval_native(tr.w, tr.exponent, P, vr[0], want_grad=False).cpu() for vp, P, vr in zip(vplans, vP, vrings)]
+            sums = tr.step().cpu()
+            record(it, sums, w_used.cpu(), vs)
+            book.end_batch()
 
     def drain(upto):
-        nonlocal done
+        """Bookkeeping of iterations done .. upto - 1; False when the chain had to be abandoned (the rest of the run has then
+        been done by plain_iterations)."""
+        nonlocal done, snap
         if upto <= done:
-            return
+            return True
         # iteration upto - 1 is still pending in the chain: its weights are the current ones, its sums come with the flush
         ring_w[(upto - 1) % R].copy_(tr.w)
         tr.flush(out=ring[(upto - 1) % R])
         h, hw = ring.cpu(), ring_w.cpu()                            # synchronises
         hv = [v.cpu() for v in vrings]
+        bits = plan.status_bits()                                   # (free: the copies above have synchronised)
+        if bits & plan.STATUS_CHAIN_TIMEOUT:
+            warnings.warn('train(): a chained step gave up waiting for its weights (iterations %d..%d); repeating them and '
+                          'finishing the run with ordinary steps' % (done, upto - 1))
+            plan.clear_status()
+            w0_, m0_, v0_, t0_ = snap
+            tr.w.copy_(w0_); tr.exp_avg.copy_(m0_); tr.exp_avg_sq.copy_(v0_); tr.t = t0_
+            plain_iterations(done)
+            done = n_it
+            return False
+        if bits & plan.STATUS_OVERFLOW:
+            warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
+                          'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
+                          % (done, upto - 1))
         for it in range(done, upto):
             sl = it % R
-            tl = float(h[sl, 0] / h[sl, 1]) if h[sl, 1] > 0 else float('nan')
-            if hv:
-                vs, vc = sum(float(v[sl, 0]) for v in hv), sum(float(v[sl, 1]) for v in hv)
-                vl = vs / vc if vc > 0 else float('nan')
-            else:
-                vl = tl
-            sd = dict(sd_const)
-            sd[w_key] = hw[sl].reshape(w_param.shape).to(w_param.dtype).clone()
-            book.record(it, tl, vl, sd, [], poses_cpu)
+            record(it, h[sl], hw[sl], [v[sl] for v in hv])
         book.end_batch()
         done = upto
+        snap = snapshot()
+        return True
 
-    for it in range(n_it):
-        if it - done >= R:
-            drain(it)
-        prev = (it - 1) % R
-        if tr.step(out_prev=ring[prev], w_used_prev=ring_w[prev], require_chain=True) is None:
-            assert it == 0
-            return False, None                                 # this plan does not chain; nothing was launched
-        for vp, P, vr in zip(vplans, vP, vrings):                # validation with the weights of THIS iteration
-            vp.eval_native(tr.w, tr.exponent, P, vr[it % R], want_grad=False)
-    drain(n_it)
-    torch.autograd.graph.increment_version(w_param)                # written through its pointer
+    snap = snapshot()
+    try:
+        for it in range(n_it):
+            if it - done >= R and not drain(it):
+                break
+            prev = (it - 1) % R
+            if tr.step(out_prev=ring[prev], w_used_prev=ring_w[prev], require_chain=True) is None:
+                assert it == 0
+                return False, None                                 # this plan does not chain; nothing was launched
+            for vp, P, vr in zip(vplans, vP, vrings):                # validation with the weights of THIS iteration
+                vp.eval_native(tr.w, tr.exponent, P, vr[it % R], want_grad=False)
+        drain(n_it)
+    except BaseException:
+        # an interrupted run keeps the iterations it finished: their records are in the ring (best.yaml, checkpoint)
+        try:
+            if tr.t > done:
+                drain(min(tr.t, n_it))
+        except Exception:
+            pass
+        raise
+    finally:
+        torch.autograd.graph.increment_version(w_param)            # written through its pointer
     return True, book.best

@@ -487,6 +487,10 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
  * option 5: number of polls a chained launch's blocks make while they wait for the weights its leading blocks publish
  *           (default 2^22, negative restores it).  A wait that runs out yields NaN sums for that evaluation and raises bit 1 of
  *           dcSequenceDesc.status (bit 0: DC_Q32 overflow), so the two causes of a NaN loss can be told apart; tests force 0. */
+/* NOT thread-safe against launches: the switches are process-wide (one value for every plan and stream).  They exist for A-B
+ * measurements and tests in a process that does nothing else meanwhile; a thread flipping one while another thread evaluates gets
+ * either variant for that launch (each launch reads them once; results are the same to the stated tolerances, timings are not).
+ * Product code never calls dc_set_option. */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)

@@ -994,6 +994,63 @@ def test_train_batched_graph_loop_equals_plain_loop(golden, tmp_path, capsys, mo
     assert n_plain == sum(f0) and 1 <= n_fast <= 3
 
 
+def test_train_native_loop_recovers_from_a_chain_timeout(golden, tmp_path, capsys, monkeypatch):
+    """train._native_loop reads the plan's status word at every drain: a chained launch whose wait for its weights
+    ran out (forced here: dc_set_option(5, 0), every wait gives up at once) poisons the sums and, through Adam, the weights.
+    The loop must notice, go back to the optimiser state of the last drain, and finish the run with ordinary steps: the same
+    13 progress lines and the same final checkpoint as the loop with per-iteration bookkeeping."""
+    import warnings
+    from depth_correction_amd import _native as nv
+    from depth_correction_amd import train as train_mod
+    g = golden('room_k10')
+    mk = lambda d, **kw: _cfg(g, n_opt_iters=13, lr=5e-3, log_dir=str(d), model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
+    ds = list(zip(_scan_arrays(g), g['poses']))
+    took = []
+    fn = train_mod._native_loop
+    monkeypatch.setattr(train_mod, '_native_loop', lambda *a, **k: (took.append(1), fn(*a, **k))[1])
+    (tmp_path / 'plain').mkdir()
+    (tmp_path / 'forced').mkdir()
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1, loop_native=False), [ds], [ds[:2]], capsys)
+    nv.check(nv.lib().dc_set_option(5, 0), 'dc_set_option')
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'forced', loop_batch=5), [ds], [ds[:2]], capsys)
+    finally:
+        nv.check(nv.lib().dc_set_option(5, -1), 'dc_set_option')
+    assert took == [1]
+    assert any('gave up waiting' in str(w.message) for w in caught), [str(w.message) for w in caught]
+    assert len(l1) == len(l0) == 13 and f0 == f1
+    assert not np.isnan(np.array(v1)).any()
+    np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-7, atol=1e-12)
+    sa, sb = torch.load(b0.model_state_dict), torch.load(b1.model_state_dict)
+    for k in sa:
+        np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-9, atol=1e-15)
+
+
+def test_train_releases_only_the_plans_it_built(golden, tmp_path, capsys):
+    """train() drops the per-sequence plans it added to the process-wide caches and leaves alone what a caller had cached
+    before; cfg.keep_plans (a declared Config field) keeps its own too."""
+    from depth_correction_amd import eval as eval_mod
+    from depth_correction_amd.config import Config
+    from depth_correction_amd.plan import PlanRegistry
+    assert 'keep_plans' in Config().__dict__
+    g = golden('room_k10')
+    ds = list(zip(_scan_arrays(g), g['poses']))
+    sentinel = torch.zeros(1)
+    eval_mod._plans.clear()                                           # (entries earlier tests of this process left behind)
+    eval_mod._plans.get([sentinel], ('outside',), lambda: 'a plan of somebody else')
+    mk = lambda d, **kw: _cfg(g, n_opt_iters=3, lr=5e-3, log_dir=str(d), model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
+    try:
+        _train_and_collect(mk(tmp_path / 'a'), [ds], [], capsys)
+        keys = eval_mod._plans.keys()
+        assert keys == [PlanRegistry.key_of([sentinel], ('outside',))], keys
+        _train_and_collect(mk(tmp_path / 'b', keep_plans=True), [ds], [], capsys)
+        assert len(eval_mod._plans.keys()) > 1
+    finally:
+        eval_mod._plans.clear()
+
+
 def test_device_scan_loaders_match_the_reference_readers(golden, tmp_path):
     """scan_io.load_*_device on the files of tests/golden/io.npz against what the LIVE reference made of them: its readers
     (datasets/kitti360.py:96-109 with the ego-box crop, asl_laser.py:33-45, fee_corridor.py:35-38) followed by
