@@ -126,7 +126,7 @@ class SequenceDesc(ctypes.Structure):
                 ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
                 ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp),
-                ('partials_count', ctypes.c_int64)]
+                ('partials_count', ctypes.c_int64), ('scan_seg', _vp)]
 
 
 def lib_path():

@@ -232,9 +232,8 @@ constexpr int kPoseRow = 7;              // doubles per staged point: the factor
 constexpr int kMaxBlockScans = 64;       // more distinct scans in one block: per-scan tree reduction instead
 
 __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool active, const double* gx, int scan,
-                                                  double* lds, double* __restrict__ pcol0) {
+                                                  double* lds, double* __restrict__ pcol0, double* s_val) {
   constexpr int NW = kBlock / kWave;
-  __shared__ double s_val[kBlock * kPoseRow];
   __shared__ int s_cnt[NW][kMaxBlockScans];
   __shared__ int s_start[kMaxBlockScans + 1];
   __shared__ int s_range[2];
@@ -330,6 +329,121 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
   }
 }
 
+// The same sums when the plan has grouped the points of every block by scan id (PointInputs.seg_start; round 4): the segments
+// are contiguous lane ranges known since set-up, so nothing is counted, ranked or sorted at run time, and NO BARRIER is left
+// at the block's tail.  Every wavefront sums its own 64 lanes: the six factors go to its part of an LDS array where they stand,
+// (scan, entry, half) items of the two to four scans its lanes belong to walk their stretch of the segment, and the sums go to
+// the wavefront's row of s_part.  A ticket in LDS tells the wavefront that finishes last to add the four rows in fixed order
+// (bitwise reproducible) and to store the block's 12 S sums as ONE contiguous row of the row-major pose partials
+// [blocks][12 S]; the others have long retired.  Before: a counting sort of the block's lanes by scan -- three more barriers,
+// a ballot loop over the scans, a prefix pass -- one running block-wide barrier before the sums, 12 S pieces of 32 B stored to
+// as many pages per block, and a 30 MB memset of the pose columns per evaluation (113 us at C2, 65 % of the wave cycles
+// waiting).
+constexpr int kTicketScans = 16;          // the four partial rows cost 96 B of LDS per scan: sequences of up to 16 scans take the ticket form
+// (module-scope LDS word: the backward kernels zero it before their staging barrier, pose_ticket_init)
+__shared__ int s_pose_ticket;
+__device__ __forceinline__ void pose_ticket_init() { if (threadIdx.x == 0) s_pose_ticket = 0; }
+__device__ __forceinline__ void reduce_pose_grads_grouped(const PointInputs& in, int64_t blk, bool active, const double* gx,
+                                                          int scan, double* __restrict__ prow, double* s_val) {
+  constexpr int NW = kBlock / kWave;
+  __shared__ double s_part[NW][12 * kTicketScans];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int S = in.n_scans;
+  if (blk < 0) {                                            // padding block of the last round: its row holds zeros
+    for (int item = tid; item < S * 12; item += kBlock) prow[item] = 0.0;
+    return;
+  }
+  const uint16_t* seg = in.seg_start + blk * (S + 1);
+  // the scans of this wavefront's lanes: ascending by lane (the plan's grouping), idle lanes only at the block's end
+  const unsigned long long act = __ballot(active);
+  const int n_act = __popcll(act);
+  const int s_lo = n_act ? __builtin_amdgcn_readfirstlane(scan) : 0;
+  const int s_hi = n_act ? __builtin_amdgcn_readlane(scan, n_act - 1) : -1;
+  const int n_items = (s_hi - s_lo + 1) * 24;
+  // bounds of the first item of this lane: requested before the LDS hand-over
+  int rr0 = 0, b0 = 0, e0 = 0;
+  if (lane < n_items) { rr0 = s_lo + (lane >> 1) / 12; b0 = seg[rr0]; e0 = seg[rr0 + 1]; }
+  for (int item = lane; item < S * 12; item += kWave) s_part[wave][item] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) s_val[tid * kPoseRow + q] = active ? gx[q] : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // own lanes' values: the wavefront's LDS operations are in order
+  __builtin_amdgcn_wave_barrier();
+  const int w_beg = wave * kWave, w_end = w_beg + kWave;
+  for (int item = lane; item < n_items; item += kWave) {
+    const int pair = item >> 1, part = item & 1;
+    const int rs_ = pair / 12, q = pair - rs_ * 12, a = q >> 2, b = q & 3;
+    const int rr = s_lo + rs_;
+    const int sb = item == lane ? b0 : (int)seg[rr], se = item == lane ? e0 : (int)seg[rr + 1];
+    const int beg = max(sb, w_beg) + part, end = min(se, w_end);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int p = beg;
+    for (; p + 6 < end; p += 8) {
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        const double ga = s_val[(p + 2 * u_) * kPoseRow + a];
+        acc[u_] = __dadd_rn(acc[u_], b == 3 ? ga : __dmul_rn(ga, s_val[(p + 2 * u_) * kPoseRow + 3 + b]));
+      }
+    }
+    for (; p < end; p += 2) {
+      const double ga = s_val[p * kPoseRow + a];
+      acc[0] = __dadd_rn(acc[0], b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
+    }
+    double sum = __dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3]));
+    sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));         // even + odd half (the two lanes are neighbours)
+    if (part == 0) s_part[wave][rr * 12 + q] = sum;
+  }
+  // ticket: the wavefront that arrives last adds the rows up and stores the block's row
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  int old = 0;
+  if (lane == 0) old = atomicAdd(&s_pose_ticket, 1);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old != NW - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int item = lane; item < S * 12; item += kWave) {
+    double t = s_part[0][item];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = __dadd_rn(t, s_part[w][item]);
+    prow[item] = t;
+  }
+}
+
+// Sequences of 17 .. 64 scans: the same static segments, summed by the whole block behind one barrier (the partial rows of the
+// ticket form would take 24 KB of LDS).
+__device__ __forceinline__ void reduce_pose_grads_grouped_wide(const PointInputs& in, int64_t blk, bool active, const double* gx,
+                                                               double* __restrict__ prow, double* s_val) {
+  const int tid = threadIdx.x;
+  const int S = in.n_scans;
+  if (blk < 0) {
+    for (int item = tid; item < S * 12; item += kBlock) prow[item] = 0.0;
+    return;
+  }
+  const uint16_t* seg = in.seg_start + blk * (S + 1);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) s_val[tid * kPoseRow + q] = active ? gx[q] : 0.0;
+  __syncthreads();
+  for (int item = tid; item < S * 24; item += kBlock) {
+    const int pair = item >> 1, part = item & 1;
+    const int rr = pair / 12, q = pair - rr * 12, a = q >> 2, b = q & 3;
+    const int beg = (int)seg[rr] + part, end = (int)seg[rr + 1];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int p = beg;
+    for (; p + 6 < end; p += 8) {
+#pragma unroll
+      for (int u_ = 0; u_ < 4; ++u_) {
+        const double ga = s_val[(p + 2 * u_) * kPoseRow + a];
+        acc[u_] = __dadd_rn(acc[u_], b == 3 ? ga : __dmul_rn(ga, s_val[(p + 2 * u_) * kPoseRow + 3 + b]));
+      }
+    }
+    for (; p < end; p += 2) {
+      const double ga = s_val[p * kPoseRow + a];
+      acc[0] = __dadd_rn(acc[0], b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
+    }
+    double sum = __dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3]));
+    sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));
+    if (part == 0) prow[pair] = sum;
+  }
+}
+
 // Parameter gradients of one block into the partial rows of its wavefronts (row = 4 * block + wave; no LDS, no barrier:
 // every wavefront leaves as soon as its lane 0 has written its sums):
 //   [0,P) w, [P,2P) exponent, [2P, 2P + 12 S) poses.  Only the slots in use are reduced.  The pose slots are summed per
@@ -337,7 +451,7 @@ __device__ __forceinline__ void reduce_pose_grads(const PointInputs& in, bool ac
 template <typename T>
 __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool active, bool want_e, bool want_pose,
                                                    double* gw, double* ge, double* gT, int scan, double* lds,
-                                                   double* __restrict__ partials) {
+                                                   double* __restrict__ partials, int64_t blk = -2) {
   const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;              // slot a lives at partials[a * rs + row]
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   double* prow = partials + (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -350,7 +464,15 @@ __device__ __forceinline__ void reduce_param_grads(const PointInputs& in, bool a
       if (lane == 0) { prow[k * rs] = sw; prow[(P + k) * rs] = se; }
     }
   }
-  if (want_pose) reduce_pose_grads(in, active, gT, scan, lds, partials + (int64_t)blockIdx.x * kWavesPerBlock + 2 * P * rs);
+  // blk: the block's logical index where the caller's lanes are the plan's points in order (the grouped layout applies), -2 otherwise
+  if (!want_pose) return;
+  __shared__ double s_val[kBlock * kPoseRow];      // ONE staging array for whichever form runs (each function's own would add up: 14 KB apiece)
+  if (in.seg_start && blk != -2) {
+    double* prow = partials + 2 * P * rs + (int64_t)blockIdx.x * 12 * in.n_scans;
+    if (in.n_scans <= kTicketScans) reduce_pose_grads_grouped(in, blk, active, gT, scan, prow, s_val);
+    else reduce_pose_grads_grouped_wide(in, blk, active, gT, prow, s_val);
+  }
+  else reduce_pose_grads(in, active, gT, scan, lds, partials + (int64_t)blockIdx.x * kWavesPerBlock + 2 * P * rs, s_val);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,6 +536,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
   __shared__ double lds[(kBlock / kWave) * 2 * DC_MAX_MODEL_TERMS];
   __shared__ double s_pose[kLdsScans * 12];
   const PoseTile poses = in.dirs ? stage_poses(in, s_pose) : PoseTile{nullptr};
+  if (WANT_POSE) pose_ticket_init();
   __syncthreads();
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
@@ -462,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_kernel(
       if (in.dirs) points_bwd_point<T>(in, poses, mp, j, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
     }
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials, lane_perm ? -2 : blk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,6 +850,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
     if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
   }
   const uint32_t nd16 = nd * 16u;                           // positions are byte offsets; 0xFFFF (empty) clamps to the zero record
+  if (WANT_POSE) pose_ticket_init();
   __syncthreads();
   if (active) {
     double g[3] = {0.0, 0.0, 0.0};
@@ -767,7 +891,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_staged_kernel(
     if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
     if (in.dirs) points_bwd_point<T>(in, poses, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials, blk);
 }
 
 // Backward over a "lane run" table (dc_block_table_build_runs): the positions of a point's incoming edges are stored
@@ -838,6 +962,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
     if (threadIdx.x < RR) tile[threadIdx.x * cap + nd] = make_int4(0, 0, 0, 0);
   }
   const uint32_t nd16 = nd * 16u;
+  if (WANT_POSE) pose_ticket_init();
   __syncthreads();
   if (active) {
     double g[3] = {0.0, 0.0, 0.0};
@@ -857,7 +982,7 @@ __global__ __launch_bounds__(kBlock) void consistency_bwd_runs_kernel(
     if (grad_points) Row3<T, 4>::store(grad_points, j, g, QParams{});
     if (in.dirs) points_bwd_point<T>(in, poses, mp, j, raw, g, gw, ge, gT, want_e != 0, want_pose != 0, &scan);
   }
-  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials);
+  if (in.dirs) reduce_param_grads<T>(in, active, want_e, want_pose, gw, ge, gT, scan, lds, partials, blk);
 }
 
 // ================================================================================================
@@ -2104,7 +2229,7 @@ constexpr int kRedBlock = 1024;
 // Sum of p[threadIdx.x], p[threadIdx.x + 1024], ... in a fixed order with 32 loads in flight per lane: the rows were
 // written by blocks on every XCD, so each read is a trip to the fabric, and with four in flight the ~31 rows per lane
 // (N = 2 M) took eight dependent round trips.
-__device__ __forceinline__ double strided_sum(const double* __restrict__ p, int64_t n_rows) {
+__device__ __forceinline__ double strided_sum(const double* __restrict__ p, int64_t n_rows, int64_t stride = 1) {
   constexpr int U = 32;                  // 32 k rows (N = 2 M: one row per wavefront) in ONE round trip per lane
   double acc[U];
 #pragma unroll
@@ -2112,12 +2237,12 @@ __device__ __forceinline__ double strided_sum(const double* __restrict__ p, int6
   int64_t r = threadIdx.x;
   for (; r + (U - 1) * kRedBlock < n_rows; r += U * kRedBlock) {
 #pragma unroll
-    for (int u_ = 0; u_ < U; ++u_) acc[u_] += p[r + u_ * kRedBlock];
+    for (int u_ = 0; u_ < U; ++u_) acc[u_] += p[(r + u_ * kRedBlock) * stride];
   }
   {
     double last[U];                      // the tail's loads are issued together, too
 #pragma unroll
-    for (int u_ = 0; u_ < U; ++u_) last[u_] = (r + u_ * kRedBlock < n_rows) ? p[r + u_ * kRedBlock] : 0.0;
+    for (int u_ = 0; u_ < U; ++u_) last[u_] = (r + u_ * kRedBlock < n_rows) ? p[(r + u_ * kRedBlock) * stride] : 0.0;
 #pragma unroll
     for (int u_ = 0; u_ < U; ++u_) acc[u_] += last[u_];
   }
@@ -2150,18 +2275,23 @@ __global__ __launch_bounds__(kRedBlock) void reduce_partials_kernel(const double
 __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __restrict__ p_fwd, const double* __restrict__ p_bwd,
                                                                 int64_t rows_fwd, int64_t rows_bwd, int n_red, int n_out,
                                                                 double* __restrict__ out, AdamArgs adam,
-                                                                const int32_t* __restrict__ status) {
+                                                                const int32_t* __restrict__ status, int pose_first = -1,
+                                                                int pose_cols = 0) {
+  // pose_first >= 0: the accumulators from 2 + pose_first on (the pose slots) were written ROW-major [rows_bwd / 4][pose_cols]
+  // behind the column-major ones (the grouped backward: one row per block)
   __shared__ double lds[kRedBlock / kWave];
   const int a = blockIdx.x;                // grid = 2 + n_red blocks: only the sums that were asked for get a block
   if (a == 0)                              // block 0 also clears the slots of gradients that were not requested
     for (int z = 2 + n_red + threadIdx.x; z < n_out; z += kRedBlock) out[z] = 0.0;
   const bool flagged = a == 0 && threadIdx.x == 0 && status && *status != 0;      // requested before the rows, not after
-  const int64_t n_rows = a < 2 ? rows_fwd : rows_bwd;
-  const double* p = (a < 2 ? p_fwd + (int64_t)a * rows_fwd : p_bwd + (int64_t)(a - 2) * rows_bwd);
+  const bool pose_row = pose_first >= 0 && a >= 2 + pose_first;
+  const int64_t n_rows = a < 2 ? rows_fwd : (pose_row ? rows_bwd / kWavesPerBlock : rows_bwd);
+  const double* p = a < 2 ? p_fwd + (int64_t)a * rows_fwd
+                          : (pose_row ? p_bwd + (int64_t)pose_first * rows_bwd + (a - 2 - pose_first) : p_bwd + (int64_t)(a - 2) * rows_bwd);
   const bool step = adam.p && a >= 2 && a - 2 < adam.n && threadIdx.x == 0;
   double p0 = 0.0, m0 = 0.0, v0 = 0.0;
   if (step) { p0 = adam.p[a - 2]; m0 = adam.m[a - 2]; v0 = adam.v[a - 2]; }      // in flight together with the partial rows
-  const double s = wave_sum(strided_sum(p, n_rows));
+  const double s = wave_sum(strided_sum(p, n_rows, pose_row ? pose_cols : 1));
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) lds[wave] = s;
   __syncthreads();
@@ -2402,7 +2532,7 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
                                 const int32_t* scan_id, const double* poses, int n_scans, int model_kind, int n_terms,
                                 const double* w, const double* e, int want_exponent_grad, int want_pose_grad,
                                 void* grad_points, double* partials_ws, double* grads_out, hipStream_t stream, bool reduce,
-                                int64_t rec_rows) {
+                                int64_t rec_rows, const uint16_t* scan_seg = nullptr) {
   if (n < 0 || !points || !rec || (stride != 3 && stride != 4)) return DC_ERR_ARG;
   BlockTab tab{};
   RunTab rtab{};
@@ -2431,6 +2561,10 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   const int n_acc = 2 * n_terms + 12 * n_scans;
   if (n == 0) return params ? (int)hipMemsetAsync(grads_out, 0, n_acc * sizeof(double), stream) : DC_OK;
   PointInputs in = make_inputs(vps, dirs, depth, inc, lmask, scan_id, poses, n_scans, model_kind, n_terms, w, e);
+  // points grouped by scan inside every block (the plan's layout): per-scan pose sums over static lane ranges -- for the
+  // kernels whose lanes are the plan's points in order (not with a lane map), and while a block's scans fit the item loop
+  const bool grouped = scan_seg && want_pose_grad && !lane_perm && n_scans <= kMaxBlockScans && !reduce && params;   // (the caller's reduction knows the row-major pose rows)
+  in.seg_start = grouped ? scan_seg : nullptr;
   const int64_t rows = xcd_grid(n_blocks(n));
   const int64_t prows = rows * kWavesPerBlock;               // partial rows: one per wavefront
   dim3 grid((unsigned)rows), block(kBlock);
@@ -2439,7 +2573,7 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   if (rec_total >= (1ull << 32)) return DC_ERR_UNSUPPORTED;
   const uint32_t rec_bytes = (uint32_t)rec_total;
   const int n_red = want_pose_grad ? n_acc : 2 * n_terms;       // slots the kernel produces
-  if (params && want_pose_grad) {
+  if (params && want_pose_grad && !grouped) {               // (the grouped reduction writes every pose slot of every row itself)
     hipError_t err = hipMemsetAsync(partials_ws + (size_t)prows * 2 * n_terms, 0, (size_t)prows * 12 * n_scans * sizeof(double), stream);
     if (err != hipSuccess) return (int)err;
   }
@@ -2780,10 +2914,12 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     rc = consistency_bwd_impl(d->x, stride, d->dtype, d->point_fmt, d->qparams, d->rec, d->csr_ptr, d->csr_src, d->lane_perm,
                               d->bwd_table, d->n, d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                               d->n_terms, w, e, want_exponent_grad, want_pose_grad, nullptr, p_bwd, out + 2, stream, false,
-                              n_rows);
+                              n_rows, d->scan_seg);
   if (rc) return rc;
+  // (as consistency_bwd_impl decides: the grouped backward leaves the pose slots row-major, one row per block)
+  const bool grouped = want_grad && want_pose_grad && d->scan_seg && !d->lane_perm && d->n_scans <= kMaxBlockScans;
   hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_red), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
-                     n_red, 2 + n_acc, out, adam, (const int32_t*)d->status);
+                     n_red, 2 + n_acc, out, adam, (const int32_t*)d->status, grouped ? 2 * n_terms : -1, 12 * d->n_scans);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

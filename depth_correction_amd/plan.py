@@ -39,7 +39,8 @@ class SequencePlan:
     @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
-                 active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True):
+                 active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
+                 scan_group=True):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -51,6 +52,8 @@ class SequencePlan:
         :param lazy_backward: build the transposed neighbour lists / backward block table on first need instead of up front.
         :param basis: use the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis) whenever an evaluation asks for neither pose
                       nor exponent gradients: the basis rows are rebuilt only when the poses or the exponents change.
+        :param scan_group: group the points of every 256-point block by scan (contiguous per-scan lane ranges for the pose-gradient
+                           sums; the set of points per block, hence every other kernel's work, is unchanged).
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
                             the loss nor to any gradient); per-point outputs then cover the masked points only.
         """
@@ -98,6 +101,25 @@ class SequencePlan:
                 local = torch.argsort(pad.reshape(nb, 256), dim=1, stable=True)
                 pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
                 order = order[pos[pos < self.n]]
+            self.scan_seg = None
+            if scan_group and not degree_sort and 1 < self.n_scans <= 64:
+                # inside every block of 256 Morton-consecutive points, group the points by scan (stable: Morton order inside a
+                # group).  Which 256 points share a block does not change -- the LDS-staged gathers do not care about the lane
+                # order -- but a block's points of one scan become a contiguous lane range known from now on, which is what the
+                # pose-gradient sums of the backward need (dcSequenceDesc.scan_seg)
+                nb = (self.n + 255) // 256
+                sid = torch.full((nb * 256,), self.n_scans, dtype=torch.int64, device=dev)         # padding sorts last
+                sid[:self.n] = scan_id[order].long()
+                sid = sid.reshape(nb, 256)
+                local = torch.argsort(sid, dim=1, stable=True)
+                pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
+                order = order[pos[:self.n]] if self.n == nb * 256 else order[pos[pos < self.n]]
+                counts = torch.zeros((nb, self.n_scans + 1), dtype=torch.int64, device=dev)
+                counts.scatter_add_(1, sid, torch.ones_like(sid))
+                seg = torch.zeros((nb, self.n_scans + 1), dtype=torch.int64, device=dev)
+                seg[:, 1:] = counts[:, :self.n_scans].cumsum(1)
+                self.scan_seg = seg.to(torch.uint16).contiguous()
+                mark('plan_scan_groups')
             rank = torch.empty_like(order)
             rank[order] = torch.arange(self.n, device=dev)
             nbr_l = nbr.long()[order]
@@ -111,6 +133,7 @@ class SequencePlan:
             mark('plan_permute')
         else:
             self.order = self.rank = None
+            self.scan_seg = None
         if not bool(vps.any()):
             vps = None                      # sensor-frame scans: viewpoints are the origin, nothing to stream
         self.ps = ops.PointSet(vps, dirs, depth, inc, lmask, scan_id)
@@ -208,6 +231,7 @@ class SequencePlan:
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)
             d.partials_count = self.partials.numel()
             d.status = p(self.status)
+            d.scan_seg = p(getattr(self, 'scan_seg', None))
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
             d.loss_kind, d.normalization, d.sqrt_ = nv.LOSS_KINDS[self.loss], int(self.normalization), int(self.sqrt)

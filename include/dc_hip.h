@@ -389,6 +389,11 @@ typedef struct dcSequenceDesc {
                                       x = X0 + (sum_k w_k c_k) u, so an evaluation needs no pass over the points */
   int64_t partials_count;          /* doubles behind `partials`: at least dc_sequence_partials_count(n, n_terms, n_scans), checked by
                                       every call (DC_ERR_WORKSPACE) -- the chained steps keep their rows behind the ordinary columns */
+  const uint16_t* scan_seg;        /* [ceil(n / 256), n_scans + 1] or NULL.  Non-NULL promises that the points of every 256-point
+                                      block are grouped by scan id: block b's points of scan s are its lanes scan_seg[b (S + 1) + s]
+                                      .. scan_seg[b (S + 1) + s + 1].  Pose gradients (train.py:300-312 with pose corrections)
+                                      then sum per scan over those static ranges instead of counting-sorting the block's lanes at
+                                      run time; used for n_scans <= 64 */
 } dcSequenceDesc;
 
 /* Doubles of dcSequenceDesc.partials for a sequence of n points evaluated with up to n_terms weights and n_scans poses:

@@ -30,8 +30,8 @@ def test_knn_200k_scan_bit_exact_vs_ckdtree(room):
 
 
 def test_knn_2m_properties(room):
-    """2 M-point global cloud: self first, ascending distances, distances recomputable, agreement with cKDTree on a
-    random sample of 20 000 query rows."""
+    """2 M-point global cloud: self first, ascending distances, distances recomputable, and every row of the table -- indices and
+    fp64 distances -- equal to cKDTree's."""
     from depth_correction_amd import ops
     scans, poses = room
     xyz = np.concatenate([s.astype(np.float64) + p[:3, 3] for s, p in zip(scans, poses)]).astype(np.float32)
@@ -44,9 +44,10 @@ def test_knn_2m_properties(room):
     d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
     assert torch.allclose(torch.sqrt(d2), dist, rtol=1e-14, atol=0)
     from scipy.spatial import cKDTree
-    rows = np.random.default_rng(0).choice(n, 20_000, replace=False)
-    dref, iref = cKDTree(xyz.astype(np.float64)).query(xyz[rows].astype(np.float64), 10, workers=-1)
-    assert np.array_equal(npy(idx)[rows], iref) and np.array_equal(npy(dist)[rows], dref)
+    # the WHOLE table against cKDTree (2 M queries, ~5 s on the box's 16 threads), not a sample of its rows
+    x64 = xyz.astype(np.float64)
+    dref, iref = cKDTree(x64).query(x64, 10, workers=-1)
+    assert np.array_equal(npy(idx), iref) and np.array_equal(npy(dist), dref)
     ptr_, src = ops.knn_transpose(idx)
     assert int(ptr_[-1]) == n * 10 and bool((ptr_[1:] >= ptr_[:-1]).all())
     j = np.random.default_rng(1).integers(0, n, 1000)
@@ -384,6 +385,54 @@ def test_c2_full_size_chained_steps_equal_ordinary_steps_and_the_oracle_adam_loo
             np.testing.assert_allclose(ref_w[it], npy(wo).ravel(), rtol=1e-5)
     finally:
         torch.set_num_threads(threads)
+
+
+def test_c2_full_size_pose_gradients_vs_oracle(room):
+    """Pose-mode evaluation at N = 2 M (what train() runs with pose corrections: train.py:300-312, eval.py:68-82): dL/d[R|t] of
+    all ten scans and, through the pose chain, dL/d pose_deltas against the oracle's autograd (eval_sequence with
+    T = T0 . xyz_axis_angle_to_matrix(delta) at delta = 0), together with loss and dL/dw -- the sums the grouped per-scan
+    reduction of the backward produces (plan.scan_seg).  Bar: 1e-5 of each scan's largest entry (the entries of one scan's
+    3 x 4 gradient differ by orders of magnitude; the small ones are differences of large sums)."""
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.transform import corrected_poses
+    scans, poses = room
+    plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
+    assert plan.scan_seg is not None and plan.scan_seg.shape == ((plan.n + 255) // 256, plan.n_scans + 1)
+    dev = plan.device
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    deltas = torch.zeros((plan.n_scans, 6), dtype=torch.float64, device=dev, requires_grad=True)
+    T = corrected_poses(info['poses'], deltas)
+    out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+    plan.eval_native(w, e, plan.poses12(T.detach()), out, want_pose=True)
+    gT = out[6:].reshape(plan.n_scans, 3, 4)
+    T.backward(torch.cat([gT, torch.zeros((plan.n_scans, 1, 4), dtype=torch.float64, device=dev)], dim=1))
+    got = npy(out)
+    got_d = npy(deltas.grad)
+
+    oc = [dict(vps=c['vps'].double().cpu(), dirs=c['dirs'].double().cpu(), depth=c['depth'].double().cpu(),
+               inc=c['inc_angles'].double().cpu(), mask=c['mask'].cpu()) for c in info['clouds']]
+    wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)
+    eo = torch.tensor([[2.0, 4.0]], dtype=torch.float64)
+    To = info['poses'].cpu().clone().requires_grad_(True)
+    do = torch.zeros((plan.n_scans, 6), dtype=torch.float64, requires_grad=True)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        lo, _ = O.eval_sequence(oc, To, wo, eo, info['neighbors'].long().cpu(), info['mask'].cpu(), pose_deltas=do, reduction='sum')
+        lo.backward()
+    finally:
+        torch.set_num_threads(threads)
+    np.testing.assert_allclose(got[0], lo.item(), rtol=1e-5)
+    gw = npy(wo.grad).ravel()
+    np.testing.assert_allclose(got[2:4], gw, rtol=1e-5, atol=1e-6 * np.abs(gw).max())
+    ref_T = npy(To.grad)[:, :3, :]                                  # dL/d(T0): at delta = 0 the applied pose IS T0
+    ref_d = npy(do.grad)
+    got_T = got[6:].reshape(plan.n_scans, 3, 4)
+    for s in range(plan.n_scans):
+        np.testing.assert_allclose(got_T[s], ref_T[s], rtol=1e-5, atol=1e-5 * np.abs(ref_T[s]).max(), err_msg='scan %d [R|t]' % s)
+        np.testing.assert_allclose(got_d[s], ref_d[s], rtol=1e-5, atol=1e-5 * np.abs(ref_d[s]).max(), err_msg='scan %d deltas' % s)
+    assert np.abs(ref_d).max() > 0 and np.abs(got_T[:, :, 3].sum(0)).max() <= 1e-6 * np.abs(got_T[:, :, 3]).sum()
 
 
 def test_chained_wait_that_expires_is_reported_not_just_nan(room):
