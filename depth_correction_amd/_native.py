@@ -102,7 +102,8 @@ _SIGNATURES = {
 class BlockTableDesc(ctypes.Structure):
     """dcBlockTable of include/dc_hip.h."""
     _fields_ = [('blk_ptr', _vp), ('blk_ids', _vp), ('slot_ptr', _vp), ('loc', _vp), ('max_rows', ctypes.c_int32),
-                ('layout', ctypes.c_int32), ('run_ptr', _vp), ('own_base', _vp)]
+                ('layout', ctypes.c_int32), ('run_ptr', _vp), ('own_base', _vp), ('packed', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('row_ptr', _vp)]
 
 
 class IcpScan(ctypes.Structure):

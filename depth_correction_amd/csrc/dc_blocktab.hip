@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kBlock) void bt_slot_count_kernel(const int32_t* __
   for (int off = kWave / 2; off > 0; off >>= 1) deg = max(deg, __shfl_down(deg, off, kWave));
   if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(&s_max, deg);
   __syncthreads();
-  if (threadIdx.x == 0) cnt[blockIdx.x] = s_max;
+  // lists of varying length (CSR): whole trips of eight slots (the ragged kernels read eight positions per trip, unguarded)
+  if (threadIdx.x == 0) cnt[blockIdx.x] = row_ptr ? (s_max + 7) & ~7 : s_max;
 }
 
 // exclusive prefix sum of cnt[0..m) into out[0..m]; one block (m is the number of 256-row blocks)

@@ -679,6 +679,46 @@ __device__ __forceinline__ int gather_slots(const int4* tile, int cap, const typ
   return n_have;
 }
 
+// The slots beyond the first 16 (radius neighbourhoods: a hundred or two per point), in trips of eight: the positions of the
+// NEXT trip are requested before the rows of this one are read, and the eight row reads of a trip are in flight together.  One
+// slot per iteration -- a dependent {position load, LDS read} pair each -- left the kernel waiting on memory for most of a
+// 200-slot row.  `packed` (dcBlockTable.packed): rows fill their slots from 0 upwards, so a wavefront stops at the first trip
+// that is empty for all its lanes -- its own longest row, not the block's.
+constexpr int kTrip = 8;
+template <typename PT>
+__device__ __forceinline__ int gather_tail(const int4* tile, int cap, const typename Pt<PT>::Raw& ci, const uint16_t* lrow,
+                                           int nslots, bool packed, CovAcc& acc) {
+  constexpr int XR = Pt<PT>::kRow16;
+  int n_have = 0;
+  uint32_t nxt[kTrip];
+#pragma unroll
+  for (int u_ = 0; u_ < kTrip; ++u_) nxt[u_] = (kPreSlots + u_ < nslots) ? (uint32_t)lrow[(kPreSlots + u_) * kBlock] : kNoLoc;
+  for (int q0 = kPreSlots; q0 < nslots; q0 += kTrip) {
+    uint32_t l[kTrip];
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) l[u_] = nxt[u_];
+    if (packed && __all((int)(l[0] == kNoLoc))) break;
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) nxt[u_] = (q0 + kTrip + u_ < nslots) ? (uint32_t)lrow[(q0 + kTrip + u_) * kBlock] : kNoLoc;
+    typename Pt<PT>::Raw cj[kTrip];
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) {
+      int4 piece[XR];
+      read_row<XR>(tile, cap, l[u_] != kNoLoc ? l[u_] : 0u, piece);
+      cj[u_] = Pt<PT>::from_row(piece);
+    }
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) {
+      const bool have = l[u_] != kNoLoc;
+      double d[3];
+      Pt<PT>::delta(have ? cj[u_] : ci, ci, d);
+      cov_add_d(acc, d[0], d[1], d[2]);
+      n_have += have ? 1 : 0;
+    }
+  }
+  return n_have;
+}
+
 template <typename T, typename PT, bool FULL_EIG>
 __global__ __launch_bounds__(kBlock) void consistency_fwd_staged_kernel(
     const PT* __restrict__ x, BlockTab tab, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
@@ -1628,6 +1668,48 @@ __device__ __forceinline__ void chain_term_f32(const int4* tile, int cap, uint32
   if constexpr (P > 2) gw[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + (size_t)cap * 32)->x), gw[2]);
 }
 
+// the second sweep over the slots beyond the first 16, in the same trips of eight; a trip's float32 sums join the fp64 sums trip by
+// trip (a row of two hundred neighbours is too long for one float32 running sum)
+template <int P>
+__device__ __forceinline__ void chain_tail_f32(const int4* tile, int cap, const uint16_t* lrow, int nslots, bool packed, const Pt<q32>::Raw& ci,
+                                               const float* cmf, const float* vs, const float* vu, float c2f, double* gw) {
+  uint32_t nxt[kTrip];
+#pragma unroll
+  for (int u_ = 0; u_ < kTrip; ++u_) nxt[u_] = (kPreSlots + u_ < nslots) ? (uint32_t)lrow[(kPreSlots + u_) * kBlock] : kNoLoc;
+  for (int q0 = kPreSlots; q0 < nslots; q0 += kTrip) {
+    uint32_t l[kTrip];
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) l[u_] = nxt[u_];
+    if (packed && __all((int)(l[0] == kNoLoc))) break;
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) nxt[u_] = (q0 + kTrip + u_ < nslots) ? (uint32_t)lrow[(q0 + kTrip + u_) * kBlock] : kNoLoc;
+    float g[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) g[k] = 0.0f;
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) chain_term_f32<P>(tile, cap, l[u_], l[u_] != kNoLoc, ci, cmf, vs, vu, c2f, g);
+#pragma unroll
+    for (int k = 0; k < P; ++k) gw[k] += (double)g[k];
+  }
+}
+template <typename PT, int P>
+__device__ __forceinline__ void chain_tail(const int4* tile, int cap, const uint16_t* lrow, int nslots, bool packed, const double* mean,
+                                           const double* v0, double c1, double c2, double* gw) {
+  uint32_t nxt[kTrip];
+#pragma unroll
+  for (int u_ = 0; u_ < kTrip; ++u_) nxt[u_] = (kPreSlots + u_ < nslots) ? (uint32_t)lrow[(kPreSlots + u_) * kBlock] : kNoLoc;
+  for (int q0 = kPreSlots; q0 < nslots; q0 += kTrip) {
+    uint32_t l[kTrip];
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) l[u_] = nxt[u_];
+    if (packed && __all((int)(l[0] == kNoLoc))) break;
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) nxt[u_] = (q0 + kTrip + u_ < nslots) ? (uint32_t)lrow[(q0 + kTrip + u_) * kBlock] : kNoLoc;
+#pragma unroll
+    for (int u_ = 0; u_ < kTrip; ++u_) chain_term<PT, P>(tile, cap, l[u_], l[u_] != kNoLoc, mean, v0, c1, c2, gw);
+  }
+}
+
 // ---- wavefront sums through DPP -------------------------------------------------------------------------------------------
 // One 32-bit half of a double moved by a DPP row operation (quad permutes, rotations inside a row of 16 lanes)
 template <int CTRL>
@@ -1994,7 +2076,7 @@ template <typename PT, int P>
 __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, int cap, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
-    StepChain ch) {
+    StepChain ch, int packed) {
   extern __shared__ int4 tile[];
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   __shared__ int s_ok;
@@ -2056,7 +2138,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     int n_have = 0;
     if (__any((int)miss)) n_have = gather_slots<PT, true>(tile, cap, ci, pre, nslots, acc);
     else n_have = gather_slots<PT, false>(tile, cap, ci, pre, nslots, acc);
-    for (int q = kPreSlots; q < nslots; ++q) n_have += slot_add<PT, true>(tile, cap, ci, lrow[q * kBlock], acc);
+    if (nslots > kPreSlots) n_have += gather_tail<PT>(tile, cap, ci, lrow, nslots, packed != 0, acc);
     acc.W = (double)n_have;
     double cm[3], v0[3], c1, c2;
     step_point2<PT, 2>(acc, n_have, false, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
@@ -2071,25 +2153,181 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
 #pragma unroll
       for (int q = 0; q < kPreSlots; ++q)
         if (q < nslots) chain_term_f32<P>(tile, cap, pre[q], pre[q] != kNoLoc, ci, cmf, vs, vu, c2f, gwf);
-      for (int q = kPreSlots; q < nslots; ++q) {
-        const uint32_t l = lrow[q * kBlock];
-        chain_term_f32<P>(tile, cap, l, l != kNoLoc, ci, cmf, vs, vu, c2f, gwf);
-      }
 #pragma unroll
-      for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * u;
+      for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k];
+      if (nslots > kPreSlots) chain_tail_f32<P>(tile, cap, lrow, nslots, packed != 0, ci, cmf, vs, vu, c2f, gw);
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] *= u;
     } else {
       double mean[3];
       StepRow<PT, P>::mean_of(ci, cm, mean);
 #pragma unroll
       for (int q = 0; q < kPreSlots; ++q)
         if (q < nslots) chain_term<PT, P>(tile, cap, pre[q], pre[q] != kNoLoc, mean, v0, c1, c2, gw);
-      for (int q = kPreSlots; q < nslots; ++q) {
-        const uint32_t l = lrow[q * kBlock];
-        chain_term<PT, P>(tile, cap, l, l != kNoLoc, mean, v0, c1, c2, gw);
-      }
+      if (nslots > kPreSlots) chain_tail<PT, P>(tile, cap, lrow, nslots, packed != 0, mean, v0, c1, c2, gw);
 #pragma unroll
       for (int k = 0; k < P; ++k) gw[k] *= u;
     }
+  }
+  if (timed_out) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
+  step_partials<P, true>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
+}
+
+// ---- the one-pass kernel for ball neighbourhoods on float32 clouds (round 4) ------------------------------------------------
+// The reference's default neighbourhood is a ball (nn_type = ball, nn_r = 0.25 m, config.py:187-189; 0.4 m in train_demo:61-63):
+// on voxel-filtered scans a row has 70-200 neighbours, so the time is the two sweeps over the slots, not the per-centre tail.
+// consistency_step_basis_slots_kernel spent ~58 VALU instructions per (centre, neighbour) pair at 0.65 of the issue peak; the
+// arithmetic needs ~40.  What went:
+//   * validity handling: an empty slot reads the lane's OWN row, whose difference to the centre is exactly zero -- one select on
+//     the 16-bit position instead of selects on every coordinate and a count; the number of neighbours is the row's length
+//     (dcBlockTable.row_ptr);
+//   * address arithmetic: the tile is static LDS (CAP rows), so both pieces of a row are immediates off the 16-bit position;
+//   * the dependent {position load, row read} pair per slot: trips of eight, the next trip's positions requested before the
+//     rows of this one are read, and a wavefront stops at ITS longest row, not the block's;
+//   * the first-sixteen-slots special case (registers kept across the per-centre tail).
+// The second sweep accumulates float32 per trip and fp64 across trips.  Same sums as the slots kernel to the rounding of that
+// order of additions.
+template <int P, int CAP>
+__global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
+    PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, const int32_t* __restrict__ row_ptr, int64_t n,
+    const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
+    StepChain ch) {
+  using Row = StepRow<q32, P>;
+  __shared__ int4 tile[Row::kPieces * CAP];
+  __shared__ double s_w[DC_MAX_MODEL_TERMS];
+  __shared__ int s_ok;
+  __shared__ double s_front[kBlock / kWave];
+  const bool chained = ch.ready != nullptr;
+  if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  double acc2[2] = {0.0, 0.0}, gw[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) gw[k] = 0.0;
+  const int64_t i = blk * kBlock + threadIdx.x;
+  const bool live = blk >= 0 && i < n;
+  int32_t nslots = 0, own = 0, base = 0, nd = 0, deg = 0;
+  const uint16_t* lrow = tab.loc;
+  uint32_t first[kTrip];
+  if (blk >= 0) {
+    const int32_t s0 = tab.slot_ptr[blk];
+    nslots = tab.slot_ptr[blk + 1] - s0;
+    lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
+    if (live) deg = row_ptr[i + 1] - row_ptr[i];
+    own = own_base[blk];
+    base = tab.blk_ptr[blk];
+    nd = tab.blk_ptr[blk + 1] - base;
+  }
+  const uint32_t own_off = (uint32_t)(own + (int)threadIdx.x) * 16u;      // where padding slots point (and idle lanes read)
+#pragma unroll
+  for (int u_ = 0; u_ < kTrip; ++u_) first[u_] = (live && nslots > 0) ? (uint32_t)lrow[u_ * kBlock] : kNoLoc;     // (slot counts are multiples of 8)
+  double wq[P];
+  bool timed_out = false;
+  if (chained) {                           // as in consistency_step_basis_kernel: fetch, wait for the weights, place
+    typename Row::Raw r0, r1;
+    const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
+    if (t0 < nd) r0 = Row::fetch(pb, tab.blk_ids[base + t0]);
+    if (t1 < nd) r1 = Row::fetch(pb, tab.blk_ids[base + t1]);
+    timed_out = !chain_wait(ch, P, &s_ok);
+    stage_weights(pb, s_w, true);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+    if (t0 < nd) Row::place(r0, wq, tile, CAP, t0);
+    if (t1 < nd) Row::place(r1, wq, tile, CAP, t1);
+    for (int t = threadIdx.x + 2 * kBlock; t < nd; t += kBlock) Row::stage(pb, wq, tab.blk_ids[base + t], tile, CAP, t);
+  } else {
+    stage_weights(pb, s_w);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
+    for (int t = threadIdx.x; t < nd; t += kBlock) Row::stage(pb, wq, tab.blk_ids[base + t], tile, CAP, t);
+  }
+  __syncthreads();
+  if (live) {
+    const char* tb = reinterpret_cast<const char*>(tile);
+    const Pt<q32>::Raw ci = Pt<q32>::from_row(reinterpret_cast<const int4*>(tb + own_off));
+    // the longest row among this wavefront's lanes bounds its trips
+    int wmax = deg;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off, kWave));
+    wmax = __builtin_amdgcn_readfirstlane(min(wmax, nslots));      // (uniform: scalar loop control)
+    CovAcc acc;
+    cov_init(acc);
+    // one trip: the eight rows at positions l[] into the moments; the NEXT trip's positions (pn, immediates off one pointer) are
+    // requested first.  Slot counts are multiples of eight and the table ends with eight rows of slack: no guards.
+    auto sweep1 = [&](const uint32_t* l, uint32_t* nx, const uint16_t* pn) {
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)pn[u_ * kBlock];
+      int4 r[kTrip];
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_) r[u_] = *reinterpret_cast<const int4*>(tb + (l[u_] == kNoLoc ? own_off : l[u_]));
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_)
+        cov_add_d(acc, (double)(r[u_].x - ci.v[0]), (double)(r[u_].y - ci.v[1]), (double)(r[u_].z - ci.v[2]));
+    };
+    {
+      uint32_t la[kTrip], lb[kTrip];
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_) la[u_] = first[u_];
+      const uint16_t* pn = lrow + kTrip * kBlock;
+      for (int q0 = 0; q0 < wmax; q0 += 2 * kTrip) {        // two trips per iteration: the position registers alternate, no moves
+        sweep1(la, lb, pn);
+        pn += kTrip * kBlock;
+        if (q0 + kTrip >= wmax) break;
+        sweep1(lb, la, pn);
+        pn += kTrip * kBlock;
+      }
+    }
+    acc.W = (double)deg;
+    double cm[3], v0[3], c1, c2;
+    step_point2<q32, 2>(acc, deg, false, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+    const double u = Pt<q32>::unit(qp);
+    float cmf[3], vs[3], vu[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
+    const float c2f = (float)c2;
+    auto sweep2 = [&](const uint32_t* l, uint32_t* nx, const uint16_t* pn) {
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)pn[u_ * kBlock];
+      float g[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) g[k] = 0.0f;
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_) {
+        const bool have = l[u_] != kNoLoc;                 // (packed rows: the same as slot < deg)
+        const char* row = tb + (have ? l[u_] : own_off);
+        const int4 p0 = *reinterpret_cast<const int4*>(row);
+        const int4 p1 = *reinterpret_cast<const int4*>(row + CAP * 16);
+        const float e0 = (float)(p0.x - ci.v[0]) - cmf[0], e1 = (float)(p0.y - ci.v[1]) - cmf[1], e2 = (float)(p0.z - ci.v[2]) - cmf[2];
+        const float u0 = __int_as_float(p0.w), u1 = __int_as_float(p1.x), u2 = __int_as_float(p1.y);
+        const float al = fmaf(vs[2], e2, fmaf(vs[1], e1, vs[0] * e0));
+        const float be = fmaf(vu[2], u2, fmaf(vu[1], u1, vu[0] * u0));
+        const float ga = fmaf(e2, u2, fmaf(e1, u1, e0 * u0));
+        float tj = fmaf(al, be, -(c2f * ga));
+        if (!have) tj = 0.0f;                              // an empty slot (the lane's own row) is not a neighbour
+        g[0] = fmaf(tj, __int_as_float(p1.z), g[0]);
+        if constexpr (P > 1) g[1] = fmaf(tj, __int_as_float(p1.w), g[1]);
+        if constexpr (P > 2) g[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + CAP * 32)->x), g[2]);
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] += (double)g[k];
+    };
+    {
+      uint32_t la[kTrip], lb[kTrip];
+#pragma unroll
+      for (int u_ = 0; u_ < kTrip; ++u_) la[u_] = first[u_];
+      const uint16_t* pn = lrow + kTrip * kBlock;
+      for (int q0 = 0; q0 < wmax; q0 += 2 * kTrip) {
+        sweep2(la, lb, pn);
+        pn += kTrip * kBlock;
+        if (q0 + kTrip >= wmax) break;
+        sweep2(lb, la, pn);
+        pn += kTrip * kBlock;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) gw[k] *= u;
   }
   if (timed_out) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
   step_partials<P, true>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
@@ -2826,7 +3064,20 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       const int var = g_step_var.load();
       // float32 clouds with a [rows, K] table: the kernel with fp64 row differences in LDS (48-B rows + its scratch, all dynamic)
       const bool q32_step = q32_pts && var == 1 && (fixed_k == 10 || fixed_k == 4 || fixed_k == 8 || fixed_k == 16) && rows_s <= kStepQ32Cap;
-      if (q32_step) {
+      // ball neighbourhoods on float32 clouds: rows of any length from a table whose padding slots point at the lanes' own rows
+      const bool ragged_step = q32_pts && var != 8 && d->fwd_table->packed == 1 && d->fwd_table->row_ptr && d->fwd_table->own_base && !d->centre_idx &&
+                               (rows_s <= 1024 || (n_terms <= 2 && rows_s <= 1920));
+      if (ragged_step) {
+        ProfScope prof(1);
+#define RAGGED_LAUNCH(P, CAP) DC_TIMED_LAUNCH((consistency_step_ragged_q32_kernel<P, CAP>), grid, block, 0, stream, pb, tab, d->fwd_table->own_base, \
+                                              d->fwd_table->row_ptr, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch)
+        // the static tile in four sizes (32 / 40 / 48 / 60 KB for two-piece rows: 4 / 4 / 3 / 2 blocks per CU)
+        if (rows_s <= 1024) { if (n_terms == 2) RAGGED_LAUNCH(2, 1024); else if (n_terms == 1) RAGGED_LAUNCH(1, 1024); else RAGGED_LAUNCH(3, 1024); }
+        else if (rows_s <= 1280) { if (n_terms == 2) RAGGED_LAUNCH(2, 1280); else RAGGED_LAUNCH(1, 1280); }
+        else if (rows_s <= 1536) { if (n_terms == 2) RAGGED_LAUNCH(2, 1536); else RAGGED_LAUNCH(1, 1536); }
+        else { if (n_terms == 2) RAGGED_LAUNCH(2, 1920); else RAGGED_LAUNCH(1, 1920); }
+#undef RAGGED_LAUNCH
+      } else if (q32_step) {
         ProfScope prof(1);
         static_assert(kStepQ32Cap == 512, "the profiler names the instantiation by its literal arguments");
 #define STEPQ_LAUNCH(NS, P) DC_TIMED_LAUNCH((consistency_step_q32_kernel<NS, P, 512>), grid, block, 0, stream, pb, tab, d->fwd_table->own_base, \
@@ -2844,7 +3095,8 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                             else if (fixed_k == 4) STEP_LAUNCH((consistency_step_basis_kernel<PT, 4, P, kStepVar>)); \
                             else if (fixed_k == 8) STEP_LAUNCH((consistency_step_basis_kernel<PT, 8, P, kStepVar>)); \
                             else if (fixed_k == 16) STEP_LAUNCH((consistency_step_basis_kernel<PT, 16, P, kStepVar>)); \
-                            else STEP_LAUNCH((consistency_step_basis_slots_kernel<PT, P>)); } while (0)
+                            else DC_TIMED_LAUNCH((consistency_step_basis_slots_kernel<PT, P>), grid, block, lds_s, stream, pb, tab, d->fwd_table->own_base, rows_s, \
+                                                 d->centre_idx, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch, d->fwd_table->packed); } while (0)
 #define STEP(PT) do { if (n_terms == 2) STEP_NS(PT, 2); else if (n_terms == 1) STEP_NS(PT, 1); else STEP_NS(PT, 3); } while (0)
         if (q32_pts) STEP(q32); else STEP(double);
 #undef STEP

@@ -13,7 +13,7 @@ from . import _native as nv
 from ._native import lib, check, need, ptr, stream_ptr, dtype_code, on_device
 
 __all__ = [
-    'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
+    'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'table_to_csr', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
     'IcpSequence', 'shadow_mask', 'shadow_filter', 'correct_depth', 'cloud_from_points',
     'as_index32',
@@ -120,14 +120,14 @@ class BlockTable:
     [rows, K] table) or as per-row runs padded to four (``run_ptr``; the backward's incoming-edge lists).  Lets the
     fused kernels gather from LDS."""
 
-    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows, run_ptr=None, own_base=None):
+    def __init__(self, blk_ptr, blk_ids, slot_ptr, loc, max_rows, n_rows, run_ptr=None, own_base=None, packed=0, row_ptr=None):
         self.blk_ptr, self.blk_ids, self.slot_ptr, self.loc, self.run_ptr = blk_ptr, blk_ids, slot_ptr, loc, run_ptr
-        self.own_base = own_base
+        self.own_base, self.packed, self.row_ptr = own_base, int(packed), row_ptr
         self.max_rows, self.n_rows = int(max_rows), int(n_rows)
         self.layout = nv.DC_TABLE_SLOTS if run_ptr is None else nv.DC_TABLE_RUNS
         self.device = blk_ptr.device
         self.desc = nv.BlockTableDesc(ptr(blk_ptr), ptr(blk_ids), ptr(slot_ptr), ptr(loc), self.max_rows, self.layout, ptr(run_ptr),
-                                      ptr(own_base))
+                                      ptr(own_base), self.packed, 0, ptr(row_ptr))
 
     def ref(self):
         return ctypes.cast(ctypes.pointer(self.desc), ctypes.c_void_p)
@@ -187,20 +187,35 @@ def block_table(nbr=None, csr=None, layout=None, own_rows=True):
             cnt = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
             check(lib().dc_block_table_slots(ptr(row_ptr), n_rows, k, ptr(cnt), ptr(slot_ptr), stream_ptr()), 'dc_block_table_slots')
             n_slot_rows = int(slot_ptr[-1])                          # one synchronisation, at set-up time
-        loc = torch.empty((max(n_slot_rows, 1) * 256,), dtype=torch.uint16, device=dev)
+        # (eight slot rows of slack: the ragged kernels request the next trip's positions before they know it is the last one)
+        loc = torch.empty(((max(n_slot_rows, 1) + 8) * 256,), dtype=torch.uint16, device=dev)
         check(lib().dc_block_table_build(ptr(row_ptr), ptr(ids), n_rows, k, n_refs, ptr(slot_ptr), n_slot_rows, ptr(blk_ptr),
                                          ptr(blk_ids), ptr(loc), ptr(info), ptr(ws), nbytes, stream_ptr()), 'dc_block_table_build')
     total, max_rows, overflow, _ = info.tolist()
     if overflow:
         return None
     own_base = None
-    if row_ptr is None and own_rows:
+    if layout == 'slots' and own_rows and (row_ptr is None or own_rows == 'csr'):
         # rows and ids of a k-NN table share one index space: where does every block find its own rows in its list?
         own_base = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)
         check(lib().dc_block_table_own_base(ptr(blk_ptr), ptr(blk_ids), n_rows, ptr(own_base), stream_ptr()),
               'dc_block_table_own_base')
+    packed = 1 if (row_ptr is not None and layout == 'slots') else 0
+    # (forward tables from CSR lists keep the offsets: the ragged one-pass kernel takes the rows' lengths from them; it needs every
+    # block's own rows in its list -- own_base >= 0 throughout -- because its padding slots read the lane's own row)
+    own_all = packed and own_base is not None and nb > 0 and bool((own_base >= 0).all())
     return BlockTable(blk_ptr, blk_ids[:max(total, 1)].clone(), slot_ptr, loc, max_rows, n_rows, run_ptr=run_ptr,
-                      own_base=own_base)
+                      own_base=own_base, packed=packed, row_ptr=row_ptr if own_all else None)
+
+
+def table_to_csr(nbr):
+    """(ptr int32 [rows + 1], ids int32 [E]) of a padded neighbour table [rows, Kmax] with -1 for missing entries (radius
+    neighbourhoods, nearest_neighbors.py:69-73): its valid entries row by row, in their order."""
+    need(nbr, (None, None), dtype=torch.int32, name='neighbors')
+    valid = nbr >= 0
+    ptr_ = torch.zeros((nbr.shape[0] + 1,), dtype=torch.int32, device=nbr.device)
+    ptr_[1:] = valid.sum(dim=1).cumsum(dim=0).to(torch.int32)
+    return ptr_, nbr[valid].contiguous()
 
 
 @on_device

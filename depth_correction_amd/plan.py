@@ -154,7 +154,15 @@ class SequencePlan:
         mark('plan_transpose')
         self.lane_perm = None          # (dc_consistency_bwd can also take a per-block lane map; the layout does it here)
         # block tables: distinct rows per 256-point block + 16-bit block-local positions (gathers served from LDS)
-        self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None) if block_tables else None
+        self.fwd_table = None
+        if block_tables:
+            # a ragged table (radius neighbourhoods: rows padded with -1 to the longest one) goes in as CSR lists: every block then
+            # has as many slots as its longest row, not as the longest row of the whole cloud, and the rows are packed (no holes)
+            ragged = nbr.shape[1] > 16 and nbr.shape[0] > 0 and bool((nbr[:, -1] < 0).any())
+            if ragged:
+                self.fwd_table = ops.block_table(csr=ops.table_to_csr(nbr), layout='slots', own_rows='csr' if self.centre_idx is None else False)
+            else:
+                self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None)
         mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 

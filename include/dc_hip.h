@@ -201,6 +201,13 @@ typedef struct dcBlockTable {
   const int32_t* own_base;    /* int32 [n_blocks] or NULL (dc_block_table_own_base): position of row 256 b in block b's list when
                                  all of the block's own rows are in it (a k-NN table references every point from its own row),
                                  else -1; lets the forward take each lane's centre point from the staged rows */
+  int32_t packed;             /* DC_TABLE_SLOTS: 1 = every row's references fill its slots from 0 upwards without holes (tables built
+                                 from CSR lists are; a [rows, K] table with -1 entries between valid ones is not): a wavefront of
+                                 the forward kernels may then stop at the first trip of slots that is empty for all its lanes */
+  int32_t reserved;
+  const int32_t* row_ptr;     /* packed tables whose own_base is >= 0 for EVERY block: int32 [rows + 1], the CSR offsets the table was
+                                 built from (row lengths), else NULL.  With it the one-pass evaluation of float32 clouds takes
+                                 consistency_step_ragged_q32_kernel (ball neighbourhoods: config.py:187-189) */
 } dcBlockTable;
 int dc_block_table_slots(const int32_t* row_ptr, int64_t n_rows, int k, int32_t* slot_cnt_ws, int32_t* slot_ptr,
                          dcStream_t stream);

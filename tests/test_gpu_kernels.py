@@ -555,7 +555,7 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
                 assert 'basis' not in names['consistency_fwd'] and 'basis' not in names['consistency_bwd'] and 'points_fwd' in timed, names
             elif path == 'default' and one_pass_expected:
                 # (float32 clouds with a [rows, K] table take the kernel with the static LDS tile)
-                assert names['consistency_fwd'].startswith(('consistency_step_basis_slots_kernel',) if ragged else
+                assert names['consistency_fwd'].startswith(('consistency_step_basis_slots_kernel', 'consistency_step_ragged_q32_kernel') if ragged else
                                                            ('consistency_step_basis_kernel', 'consistency_step_q32_kernel')), names
                 assert 'consistency_bwd' not in timed and 'points_fwd' not in timed
             else:

@@ -2,7 +2,7 @@
 """Workloads for profiling the kernels bench.py's timed loop does not launch (rocprofv3 runs this script once per workload so
 that a kernel name stands for one problem size):
 
-    python3 tools/profile_paths.py --what knn2m | knn200k | c1 | pose | c4 | online [--reps N]
+    python3 tools/profile_paths.py --what knn2m | knn200k | c1 | pose | c4 | online | radius | radius25 [--reps N]
 
 knn2m / knn200k: dc_knn_build (knn_query_kernel<10>) on the 2 M-point global cloud / one 200 k-point scan;  c1: features_fwd_kernel
 <float, 3> on a 200 k-point scan (BASELINE config 1);  pose: the C2 sequence with pose gradients (general path: points_fwd, fixed-K
@@ -24,10 +24,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--what', required=True)
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--step-var', type=int, default=None, help='dc_set_option(6, v) before the workload (A-B runs)')
     args = ap.parse_args()
     from depth_correction_amd import ops
     from depth_correction_amd.dataset import RoomBoxDataset, KittiLikeDataset
     dev = torch.device('cuda:0')
+    if args.step_var is not None:
+        from depth_correction_amd import _native as nv
+        nv.check(nv.lib().dc_set_option(6, args.step_var), 'dc_set_option')
     if args.what in ('knn2m', 'knn200k', 'c1', 'pose', 'online'):
         ds = RoomBoxDataset(n_pts=200_000, n_poses=10, seed_base=1000, dtype=np.float32)
         scans = [np.stack([c[f] for f in 'xyz'], axis=1) for c, _ in ds]
@@ -77,6 +81,20 @@ def main():
         raw = torch.as_tensor(scans[0], device=dev)
         for _ in range(args.reps):
             correct_cloud(cloud_on_device(raw, dtype=torch.float32, device=dev), model, cfg)
+    elif args.what in ('radius', 'radius25'):
+        # ball neighbourhoods (the reference's default): ten room scans, voxel grid 0.2 m, r = 0.4 m / 0.25 m
+        from depth_correction_amd.filters import filter_grid
+        from depth_correction_amd.pipeline import build_sequence
+        from depth_correction_amd.plan import SequenceTrainer
+        ds = RoomBoxDataset(n_pts=200_000, n_poses=10, seed_base=1000, dtype=np.float32)
+        rng = np.random.default_rng(135)
+        kept = [filter_grid(np.stack([c[f] for f in 'xyz'], axis=1), 0.2, keep='random', rng=rng) for c, _ in ds]
+        poses = np.stack([p for _, p in ds])
+        plan, info = build_sequence(kept, poses, k=None, r=0.4 if args.what == 'radius' else 0.25, dtype=torch.float32, device=dev)
+        tr = SequenceTrainer([plan], [1e-3, 2e-3], [2.0, 4.0], [info['poses']], lr=1e-3, chained=True)
+        for _ in range(args.reps):
+            tr.step()
+        tr.flush()
     else:
         raise SystemExit('unknown workload ' + args.what)
     torch.cuda.synchronize()
