@@ -2181,7 +2181,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
 //   * validity handling: an empty slot reads the lane's OWN row, whose difference to the centre is exactly zero -- one select on
 //     the 16-bit position instead of selects on every coordinate and a count; the number of neighbours is the row's length
 //     (dcBlockTable.row_ptr);
-//   * address arithmetic: the tile is static LDS (CAP rows), so both pieces of a row are immediates off the 16-bit position;
+//   * address arithmetic: the tile's row capacity is a template argument, so the second piece of a row is an immediate off the
+//     16-bit position;
 //   * the dependent {position load, row read} pair per slot: trips of eight, the next trip's positions requested before the
 //     rows of this one are read, and a wavefront stops at ITS longest row, not the block's;
 //   * the first-sixteen-slots special case (registers kept across the per-centre tail).
@@ -2193,7 +2194,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
     StepChain ch) {
   using Row = StepRow<q32, P>;
-  __shared__ int4 tile[Row::kPieces * CAP];
+  extern __shared__ int4 tile[];                   // Row::kPieces * CAP rows of 16 B (dynamic: up to 128 KB, see ragged_launch)
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   __shared__ int s_ok;
   __shared__ double s_front[kBlock / kWave];
@@ -2581,6 +2582,24 @@ static std::atomic<int> g_step_var{1};          // dc_set_option(6, v): 1 = cons
                                                 // 7 = consistency_step_basis_kernel<.., kStepVar> for them too, 0 = its round-2 form (K = 10, P = 2 only: A-B baseline)
 static std::atomic<int> g_chain_spin{1 << 22};  // dc_set_option(5, n): polls of a chained launch's wait for its weights (tests force 0)
 static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's basis rows (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
+
+// consistency_step_ragged_q32_kernel with a tile of CAP rows: more than 64 KB of LDS per block needs the attribute (once per
+// instantiation and process).  Capacities up to the table's own limit (4095 rows), so every ball-neighbourhood table that can be
+// built runs fused -- at one block per CU for the densest (voxel grid 0.1 m, r = 0.25 m: 2 000 distinct rows per block).
+template <int P, int CAP>
+static int ragged_launch(dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const PointBasis& pb, const BlockTab& tab,
+                         const dcBlockTable* t, int64_t n_rows, const uint8_t* mask, const LossParams& lp, const QParams& qp, double* p_fwd,
+                         double* p_bwd, const StepChain& ch) {
+  constexpr size_t bytes = (size_t)StepRow<q32, P>::kPieces * CAP * 16;
+  static std::atomic<bool> attr_set{false};
+  if (bytes > 60 * 1024 && !attr_set.exchange(true)) {
+    hipError_t err = hipFuncSetAttribute((const void*)consistency_step_ragged_q32_kernel<P, CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err != hipSuccess) { attr_set.store(false); return (int)err; }
+  }
+  hipExtLaunchKernelGGL((consistency_step_ragged_q32_kernel<P, CAP>), grid, dim3(kBlock), bytes, stream, ev0, ev1, 0, pb, tab, t->own_base, t->row_ptr, n_rows,
+                        mask, lp, qp, p_fwd, p_bwd, ch);
+  return DC_OK;
+}
 
 // a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
 static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit,
@@ -3025,15 +3044,21 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   size_t lds_f = 0, lds_b = 0;
   int rows_f = 0, rows_b = 0;
   const bool q32_pts = d->point_fmt == DC_Q32 && d->dtype == DC_F32, f64_pts = d->point_fmt == DC_F64 && d->dtype == DC_F64;
+  // ball neighbourhoods on float32 clouds (a packed table from CSR lists that knows its rows' lengths): the ragged one-pass
+  // kernel, whose tile may take up to 128 KB of LDS
+  const int rag_pieces = n_terms <= 2 ? 2 : 3;
+  const bool ragged_ok = q32_pts && d->fwd_table && d->fwd_table->layout == DC_TABLE_SLOTS && d->fwd_table->packed == 1 && d->fwd_table->row_ptr &&
+                         d->fwd_table->own_base && !d->centre_idx && d->fwd_table->max_rows > 0 && !g_no_tab.load() && g_step_var.load() != 8 &&
+                         (size_t)d->fwd_table->max_rows * rag_pieces * 16 <= 128 * 1024 && d->fwd_table->max_rows <= (n_terms <= 2 ? 4096 : 2560);
   const bool basis_fwd = d->basis && (q32_pts || f64_pts) && n_terms > 0 && w &&
                          !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
-                         use_table(d->fwd_table, DC_TABLE_SLOTS, stride, q32_pts ? 16u : 32u, 0, 60 * 1024, &lds_f, &rows_f);
+                         (use_table(d->fwd_table, DC_TABLE_SLOTS, stride, q32_pts ? 16u : 32u, 0, 60 * 1024, &lds_f, &rows_f) || (ragged_ok && want_grad && n_terms <= 3 && !g_two_pass.load()));
   // loss and dL/dw in ONE pass (forward-mode) for up to three weights: no record, no backward launch, no transposed table
   size_t lds_s = 0;
   int rows_s = 0;
   const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : (6 + n_terms + 1) / 2);
   const bool one_pass = basis_fwd && want_grad && n_terms <= 3 && !g_two_pass.load() &&
-                        use_table(d->fwd_table, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s);
+                        (use_table(d->fwd_table, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s) || ragged_ok);
   // every other way to a gradient walks the transposed neighbour lists: the caller provides them on demand
   if (want_grad && !one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
   const bool basis = basis_fwd &&
@@ -3064,19 +3089,21 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       const int var = g_step_var.load();
       // float32 clouds with a [rows, K] table: the kernel with fp64 row differences in LDS (48-B rows + its scratch, all dynamic)
       const bool q32_step = q32_pts && var == 1 && (fixed_k == 10 || fixed_k == 4 || fixed_k == 8 || fixed_k == 16) && rows_s <= kStepQ32Cap;
-      // ball neighbourhoods on float32 clouds: rows of any length from a table whose padding slots point at the lanes' own rows
-      const bool ragged_step = q32_pts && var != 8 && d->fwd_table->packed == 1 && d->fwd_table->row_ptr && d->fwd_table->own_base && !d->centre_idx &&
-                               (rows_s <= 1024 || (n_terms <= 2 && rows_s <= 1920));
+      const bool ragged_step = ragged_ok;
       if (ragged_step) {
         ProfScope prof(1);
-#define RAGGED_LAUNCH(P, CAP) DC_TIMED_LAUNCH((consistency_step_ragged_q32_kernel<P, CAP>), grid, block, 0, stream, pb, tab, d->fwd_table->own_base, \
-                                              d->fwd_table->row_ptr, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch)
-        // the static tile in four sizes (32 / 40 / 48 / 60 KB for two-piece rows: 4 / 4 / 3 / 2 blocks per CU)
-        if (rows_s <= 1024) { if (n_terms == 2) RAGGED_LAUNCH(2, 1024); else if (n_terms == 1) RAGGED_LAUNCH(1, 1024); else RAGGED_LAUNCH(3, 1024); }
-        else if (rows_s <= 1280) { if (n_terms == 2) RAGGED_LAUNCH(2, 1280); else RAGGED_LAUNCH(1, 1280); }
-        else if (rows_s <= 1536) { if (n_terms == 2) RAGGED_LAUNCH(2, 1536); else RAGGED_LAUNCH(1, 1536); }
-        else { if (n_terms == 2) RAGGED_LAUNCH(2, 1920); else RAGGED_LAUNCH(1, 1920); }
-#undef RAGGED_LAUNCH
+        const int mr = d->fwd_table->max_rows;
+        int rc = DC_OK;
+#define RAGGED(P, CAP) (prof.name("(consistency_step_ragged_q32_kernel<" #P ", " #CAP ">)"), \
+                        ragged_launch<P, CAP>(grid, stream, prof.start(), prof.stop(), pb, tab, d->fwd_table, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch))
+#define RAGGED_CAPS(P) (mr <= 1024 ? RAGGED(P, 1024) : mr <= 1280 ? RAGGED(P, 1280) : mr <= 1600 ? RAGGED(P, 1600) : mr <= 2048 ? RAGGED(P, 2048) : \
+                        mr <= 2560 ? RAGGED(P, 2560) : RAGGED(P, 4096))
+        if (n_terms == 2) rc = RAGGED_CAPS(2);
+        else if (n_terms == 1) rc = RAGGED_CAPS(1);
+        else rc = mr <= 1024 ? RAGGED(3, 1024) : mr <= 1600 ? RAGGED(3, 1600) : RAGGED(3, 2560);
+#undef RAGGED_CAPS
+#undef RAGGED
+        if (rc) return rc;
       } else if (q32_step) {
         ProfScope prof(1);
         static_assert(kStepQ32Cap == 512, "the profiler names the instantiation by its literal arguments");
