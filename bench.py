@@ -427,6 +427,31 @@ def main():
     # ---- side measurements, after the timed region (the GPU goes idle between their host-synchronised calls; run before
     # the loop they left it at idle clocks for the first timed steps)
     extras = {}
+    if world == 1 and not args.autograd and not args.no_extras:
+        # the same chained step (a) sustained -- 2 000 steps back to back, what a training run of the reference's default length
+        # and longer sees -- and (b) cold -- the first `steps` steps after the device has sat idle for a second (clocks down, no
+        # device warm-up: what `--device-warmup-ms 0` times).  Their own trainer: the timed run's state is left alone.
+        tr2 = SequenceTrainer([plan], w0, e0, [poses_t], lr=1e-3, chained=not args.no_chain)
+        for _ in range(100):
+            tr2.step()
+        tr2.flush()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            tr2.step()
+        tr2.flush()
+        torch.cuda.synchronize()
+        extras['sustained_ms_per_step'] = (time.perf_counter() - t0) / 2000 * 1e3
+        extras['sustained_steps'] = 2000
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr2.step()
+        tr2.flush()
+        torch.cuda.synchronize()
+        extras['cold_ms_per_step'] = (time.perf_counter() - t0) / args.steps * 1e3
+        extras['cold_note'] = '%d chained steps + flush started after one second of an idle device, no device warm-up' % args.steps
+        del tr2
     if world == 1 and not args.no_extras:        # single-process runs only: the other ranks must not wait for rank 0
         # the same step without the loop-invariant hoisting (general path: dc_points_fwd + forward + backward every iteration,
         # what the reference's own loop recomputes) and with separate forward / backward kernels, for comparison
@@ -605,7 +630,11 @@ def main():
                        'loop': ('autograd+' + ('optim.Adam (dc_adam_step)' if args.dc_adam else 'torch.optim.Adam') + (' replayed as one hipGraph' if args.graph else '')) if args.autograd else ('native, chained: one launch per step (dc_sequence_step_chained), the last one flushed' if trainer.chained else
                                                      ('native: evaluation (+ the previous Adam update in its launch) -> reduction -> all-reduce'
                                                       if trainer.update_in_next else 'native (dc_sequence_step)')),
-                       'masked_points': total_count, 'active_only': bool(args.active_only), 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
+                       'masked_points': total_count, 'active_only': bool(args.active_only),
+                       'skipped_wavefronts_share': getattr(plan, 'skipped_wavefronts', 0.0),
+                       'skipped_note': 'share of the 64-centre wavefronts whose centres are ALL outside the loss mask: they stage their rows '
+                                       'and skip the moments, the eigen-solve and the second sweep (every term they would add carries the mask); '
+                                       'the plan groups masked-out points at the end of every 256-point block', 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
                        'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s,
                        'setup_note': 'setup_ms: the whole set-up phase (upload, 10 local feature clouds, global k-NN, masks, Morton '

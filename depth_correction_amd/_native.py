@@ -127,7 +127,8 @@ class SequenceDesc(ctypes.Structure):
                 ('partials', _vp), ('model_kind', ctypes.c_int32), ('n_terms', ctypes.c_int32),
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
                 ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp),
-                ('partials_count', ctypes.c_int64), ('scan_seg', _vp)]
+                ('partials_count', ctypes.c_int64), ('scan_seg', _vp), ('blk_skip', _vp), ('fwd_rows_active', ctypes.c_int32),
+                ('reserved2', ctypes.c_int32)]
 
 
 def lib_path():

@@ -348,32 +348,32 @@ __device__ __forceinline__ void reduce_pose_grads_grouped(const PointInputs& in,
   constexpr int NW = kBlock / kWave;
   __shared__ double s_part[NW][12 * kTicketScans];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int S = in.n_scans;
+  const int S = in.n_scans, V = 2 * S;                      // V segments per block: (inside the loss mask, scan) then (outside, scan)
   if (blk < 0) {                                            // padding block of the last round: its row holds zeros
     for (int item = tid; item < S * 12; item += kBlock) prow[item] = 0.0;
     return;
   }
-  const uint16_t* seg = in.seg_start + blk * (S + 1);
-  // the scans of this wavefront's lanes: ascending by lane (the plan's grouping), idle lanes only at the block's end
-  const unsigned long long act = __ballot(active);
-  const int n_act = __popcll(act);
-  const int s_lo = n_act ? __builtin_amdgcn_readfirstlane(scan) : 0;
-  const int s_hi = n_act ? __builtin_amdgcn_readlane(scan, n_act - 1) : -1;
-  const int n_items = (s_hi - s_lo + 1) * 24;
-  // bounds of the first item of this lane: requested before the LDS hand-over
-  int rr0 = 0, b0 = 0, e0 = 0;
-  if (lane < n_items) { rr0 = s_lo + (lane >> 1) / 12; b0 = seg[rr0]; e0 = seg[rr0 + 1]; }
+  const uint16_t* seg = in.seg_start + blk * (V + 1);
+  // the segments that reach into this wavefront's 64 lanes: lane v < V looks at segment v
+  const int w_beg = wave * kWave, w_end = w_beg + kWave;
+  int sb_l = 0, se_l = 0;
+  if (lane < V) { sb_l = seg[lane]; se_l = seg[lane + 1]; }
+  const unsigned long long present = __ballot(lane < V && sb_l < w_end && se_l > w_beg && se_l > sb_l);
+  const int v_lo = present ? __builtin_ctzll(present) : 0, v_hi = present ? 63 - __builtin_clzll(present) : -1;
+  const int n_items = (v_hi - v_lo + 1) * 24;
   for (int item = lane; item < S * 12; item += kWave) s_part[wave][item] = 0.0;
 #pragma unroll
   for (int q = 0; q < 6; ++q) s_val[tid * kPoseRow + q] = active ? gx[q] : 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // own lanes' values: the wavefront's LDS operations are in order
   __builtin_amdgcn_wave_barrier();
-  const int w_beg = wave * kWave, w_end = w_beg + kWave;
-  for (int item = lane; item < n_items; item += kWave) {
+  for (int item0 = 0; item0 < n_items; item0 += kWave) {
+    const int item = item0 + lane;
     const int pair = item >> 1, part = item & 1;
     const int rs_ = pair / 12, q = pair - rs_ * 12, a = q >> 2, b = q & 3;
-    const int rr = s_lo + rs_;
-    const int sb = item == lane ? b0 : (int)seg[rr], se = item == lane ? e0 : (int)seg[rr + 1];
+    const int v = min(v_lo + rs_, V - 1);
+    // (the shuffles run with every lane active: a masked-off source lane would hand back zero)
+    const int sb = __shfl(sb_l, v, kWave), se = __shfl(se_l, v, kWave);
+    if (item >= n_items) continue;
     const int beg = max(sb, w_beg) + part, end = min(se, w_end);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     int p = beg;
@@ -390,7 +390,9 @@ __device__ __forceinline__ void reduce_pose_grads_grouped(const PointInputs& in,
     }
     double sum = __dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3]));
     sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));         // even + odd half (the two lanes are neighbours)
-    if (part == 0) s_part[wave][rr * 12 + q] = sum;
+    // the two segments of a scan (inside / outside the mask) can both reach into one wavefront: an add, not a store (two
+    // addends on a zeroed slot: the same sum in either order)
+    if (part == 0) atomicAdd(&s_part[wave][(v >= S ? v - S : v) * 12 + q], sum);
   }
   // ticket: the wavefront that arrives last adds the rows up and stores the block's row
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -412,33 +414,36 @@ __device__ __forceinline__ void reduce_pose_grads_grouped(const PointInputs& in,
 __device__ __forceinline__ void reduce_pose_grads_grouped_wide(const PointInputs& in, int64_t blk, bool active, const double* gx,
                                                                double* __restrict__ prow, double* s_val) {
   const int tid = threadIdx.x;
-  const int S = in.n_scans;
+  const int S = in.n_scans, V = 2 * S;
   if (blk < 0) {
     for (int item = tid; item < S * 12; item += kBlock) prow[item] = 0.0;
     return;
   }
-  const uint16_t* seg = in.seg_start + blk * (S + 1);
+  const uint16_t* seg = in.seg_start + blk * (V + 1);
 #pragma unroll
   for (int q = 0; q < 6; ++q) s_val[tid * kPoseRow + q] = active ? gx[q] : 0.0;
   __syncthreads();
   for (int item = tid; item < S * 24; item += kBlock) {
     const int pair = item >> 1, part = item & 1;
     const int rr = pair / 12, q = pair - rr * 12, a = q >> 2, b = q & 3;
-    const int beg = (int)seg[rr] + part, end = (int)seg[rr + 1];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    int p = beg;
-    for (; p + 6 < end; p += 8) {
+    double sum = 0.0;
+    for (int half = 0; half < 2; ++half) {                  // the scan's points inside the loss mask, then those outside
+      const int beg = (int)seg[rr + half * S] + part, end = (int)seg[rr + half * S + 1];
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      int p = beg;
+      for (; p + 6 < end; p += 8) {
 #pragma unroll
-      for (int u_ = 0; u_ < 4; ++u_) {
-        const double ga = s_val[(p + 2 * u_) * kPoseRow + a];
-        acc[u_] = __dadd_rn(acc[u_], b == 3 ? ga : __dmul_rn(ga, s_val[(p + 2 * u_) * kPoseRow + 3 + b]));
+        for (int u_ = 0; u_ < 4; ++u_) {
+          const double ga = s_val[(p + 2 * u_) * kPoseRow + a];
+          acc[u_] = __dadd_rn(acc[u_], b == 3 ? ga : __dmul_rn(ga, s_val[(p + 2 * u_) * kPoseRow + 3 + b]));
+        }
       }
+      for (; p < end; p += 2) {
+        const double ga = s_val[p * kPoseRow + a];
+        acc[0] = __dadd_rn(acc[0], b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
+      }
+      sum = __dadd_rn(sum, __dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3])));
     }
-    for (; p < end; p += 2) {
-      const double ga = s_val[p * kPoseRow + a];
-      acc[0] = __dadd_rn(acc[0], b == 3 ? ga : __dmul_rn(ga, s_val[p * kPoseRow + 3 + b]));
-    }
-    double sum = __dadd_rn(__dadd_rn(acc[0], acc[1]), __dadd_rn(acc[2], acc[3]));
     sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));
     if (part == 0) prow[pair] = sum;
   }
@@ -1357,6 +1362,8 @@ struct StepChain {
   int32_t* status;           // bit 0: a point left the q32 extent (read); bit 1: a wait for the weights ran out (raised here)
   int spin_limit;            // polls a waiting block makes before it gives up (dc_set_option(5, n); 0: gives up at once)
   AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
+  const uint8_t* blk_skip;   // [blocks] or nullptr: blocks none of whose centres is inside the loss mask (dcSequenceDesc.blk_skip): they add
+                             // nothing to the loss, the count or dL/dw and are treated like the padding blocks of the last round
 };
 constexpr int32_t kStatusChainTimeout = 2;     // (bit 0: q32 overflow, raised by quantize())
 constexpr int kChainFront = 8;             // leading blocks of a chained launch (a multiple of the XCD count)
@@ -1788,7 +1795,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  if (blk >= 0 && ch.blk_skip && ch.blk_skip[blk]) blk = -1;            // no centre of this block is inside the loss mask
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
@@ -1797,6 +1805,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
   if (blk >= 0 && !bad) {
     const int64_t i = blk * kBlock + threadIdx.x;
     const bool live = i < n;
+    const bool in_mask = live && (mask ? mask[i] != 0 : true);
     const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
     uint32_t pre[NS];
 #pragma unroll
@@ -1831,7 +1840,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
     if (own < 0) ci = Basis<PT>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
     __syncthreads();
     if (own >= 0) ci = staged_point<PT>(tile, cap, own + (live ? (int)threadIdx.x : 0));
-    if (live) {
+    if (live && (!mask || __any((int)in_mask))) {        // (a wavefront of masked-out centres only: nothing to add, see consistency_step_q32_kernel)
       CovAcc acc;
       cov_init(acc);
       uint32_t mx = pre[0];
@@ -1843,7 +1852,6 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
       else n_have = gather_fixed<PT, NS, false>(tile, cap, ci, pre, acc);
       acc.W = (double)n_have;
       double cm[3], v0[3], c1, c2;
-      const bool in_mask = mask ? mask[i] != 0 : true;
       if constexpr ((VAR & kVarSlimTail) != 0) step_point2<PT, NS>(acc, n_have, !any_miss, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
       else step_point<PT>(acc, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
       const double u = Pt<PT>::unit(qp);
@@ -1960,7 +1968,8 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  if (blk >= 0 && ch.blk_skip && ch.blk_skip[blk]) blk = -1;            // no centre of this block is inside the loss mask
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
@@ -1969,6 +1978,7 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
   if (blk >= 0 && !bad) {
     const int64_t i = blk * kBlock + threadIdx.x;
     const bool live = i < n;
+    const bool in_mask = live && (mask ? mask[i] != 0 : true);
     const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + threadIdx.x;
     uint32_t pre[NS];
 #pragma unroll
@@ -2001,7 +2011,10 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
     if (own < 0) ci = Basis<q32>::template point<P>(pb, wq, live ? (centre_idx ? (int64_t)centre_idx[i] : i) : 0);
     __syncthreads();
     if (own >= 0) ci = staged_point<q32>(tile, cap, own + (live ? (int)threadIdx.x : 0));
-    if (live) {
+    // a wavefront whose centres are ALL outside the loss mask adds nothing to the loss, the count or dL/dw (every term carries the
+    // centre's mask): it has staged its rows and is done.  The plan groups masked-out points at the end of every block, so
+    // these are whole wavefronts (bench.py reports their share).
+    if (live && (!mask || __any((int)in_mask))) {
       CovAcc acc;
       cov_init(acc);
       // positions are multiples of 16, the empty-slot mark 0xFFFF is not: bit 0 of the OR of a lane's positions tells
@@ -2014,7 +2027,7 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
       else n_have = gather_fixed<q32, NS, false>(tile, cap, ci, pre, acc);
       acc.W = (double)n_have;
       double cm[3], v0[3], c1, c2;
-      step_point2<q32, NS>(acc, n_have, !any_miss, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+      step_point2<q32, NS>(acc, n_have, !any_miss, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
       float cmf[3], vs[3], vu[3], gwf[P];
 #pragma unroll
       for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
@@ -2084,7 +2097,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  if (blk >= 0 && ch.blk_skip && ch.blk_skip[blk]) blk = -1;            // no centre of this block is inside the loss mask
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
@@ -2201,7 +2215,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  if (blk >= 0 && ch.blk_skip && ch.blk_skip[blk]) blk = -1;            // no centre of this block is inside the loss mask
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
@@ -2245,7 +2260,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
     for (int t = threadIdx.x; t < nd; t += kBlock) Row::stage(pb, wq, tab.blk_ids[base + t], tile, CAP, t);
   }
   __syncthreads();
-  if (live) {
+  const bool in_mask = live && (mask ? mask[i] != 0 : true);
+  if (live && (!mask || __any((int)in_mask))) {          // (a wavefront of masked-out centres only: nothing to add, see consistency_step_q32_kernel)
     const char* tb = reinterpret_cast<const char*>(tile);
     const Pt<q32>::Raw ci = Pt<q32>::from_row(reinterpret_cast<const int4*>(tb + own_off));
     // the longest row among this wavefront's lanes bounds its trips
@@ -2282,7 +2298,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
     }
     acc.W = (double)deg;
     double cm[3], v0[3], c1, c2;
-    step_point2<q32, 2>(acc, deg, false, mask ? mask[i] != 0 : true, lp, qp, acc2, cm, v0, &c1, &c2);
+    step_point2<q32, 2>(acc, deg, false, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
     const double u = Pt<q32>::unit(qp);
     float cmf[3], vs[3], vu[3];
 #pragma unroll
@@ -3047,9 +3063,11 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   // ball neighbourhoods on float32 clouds (a packed table from CSR lists that knows its rows' lengths): the ragged one-pass
   // kernel, whose tile may take up to 128 KB of LDS
   const int rag_pieces = n_terms <= 2 ? 2 : 3;
+  const int rag_rows = !d->fwd_table ? 0 : ((d->blk_skip && d->mask && !d->centre_idx && d->fwd_rows_active > 0 && d->fwd_rows_active < d->fwd_table->max_rows)
+                                              ? d->fwd_rows_active : d->fwd_table->max_rows);
   const bool ragged_ok = q32_pts && d->fwd_table && d->fwd_table->layout == DC_TABLE_SLOTS && d->fwd_table->packed == 1 && d->fwd_table->row_ptr &&
                          d->fwd_table->own_base && !d->centre_idx && d->fwd_table->max_rows > 0 && !g_no_tab.load() && g_step_var.load() != 8 &&
-                         (size_t)d->fwd_table->max_rows * rag_pieces * 16 <= 128 * 1024 && d->fwd_table->max_rows <= (n_terms <= 2 ? 4096 : 2560);
+                         (size_t)rag_rows * rag_pieces * 16 <= 128 * 1024 && rag_rows <= (n_terms <= 2 ? 4096 : 2560);
   const bool basis_fwd = d->basis && (q32_pts || f64_pts) && n_terms > 0 && w &&
                          !want_exponent_grad && !want_pose_grad && !g_no_basis.load() &&
                          (use_table(d->fwd_table, DC_TABLE_SLOTS, stride, q32_pts ? 16u : 32u, 0, 60 * 1024, &lds_f, &rows_f) || (ragged_ok && want_grad && n_terms <= 3 && !g_two_pass.load()));
@@ -3057,8 +3075,14 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   size_t lds_s = 0;
   int rows_s = 0;
   const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : (6 + n_terms + 1) / 2);
+  // (the one-pass kernels never stage the blocks they skip: their tile is sized by the longest list among the others)
+  dcBlockTable ft_active{};
+  if (d->fwd_table) {
+    ft_active = *d->fwd_table;
+    if (d->blk_skip && d->mask && !d->centre_idx && d->fwd_rows_active > 0 && d->fwd_rows_active < ft_active.max_rows) ft_active.max_rows = d->fwd_rows_active;
+  }
   const bool one_pass = basis_fwd && want_grad && n_terms <= 3 && !g_two_pass.load() &&
-                        (use_table(d->fwd_table, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s) || ragged_ok);
+                        (use_table(d->fwd_table ? &ft_active : nullptr, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s) || ragged_ok);
   // every other way to a gradient walks the transposed neighbour lists: the caller provides them on demand
   if (want_grad && !one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
   const bool basis = basis_fwd &&
@@ -3077,6 +3101,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     if (one_pass) {
       const int64_t g_blocks = xcd_grid(n_blocks(n_rows));
       StepChain ch{};
+      ch.blk_skip = (d->mask && !d->centre_idx) ? d->blk_skip : nullptr;
       if (chain) {
         p_fwd = chain_buffer(d, n_terms, chain->parity);
         p_bwd = p_fwd + 2 * g_blocks;
@@ -3092,7 +3117,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       const bool ragged_step = ragged_ok;
       if (ragged_step) {
         ProfScope prof(1);
-        const int mr = d->fwd_table->max_rows;
+        const int mr = rag_rows;
         int rc = DC_OK;
 #define RAGGED(P, CAP) (prof.name("(consistency_step_ragged_q32_kernel<" #P ", " #CAP ">)"), \
                         ragged_launch<P, CAP>(grid, stream, prof.start(), prof.stop(), pb, tab, d->fwd_table, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch))

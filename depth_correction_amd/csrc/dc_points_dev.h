@@ -18,8 +18,9 @@ struct PointInputs {
   const double* w;        // [P] device
   const double* e;        // [P] device
   int model_kind, n_terms, n_scans;
-  // [blocks, n_scans + 1] or null: the points of every 256-point block are grouped by scan id (the plan ordered them so) and
-  // block b's points of scan s are its lanes seg_start[b (S + 1) + s] .. seg_start[b (S + 1) + s + 1]  (reduce_pose_grads_grouped)
+  // [blocks, 2 n_scans + 1] or null: the points of every 256-point block are grouped -- those inside the loss mask first, by scan
+  // id, then those outside it, by scan id (the plan ordered them so) -- and segment v of block b (v < S: inside, scan v; v >= S:
+  // outside, scan v - S) is its lanes seg_start[b (2 S + 1) + v] .. seg_start[b (2 S + 1) + v + 1]  (reduce_pose_grads_grouped)
   const uint16_t* seg_start = nullptr;
 };
 

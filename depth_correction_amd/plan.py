@@ -36,11 +36,13 @@ __all__ = ['SequencePlan', 'SequenceTrainer', 'consistency_loss', 'KernelTimer',
 
 
 class SequencePlan:
+    kMaskGroup = 2048          # super-block inside which masked-in points are put before masked-out ones (mask_first)
+
     @on_device
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
-                 scan_group=True):
+                 scan_group=True, mask_first=False):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -52,6 +54,11 @@ class SequencePlan:
         :param lazy_backward: build the transposed neighbour lists / backward block table on first need instead of up front.
         :param basis: use the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis) whenever an evaluation asks for neither pose
                       nor exponent gradients: the basis rows are rebuilt only when the poses or the exponents change.
+        :param mask_first: additionally collect the masked-out points of every 2048-point stretch into blocks of their own, which
+                           the one-pass kernels skip whole (24 % of the wavefronts at C2 instead of 11 %).  OFF by default:
+                           measured at C2 the remaining blocks then draw their neighbours from a third more distinct rows --
+                           larger LDS tiles, fewer resident blocks -- and the step got SLOWER (44 -> 55 us); the two-kernel
+                           forms lose more.  Results are the same either way.
         :param scan_group: group the points of every 256-point block by scan (contiguous per-scan lane ranges for the pose-gradient
                            sums; the set of points per block, hence every other kernel's work, is unchanged).
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
@@ -101,24 +108,41 @@ class SequencePlan:
                 local = torch.argsort(pad.reshape(nb, 256), dim=1, stable=True)
                 pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
                 order = order[pos[pos < self.n]]
-            self.scan_seg = None
-            if scan_group and not degree_sort and 1 < self.n_scans <= 64:
-                # inside every block of 256 Morton-consecutive points, group the points by scan (stable: Morton order inside a
-                # group).  Which 256 points share a block does not change -- the LDS-staged gathers do not care about the lane
-                # order -- but a block's points of one scan become a contiguous lane range known from now on, which is what the
-                # pose-gradient sums of the backward need (dcSequenceDesc.scan_seg)
-                nb = (self.n + 255) // 256
-                sid = torch.full((nb * 256,), self.n_scans, dtype=torch.int64, device=dev)         # padding sorts last
-                sid[:self.n] = scan_id[order].long()
-                sid = sid.reshape(nb, 256)
-                local = torch.argsort(sid, dim=1, stable=True)
+            self.scan_seg, self.skipped_wavefronts, self.blk_skip = None, 0.0, None
+            if mask_first and mask is not None and not degree_sort and not active_only:
+                # inside every super-block of kMaskGroup Morton-consecutive points: the points inside the loss mask first, then those
+                # outside (Morton order inside each part).  Most blocks of 256 are then all-in or all-out, and the one-pass kernels
+                # skip the all-out ones (dcSequenceDesc.blk_skip): a centre outside the mask adds nothing to the loss, the count or
+                # dL/dw.  Every point stays in the table -- masked-out points are neighbours like any other -- and every block
+                # still draws its neighbours from one super-block's surroundings (the LDS tiles grow by a third, not by an order)
+                sb = torch.arange(self.n, device=dev) // self.kMaskGroup
+                order = order[torch.argsort(sb * 2 + (~mask[order]).long(), stable=True)]
+                mark('plan_mask_first')
+            if scan_group and not degree_sort and self.n_scans <= 64:
+                # inside every block of 256 Morton-consecutive points: the points inside the loss mask first, then those outside;
+                # each group ordered by scan (stable: Morton order inside a (mask, scan) segment).  Which 256 points share a block
+                # does not change -- the LDS-staged gathers do not care about the lane order -- but (a) a block's points of one scan
+                # become contiguous lane ranges known from now on, which is what the pose-gradient sums of the backward need, and
+                # (b) its masked-out points fill whole wavefronts at its end, which the one-pass kernels skip (they add nothing to
+                # the loss, the count or dL/dw).  dcSequenceDesc.scan_seg: [blocks, 2 S + 1]
+                nb, S = (self.n + 255) // 256, self.n_scans
+                key = torch.full((nb * 256,), 2 * S, dtype=torch.int64, device=dev)                # padding sorts last
+                key[:self.n] = scan_id[order].long() + (0 if mask is None else (~mask[order]).long() * S)
+                key = key.reshape(nb, 256)
+                local = torch.argsort(key, dim=1, stable=True)
                 pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
                 order = order[pos[:self.n]] if self.n == nb * 256 else order[pos[pos < self.n]]
-                counts = torch.zeros((nb, self.n_scans + 1), dtype=torch.int64, device=dev)
-                counts.scatter_add_(1, sid, torch.ones_like(sid))
-                seg = torch.zeros((nb, self.n_scans + 1), dtype=torch.int64, device=dev)
-                seg[:, 1:] = counts[:, :self.n_scans].cumsum(1)
+                counts = torch.zeros((nb, 2 * S + 1), dtype=torch.int64, device=dev)
+                counts.scatter_add_(1, key, torch.ones_like(key))
+                seg = torch.zeros((nb, 2 * S + 1), dtype=torch.int64, device=dev)
+                seg[:, 1:] = counts[:, :2 * S].cumsum(1)
                 self.scan_seg = seg.to(torch.uint16).contiguous()
+                # share of the wavefronts (64 lanes) whose centres are all outside the mask: what the one-pass kernels skip
+                inside = seg[:, S]                                                                 # masked-in points per block
+                skipped = (4 - ((inside + 63) // 64)).clamp(min=0).sum() - (nb * 4 - (self.n + 63) // 64)
+                self.skipped_wavefronts = float(skipped) / max((self.n + 63) // 64, 1)
+                if mask is not None:
+                    self.blk_skip = (inside == 0).to(torch.uint8).contiguous()
                 mark('plan_scan_groups')
             rank = torch.empty_like(order)
             rank[order] = torch.arange(self.n, device=dev)
@@ -133,7 +157,7 @@ class SequencePlan:
             mark('plan_permute')
         else:
             self.order = self.rank = None
-            self.scan_seg = None
+            self.scan_seg, self.skipped_wavefronts, self.blk_skip = None, 0.0, None
         if not bool(vps.any()):
             vps = None                      # sensor-frame scans: viewpoints are the origin, nothing to stream
         self.ps = ops.PointSet(vps, dirs, depth, inc, lmask, scan_id)
@@ -163,6 +187,11 @@ class SequencePlan:
                 self.fwd_table = ops.block_table(csr=ops.table_to_csr(nbr), layout='slots', own_rows='csr' if self.centre_idx is None else False)
             else:
                 self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None)
+        self.fwd_rows_active = 0
+        if self.fwd_table is not None and getattr(self, 'blk_skip', None) is not None and self.centre_idx is None:
+            rows_per_block = self.fwd_table.blk_ptr[1:] - self.fwd_table.blk_ptr[:-1]
+            keep = self.blk_skip == 0
+            self.fwd_rows_active = int(rows_per_block[keep].max().item()) if bool(keep.any()) else 0
         mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
@@ -240,6 +269,8 @@ class SequencePlan:
             d.partials_count = self.partials.numel()
             d.status = p(self.status)
             d.scan_seg = p(getattr(self, 'scan_seg', None))
+            skip = getattr(self, 'blk_skip', None) if (self.mask is not None and self.centre_idx is None) else None
+            d.blk_skip, d.fwd_rows_active = p(skip), int(getattr(self, 'fwd_rows_active', 0)) if skip is not None else 0
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
             d.loss_kind, d.normalization, d.sqrt_ = nv.LOSS_KINDS[self.loss], int(self.normalization), int(self.sqrt)

@@ -396,11 +396,20 @@ typedef struct dcSequenceDesc {
                                       x = X0 + (sum_k w_k c_k) u, so an evaluation needs no pass over the points */
   int64_t partials_count;          /* doubles behind `partials`: at least dc_sequence_partials_count(n, n_terms, n_scans), checked by
                                       every call (DC_ERR_WORKSPACE) -- the chained steps keep their rows behind the ordinary columns */
-  const uint16_t* scan_seg;        /* [ceil(n / 256), n_scans + 1] or NULL.  Non-NULL promises that the points of every 256-point
-                                      block are grouped by scan id: block b's points of scan s are its lanes scan_seg[b (S + 1) + s]
-                                      .. scan_seg[b (S + 1) + s + 1].  Pose gradients (train.py:300-312 with pose corrections)
-                                      then sum per scan over those static ranges instead of counting-sorting the block's lanes at
-                                      run time; used for n_scans <= 64 */
+  const uint16_t* scan_seg;        /* [ceil(n / 256), 2 n_scans + 1] or NULL.  Non-NULL promises that the points of every 256-point
+                                      block are grouped: first those inside `mask`, by scan id, then those outside, by scan id;
+                                      segment v of block b (v < S: inside, scan v; v >= S: outside, scan v - S) is its lanes
+                                      scan_seg[b (2 S + 1) + v] .. scan_seg[b (2 S + 1) + v + 1].  Pose gradients (train.py:300-312
+                                      with pose corrections) then sum per scan over those static ranges instead of counting-sorting
+                                      the block's lanes at run time (n_scans <= 64); and the masked-out points of a block fill whole
+                                      wavefronts at its end, which the one-pass kernels skip */
+  const uint8_t* blk_skip;         /* [ceil(n / 256)] or NULL: 1 = none of the block's centres is inside `mask` (the plan's layout collects
+                                      masked-out points into blocks of their own).  The one-pass evaluation skips such a block -- a
+                                      centre outside the mask adds nothing to the loss, the count or dL/dw; its points remain
+                                      neighbours of others like any other point */
+  int32_t fwd_rows_active;         /* with blk_skip: the longest distinct-row list among the blocks that are NOT skipped (sizes the
+                                      one-pass kernels' LDS tile; 0 = use fwd_table->max_rows) */
+  int32_t reserved2;
 } dcSequenceDesc;
 
 /* Doubles of dcSequenceDesc.partials for a sequence of n points evaluated with up to n_terms weights and n_scans poses:

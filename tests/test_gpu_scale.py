@@ -397,7 +397,7 @@ def test_c2_full_size_pose_gradients_vs_oracle(room):
     from depth_correction_amd.transform import corrected_poses
     scans, poses = room
     plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32)
-    assert plan.scan_seg is not None and plan.scan_seg.shape == ((plan.n + 255) // 256, plan.n_scans + 1)
+    assert plan.scan_seg is not None and plan.scan_seg.shape == ((plan.n + 255) // 256, 2 * plan.n_scans + 1)
     dev = plan.device
     w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
     e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
