@@ -39,6 +39,11 @@ CLOCK_GHZ, N_SIMD = 2.4, 1024     # peak engine clock; 256 CUs x 4 SIMDs; one wa
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4'],
+                    help="c2 (default): BASELINE config 2 / 3, the metric's workload; c4: BASELINE config 4 shape -- KITTI-360-like "
+                         'sequences, one per rank, joint model + pose optimisation with the point-to-plane ICP loss through train()')
+    ap.add_argument('--c4-scans', type=int, default=10, help='--workload c4: scans per sequence')
+    ap.add_argument('--c4-sequences', type=int, default=0, help='--workload c4: sequences (default: one per rank)')
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--scans', type=int, default=10)
@@ -256,6 +261,8 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    if args.workload == 'c4':
+        return main_c4(args, world, rank, local_rank, dev, dist)
     from depth_correction_amd.dataset import RoomBoxDataset
     from depth_correction_amd.pipeline import build_sequence
     from depth_correction_amd.plan import consistency_loss
@@ -660,6 +667,92 @@ def main():
             out['config']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main_c4(args, world, rank, local_rank, dev, dist):
+    """BASELINE config 4 shape (KITTI-360-like sequences of 64 x 2048-ray scans, depth 5-25 m and 0.2 m voxel pre-filters, ball
+    neighbourhoods of 0.4 m, joint model + per-pose optimisation with the point-to-plane ICP loss) through the reference-API
+    train() (train.py:94-322): sequence q lives on rank q mod N, every rank back-propagates the ICP losses of its sequences and
+    ONE packed all-reduce per iteration (distributed.GradReducer: [weighted loss, weight, grads of the shared model weights])
+    joins them; pose corrections stay with their owner.  W warm-up + K timed iterations of ONE train() call; the clock starts in
+    the callback of iteration W behind a barrier + device synchronisation and stops behind the same pair after train() returns."""
+    import contextlib
+    import io
+    import tempfile
+    from depth_correction_amd.config import Config, Loss, PoseCorrection
+    from depth_correction_amd.dataset import KittiLikeDataset
+    from depth_correction_amd.preproc import filtered_cloud
+    from depth_correction_amd.train import TrainCallbacks, train
+    n_seq = args.c4_sequences or world
+    cfg = Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2, min_depth=5.0,
+                 max_depth=25.0, vp_dispersion_bounds=[], n_opt_iters=args.warmup + args.steps, lr=1e-3, device=str(dev),
+                 log_dir=tempfile.mkdtemp(), model_kwargs={'w': [1e-3, -1e-3], 'exponent': [2.0, 4.0]})
+    # every rank describes all sequences (train() loads only the ones it owns); a sequence's seeds differ by its index
+    seqs, n_points = [], 0
+    for q in range(n_seq):
+        ds = KittiLikeDataset(n_poses=args.c4_scans, seed_base=2000 + 100 * q)
+        if q % world == rank or world == 1:
+            seq = [(filtered_cloud(cloud, cfg), pose) for cloud, pose in ds]
+            n_points += sum(len(c) for c, _ in seq)
+        else:
+            seq = None                                   # another rank's: train() never touches it here
+        seqs.append(seq)
+    clock = {}
+
+    class Clock(TrainCallbacks):
+        def iteration_started(self, it):
+            if it == args.warmup:
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                clock['t0'] = time.perf_counter()
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        train(cfg, callbacks=Clock(cfg), train_datasets=seqs, val_datasets=[])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - clock['t0']
+    stats = torch.tensor([elapsed, float(n_points)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        el = stats[:1].clone()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        pts = stats[1:].clone()
+        dist.all_reduce(pts)
+        elapsed, n_points = float(el.item()), float(pts.item())
+    rccl = None
+    if dist is not None:
+        buf = torch.zeros((2 + 2,), dtype=torch.float64, device=dev)
+        for _ in range(10):
+            dist.all_reduce(buf)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(100):
+            dist.all_reduce(buf)
+        a1.record()
+        torch.cuda.synchronize()
+        rccl = {'rccl_ranks': dist.get_world_size(), 'allreduce_us_per_step': a0.elapsed_time(a1) * 10.0}
+    if rank == 0:
+        out = {'metric': 'points/sec through the point-to-plane ICP loss fwd+bwd + Adam (BASELINE config 4 shape, joint model + pose '
+                         'optimisation through train())',
+               'value': n_points * args.steps / elapsed, 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': 'C4: %d KITTI-360-like sequence(s) of %d scans x 64 x 2048 rays, one per rank; depth 5-25 m + 0.2 m '
+                                      'voxel pre-filters (%d points left in all), ball neighbourhoods r = 0.4 m, icp_loss (point to '
+                                      'plane), ScaledPolynomial + per-pose corrections, Adam; train() of the reference API'
+                                      % (n_seq, args.c4_scans, int(n_points)),
+                          'points': 'points of all sequences after the pre-filters (every one is a row of the neighbourhood / feature '
+                                    'set-up; the ICP loss itself pairs ~a tenth of them per iteration)',
+                          'loop': 'depth_correction_amd.train.train(), per-iteration bookkeeping (several ranks: the plain loop with one '
+                                  'all-reduce per iteration)'},
+               'roofline': None, 'cpu_baseline': None}
+        if rccl:
+            out['config'].update(rccl)
+            out.update(rccl)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -723,7 +723,7 @@ class SequenceTrainer:
         # t + 1 (dc_sequence_eval_after_update), three launches per step instead of four; the returned sums are current, only
         # the weights lag by the one update flush() applies
         self.update_in_next = (bool(chained) and not self.fused_step and evaluate is None and adam is None
-                               and len(self.plans) == 1 and self.nt > 0)
+                               and len(self.plans) >= 1 and self.nt > 0)
         self._pending = False
         self.ready = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
@@ -745,7 +745,8 @@ class SequenceTrainer:
         update); returns the sums.  No-op otherwise."""
         buf = self.outs[0] if out is None else out
         if self._pending and self.update_in_next:
-            self.adam(self.outs[0][2:2 + self.nt])                # the last evaluation's (all-reduced) gradient, step self.t
+            g = self.acc if len(self.plans) > 1 else self.outs[0]
+            self.adam(g[2:2 + self.nt])                           # the last evaluation's (all-reduced) gradient, step self.t
             self._pending = False
         elif self._pending:
             self.plans[0].chain_flush(self.w, buf, self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
@@ -783,12 +784,21 @@ class SequenceTrainer:
                                             self.weight_decay)
             return out[:2 + self.nt]
         if self.update_in_next:
-            acc = self.outs[0][:2 + self.nt]
+            several = len(self.plans) > 1
+            acc = self.acc if several else self.outs[0][:2 + self.nt]
             # (the launch reads the gradient before the reduction that follows it on the stream overwrites `out`)
             ok = self.plans[0].eval_after_update(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg, self.exp_avg_sq,
                                                  self.t + 1, acc[2:] if self._pending else None, self.ready, self._grad_scale(),
                                                  self.lr, self.betas, self.eps, self.weight_decay)
             if ok:
+                if several:
+                    # the other local sequences follow on the stream: their launches start after the first one has published
+                    # the updated weights (kernels of one stream run in order); their sums join the first one's
+                    for plan, P, out in zip(self.plans[1:], self.poses12[1:], self.outs[1:]):
+                        self.evaluate(plan, self.w, self.exponent, P, out)
+                    acc.zero_()
+                    for o in self.outs:
+                        acc += o[:2 + self.nt]
                 if self.distributed:
                     from .distributed import all_reduce_sum
                     all_reduce_sum(acc, self.group)

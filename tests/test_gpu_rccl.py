@@ -83,3 +83,104 @@ def test_grad_reducer_and_object_gather_over_rccl(nccl_group):
     # world size 1 short-cuts the object gather; the device argument is what a multi-rank launcher relies on
     out = gather_objects(([0], [torch.ones(2)]), device='cuda:0')
     assert len(out) == 1 and out[0][0] == [0]
+
+
+def test_two_local_sequences_keep_the_update_in_next_path(golden, nccl_group):
+    """Config 3 with more sequences than GPUs: a rank that owns SEVERAL sequences still takes the Adam update of step t in the
+    first launch of step t + 1 (dc_sequence_eval_after_update on its first sequence; the others follow on the stream and read
+    the published weights) -- weights and sums follow the plain trainer (evaluate all -> sum -> all-reduce -> dc_adam_step)."""
+    from depth_correction_amd.plan import SequencePlan, SequenceTrainer
+    g = golden('room_k10')
+    cfg = _cfg(g, float_type='float32')
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    mask2 = mask & (torch.arange(len(mask), device=mask.device) % 3 != 0)
+    mk = lambda: [SequencePlan(clouds, poses, ns[0], mask), SequencePlan(clouds, poses, ns[0].clone(), mask2)]
+    plain = SequenceTrainer(mk(), g['w'], g['exponent'], [poses, poses], lr=1e-2, distributed=True)
+    fast = SequenceTrainer(mk(), g['w'], g['exponent'], [poses, poses], lr=1e-2, distributed=True, chained=True)
+    assert fast.update_in_next and not plain.update_in_next
+    for it in range(8):
+        a, b = npy(fast.step()).copy(), npy(plain.step()).copy()
+        assert fast.update_in_next
+        assert a[1] == b[1] == float(mask.sum() + mask2.sum())
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-10)
+        np.testing.assert_allclose(a[2:], b[2:], rtol=1e-8, atol=1e-12 * np.abs(b[2:]).max())
+    fast.flush()
+    np.testing.assert_allclose(npy(fast.w), npy(plain.w), rtol=1e-9)
+    assert abs(npy(fast.w)[0] - float(g['w'].reshape(-1)[0])) > 1e-3
+
+
+def _train_rank(rank, world, port, log_dir, result):
+    """One RCCL rank of test_train_two_rccl_ranks: its own process (spawned by a parent that never touched the GPU from this
+    test's point of view: the child initialises the device itself), GPU `rank`."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    try:
+        hist = _train_sequences('cuda', log_dir, None)          # index-less device: the launcher's set_device decides (ADVICE r3)
+        result[rank] = hist
+    finally:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+def _train_sequences(device, log_dir, distributed):
+    """train() on three small room sequences with per-sequence pose corrections and the min-eigenvalue loss; per iteration
+    [global train loss, w...]."""
+    from depth_correction_amd.config import Config, PoseCorrection
+    from depth_correction_amd.dataset import RoomBoxDataset
+    from depth_correction_amd import train as T
+    cfg = Config(pose_correction=PoseCorrection.sequence, nn_k=8, nn_r=None, min_depth=0.0, max_depth=float('inf'), grid_res=0.0,
+                 vp_dispersion_bounds=[], n_opt_iters=6, lr=1e-3, device=device, float_type='float64', log_dir=log_dir,
+                 distributed=distributed, model_kwargs={'w': [1e-3, -2e-3], 'exponent': [2.0, 4.0]})
+    seqs = [list(RoomBoxDataset(n_pts=3000, n_poses=3, seed_base=1000 + 100 * q, dtype=np.float64)) for q in range(3)]
+    hist = []
+
+    class CB(T.TrainCallbacks):
+        def train_loss(self, it, model, clouds, pose_deltas, poses, masks, loss_):
+            hist.append([float(loss_.detach())] + model.w.detach().reshape(-1).tolist())
+
+    T.train(cfg, callbacks=CB(), train_datasets=seqs, val_datasets=[])
+    return np.asarray(hist)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the one-GPU box collects and skips it)')
+def test_train_two_rccl_ranks(tmp_path):
+    """train() itself on TWO RCCL ranks (BASELINE config 3 / 4 in code: sequence q on rank q mod 2, per-sequence pose corrections
+    with their owner, the model weights in one packed all-reduce per iteration) reaches its checkpoints and follows the
+    single-process run: global loss and weights per iteration on both ranks, rank 0's checkpoint with every sequence's
+    corrections."""
+    import glob
+    import torch.multiprocessing as mp
+    ref = _train_sequences('cuda:0', str(tmp_path / 'single'), False)
+    ctx = mp.get_context('spawn')
+    result = ctx.Manager().dict()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_train_rank, args=(r, 2, port, str(tmp_path / 'sharded'), result)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(result[r], ref, rtol=1e-8, atol=1e-12)
+    ckpt = sorted(glob.glob(os.path.join(str(tmp_path / 'sharded'), '*_pose_deltas.pth')))
+    assert ckpt and len(torch.load(ckpt[-1])) == 3
+
+
+def test_train_sequences_single_process(tmp_path):
+    """The single-process arm of test_train_two_rccl_ranks on a one-GPU box (so the arm that is skipped here does not rot): six
+    iterations over three sequences with per-sequence pose corrections; the model moves and a checkpoint with three corrections
+    is written."""
+    import glob
+    hist = _train_sequences('cuda:0', str(tmp_path), False)
+    assert hist.shape == (6, 3) and np.isfinite(hist).all() and not np.allclose(hist[0, 1:], hist[-1, 1:])
+    ckpt = sorted(glob.glob(os.path.join(str(tmp_path), '*_pose_deltas.pth')))
+    assert ckpt and len(torch.load(ckpt[-1])) == 3
