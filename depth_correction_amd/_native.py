@@ -56,6 +56,7 @@ _SIGNATURES = {
     'dc_block_table_slots': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_workspace_bytes': (_sz, [_i64]),
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'dc_block_group': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_own_base': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'dc_block_table_run_capacity': (_i64, [_i64, _i64]),
     'dc_block_table_build_runs': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -160,6 +161,9 @@ def check(status, what):
 
 def stream_ptr():
     """torch's current stream of the CURRENT device; launches run under ``on_device`` so that this is the operands' device."""
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is not None:                         # the handle itself, without building a torch.cuda.Stream object per launch
+        return ctypes.c_void_p(raw(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

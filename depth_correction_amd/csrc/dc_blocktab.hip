@@ -166,6 +166,51 @@ __global__ __launch_bounds__(kBlock) void bt_info_kernel(const int32_t* __restri
   if (b == 0) info[0] = blk_ptr[n_blocks];
 }
 
+// Inside every block of 256 consecutive positions of `order` (the plan's Morton order): the points inside the loss mask first, by
+// scan id, then those outside, by scan id -- a stable counting sort of the block's lanes by the key (outside ? S : 0) + scan, and
+// the segment starts seg[b][0 .. 2 S] (seg[b][2 S] = the block's point count).  What the set of points of a block is does not
+// change.  (dcSequenceDesc.scan_seg; round 4 -- as torch ops this was a stable argsort of [blocks, 256] keys, whose first use in a
+// process loads torch's sort kernels: 0.4 s of the first set-up.)
+constexpr int kMaxGroupKeys = 2 * 64 + 1;
+__global__ __launch_bounds__(kBlock) void bt_block_group_kernel(const int32_t* __restrict__ order_in, const int32_t* __restrict__ scan_id,
+                                                                const uint8_t* __restrict__ mask, int64_t n, int n_scans,
+                                                                int32_t* __restrict__ order_out, uint16_t* __restrict__ seg) {
+  constexpr int NW = kBlock / kWave;
+  __shared__ int s_cnt[NW][kMaxGroupKeys];
+  __shared__ int s_start[kMaxGroupKeys + 1];
+  const int V = 2 * n_scans;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + tid;
+  const bool valid = p < n;
+  int32_t o = 0;
+  int key = V;                                               // positions past the end sort last
+  if (valid) {
+    o = order_in[p];
+    key = scan_id[o] + ((mask && !mask[o]) ? n_scans : 0);
+  }
+  int rank_in_wave = 0;
+  for (int q = 0; q <= V; ++q) {
+    const unsigned long long m = __ballot(key == q);
+    if (lane == 0) s_cnt[wave][q] = __popcll(m);
+    if (key == q) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int at = 0;
+    for (int q = 0; q <= V; ++q) {
+      s_start[q] = at;
+      for (int w = 0; w < NW; ++w) at += s_cnt[w][q];
+    }
+  }
+  __syncthreads();
+  if (tid <= V) seg[(int64_t)blockIdx.x * (V + 1) + tid] = (uint16_t)s_start[tid];
+  if (valid) {
+    int pos = s_start[key] + rank_in_wave;
+    for (int w = 0; w < wave; ++w) pos += s_cnt[w][key];
+    order_out[(int64_t)blockIdx.x * kBlock + pos] = o;
+  }
+}
+
 static inline int64_t blocks_of(int64_t n) { return (n + kBlock - 1) / kBlock; }
 static inline unsigned grid_of(int64_t n) { return (unsigned)(n > 0 ? (n + kBlock - 1) / kBlock : 1); }
 
@@ -257,6 +302,16 @@ int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int6
   const int64_t nb = blocks_of(n_rows);
   if (nb == 0) return DC_OK;
   hipLaunchKernelGGL(bt_own_base_kernel, dim3(grid_of(nb)), dim3(kBlock), 0, stream, blk_ptr, blk_ids, n_rows, nb, own_base);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_t* mask, int64_t n, int n_scans, int32_t* order_out,
+                   uint16_t* seg_out, hipStream_t stream) {
+  if (n < 0 || n_scans < 1 || n_scans > 64 || !order_in || !scan_id || !order_out || !seg_out || order_in == order_out) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  hipLaunchKernelGGL(bt_block_group_kernel, dim3((unsigned)blocks_of(n)), dim3(kBlock), 0, stream, order_in, scan_id, mask, n, n_scans,
+                     order_out, seg_out);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

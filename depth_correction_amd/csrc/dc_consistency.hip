@@ -3207,6 +3207,10 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     return DC_OK;
   }
 
+  // (measured in round 4 and dropped: a forward that FORMS the rows it stages from the raw inputs -- model, pose, ray end point per
+  // staged row, the owning block writing x for the backward -- instead of dc_points_fwd + a forward over x.  It removes a 22 us launch
+  // and 48 B per point of traffic, but a block stages 1.47 rows per point and each costs five scattered loads and ~80 fp64
+  // instructions in front of the staging barrier: 106 us against 22 + 46.)
   int rc = dc_points_fwd(d->vps, d->dirs, d->depth, d->inc, d->lmask, d->scan_id, poses, d->n_scans, d->model_kind,
                          d->n_terms, w, e, d->n, d->dtype, d->point_fmt, d->qparams, stride, d->x, nullptr, nullptr,
                          nullptr, d->status, stream);

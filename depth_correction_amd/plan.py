@@ -126,17 +126,15 @@ class SequencePlan:
                 # (b) its masked-out points fill whole wavefronts at its end, which the one-pass kernels skip (they add nothing to
                 # the loss, the count or dL/dw).  dcSequenceDesc.scan_seg: [blocks, 2 S + 1]
                 nb, S = (self.n + 255) // 256, self.n_scans
-                key = torch.full((nb * 256,), 2 * S, dtype=torch.int64, device=dev)                # padding sorts last
-                key[:self.n] = scan_id[order].long() + (0 if mask is None else (~mask[order]).long() * S)
-                key = key.reshape(nb, 256)
-                local = torch.argsort(key, dim=1, stable=True)
-                pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
-                order = order[pos[:self.n]] if self.n == nb * 256 else order[pos[pos < self.n]]
-                counts = torch.zeros((nb, 2 * S + 1), dtype=torch.int64, device=dev)
-                counts.scatter_add_(1, key, torch.ones_like(key))
-                seg = torch.zeros((nb, 2 * S + 1), dtype=torch.int64, device=dev)
-                seg[:, 1:] = counts[:, :2 * S].cumsum(1)
-                self.scan_seg = seg.to(torch.uint16).contiguous()
+                order32 = order.to(torch.int32).contiguous()
+                grouped = torch.empty_like(order32)
+                seg16 = torch.empty((nb, 2 * S + 1), dtype=torch.uint16, device=dev)
+                m8 = None if mask is None else mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+                check(lib().dc_block_group(ptr(order32), ptr(scan_id), ptr(m8), self.n, S, ptr(grouped), ptr(seg16), stream_ptr()),
+                      'dc_block_group')
+                order = grouped.long()
+                self.scan_seg = seg16
+                seg = seg16.view(torch.int16).long() & 0xFFFF
                 # share of the wavefronts (64 lanes) whose centres are all outside the mask: what the one-pass kernels skip
                 inside = seg[:, S]                                                                 # masked-in points per block
                 skipped = (4 - ((inside + 63) // 64)).clamp(min=0).sum() - (nb * 4 - (self.n + 63) // 64)

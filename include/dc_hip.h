@@ -216,6 +216,12 @@ int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_r
                          const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
                          int32_t* info, void* ws, size_t ws_bytes, dcStream_t stream);
 int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int64_t n_rows, int32_t* own_base, dcStream_t stream);
+/* The layout step behind dcSequenceDesc.scan_seg: inside every block of 256 consecutive entries of `order_in` (point indices in the
+ * plan's order) the points inside `mask` (uint8 [n] in the ORIGINAL order, or NULL: all) first, by scan id (`scan_id` int32 [n],
+ * original order), then those outside, by scan id; stable.  order_out int32 [n] (not order_in), seg_out uint16
+ * [ceil(n / 256), 2 n_scans + 1].  n_scans <= 64.  (No reference counterpart: the reference keeps scans one after the other.) */
+int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_t* mask, int64_t n, int n_scans, int32_t* order_out,
+                   uint16_t* seg_out, dcStream_t stream);
 int64_t dc_block_table_run_capacity(int64_t n_rows, int64_t n_refs);
 int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int64_t n_refs, int32_t* run_ptr,
                               int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes,
