@@ -459,6 +459,33 @@ def main():
         extras['cold_ms_per_step'] = (time.perf_counter() - t0) / args.steps * 1e3
         extras['cold_note'] = '%d chained steps + flush started after one second of an idle device, no device warm-up' % args.steps
         del tr2
+    if world == 1 and not args.autograd and not args.no_extras and args.dtype == 'float32' and args.scans * args.points <= 4_000_000:
+        # the reference's DEFAULT float_type is float64 (config.py:179): the same sequence with float64 clouds (fp64 points and
+        # basis rows, consistency_step_basis_kernel<double, ...>), 200 chained steps
+        scans64 = [s_.astype(np.float64) for s_ in scans_xyz]
+        plan64, info64 = build_sequence(scans64, poses, k=args.k, dtype=torch.float64, device=dev)
+        tr64 = SequenceTrainer([plan64], w0, e0, [info64['poses']], lr=1e-3, chained=not args.no_chain)
+        for _ in range(100):
+            tr64.step()
+        tr64.flush()
+        torch.cuda.synchronize()
+        with KernelTimer(every=8) as kt64:
+            t0 = time.perf_counter()
+            for _ in range(200):
+                tr64.step()
+            tr64.flush()
+            torch.cuda.synchronize()
+            ms64 = (time.perf_counter() - t0) / 200 * 1e3
+            k64 = kt64.kernels().get('consistency_fwd')
+            kms64 = kt64.read().get('consistency_fwd', (None, 0))[0]
+        prof64 = load_profile_table().get('%s/N%d' % (k64, plan64.n))
+        extras['fp64_cloud_step'] = {'ms_per_step': ms64, 'kernel': k64, 'kernel_ms': kms64, 'points_per_s': plan64.n / (ms64 * 1e-3),
+                                     'hbm_bytes': prof64['hbm_bytes'] if prof64 else None,
+                                     'hbm_frac': (prof64['hbm_bytes'] / (kms64 * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (prof64 and kms64) else None,
+                                     'valu_insts_per_point': prof64['valu_insts_per_point'] if prof64 else None,
+                                     'what': 'float64 clouds (the reference default float_type): fp64 points, fp64 basis rows, fp64 second sweep'}
+        del tr64, plan64, info64, scans64
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_extras:        # single-process runs only: the other ranks must not wait for rank 0
         # the same step without the loop-invariant hoisting (general path: dc_points_fwd + forward + backward every iteration,
         # what the reference's own loop recomputes) and with separate forward / backward kernels, for comparison
@@ -550,6 +577,19 @@ def main():
                                   '2.4 MB table cost ~7 us by themselves on this chip whatever the cache policy '
                                   '(profiles/r04_ubench_gather_rows.txt); the same kernel on the same points in Morton order: '
                                   'tools/features_bench.py' % (n1, n1 * (args.k - 1))}
+        # the same kernel on the same scan with its points in Morton order (a scan in sensor order -- ring by ring -- is spatially
+        # coherent like that; this generator draws its rays at random): neighbours share cache lines, the gathers cost a third
+        order1 = ops.spatial_order(x1).long()
+        xs1, ds1 = x1[order1].contiguous(), c0['dirs'][order1].contiguous()
+        _, idx_s1 = ops.knn(xs1, args.k)
+        for _ in range(20):
+            ops.features_fwd(xs1, idx_s1, dirs=ds1)
+        with KernelTimer(every=1) as ft:
+            for _ in range(220):
+                ops.features_fwd(xs1, idx_s1, dirs=ds1)
+            torch.cuda.synchronize()
+            c1['features_fwd_ms_points_in_morton_order'] = ft.read()['features_fwd'][0]
+        del xs1, ds1, idx_s1, order1
         extras['c1_forward_only'] = c1
         # the online correction node's per-scan work (scripts/depth_correction:31-58): local_feature_cloud (shadow filter,
         # neighbourhoods, features, mask) -> model -> update_points, on an already uploaded 200k-point scan

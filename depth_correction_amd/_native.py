@@ -18,6 +18,7 @@ __all__ = ['lib', 'lib_path', 'on_device', 'DC_F32', 'DC_F64', 'DC_Q32', 'LOSS_K
 DC_F32, DC_F64, DC_Q32 = 0, 1, 2
 DC_TABLE_SLOTS, DC_TABLE_RUNS = 0, 1
 LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
+DC_LOSS_RAW_POINTWISE, DC_LOSS_SKIP_NANS, DC_LOSS_ONLY_FINITE = 0x100, 0x200, 0x400      # OR-ed into a loss kind (include/dc_hip.h)
 LOSS_RAW_POINTWISE = 0x100
 DC_ERR_BACKWARD_TABLES = -5
 MODEL_KINDS = {None: 0, 'BaseModel': 0, 'Polynomial': 1, 'ScaledPolynomial': 2, 'Linear': 3, 'InvCos': 4, 'ScaledInvCos': 5}

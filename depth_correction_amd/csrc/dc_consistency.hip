@@ -93,7 +93,9 @@ __device__ __forceinline__ void consistency_point(CovAcc& acc, const typename Pt
   }
   double raw;
   l = loss_and_coeffs(lp, lam0, tr, D, off, m, &c1, &c2, &raw);
-  if (m) { acc2[0] = l; acc2[1] = 1.0; }
+  const bool drop = loss_dropped(lp, l);
+  if (drop) c1 = c2 = 0.0;
+  if (m && !drop) { acc2[0] = l; acc2[1] = 1.0; }
   // record: covariance mean in the point format; coefficients act on differences in metres
   if (rec) RecRaw<PT>::store(rec, i, Pt<PT>::offset(ci, cm), c1, v0, c2);
   if (pointwise) pointwise[i] = (T)(lp.raw_pointwise ? raw : l);
@@ -1573,7 +1575,9 @@ __device__ __forceinline__ void step_point(CovAcc& acc, bool m, const LossParams
   cov_finish(acc, 0.0, moff, cm, C, &D, &omega, u * u);
   eig3_smallest_r2(C[0], C[1], C[2], C[3], C[4], C[5], &lam0, v0, &tr);      // (the A-B baseline form, dc_set_option(6, 0))
   const double l = loss_and_coeffs(lp, lam0, tr, D, 0.0, m, c1, c2);
-  if (m) { acc2[0] = l; acc2[1] = 1.0; }
+  const bool drop = loss_dropped(lp, l);
+  if (drop) *c1 = *c2 = 0.0;
+  if (m && !drop) { acc2[0] = l; acc2[1] = 1.0; }
   if (!(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
 }
 
@@ -1646,10 +1650,11 @@ __device__ __forceinline__ void step_point2(const CovAcc& acc, int n_have, bool 
     a = (l > 0.0) ? a * 0.5 / sq : 0.0;
     l = sq;
   }
-  const double fd = 2.0 * a * invD;
+  const bool drop = loss_dropped(lp, l);                    // (skip_nans / only_finite: not part of the reduction at all)
+  const double fd = drop ? 0.0 : 2.0 * a * invD;
   *c1 = fd * g_vv;
   *c2 = -fd * g_eye;
-  if (m) { acc2[0] = l; acc2[1] = 1.0; }
+  if (m && !drop) { acc2[0] = l; acc2[1] = 1.0; }
   // an empty neighbourhood (NaN mean) must contribute nothing to the second sweep: only possible when slots are missing
   if (!full && !(*c1 != 0.0 || *c2 != 0.0)) { cm[0] = cm[1] = cm[2] = 0.0; v0[0] = v0[1] = v0[2] = 0.0; }
 }
@@ -2304,31 +2309,40 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
 #pragma unroll
     for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
     const float c2f = (float)c2;
+    // (two neighbours per packed float32 instruction: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes' worth of work in
+    // one issue slot -- the arithmetic of a neighbour's term drops from ~24 to ~15 instructions)
     auto sweep2 = [&](const uint32_t* l, uint32_t* nx, const uint16_t* pn) {
 #pragma unroll
       for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)pn[u_ * kBlock];
-      float g[P];
+      float2v g[P];
 #pragma unroll
-      for (int k = 0; k < P; ++k) g[k] = 0.0f;
+      for (int k = 0; k < P; ++k) g[k] = float2v{0.0f, 0.0f};
 #pragma unroll
-      for (int u_ = 0; u_ < kTrip; ++u_) {
-        const bool have = l[u_] != kNoLoc;                 // (packed rows: the same as slot < deg)
-        const char* row = tb + (have ? l[u_] : own_off);
-        const int4 p0 = *reinterpret_cast<const int4*>(row);
-        const int4 p1 = *reinterpret_cast<const int4*>(row + CAP * 16);
-        const float e0 = (float)(p0.x - ci.v[0]) - cmf[0], e1 = (float)(p0.y - ci.v[1]) - cmf[1], e2 = (float)(p0.z - ci.v[2]) - cmf[2];
-        const float u0 = __int_as_float(p0.w), u1 = __int_as_float(p1.x), u2 = __int_as_float(p1.y);
-        const float al = fmaf(vs[2], e2, fmaf(vs[1], e1, vs[0] * e0));
-        const float be = fmaf(vu[2], u2, fmaf(vu[1], u1, vu[0] * u0));
-        const float ga = fmaf(e2, u2, fmaf(e1, u1, e0 * u0));
-        float tj = fmaf(al, be, -(c2f * ga));
-        if (!have) tj = 0.0f;                              // an empty slot (the lane's own row) is not a neighbour
-        g[0] = fmaf(tj, __int_as_float(p1.z), g[0]);
-        if constexpr (P > 1) g[1] = fmaf(tj, __int_as_float(p1.w), g[1]);
-        if constexpr (P > 2) g[2] = fmaf(tj, __int_as_float(reinterpret_cast<const int4*>(row + CAP * 32)->x), g[2]);
+      for (int u_ = 0; u_ < kTrip; u_ += 2) {
+        const bool ha = l[u_] != kNoLoc, hb = l[u_ + 1] != kNoLoc;      // (packed rows: the same as slot < deg)
+        const char* ra = tb + (ha ? l[u_] : own_off);
+        const char* rb = tb + (hb ? l[u_ + 1] : own_off);
+        const int4 a0 = *reinterpret_cast<const int4*>(ra), a1 = *reinterpret_cast<const int4*>(ra + CAP * 16);
+        const int4 b0 = *reinterpret_cast<const int4*>(rb), b1 = *reinterpret_cast<const int4*>(rb + CAP * 16);
+        const float2v e0 = float2v{(float)(a0.x - ci.v[0]), (float)(b0.x - ci.v[0])} - float2v{cmf[0], cmf[0]};
+        const float2v e1 = float2v{(float)(a0.y - ci.v[1]), (float)(b0.y - ci.v[1])} - float2v{cmf[1], cmf[1]};
+        const float2v e2 = float2v{(float)(a0.z - ci.v[2]), (float)(b0.z - ci.v[2])} - float2v{cmf[2], cmf[2]};
+        const float2v u0 = float2v{__int_as_float(a0.w), __int_as_float(b0.w)};
+        const float2v u1 = float2v{__int_as_float(a1.x), __int_as_float(b1.x)};
+        const float2v u2 = float2v{__int_as_float(a1.y), __int_as_float(b1.y)};
+        const float2v al = __builtin_elementwise_fma(float2v{vs[2], vs[2]}, e2, __builtin_elementwise_fma(float2v{vs[1], vs[1]}, e1, float2v{vs[0], vs[0]} * e0));
+        const float2v be = __builtin_elementwise_fma(float2v{vu[2], vu[2]}, u2, __builtin_elementwise_fma(float2v{vu[1], vu[1]}, u1, float2v{vu[0], vu[0]} * u0));
+        const float2v ga = __builtin_elementwise_fma(e2, u2, __builtin_elementwise_fma(e1, u1, e0 * u0));
+        float2v tj = __builtin_elementwise_fma(al, be, -(float2v{c2f, c2f} * ga));
+        tj = float2v{ha ? tj.x : 0.0f, hb ? tj.y : 0.0f};           // an empty slot (the lane's own row) is not a neighbour
+        g[0] = __builtin_elementwise_fma(tj, float2v{__int_as_float(a1.z), __int_as_float(b1.z)}, g[0]);
+        if constexpr (P > 1) g[1] = __builtin_elementwise_fma(tj, float2v{__int_as_float(a1.w), __int_as_float(b1.w)}, g[1]);
+        if constexpr (P > 2)
+          g[2] = __builtin_elementwise_fma(tj, float2v{__int_as_float(reinterpret_cast<const int4*>(ra + CAP * 32)->x),
+                                                       __int_as_float(reinterpret_cast<const int4*>(rb + CAP * 32)->x)}, g[2]);
       }
 #pragma unroll
-      for (int k = 0; k < P; ++k) gw[k] += (double)g[k];
+      for (int k = 0; k < P; ++k) gw[k] += (double)(g[k].x + g[k].y);
     };
     {
       uint32_t la[kTrip], lb[kTrip];
@@ -2744,7 +2758,8 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
                                 double* sums_out, hipStream_t stream, bool reduce) {
   if (n == 0 && sums_out) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
   if (n < 0 || k < 1 || !points || !partials_ws || !sums_out || (stride != 3 && stride != 4)) return DC_ERR_ARG;
-  if ((loss_kind & ~DC_LOSS_RAW_POINTWISE) != DC_LOSS_MIN_EIGVAL && (loss_kind & ~DC_LOSS_RAW_POINTWISE) != DC_LOSS_TRACE) return DC_ERR_ARG;
+  if ((loss_kind & 0xFF) != DC_LOSS_MIN_EIGVAL && (loss_kind & 0xFF) != DC_LOSS_TRACE) return DC_ERR_ARG;
+  if (loss_kind & ~(0xFF | DC_LOSS_RAW_POINTWISE | DC_LOSS_SKIP_NANS | DC_LOSS_ONLY_FINITE)) return DC_ERR_ARG;
   BlockTab tab{};
   size_t lds_bytes = 0;
   int lds_rows = 0;
@@ -2756,7 +2771,7 @@ static int consistency_fwd_impl(const void* points, int stride, int dtype, int p
   int rc = make_qparams(point_fmt, dtype, stride, qparams, &qp);
   if (rc) return rc;
   if (n == 0) return (int)hipMemsetAsync(sums_out, 0, 2 * sizeof(double), stream);
-  LossParams lp{loss_kind & ~DC_LOSS_RAW_POINTWISE, normalization, sqrt_, (loss_kind & DC_LOSS_RAW_POINTWISE) != 0};
+  const LossParams lp = make_loss_params(loss_kind, normalization, sqrt_);
   const int64_t rows = xcd_grid(n_blocks(n));
   dim3 grid((unsigned)rows), block(kBlock);
 #define FWD_ARGS(T, PT) (const PT*)points, nbr, centre_idx, n, k, mask, (const T*)offset, lp, qp, (PT*)rec, (T*)pointwise, (T*)eigvals, partials_ws
@@ -3095,7 +3110,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
     if (rc) return rc;
     PointBasis pb{d->basis, w, n_terms, q32_pts ? qp.inv_scale : 1.0};
-    LossParams lp{d->loss_kind, d->normalization, d->sqrt_, 0};
+    const LossParams lp = make_loss_params(d->loss_kind & ~DC_LOSS_RAW_POINTWISE, d->normalization, d->sqrt_);
     BlockTab tab{d->fwd_table->blk_ptr, d->fwd_table->blk_ids, d->fwd_table->slot_ptr, d->fwd_table->loc};
     const dim3 block(kBlock);
     if (one_pass) {

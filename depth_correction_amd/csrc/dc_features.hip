@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void features_fwd_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // The same features, tiled (round 4): what dc_features_fwd launches for the neighbour counts the reference's configurations
-// use (K = 4 / 8 / 10 / 16 compiled in), validity weights and 16-B aligned arrays.  features_fwd_kernel above walks a run-time
+// use (K = 4 / 8 / 10 / 16 compiled in), validity weights in the mean and 16-B aligned arrays.  features_fwd_kernel above walks a run-time
 // slot loop -- one dependent {index, row} round trip per neighbour, 75 % of its wave cycles waiting -- reads the [N, K] index
 // table with a lane stride of 4 K bytes and writes 28 output words per lane with strides of 12 / 36 bytes.  Here a WAVEFRONT
 // owns 64 consecutive centres and its own LDS region -- one wavefront per workgroup: no block barrier, and the dispatcher balances
@@ -136,8 +136,8 @@ template <typename T, int STRIDE, int K>
 __global__ __launch_bounds__(kWave) void features_fwd_tile_kernel(
     const T* __restrict__ x, const int32_t* __restrict__ nbr, const T* __restrict__ dirs, int64_t n, double scale,
     T* __restrict__ mean, T* __restrict__ cov, T* __restrict__ eigvals, T* __restrict__ eigvecs, T* __restrict__ normals,
-    T* __restrict__ inc, int32_t* __restrict__ nvalid, T* __restrict__ cmean_out, T* __restrict__ invd_out) {
-  constexpr int kIdxBytes = 64 * K * 4, kStageBytes = 64 * 9 * (int)sizeof(T);
+    T* __restrict__ inc, int32_t* __restrict__ nvalid, T* __restrict__ cmean_out, T* __restrict__ invd_out, T* __restrict__ weights_out) {
+  constexpr int kIdxBytes = 64 * K * 4, kStageBytes = 64 * (K > 9 ? K : 9) * (int)sizeof(T);
   constexpr int kRegion16 = (kIdxBytes > kStageBytes ? kIdxBytes : kStageBytes) / 16;
   __shared__ int4 region[kRegion16];
   const int64_t nblocks = (n + kWave - 1) / kWave;
@@ -212,6 +212,12 @@ __global__ __launch_bounds__(kWave) void features_fwd_tile_kernel(
     wave_store_rows<T, 3>(cmean_out, i0, lane, full, active, v, stage);
   }
   if (invd_out && active) invd_out[i] = (T)(omega / D);
+  if (weights_out) {                       // update_weights (depth_cloud.py:356-364): the centre's weight on its valid neighbours
+    double v[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = row[q] >= 0 ? omega : 0.0;
+    wave_store_rows<T, K>(weights_out, i0, lane, full, active, v, stage);
+  }
   if (nvalid && active) nvalid[i] = (int32_t)acc.W;
   if (cov) {
     const double v[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
@@ -327,16 +333,16 @@ int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nb
   // the tiled kernel: compiled-in neighbour counts, validity weights, every array 16-B aligned (torch allocations are; a
   // sliced view may not be) -- anything else takes the general kernel
   {
-    const void* arrs[] = {points, nbr, dirs, mean, cov, eigvals, eigvecs, normals, inc_angles, nvalid, cmean_out, invd_out};
+    const void* arrs[] = {points, nbr, dirs, mean, cov, eigvals, eigvecs, normals, inc_angles, nvalid, cmean_out, invd_out, weights_out};
     bool aligned = true;
     for (const void* a : arrs) aligned = aligned && (((uintptr_t)a & 15u) == 0);
-    const bool tiled = aligned && !mean_weights && !weights_out && (k == 4 || k == 8 || k == 10 || k == 16) &&
+    const bool tiled = aligned && !mean_weights && (k == 4 || k == 8 || k == 10 || k == 16) &&
                        (dtype == DC_F32 || dtype == DC_F64) && g_features_tiled.load(std::memory_order_relaxed);
     if (tiled) {
 #define TILE(T, S, KK) \
   DC_TIMED_LAUNCH((features_fwd_tile_kernel<T, S, KK>), dim3((unsigned)xcd_grid((n + kWave - 1) / kWave)), dim3(kWave), 0, stream, \
                   (const T*)points, nbr, (const T*)dirs, n, scale, (T*)mean, (T*)cov, (T*)eigvals, (T*)eigvecs, (T*)normals, \
-                  (T*)inc_angles, nvalid, (T*)cmean_out, (T*)invd_out)
+                  (T*)inc_angles, nvalid, (T*)cmean_out, (T*)invd_out, (T*)weights_out)
 #define TILE_K(T, S) \
   do { if (k == 4) TILE(T, S, 4); else if (k == 8) TILE(T, S, 8); else if (k == 10) TILE(T, S, 10); else TILE(T, S, 16); } while (0)
       if (dtype == DC_F32) { if (stride == 3) TILE_K(float, 3); else TILE_K(float, 4); }

@@ -167,7 +167,16 @@ struct LossParams {
   int normalization;   // min-eigenvalue / total variance (loss.py:253-254)
   int sqrt_;           // loss.py:286-287
   int raw_pointwise;   // the optional per-point output holds the loss BEFORE relu / sqrt (what loss.py:256-277 gates on)
+  int skip;            // 0: every masked point counts; 1: NaN losses are dropped (skip_nans); 2: non-finite ones (only_finite) -- loss.py:125-137
 };
+// the pointwise loss `l` of a masked point is dropped from the reduction: no term in the sum, the count or the gradients
+DC_HD bool loss_dropped(const LossParams& lp, double l) {
+  return lp.skip != 0 && (l != l || (lp.skip == 2 && !(fabs(l) < (double)INFINITY)));
+}
+DC_HD LossParams make_loss_params(int loss_kind, int normalization, int sqrt_) {
+  return LossParams{loss_kind & 0xFF, normalization, sqrt_, (loss_kind & DC_LOSS_RAW_POINTWISE) != 0,
+                    (loss_kind & DC_LOSS_ONLY_FINITE) ? 2 : ((loss_kind & DC_LOSS_SKIP_NANS) ? 1 : 0)};
+}
 
 // Pointwise loss l_i (after offset, relu, sqrt) and the coefficients of
 //   dL/dx_j += c1 * (v0 . d) v0 - c2 * d,  d = x_j - cmean_i,

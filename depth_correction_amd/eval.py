@@ -52,7 +52,9 @@ def fused_supported(clouds, model, cfg: Config):
     kw = cfg.loss_kwargs
     return (getattr(cfg, 'fused', True) and cfg.nn_type == NeighborhoodType.ball
             and cfg.loss in ('min_eigval_loss', 'trace_loss') and not cfg.loss_offset and not cfg.nn_scale
-            and not kw.get('only_finite') and not kw.get('skip_nans')       # NaN-dropping reductions: un-fused operators
+            # NaN-dropping reductions run inside the fused kernels (round 4); together with quantile gating: un-fused operators
+            and not ((kw.get('only_finite') or kw.get('skip_nans'))
+                     and (kw.get('inlier_ratio', 1.0) < 1.0 or kw.get('inlier_max_loss') is not None))
             and (model is None or getattr(model, 'kernel_kind', None) is not None)
             and clouds[0][0].dirs.is_cuda and all(c.inc_angles is not None for seq in clouds for c in seq))
 
@@ -123,14 +125,15 @@ def _plan_for(seq_clouds, poses, nn, mask, model, cfg):
     by the identity and version of every tensor it was built from (plan.PlanRegistry)."""
     neighbors = nn[0]
     kw = cfg.loss_kwargs
+    nan_policy = 'only_finite' if kw.get('only_finite') else ('skip_nans' if kw.get('skip_nans') else None)     # loss.py:125-137
     flags = (cfg.loss, bool(kw.get('normalization', False)), bool(kw.get('sqrt', False)),
-             getattr(model, 'kernel_kind', None) if model is not None else None)
+             getattr(model, 'kernel_kind', None) if model is not None else None, nan_policy)
     tensors = [t for c in seq_clouds for t in (c.vps, c.dirs, c.depth, c.inc_angles, c.mask)] + [neighbors, mask]
 
     def build():
         return SequencePlan(seq_clouds, poses.detach(), neighbors, None if mask is None else mask.to(neighbors.device),
                             model_kind=flags[3] or 'ScaledPolynomial', loss=cfg.loss,
-                            normalization=flags[1] and cfg.loss == 'min_eigval_loss', sqrt=flags[2])
+                            normalization=flags[1] and cfg.loss == 'min_eigval_loss', sqrt=flags[2], nan_policy=nan_policy)
     return _plans.get(tensors, flags, build)
 
 
@@ -166,7 +169,7 @@ def eval_loss_clouds(clouds, poses, pose_deltas, masks, ns, model, loss_fun, cfg
             s, cnt = consistency_loss(plan, w, e, p, **gating)          # cnt: masked points, or inliers (device scalar)
             total, count = total + s, count + cnt
             views.append(PlanCloud(plan, w, e, p, count=cnt,
-                                   inliers=plan.inlier_rows if isinstance(cnt, torch.Tensor) else None))
+                                   inliers=getattr(plan, 'inlier_rows', None) if (isinstance(cnt, torch.Tensor) and not plan.nan_policy) else None))
         if isinstance(count, torch.Tensor):
             loss = total / count                                          # 0 / 0 = nan, like the mean of no inliers
         else:

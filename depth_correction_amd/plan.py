@@ -42,7 +42,7 @@ class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
-                 scan_group=True, mask_first=False):
+                 scan_group=True, mask_first=False, nan_policy=None):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -54,6 +54,8 @@ class SequencePlan:
         :param lazy_backward: build the transposed neighbour lists / backward block table on first need instead of up front.
         :param basis: use the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis) whenever an evaluation asks for neither pose
                       nor exponent gradients: the basis rows are rebuilt only when the poses or the exponents change.
+        :param nan_policy: None, 'skip_nans' or 'only_finite' (loss.py:125-137): pointwise losses that are NaN / not finite are left
+                           out of the sum, the count and the gradients; the count of an evaluation is then its own (out[1]).
         :param mask_first: additionally collect the masked-out points of every 2048-point stretch into blocks of their own, which
                            the one-pass kernels skip whole (24 % of the wavefronts at C2 instead of 11 %).  OFF by default:
                            measured at C2 the remaining blocks then draw their neighbours from a third more distinct rows --
@@ -81,6 +83,8 @@ class SequencePlan:
         self._poses_key = self._poses12 = self._poses_ref = None
         self.sizes = sizes
         self.model_kind, self.loss, self.normalization, self.sqrt = model_kind, loss, bool(normalization), bool(sqrt)
+        assert nan_policy in (None, 'skip_nans', 'only_finite')
+        self.nan_policy = nan_policy
         g = getattr(neighbors, '_dc_graph', None)          # the int32 table the reference-typed indices were made from
         nbr = g.nbr if g is not None and g.version == neighbors._version else ops.as_index32(neighbors)
         need(nbr, (self.n, None), dtype=torch.int32, name='neighbors', device=dev)
@@ -272,6 +276,7 @@ class SequencePlan:
             d.model_kind = nv.MODEL_KINDS[self.model_kind] if n_terms > 0 else 0
             d.n_terms = n_terms
             d.loss_kind, d.normalization, d.sqrt_ = nv.LOSS_KINDS[self.loss], int(self.normalization), int(self.sqrt)
+            d.loss_kind |= {None: 0, 'skip_nans': nv.DC_LOSS_SKIP_NANS, 'only_finite': nv.DC_LOSS_ONLY_FINITE}[self.nan_policy]
             if d.model_kind != 0 and ps.inc is None:
                 raise ValueError('the model needs incidence angles')
             self._desc = d
@@ -600,10 +605,10 @@ class _ConsistencyLoss(torch.autograd.Function):
         ctx.meta = (nt, plan.n_scans, None if w is None else (w.shape, w.dtype, w.device),
                     (exponent.shape, exponent.dtype, exponent.device) if isinstance(exponent, torch.Tensor) else None,
                     (poses.dtype, poses.device) if isinstance(poses, torch.Tensor) else None)
-        if gating:
-            n_inliers = out[1]
-            ctx.mark_non_differentiable(n_inliers)
-            return out[0], n_inliers
+        if gating or plan.nan_policy:                    # the evaluation's own count: inliers / points whose loss was kept
+            n_kept = out[1]
+            ctx.mark_non_differentiable(n_kept)
+            return out[0], n_kept
         return out[0]                                    # a view: no copy kernel; `out` itself is what backward reads
 
     @staticmethod
@@ -651,6 +656,8 @@ def consistency_loss(plan, w, exponent, poses, inlier_ratio=1.0, inlier_max_loss
     if inlier_ratio < 1.0 or inlier_max_loss is not None:
         gating = dict(inlier_ratio=float(inlier_ratio), inlier_max_loss=inlier_max_loss, inlier_loss_mult=float(inlier_loss_mult))
         return _ConsistencyLoss.apply(plan, w, exponent, poses, gating)
+    if plan.nan_policy:                                  # NaN-dropping reduction: the count is this evaluation's (a device scalar)
+        return _ConsistencyLoss.apply(plan, w, exponent, poses)
     return _ConsistencyLoss.apply(plan, w, exponent, poses), plan.count
 
 

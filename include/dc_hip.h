@@ -30,6 +30,10 @@ extern "C" {
 #define DC_LOSS_MIN_EIGVAL 0
 #define DC_LOSS_TRACE 1
 #define DC_LOSS_RAW_POINTWISE 0x100 /* OR-ed into loss_kind of dc_consistency_fwd: `pointwise` receives the loss before relu / sqrt */
+/* OR-ed into loss_kind (dc_consistency_fwd, dcSequenceDesc.loss_kind): the reduction drops NaN (skip_nans) / non-finite
+ * (only_finite) pointwise losses -- neither the sum nor the count nor any gradient sees them (loss.py:125-137) */
+#define DC_LOSS_SKIP_NANS 0x200
+#define DC_LOSS_ONLY_FINITE 0x400
 #define DC_MODEL_NONE 0
 #define DC_MODEL_POLYNOMIAL 1
 #define DC_MODEL_SCALED_POLYNOMIAL 2

@@ -544,6 +544,50 @@ def test_unfused_options_match_oracle(golden):
     assert fused_supported([[cloud]], None, cfg)             # quantile inliers are gated inside the fused path
     cfg.loss_offset = True
     assert not fused_supported([[cloud]], None, cfg)
+    cfg.loss_offset = False
+    cfg.loss_kwargs.update(inlier_ratio=1.0, skip_nans=True)
+    assert fused_supported([[cloud]], None, cfg)             # NaN-dropping reductions too (round 4)
+
+
+@pytest.mark.parametrize('policy', ['skip_nans', 'only_finite'])
+@pytest.mark.parametrize('form', ['one_pass', 'general'])
+def test_nan_dropping_reductions_in_the_fused_kernels(golden, policy, form):
+    """loss.py:125-137 inside the fused plan (round 4): pointwise losses that are NaN (here: neighbourhoods without a single valid
+    member, W = 0 -> NaN mean) are left out of the sum, the count and the gradients -- by the one-pass kernel and by the
+    forward / backward pair -- as the oracle's masked mean over the finite entries has it; without the policy the loss is NaN."""
+    from depth_correction_amd import _native as nv
+    from depth_correction_amd.plan import SequencePlan, consistency_loss
+    g = golden('room_k10')
+    cfg = _cfg(g, float_type='float64')
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    nbr = ns[0].clone()
+    dead = torch.nonzero(mask).reshape(-1)[::97][:40]                 # masked-in centres that lose every neighbour
+    nbr[dead] = -1
+    w = torch.nn.Parameter(t(g['w'], 'cuda:0').reshape(1, -1).clone())
+    e = t(g['exponent'], 'cuda:0').reshape(1, -1)
+    nv.check(nv.lib().dc_set_option(3, 1 if form == 'general' else 0), 'dc_set_option')
+    try:
+        plain = SequencePlan(clouds, poses, nbr, mask)
+        s0, c0 = consistency_loss(plain, w, e, poses)
+        assert torch.isnan(s0) and c0 == float(mask.sum())
+        plan = SequencePlan(clouds, poses, nbr, mask, nan_policy=policy)
+        s, cnt = consistency_loss(plan, w, e, poses)
+        (s / cnt).backward()
+    finally:
+        nv.check(nv.lib().dc_set_option(3, 0), 'dc_set_option')
+    assert int(cnt) == int(mask.sum()) - len(dead)
+    # oracle: the mean over the kept entries.  (LAPACK refuses the NaN covariances of the emptied neighbourhoods -- eigh raises,
+    # in the reference too -- so the oracle gets the untouched table and the emptied centres masked out: the same set of terms)
+    oc = [dict(vps=c.vps.cpu(), dirs=c.dirs.cpu(), depth=c.depth.cpu(), inc=c.inc_angles.cpu(), mask=c.mask.cpu()) for c in clouds]
+    wo = torch.tensor(g['w'].reshape(1, -1), dtype=torch.float64, requires_grad=True)
+    kept = mask.clone()
+    kept[dead] = False
+    lo, _ = O.eval_sequence(oc, poses.cpu(), wo, e.cpu(), ns[0].long().cpu(), kept.cpu(), reduction='none')
+    assert int(lo.numel()) == int(cnt) and bool(lo.isfinite().all())
+    ref = lo.mean()
+    ref.backward()
+    np.testing.assert_allclose((s / cnt).item(), ref.item(), rtol=1e-9)
+    np.testing.assert_allclose(npy(w.grad).ravel(), npy(wo.grad).ravel(), rtol=1e-7, atol=1e-12 * np.abs(npy(wo.grad)).max())
 
 
 def test_icp_training_matches_oracle_loop(tmp_path):
