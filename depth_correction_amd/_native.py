@@ -58,6 +58,8 @@ _SIGNATURES = {
     'dc_block_table_workspace_bytes': (_sz, [_i64]),
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_block_group': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
     'dc_block_table_own_base': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'dc_block_table_run_capacity': (_i64, [_i64, _i64]),
     'dc_block_table_build_runs': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -108,6 +110,11 @@ class BlockTableDesc(ctypes.Structure):
                 ('reserved', ctypes.c_int32), ('row_ptr', _vp)]
 
 
+class PoseTableDesc(ctypes.Structure):
+    """dcPoseTable of include/dc_hip.h."""
+    _fields_ = [('blk_ptr', _vp), ('ids', _vp), ('loc', _vp), ('own_pos', _vp), ('row_seg', _vp), ('rt_ptr', _vp), ('rt_lane', _vp)]
+
+
 class IcpScan(ctypes.Structure):
     """dcIcpScan of include/dc_hip.h."""
     _fields_ = [('vps', _vp), ('dirs', _vp), ('depth', _vp), ('inc', _vp), ('lmask', _vp), ('normals', _vp)]
@@ -130,7 +137,7 @@ class SequenceDesc(ctypes.Structure):
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
                 ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp),
                 ('partials_count', ctypes.c_int64), ('scan_seg', _vp), ('blk_skip', _vp), ('fwd_rows_active', ctypes.c_int32),
-                ('reserved2', ctypes.c_int32)]
+                ('reserved2', ctypes.c_int32), ('pose_table', _vp), ('local_basis', _vp)]
 
 
 def lib_path():

@@ -1592,7 +1592,7 @@ constexpr int kStepVar = kVarF32Sweep | kVarSlimTail | kVarDppSums;     // what 
 // multiplies the trace alone; `full` (wave-uniform): every lane of the wavefront has all NS neighbours, W and D are constants.
 template <typename PT, int NS>
 __device__ __forceinline__ void step_point2(const CovAcc& acc, int n_have, bool full, bool m, const LossParams& lp, const QParams& qp,
-                                            double* acc2, double* cm, double* v0, double* c1, double* c2) {
+                                            double* acc2, double* cm, double* v0, double* c1, double* c2, double* sum_e2 = nullptr) {
   const double u = Pt<PT>::unit(qp);
   double invW, D, invD;
   if (full) {
@@ -1610,6 +1610,7 @@ __device__ __forceinline__ void step_point2(const CovAcc& acc, int n_have, bool 
   Cp[0] = fma(-acc.s[0], cm[0], acc.S[0]); Cp[1] = fma(-acc.s[0], cm[1], acc.S[1]); Cp[2] = fma(-acc.s[0], cm[2], acc.S[2]);
   Cp[3] = fma(-acc.s[1], cm[1], acc.S[3]); Cp[4] = fma(-acc.s[1], cm[2], acc.S[4]); Cp[5] = fma(-acc.s[2], cm[2], acc.S[5]);
   const double mp = (Cp[0] + Cp[3]) + Cp[5];            // trace in the units of the differences
+  if (sum_e2) *sum_e2 = mp;                             // = sum_j |x_j - mean|^2
   const double f = (u * u) * invD;
   const double tr = mp * f;
   double lam_rel, inv_tr;
@@ -2364,6 +2365,356 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
   step_partials<P, true>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
 }
 
+// ================================================================================================
+// Pose mode in ONE pass (round 4): loss, dL/dw AND dL/d[R|t] of every scan from one launch
+// ================================================================================================
+// train() with pose corrections (train.py:300-312, eval.py:68-82; scripts/model_poses_learning:71) moves the poses every
+// iteration, so the basis rows of the model-only step (X0 = R x + t) are stale after every step and the general path ran three
+// full passes: dc_points_fwd (22 us) -> forward writing a record per centre (46) -> backward over the transposed table with
+// per-scan sums (86; 113 in round 3).  Here one kernel does it:
+//   * LOCAL basis rows (dc_points_local_basis, once per exponent set): {d0, dir, c_k, scan} in the SENSOR frame -- 32 B, nothing
+//     in them depends on a pose.  Staging forms a row's world point with the CURRENT pose and weights: d' = d0 + sum w_k c_k,
+//     x = R_s (d' dir) + t_s on the q32 grid, u = R_s dir; the sweeps then run as in consistency_step_q32_kernel.
+//   * reverse mode INSIDE the block for the poses: each centre leaves its record {mean, c1, v0, c2} in LDS (32 B, the
+//     general path's Rec8<q32> -- never in global memory), and every staged row j gathers g_j = sum over the block's centres i that
+//     list it of c1_i (v0_i . e) v0_i - c2_i e, e = x_j - mean_i, through a block-local transposed list (dcPoseTable.rt_*: which
+//     lanes reference which staged row -- static, built once from the forward table).  Rows shared by several blocks get a
+//     partial sum in each; the sums over blocks are the reduction's.
+//   * the block's distinct rows are listed BY SCAN (dcPoseTable.ids: (scan, id) order, row_seg = where each scan starts), so
+//     dL/d[R|t]_s += g_j (x) [x_local_j, 1] runs over contiguous row ranges: (scan, entry) items, fixed order, one row of the
+//     row-major pose partials per block.  Bitwise reproducible like everything else.
+// 154 us of kernels in three launches -> one launch; see DESIGN 4 for the measured time.
+struct PoseTab {
+  const int32_t* __restrict__ blk_ptr;     // [blocks + 1], the forward table's
+  const int32_t* __restrict__ ids;         // distinct rows of every block in (scan, id) order
+  const uint16_t* __restrict__ loc;        // [blocks * K][256]: 16 x position in that order, 0xFFFF = empty slot
+  const uint16_t* __restrict__ own_pos;    // [N]: 16 x position of the point's own row in its block's list
+  const uint16_t* __restrict__ row_seg;    // [blocks][S + 1]: first row of every scan in the block's list; [S] = the row count
+  const uint16_t* __restrict__ rt_ptr;     // [blk_ptr[b] + b + t], t = 0 .. rows of b: offsets into rt_lane + b * 256 * K
+  const uint8_t* __restrict__ rt_lane;     // [blocks * 256 * K]: the lanes (centres of the block) that list row t, ascending
+};
+constexpr int kPoseCap = 512;              // rows of the static tile (the table builder refuses blocks with longer lists)
+
+// Per block: (scan, id) order of its distinct rows, remapped positions, own positions, transposed lists.  info[0] <- 1 when a
+// block cannot take the pose kernel (more than kPoseCap rows, or a block whose list misses one of its own rows).
+template <int K>
+__global__ __launch_bounds__(kBlock) void pose_table_kernel(BlockTab tab, const int32_t* __restrict__ own_base,
+                                                            const int32_t* __restrict__ scan_id, int64_t n, int n_scans,
+                                                            int32_t* __restrict__ ids_out, uint16_t* __restrict__ loc_out,
+                                                            uint16_t* __restrict__ own_pos, uint16_t* __restrict__ row_seg,
+                                                            uint16_t* __restrict__ rt_ptr, uint8_t* __restrict__ rt_lane,
+                                                            int32_t* __restrict__ info) {
+  __shared__ int32_t s_id[kPoseCap];
+  __shared__ uint8_t s_scan[kPoseCap];
+  __shared__ uint16_t s_new[kPoseCap];
+  __shared__ int s_start[kMaxBlockScans + 1];
+  __shared__ int s_cnt[kPoseCap + 1], s_fill[kPoseCap];
+  __shared__ uint8_t s_list[kBlock * K];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int32_t base = tab.blk_ptr[b], nd = tab.blk_ptr[b + 1] - base;
+  const int32_t own = own_base[b];
+  if (nd > kPoseCap || own < 0 || tab.slot_ptr[b + 1] - tab.slot_ptr[b] != K) {        // block-uniform
+    if (tid == 0) atomicMax(info, 1);
+    return;
+  }
+  for (int t = tid; t < kPoseCap; t += kBlock) { s_cnt[t] = 0; s_fill[t] = 0; }
+  if (tid <= n_scans) s_start[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < nd; t += kBlock) {
+    const int32_t id = tab.blk_ids[base + t];
+    const int sc = scan_id ? scan_id[id] : 0;
+    s_id[t] = id;
+    s_scan[t] = (uint8_t)sc;
+    atomicAdd(&s_start[sc + 1], 1);                      // histogram, shifted by one for the prefix
+  }
+  __syncthreads();
+  if (tid == 0) for (int q = 0; q < n_scans; ++q) s_start[q + 1] += s_start[q];
+  __syncthreads();
+  for (int t = tid; t < nd; t += kBlock) {
+    const int sc = s_scan[t];
+    int rank = 0;
+    for (int t2 = 0; t2 < t; ++t2) rank += s_scan[t2] == sc ? 1 : 0;      // stable: ascending id inside a scan
+    const int p = s_start[sc] + rank;
+    s_new[t] = (uint16_t)p;
+    ids_out[base + p] = s_id[t];
+  }
+  if (tid <= n_scans) row_seg[b * (n_scans + 1) + tid] = (uint16_t)s_start[tid];
+  __syncthreads();
+  const int64_t i = b * kBlock + tid;
+  own_pos[i < n ? i : n - 1] = (uint16_t)(s_new[own + (i < n ? tid : 0)] << 4);
+  const uint16_t* lrow = tab.loc + (int64_t)tab.slot_ptr[b] * kBlock + tid;
+  uint16_t np[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const uint16_t l = lrow[q * kBlock];
+    np[q] = l == 0xFFFF ? (uint16_t)0xFFFF : (uint16_t)(s_new[l >> 4] << 4);
+    loc_out[((int64_t)b * K + q) * kBlock + tid] = np[q];
+    if (np[q] != 0xFFFF) atomicAdd(&s_cnt[(np[q] >> 4) + 1], 1);
+  }
+  __syncthreads();
+  if (tid == 0) for (int t = 0; t < nd; ++t) s_cnt[t + 1] += s_cnt[t];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    if (np[q] != 0xFFFF) {
+      const int p = np[q] >> 4;
+      s_list[s_cnt[p] + atomicAdd(&s_fill[p], 1)] = (uint8_t)tid;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < nd; t += kBlock) {               // every row's lanes ascending: the order g_j is summed in, whatever the atomics did
+    const int lo = s_cnt[t], hi = s_cnt[t + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+      const uint8_t v = s_list[a];
+      int c = a;
+      while (c > lo && s_list[c - 1] > v) { s_list[c] = s_list[c - 1]; --c; }
+      s_list[c] = v;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t <= nd; t += kBlock) rt_ptr[base + b + t] = (uint16_t)s_cnt[t];
+  for (int e = tid; e < kBlock * K; e += kBlock) rt_lane[(int64_t)b * kBlock * K + e] = e < s_cnt[nd] ? s_list[e] : (uint8_t)0;
+}
+
+// {d0, dir, c_k, scan}: the pose-independent part of a ray (sensor frame; viewpoints at the sensor origin), 8 words
+template <typename T>
+__global__ __launch_bounds__(kBlock) void points_local_basis_kernel(PointInputs in, int64_t n, int32_t* __restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  ModelParams mp;
+  load_model(in, mp);
+  const T* dp = (const T*)in.dirs + i * 3;
+  const double d = (double)((const T*)in.depth)[i];
+  const bool lm = in.lmask ? in.lmask[i] != 0 : true;
+  const bool on = mp.kind != DC_MODEL_NONE && lm;
+  const double inc = on ? (double)((const T*)in.inc)[i] : 0.0;
+  const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;
+  float c[2] = {0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k < mp.n_terms && on) {
+      const double dk = mp.kind > DC_MODEL_SCALED_POLYNOMIAL ? model_dw_other(mp, k, d, inc)
+                                                             : (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
+      c[k] = (float)dk;
+    }
+  }
+  int4* r = reinterpret_cast<int4*>(rows) + 2 * i;
+  r[0] = make_int4(__float_as_int((float)d0), __float_as_int((float)dp[0]), __float_as_int((float)dp[1]), __float_as_int((float)dp[2]));
+  r[1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), in.scan_id ? in.scan_id[i] : 0, 0);
+}
+
+// second sweep of the pose kernel, one neighbour: chain_term_q32 plus the edge's gradient g_ij = al v0 - c2 e_j ADDED to the
+// neighbour's row of the block's gradient planes.  The sums are 64-bit integers, so the order the wavefronts' LDS atomics land in
+// does not matter (bit-reproducible); the coefficients arrive scaled by the block's power of two S with |g_ij| S < 2^50, and
+// double(g) + 1.5 2^52 holds round(g) in its mantissa: the bit pattern minus that of 1.5 2^52 (low word zero) IS the integer.
+template <int P, int CAP>
+__device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long long* s_g, uint32_t off, bool have, const Pt<q32>::Raw& ci,
+                                                const float* cmf, const float* vs, const float* vu, float c2f, float* gw) {
+  const char* row = reinterpret_cast<const char*>(tile) + (have ? off : 0u);
+  const int4 p0 = *reinterpret_cast<const int4*>(row);
+  const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)CAP * 16);
+  const float2v e01 = float2v{(float)(p0.x - ci.v[0]), (float)(p0.y - ci.v[1])} - float2v{cmf[0], cmf[1]};
+  const float e0 = e01.x, e1 = e01.y, e2 = (float)(p0.z - ci.v[2]) - cmf[2];
+  const float u0 = __int_as_float(p0.w), u1 = __int_as_float(p1.x), u2 = __int_as_float(p1.y);
+  const float al = fmaf(vs[2], e2, fmaf(vs[1], e1, vs[0] * e0));                       // c1 (v . e_j)
+  const float g0 = fmaf(al, vu[0], -(c2f * e0)), g1 = fmaf(al, vu[1], -(c2f * e1)), g2 = fmaf(al, vu[2], -(c2f * e2));
+  float tj = fmaf(g2, u2, fmaf(g1, u1, g0 * u0));                                      // g_ij . u_j
+  if (!have) tj = 0.0f;
+  if constexpr (P == 2) {
+    float2v g = float2v{gw[0], gw[1]};
+    g = __builtin_elementwise_fma(float2v{tj, tj}, float2v{__int_as_float(p1.z), __int_as_float(p1.w)}, g);
+    gw[0] = g.x; gw[1] = g.y;
+  } else {
+    gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
+  }
+  if (have) {
+    constexpr double kMagic = 6755399441055744.0;                                      // 1.5 2^52
+    unsigned long long* cell = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(s_g) + (off >> 1));
+    const float gg[3] = {g0, g1, g2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong((double)gg[a] + kMagic) - 0x4338000000000000ull;
+      atomicAdd(cell + a * CAP, bits);
+    }
+  }
+}
+
+// Pose-mode evaluation in ONE launch (float32 sequences, [rows, K] tables, no exponent gradients).  A block stages its distinct
+// rows from the pose-independent local basis rows {d0, dir, c0, c1, scan} with the CURRENT poses and weights, runs the step kernel's
+// two sweeps, and in the second sweep every centre adds its edges' gradients to the block's per-row gradient planes in LDS
+// (chain_term_pose); the rows of one scan are contiguous in the block's list (dc_pose_table_build), so dL/d[R|t]_s of the block
+// is a sum over a row range: one row [12 S] of the row-major pose partials per block, summed by reduce_eval_kernel.
+template <int NS, int P>
+__global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
+    const int32_t* __restrict__ lrows, PoseTab tab, const double* __restrict__ poses, int n_scans, const double* __restrict__ w,
+    int64_t n, const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+  constexpr int CAP = kPoseCap;
+  __shared__ int4 tile[2 * CAP];                            // piece 0 {X, u0}, later {x_local} | piece 1 {u1, u2, c0, c1}
+  __shared__ unsigned long long s_g[3 * CAP];               // three planes: the rows' gradient sums (integers), later doubles
+  __shared__ double s_pose[kLdsScans * 12];
+  __shared__ float s_bound[kWavesPerBlock];
+  const int tid = threadIdx.x;
+  const int64_t nblocks = (n + kBlock - 1) / kBlock;
+  const int64_t blk = xcd_block(nblocks);
+  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;
+  double* prow = p_bwd + 2 * P * rs + (int64_t)blockIdx.x * 12 * n_scans;        // this block's row of the row-major pose partials
+  double acc2[2] = {0.0, 0.0}, gw[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) gw[k] = 0.0;
+  if (blk < 0) {                                            // padding block of the last round (block-uniform): zero rows
+    for (int item = tid; item < 12 * n_scans; item += kBlock) prow[item] = 0.0;
+  } else {
+    for (int t = tid; t < n_scans * 12; t += kBlock) s_pose[t] = poses[t];
+    double wq[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) wq[k] = w[k];
+    const int64_t i = blk * kBlock + tid;
+    const bool live = i < n;
+    const bool in_mask = live && (mask ? mask[i] != 0 : true);
+    const uint16_t* lrow = tab.loc + (blk * NS) * kBlock + tid;
+    uint32_t pre[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) pre[q] = live ? (uint32_t)lrow[q * kBlock] : kNoLoc;
+    const uint32_t own = live ? (uint32_t)tab.own_pos[i] : 0u;
+    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    for (int t = tid; t < 3 * CAP; t += kBlock) s_g[t] = 0ull;
+    __syncthreads();                                        // the poses are in LDS
+    // ---- staging: the world point of every distinct row from its local basis row, the current pose and weights ----
+    for (int t = tid; t < nd; t += kBlock) {
+      const int64_t id = tab.ids[base + t];
+      const int4 r0 = reinterpret_cast<const int4*>(lrows)[2 * id], r1 = reinterpret_cast<const int4*>(lrows)[2 * id + 1];
+      const float c0 = __int_as_float(r1.x), c1f = __int_as_float(r1.y);
+      const int sc = r1.z;
+      double dp = (double)__int_as_float(r0.x) + wq[0] * (double)c0;
+      if constexpr (P > 1) dp += wq[1] * (double)c1f;
+      const double dl[3] = {(double)__int_as_float(r0.y), (double)__int_as_float(r0.z), (double)__int_as_float(r0.w)};
+      const double* Tp = s_pose + sc * 12;
+      double u[3], x[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        u[a] = Tp[4 * a] * dl[0] + Tp[4 * a + 1] * dl[1] + Tp[4 * a + 2] * dl[2];
+        x[a] = Tp[4 * a + 3] + dp * u[a];
+      }
+      tile[t] = make_int4(quantize(x[0], qp.origin[0], qp.inv_scale, qp.flag), quantize(x[1], qp.origin[1], qp.inv_scale, qp.flag),
+                          quantize(x[2], qp.origin[2], qp.inv_scale, qp.flag), __float_as_int((float)u[0]));
+      tile[CAP + t] = make_int4(__float_as_int((float)u[1]), __float_as_int((float)u[2]), r1.x, r1.y);
+    }
+    __syncthreads();
+    // ---- the centre: moments, smallest eigenpair, loss (as consistency_step_q32_kernel) and a bound of its edges' gradients ----
+    const bool work = live && (!mask || __any((int)in_mask));
+    Pt<q32>::Raw ci;
+    double cm[3] = {0.0, 0.0, 0.0}, v0[3] = {0.0, 0.0, 0.0}, c1 = 0.0, c2 = 0.0;
+    float bound = 0.0f;
+    if (work) {
+      const char* tb = reinterpret_cast<const char*>(tile);
+      ci = Pt<q32>::from_row(reinterpret_cast<const int4*>(tb + own));
+      CovAcc acc;
+      cov_init(acc);
+      uint32_t mo = pre[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) mo |= pre[q];
+      const bool any_miss = __any((int)(mo & 1u)) != 0;
+      int n_have;
+      if (any_miss) n_have = gather_fixed<q32, NS, true>(tile, CAP, ci, pre, acc);
+      else n_have = gather_fixed<q32, NS, false>(tile, CAP, ci, pre, acc);
+      acc.W = (double)n_have;
+      double se2;
+      step_point2<q32, NS>(acc, n_have, !any_miss, in_mask, lp, qp, acc2, cm, v0, &c1, &c2, &se2);
+      // |g_ij| <= (|c1| + |c2|) |e_j| and |e_j|^2 <= sum_j |e_j|^2 (at least one grid unit, so that c S stays finite)
+      const float r = sqrtf((float)se2);
+      bound = (float)(fabs(c1) + fabs(c2)) * (r > 1.0f ? r : 1.0f);
+    }
+    bound = bound == bound ? bound : INFINITY;              // a NaN coefficient poisons the block's sums like an infinite one
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, kWave));
+    if ((tid & (kWave - 1)) == 0) s_bound[tid / kWave] = bound;
+    __syncthreads();
+    bound = s_bound[0];
+#pragma unroll
+    for (int q = 1; q < kWavesPerBlock; ++q) bound = fmaxf(bound, s_bound[q]);
+    const bool poisoned = !(bound < INFINITY);              // block-uniform
+    int sh = 0;
+    if (bound > 0.0f && !poisoned) {
+      int ex;
+      (void)frexpf(bound, &ex);                             // bound < 2^ex
+      sh = 50 - ex;
+      sh = sh > 100 ? 100 : sh;
+    }
+    const double S = ldexp(1.0, sh), invS = ldexp(1.0, -sh);
+    // ---- second sweep: dL/dw of the centre, and its edges' gradients into the rows' planes ----
+    if (work && !poisoned) {
+      float cmf[3], vs[3], vu[3], gwf[P];
+      const double c1s = c1 * S;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1s * v0[a]); vu[a] = (float)v0[a]; }
+      const float c2f = (float)(c2 * S);
+#pragma unroll
+      for (int k = 0; k < P; ++k) gwf[k] = 0.0f;
+      if (__any((int)(c1 != 0.0 || c2 != 0.0))) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
+          chain_term_pose<P, CAP>(tile, s_g, pre[q], pre[q] != kNoLoc && (c1 != 0.0 || c2 != 0.0), ci, cmf, vs, vu, c2f, gwf);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * (qp.scale * invS);
+    }
+    __syncthreads();                                        // every edge has been added
+    // ---- per staged row: its gradient as doubles (in place), and x_local = d' dir once more from the local basis row (32 B from
+    //      L2: cheaper than 8 KB of LDS for a third piece) over piece 0, which nobody reads any more ----
+    const double unscale = qp.scale * invS;
+    for (int t = tid; t < nd; t += kBlock) {
+      const int64_t id = tab.ids[base + t];
+      const int4 r0 = reinterpret_cast<const int4*>(lrows)[2 * id], r1 = reinterpret_cast<const int4*>(lrows)[2 * id + 1];
+      double dp = (double)__int_as_float(r0.x) + wq[0] * (double)__int_as_float(r1.x);
+      if constexpr (P > 1) dp += wq[1] * (double)__int_as_float(r1.y);
+      const float dpf = (float)dp;
+      tile[t] = make_int4(__float_as_int(dpf * __int_as_float(r0.y)), __float_as_int(dpf * __int_as_float(r0.z)),
+                          __float_as_int(dpf * __int_as_float(r0.w)), 0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double g = (double)(long long)s_g[a * CAP + t] * unscale;
+        s_g[a * CAP + t] = (unsigned long long)__double_as_longlong(poisoned ? (double)NAN : g);
+      }
+    }
+    __syncthreads();
+    // ---- dL/d[R|t]_s += g_j (x) [x_local_j, 1] over the rows of scan s: contiguous in the block's list ----
+    const uint16_t* seg = tab.row_seg + blk * (n_scans + 1);
+    for (int item = tid; item < n_scans * 24; item += kBlock) {
+      const int pair = item >> 1, part = item & 1;
+      const int rr = pair / 12, q = pair - rr * 12, a = q >> 2, b = q & 3;
+      const int beg = (int)seg[rr] + part, end = (int)seg[rr + 1];
+      const double* gp = reinterpret_cast<const double*>(s_g) + a * CAP;
+      const float* xl = reinterpret_cast<const float*>(tile) + (b < 3 ? b : 0);
+      double sacc[2] = {0.0, 0.0};
+      int p = beg;
+      for (; p + 2 < end; p += 4) {
+#pragma unroll
+        for (int u_ = 0; u_ < 2; ++u_) {
+          const int r = p + 2 * u_;
+          const double ga = gp[r];
+          sacc[u_] = __dadd_rn(sacc[u_], b == 3 ? ga : __dmul_rn(ga, (double)xl[r * 4]));
+        }
+      }
+      for (; p < end; p += 2) {
+        const double ga = gp[p];
+        sacc[0] = __dadd_rn(sacc[0], b == 3 ? ga : __dmul_rn(ga, (double)xl[p * 4]));
+      }
+      double sum = __dadd_rn(sacc[0], sacc[1]);
+      sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));       // even + odd rows (the two lanes are neighbours)
+      if (part == 0) prow[pair] = sum;
+    }
+  }
+  // {sum loss, count, dL/dw} of the wavefront; the exponent-gradient columns [P, 2P) of this evaluation are zero
+  step_partials<P, true>(acc2, gw, p_fwd, p_bwd);
+  {
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    if (lane < P) p_bwd[(P + lane) * rs + (int64_t)blockIdx.x * kWavesPerBlock + wave] = 0.0;
+  }
+}
+
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
 // partial rows: [0, P) dL/dw (the exponent slots [P, 2P) are written as zeros).
 template <typename PT, int P>
@@ -2605,6 +2956,7 @@ using namespace dc;
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
+static std::atomic<bool> g_pose_three_pass{false};   // dc_set_option(7, 1): pose gradients through the three-kernel general path (A-B, tests)
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
 static std::atomic<bool> g_two_pass{false};     // dc_set_option(4, 1): basis form with separate forward and backward kernels
@@ -2745,6 +3097,37 @@ int dc_points_basis(const void* vps, const void* dirs, const void* depth, const 
     hipLaunchKernelGGL((points_basis_kernel<q32>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, rows_out);
   else
     hipLaunchKernelGGL((points_basis_kernel<double>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, qp, rows_out);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_points_local_basis(const void* dirs, const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+                          int model_kind, int n_terms, const double* e, int64_t n, int dtype, void* rows_out, hipStream_t stream) {
+  if (n == 0) return DC_OK;
+  if (n < 0 || !dirs || !depth || !rows_out || n_terms < 1 || n_terms > 2) return DC_ERR_ARG;
+  if (dtype != DC_F32) return DC_ERR_DTYPE;                  // float32 clouds (q32 points): what the pose kernel takes
+  int rc = check_model(model_kind, n_terms, inc, e, e);
+  if (rc || model_kind == DC_MODEL_NONE) return rc ? rc : DC_ERR_ARG;
+  PointInputs in = make_inputs(nullptr, dirs, depth, inc, lmask, scan_id, nullptr, 1, model_kind, n_terms, e, e);
+  hipLaunchKernelGGL((points_local_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, (int32_t*)rows_out);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
+}
+
+int dc_pose_table_build(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int k, int32_t* ids_out,
+                        uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint16_t* rt_ptr, uint8_t* rt_lane, int32_t* info,
+                        hipStream_t stream) {
+  if (!fwd || fwd->layout != DC_TABLE_SLOTS || !fwd->blk_ptr || !fwd->blk_ids || !fwd->slot_ptr || !fwd->loc || !fwd->own_base) return DC_ERR_ARG;
+  if (n < 1 || n_scans < 1 || n_scans > kMaxBlockScans || !ids_out || !loc_out || !own_pos || !row_seg || !rt_ptr || !rt_lane || !info) return DC_ERR_ARG;
+  if (k != 4 && k != 8 && k != 10 && k != 16) return DC_ERR_UNSUPPORTED;
+  hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), stream);
+  if (err != hipSuccess) return (int)err;
+  BlockTab tab{fwd->blk_ptr, fwd->blk_ids, fwd->slot_ptr, fwd->loc};
+  const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
+#define PT_K(KK) hipLaunchKernelGGL((pose_table_kernel<KK>), grid, block, 0, stream, tab, fwd->own_base, scan_id, n, n_scans, ids_out, loc_out, own_pos, \
+                                    row_seg, rt_ptr, rt_lane, info)
+  if (k == 10) PT_K(10); else if (k == 4) PT_K(4); else if (k == 8) PT_K(8); else PT_K(16);
+#undef PT_K
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
@@ -2962,6 +3345,7 @@ int dc_set_option(int option, int value) {
   if (option == 4) { g_two_pass.store(value != 0); return DC_OK; }
   if (option == 5) { g_chain_spin.store(value < 0 ? (1 << 22) : value); return DC_OK; }
   if (option == 6) { g_step_var.store(value); return DC_OK; }
+  if (option == 7) { g_pose_three_pass.store(value != 0); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -3098,8 +3482,13 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   }
   const bool one_pass = basis_fwd && want_grad && n_terms <= 3 && !g_two_pass.load() &&
                         (use_table(d->fwd_table ? &ft_active : nullptr, DC_TABLE_SLOTS, stride, step_row_bytes, 0, 60 * 1024, &lds_s, &rows_s) || ragged_ok);
+  // pose gradients (no exponent gradients) of a float32 sequence with a [rows, K] table whose pose tables and local basis rows the
+  // plan has built: one launch, no transposed lists (consistency_step_pose_kernel)
+  const bool pose_one_pass = want_grad && want_pose_grad && !want_exponent_grad && d->pose_table && d->local_basis && !d->vps && !d->centre_idx &&
+                             d->point_fmt == DC_Q32 && d->dtype == DC_F32 && (n_terms == 1 || n_terms == 2) && d->n_scans <= kLdsScans && w &&
+                             (d->k == 4 || d->k == 8 || d->k == 10 || d->k == 16) && !g_pose_three_pass.load();
   // every other way to a gradient walks the transposed neighbour lists: the caller provides them on demand
-  if (want_grad && !one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
+  if (want_grad && !one_pass && !pose_one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
   const bool basis = basis_fwd &&
                      (!want_grad || one_pass || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
   const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
@@ -3222,6 +3611,31 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     return DC_OK;
   }
 
+  // pose gradients (no exponent gradients) of a float32 sequence with a [rows, K] table: everything in ONE launch
+  // (consistency_step_pose_kernel) when the plan has built the pose tables and the local basis rows for these exponents
+  if (pose_one_pass) {
+    QParams qp;
+    int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp, d->status);
+    if (rc) return rc;
+    const dcPoseTable* pt = d->pose_table;
+    PoseTab tab{pt->blk_ptr, pt->ids, pt->loc, pt->own_pos, pt->row_seg, pt->rt_ptr, pt->rt_lane};
+    const LossParams lp = make_loss_params(d->loss_kind & ~DC_LOSS_RAW_POINTWISE, d->normalization, d->sqrt_);
+    const dim3 grid((unsigned)xcd_grid(n_blocks(d->n))), block(kBlock);
+    {
+      ProfScope prof(1);
+#define POSE_NS(NS, P) DC_TIMED_LAUNCH((consistency_step_pose_kernel<NS, P>), grid, block, 0, stream, (const int32_t*)d->local_basis, tab, poses, d->n_scans, \
+                                       w, d->n, d->mask, lp, qp, p_fwd, p_bwd)
+#define POSE_P(NS) do { if (n_terms == 2) POSE_NS(NS, 2); else POSE_NS(NS, 1); } while (0)
+      if (d->k == 10) POSE_P(10); else if (d->k == 4) POSE_P(4); else if (d->k == 8) POSE_P(8); else POSE_P(16);
+#undef POSE_P
+#undef POSE_NS
+    }
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows, rows, n_acc, 2 + n_acc, out, adam,
+                       (const int32_t*)d->status, 2 * n_terms, 12 * d->n_scans);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+  }
   // (measured in round 4 and dropped: a forward that FORMS the rows it stages from the raw inputs -- model, pose, ray end point per
   // staged row, the owning block writing x for the backward -- instead of dc_points_fwd + a forward over x.  It removes a 22 us launch
   // and 48 B per point of traffic, but a block stages 1.47 rows per point and each costs five scattered loads and ~80 fp64

@@ -42,7 +42,7 @@ class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
-                 scan_group=True, mask_first=False, nan_policy=None):
+                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -54,6 +54,7 @@ class SequencePlan:
         :param lazy_backward: build the transposed neighbour lists / backward block table on first need instead of up front.
         :param basis: use the basis form x = X0 + (sum_k w_k c_k) u (dc_points_basis) whenever an evaluation asks for neither pose
                       nor exponent gradients: the basis rows are rebuilt only when the poses or the exponents change.
+        :param pose_kernel: evaluations with pose gradients in one launch (consistency_step_pose_kernel) where the plan allows it.
         :param nan_policy: None, 'skip_nans' or 'only_finite' (loss.py:125-137): pointwise losses that are NaN / not finite are left
                            out of the sum, the count and the gradients; the count of an evaluation is then its own (out[1]).
         :param mask_first: additionally collect the masked-out points of every 2048-point stretch into blocks of their own, which
@@ -227,6 +228,8 @@ class SequencePlan:
         self.version = 0
         self._desc = None
         self.use_basis = bool(basis)
+        self.use_pose_kernel = bool(pose_kernel)
+        self._pose_table = self._local_basis = None      # built on the first pose-gradient evaluation
         self._basis = None             # (key, rows, poses12, exponent): the last two pin the storage the key names
         self._poses_key = self._poses12 = self._poses_ref = None
 
@@ -282,6 +285,51 @@ class SequencePlan:
             self._desc = d
         return self._desc
 
+    def _set_pose_tables(self, d, w, exponent, want_grad, want_exponent, want_pose):
+        """Point the descriptor at the pose tables (built once, on the first evaluation that asks for pose gradients) and at the
+        local basis rows valid for ``exponent`` (rebuilt when the exponent tensor changes identity or version), or clear the
+        fields: pose-gradient evaluations then run as one launch (consistency_step_pose_kernel)."""
+        ok = (self.use_pose_kernel and want_grad and want_pose and not want_exponent and w is not None and w.numel() in (1, 2)
+              and self.qfmt is not None and self.ps.vps is None and self.centre_idx is None and self.fwd_table is not None
+              and self.fwd_table.own_base is not None and self.k in (4, 8, 10, 16) and self.n_scans <= 32
+              and d.model_kind != 0 and self._block_tables and self.nbr.shape[1] == self.k)
+        if ok and self._pose_table is None:
+            self._pose_table = self._build_pose_table()
+        if not ok or self._pose_table is False:
+            d.pose_table = d.local_basis = None
+            return
+        nt = w.numel()
+        key = (exponent.data_ptr(), exponent._version, nt, d.model_kind)
+        lb = self._local_basis
+        if lb is None or lb[0] != key:
+            ps = self.ps
+            rows = torch.empty((self.n, 8), dtype=torch.int32, device=self.device)
+            check(lib().dc_points_local_basis(ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id), d.model_kind, nt,
+                                              ptr(exponent), self.n, nv.DC_F32, ptr(rows), stream_ptr()), 'dc_points_local_basis')
+            self._local_basis = lb = (key, rows, exponent)
+        d.pose_table = ctypes.cast(ctypes.pointer(self._pose_table[0]), ctypes.c_void_p)
+        d.local_basis = lb[1].data_ptr()
+
+    def _build_pose_table(self):
+        """dcPoseTable of this plan's forward table (dc_pose_table_build), or False when some block cannot take the pose kernel."""
+        ft, dev, nb = self.fwd_table, self.device, (self.n + 255) // 256
+        total = int(ft.blk_ptr[-1].item())
+        t = dict(ids=torch.empty((max(total, 1),), dtype=torch.int32, device=dev),
+                 loc=torch.empty((nb * self.k * 256,), dtype=torch.uint16, device=dev),
+                 own_pos=torch.empty((self.n,), dtype=torch.uint16, device=dev),
+                 row_seg=torch.empty((nb * (self.n_scans + 1),), dtype=torch.uint16, device=dev),
+                 rt_ptr=torch.empty((total + nb,), dtype=torch.uint16, device=dev),
+                 rt_lane=torch.empty((nb * 256 * self.k,), dtype=torch.uint8, device=dev))
+        info = torch.zeros((1,), dtype=torch.int32, device=dev)
+        check(lib().dc_pose_table_build(ft.ref(), ptr(self.ps.scan_id), self.n, self.n_scans, self.k, ptr(t['ids']), ptr(t['loc']),
+                                        ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['rt_ptr']), ptr(t['rt_lane']), ptr(info), stream_ptr()),
+              'dc_pose_table_build')
+        if int(info.item()) != 0:
+            return False
+        desc = nv.PoseTableDesc(ptr(ft.blk_ptr), ptr(t['ids']), ptr(t['loc']), ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['rt_ptr']),
+                                ptr(t['rt_lane']))
+        return desc, t
+
     def _set_basis(self, d, w, exponent, poses12, want_exponent, want_pose):
         """Point the descriptor at the basis rows valid for (poses12, exponent), building them when either changed; or clear the
         fields when this evaluation cannot use the basis form (pose / exponent gradients, other formats, no tables)."""
@@ -321,6 +369,7 @@ class SequencePlan:
             need(exponent, (nt,), dtype=torch.float64, name='exponent', device=self.device)
         for attempt in (0, 1):
             self._set_basis(d, w, exponent, poses12, want_exponent, want_pose)
+            self._set_pose_tables(d, w, exponent, want_grad, want_exponent, want_pose)
             rc = lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
                                         int(want_exponent), int(want_pose), ptr(out), stream_ptr())
             if rc != nv.DC_ERR_BACKWARD_TABLES or attempt:

@@ -382,6 +382,31 @@ int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, con
  * to three weights a single kernel that returns the loss AND dL/dw (second sweep over each centre's own neighbours; no
  * backward record, no transposed table).
  * x [n,4] / rec [n,8] in point_fmt, partials fp64 [dc_sequence_partials_count(n, P, S)] are scratch. */
+/* ---- pose mode in one pass (round 4; train.py:300-312 with pose corrections, eval.py:68-82) ---------------------------------
+ * dcPoseTable: per 256-point block, derived once from the forward block table of a [rows, K] neighbour table (K = 4 / 8 / 10 / 16):
+ * its distinct rows listed by (scan, id), the references' positions in that order, every point's own position, where each
+ * scan's rows start, and which lanes of the block list each row (block-local transposed lists).  dc_pose_table_build fills
+ * caller-allocated arrays: ids int32 [blk_ptr[blocks]], loc uint16 [blocks * K * 256], own_pos uint16 [n], row_seg uint16
+ * [blocks * (n_scans + 1)], rt_ptr uint16 [blk_ptr[blocks] + blocks], rt_lane uint8 [blocks * 256 * K]; info int32 [1] <- 1 when
+ * some block cannot take the pose kernel (more than 512 distinct rows, or a block whose list misses one of its own rows). */
+typedef struct dcPoseTable {
+  const int32_t* blk_ptr;
+  const int32_t* ids;
+  const uint16_t* loc;
+  const uint16_t* own_pos;
+  const uint16_t* row_seg;
+  const uint16_t* rt_ptr;
+  const uint8_t* rt_lane;
+} dcPoseTable;
+int dc_pose_table_build(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int k, int32_t* ids_out,
+                        uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint16_t* rt_ptr, uint8_t* rt_lane, int32_t* info,
+                        dcStream_t stream);
+/* Pose-independent rows of the rays (sensor frame, viewpoints at the sensor origin): {d0, dir, c_k = dd'/dw_k, scan} as 8 words
+ * per point for float32 clouds and models of one or two weights (model.py:113-349 are affine in their weights); valid for the
+ * exponents `e`.  rows_out int32 [n, 8]. */
+int dc_points_local_basis(const void* dirs, const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
+                          int model_kind, int n_terms, const double* e, int64_t n, int dtype, void* rows_out, dcStream_t stream);
+
 typedef struct dcSequenceDesc {
   int64_t n;
   int32_t k, n_scans, dtype, point_fmt;
@@ -420,6 +445,10 @@ typedef struct dcSequenceDesc {
   int32_t fwd_rows_active;         /* with blk_skip: the longest distinct-row list among the blocks that are NOT skipped (sizes the
                                       one-pass kernels' LDS tile; 0 = use fwd_table->max_rows) */
   int32_t reserved2;
+  const dcPoseTable* pose_table;   /* with local_basis: evaluations that ask for pose gradients (and no exponent gradients) of a float32
+                                      sequence run as ONE launch (consistency_step_pose_kernel) instead of dc_points_fwd + forward +
+                                      backward; NULL: the three-kernel path */
+  const void* local_basis;         /* dc_points_local_basis rows, valid FOR THE EXPONENTS OF THE CALL, or NULL */
 } dcSequenceDesc;
 
 /* Doubles of dcSequenceDesc.partials for a sequence of n points evaluated with up to n_terms weights and n_scans poses:
@@ -515,6 +544,7 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
  * option 3: value 1 makes dc_sequence_eval / _step ignore dcSequenceDesc.basis (general path).
  * option 4: value 1 makes basis-form evaluations run the forward and the backward kernel separately instead of the one-pass
  *           loss + dL/dw kernel.
+ * option 7: value 1 sends pose-gradient evaluations through the three-kernel general path even when dcSequenceDesc.pose_table is set.
  * option 5: number of polls a chained launch's blocks make while they wait for the weights its leading blocks publish
  *           (default 2^22, negative restores it).  A wait that runs out yields NaN sums for that evaluation and raises bit 1 of
  *           dcSequenceDesc.status (bit 0: DC_Q32 overflow), so the two causes of a NaN loss can be told apart; tests force 0. */

@@ -43,8 +43,10 @@ def main():
     lines = open(os.path.join(tmp, asm)).read().split('\n')
     start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\w*' + re.escape(args.kernel) + r'\w*:', l))
     end = next(i for i in range(start, len(lines)) if '.amdhsa_kernel' in lines[i])
+    name = lines[start].split(':')[0]
+    dstart = next(i for i in range(start, len(lines)) if re.match(r'\s*\.amdhsa_kernel\s+' + re.escape(name) + r'\s*$', lines[i]))
     desc = {}
-    for l in lines[end:end + 60]:
+    for l in lines[dstart:dstart + 60]:
         m = re.match(r'\s*\.amdhsa_(next_free_vgpr|next_free_sgpr|group_segment_fixed_size|private_segment_fixed_size)\s+(\d+)', l)
         if m:
             desc[m.group(1)] = int(m.group(2))
