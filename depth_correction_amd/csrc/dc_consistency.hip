@@ -1736,6 +1736,8 @@ constexpr int kDppXor1 = 0xB1;      // quad_perm:[1,0,3,2]
 constexpr int kDppXor2 = 0x4E;      // quad_perm:[2,3,0,1]
 constexpr int kDppRor4 = 0x124;     // row_ror:4
 constexpr int kDppRor8 = 0x128;     // row_ror:8
+constexpr int kDppShl4 = 0x104;     // row_shl:4 (lane l reads lane l + 4 of its row)
+constexpr int kDppQuad3 = 0xFF;     // quad_perm:[3,3,3,3]
 // Four values per lane -> lane l < 4 of the wavefront holds the total of value bitrev2(l) (as wave_sum_packed<4>): two quad
 // steps that also halve what a lane carries, two rotations inside the rows, two cross-row exchanges.
 __device__ __forceinline__ double wave_sum4_dpp(double* v) {
@@ -2510,7 +2512,7 @@ __global__ __launch_bounds__(kBlock) void points_local_basis_kernel(PointInputs 
 // double(g) + 1.5 2^52 holds round(g) in its mantissa: the bit pattern minus that of 1.5 2^52 (low word zero) IS the integer.
 template <int P, int CAP>
 __device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long long* s_g, uint32_t off, bool have, const Pt<q32>::Raw& ci,
-                                                const float* cmf, const float* vs, const float* vu, float c2f, float* gw) {
+                                                const float* cmf, const float* vs, const float* vu, float c2f, float* gw, int dbg) {
   const char* row = reinterpret_cast<const char*>(tile) + (have ? off : 0u);
   const int4 p0 = *reinterpret_cast<const int4*>(row);
   const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)CAP * 16);
@@ -2528,7 +2530,7 @@ __device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long 
   } else {
     gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
   }
-  if (have) {
+  if (have && !(dbg & 2)) {
     constexpr double kMagic = 6755399441055744.0;                                      // 1.5 2^52
     unsigned long long* cell = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(s_g) + (off >> 1));
     const float gg[3] = {g0, g1, g2};
@@ -2548,10 +2550,10 @@ __device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long 
 template <int NS, int P>
 __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
     const int32_t* __restrict__ lrows, PoseTab tab, const double* __restrict__ poses, int n_scans, const double* __restrict__ w,
-    int64_t n, const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
+    int64_t n, const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd, int dbg) {
   constexpr int CAP = kPoseCap;
-  __shared__ int4 tile[2 * CAP];                            // piece 0 {X, u0}, later {x_local} | piece 1 {u1, u2, c0, c1}
-  __shared__ unsigned long long s_g[3 * CAP];               // three planes: the rows' gradient sums (integers), later doubles
+  __shared__ int4 tile[2 * CAP];                            // piece 0 {X, u0} | piece 1 {u1, u2, c0, c1}
+  __shared__ unsigned long long s_g[3 * CAP];               // three planes: the rows' gradient sums (64-bit integers)
   __shared__ double s_pose[kLdsScans * 12];
   __shared__ float s_bound[kWavesPerBlock];
   const int tid = threadIdx.x;
@@ -2578,12 +2580,26 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
     for (int q = 0; q < NS; ++q) pre[q] = live ? (uint32_t)lrow[q * kBlock] : kNoLoc;
     const uint32_t own = live ? (uint32_t)tab.own_pos[i] : 0u;
     const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
+    // the (at most two) rows this thread stages: both ids, then both local basis rows, in flight before the first barrier
+    static_assert(CAP <= 2 * kBlock, "two staged rows per thread");
+    int32_t sid[2];
+    int4 ra[2], rb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sid[j] = tid + j * kBlock < nd ? tab.ids[base + tid + j * kBlock] : -1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t id = sid[j] < 0 ? 0 : sid[j];
+      ra[j] = reinterpret_cast<const int4*>(lrows)[2 * id];
+      rb[j] = reinterpret_cast<const int4*>(lrows)[2 * id + 1];
+    }
     for (int t = tid; t < 3 * CAP; t += kBlock) s_g[t] = 0ull;
     __syncthreads();                                        // the poses are in LDS
     // ---- staging: the world point of every distinct row from its local basis row, the current pose and weights ----
-    for (int t = tid; t < nd; t += kBlock) {
-      const int64_t id = tab.ids[base + t];
-      const int4 r0 = reinterpret_cast<const int4*>(lrows)[2 * id], r1 = reinterpret_cast<const int4*>(lrows)[2 * id + 1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = tid + j * kBlock;
+      if (sid[j] < 0) continue;
+      const int4 r0 = ra[j], r1 = rb[j];
       const float c0 = __int_as_float(r1.x), c1f = __int_as_float(r1.y);
       const int sc = r1.z;
       double dp = (double)__int_as_float(r0.x) + wq[0] * (double)c0;
@@ -2602,7 +2618,7 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
     }
     __syncthreads();
     // ---- the centre: moments, smallest eigenpair, loss (as consistency_step_q32_kernel) and a bound of its edges' gradients ----
-    const bool work = live && (!mask || __any((int)in_mask));
+    const bool work = live && (!mask || __any((int)in_mask)) && !(dbg & 16);
     Pt<q32>::Raw ci;
     double cm[3] = {0.0, 0.0, 0.0}, v0[3] = {0.0, 0.0, 0.0}, c1 = 0.0, c2 = 0.0;
     float bound = 0.0f;
@@ -2643,7 +2659,7 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
     }
     const double S = ldexp(1.0, sh), invS = ldexp(1.0, -sh);
     // ---- second sweep: dL/dw of the centre, and its edges' gradients into the rows' planes ----
-    if (work && !poisoned) {
+    if (work && !poisoned && !(dbg & 4)) {
       float cmf[3], vs[3], vu[3], gwf[P];
       const double c1s = c1 * S;
 #pragma unroll
@@ -2655,56 +2671,64 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
-          chain_term_pose<P, CAP>(tile, s_g, pre[q], pre[q] != kNoLoc && (c1 != 0.0 || c2 != 0.0), ci, cmf, vs, vu, c2f, gwf);
+          chain_term_pose<P, CAP>(tile, s_g, pre[q], pre[q] != kNoLoc && (c1 != 0.0 || c2 != 0.0), ci, cmf, vs, vu, c2f, gwf, dbg);
         }
       }
 #pragma unroll
       for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * (qp.scale * invS);
     }
     __syncthreads();                                        // every edge has been added
-    // ---- per staged row: its gradient as doubles (in place), and x_local = d' dir once more from the local basis row (32 B from
-    //      L2: cheaper than 8 KB of LDS for a third piece) over piece 0, which nobody reads any more ----
-    const double unscale = qp.scale * invS;
-    for (int t = tid; t < nd; t += kBlock) {
-      const int64_t id = tab.ids[base + t];
-      const int4 r0 = reinterpret_cast<const int4*>(lrows)[2 * id], r1 = reinterpret_cast<const int4*>(lrows)[2 * id + 1];
-      double dp = (double)__int_as_float(r0.x) + wq[0] * (double)__int_as_float(r1.x);
-      if constexpr (P > 1) dp += wq[1] * (double)__int_as_float(r1.y);
-      const float dpf = (float)dp;
-      tile[t] = make_int4(__float_as_int(dpf * __int_as_float(r0.y)), __float_as_int(dpf * __int_as_float(r0.z)),
-                          __float_as_int(dpf * __int_as_float(r0.w)), 0);
+    // ---- dL/d[R|t]_s = sum_j g_j (x) [x_local_j, 1] over the rows of scan s, contiguous in the block's list.  With
+    //      x_local = R^T (x - t) the sum is (sum_j g_j (x_j - t)^T) R: eight lanes per scan (n_scans <= 32) take every eighth row
+    //      each and sum g (x) q and g over them -- q the row's grid coordinates, g its three integer sums, all in LDS -- the eight
+    //      lanes' twelve sums are added by DPP quad / row operations that also halve what a lane carries (as wave_sum4_dpp), and
+    //      lanes 0..2 of the eight finish row a of [dL/dR | dL/dt] with the scan's pose ----
+    {
+      const uint16_t* seg = tab.row_seg + blk * (n_scans + 1);
+      const int sc = tid >> 3, part = tid & 7;
+      const bool mine = sc < n_scans;
+      const int end = (mine && !(dbg & 1)) ? (int)seg[sc + 1] : 0;
+      // slot (p & 1) 6 + (p >> 1) 3 + c ends on lane p of the eight: lanes 0..2 get {sum g_a q_c}, a = p; lane 3 {sum g_a}
+      double sacc[12];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double g = (double)(long long)s_g[a * CAP + t] * unscale;
-        s_g[a * CAP + t] = (unsigned long long)__double_as_longlong(poisoned ? (double)NAN : g);
-      }
-    }
-    __syncthreads();
-    // ---- dL/d[R|t]_s += g_j (x) [x_local_j, 1] over the rows of scan s: contiguous in the block's list ----
-    const uint16_t* seg = tab.row_seg + blk * (n_scans + 1);
-    for (int item = tid; item < n_scans * 24; item += kBlock) {
-      const int pair = item >> 1, part = item & 1;
-      const int rr = pair / 12, q = pair - rr * 12, a = q >> 2, b = q & 3;
-      const int beg = (int)seg[rr] + part, end = (int)seg[rr + 1];
-      const double* gp = reinterpret_cast<const double*>(s_g) + a * CAP;
-      const float* xl = reinterpret_cast<const float*>(tile) + (b < 3 ? b : 0);
-      double sacc[2] = {0.0, 0.0};
-      int p = beg;
-      for (; p + 2 < end; p += 4) {
+      for (int q = 0; q < 12; ++q) sacc[q] = 0.0;
+      for (int p = mine ? (int)seg[sc] + part : 0; p < end; p += 8) {
+        const int4 xr = tile[p];
+        const double qd[3] = {(double)xr.x, (double)xr.y, (double)xr.z};
 #pragma unroll
-        for (int u_ = 0; u_ < 2; ++u_) {
-          const int r = p + 2 * u_;
-          const double ga = gp[r];
-          sacc[u_] = __dadd_rn(sacc[u_], b == 3 ? ga : __dmul_rn(ga, (double)xl[r * 4]));
+        for (int a = 0; a < 3; ++a) {
+          const unsigned long long bits = s_g[a * CAP + p];
+          const double g = fma((double)(int)(uint32_t)(bits >> 32), 4294967296.0, (double)(uint32_t)bits);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) sacc[(a & 1) * 6 + (a >> 1) * 3 + c] = fma(g, qd[c], sacc[(a & 1) * 6 + (a >> 1) * 3 + c]);
+          sacc[9 + a] += g;                                 // lane 3: (3 & 1) 6 + (3 >> 1) 3 = 9
         }
       }
-      for (; p < end; p += 2) {
-        const double ga = gp[p];
-        sacc[0] = __dadd_rn(sacc[0], b == 3 ? ga : __dmul_rn(ga, (double)xl[p * 4]));
+      const bool up1 = (part & 1) != 0, up2 = (part & 2) != 0;
+      double h[6], r3[3], gs[3];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) h[q] = (up1 ? sacc[6 + q] : sacc[q]) + dpp_f64<kDppXor1>(up1 ? sacc[q] : sacc[6 + q]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        r3[q] = (up2 ? h[3 + q] : h[q]) + dpp_f64<kDppXor2>(up2 ? h[q] : h[3 + q]);
+        r3[q] += dpp_f64<kDppShl4>(r3[q]);                  // lanes 0..3 of the eight: + lanes 4..7
+        gs[q] = dpp_f64<kDppQuad3>(r3[q]);                  // {sum g_a} from lane 3 of the quad
       }
-      double sum = __dadd_rn(sacc[0], sacc[1]);
-      sum = __dadd_rn(sum, __shfl_xor(sum, 1, kWave));       // even + odd rows (the two lanes are neighbours)
-      if (part == 0) prow[pair] = sum;
+      if (mine && part < 3) {
+        const double unscale = qp.scale * invS;             // the block's gradient unit
+        const double* Tp = s_pose + sc * 12;
+        const double ga = (part == 0 ? gs[0] : (part == 1 ? gs[1] : gs[2])) * unscale;
+        double m[3];                                        // row a of sum_j g_j (x_j - t)^T
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m[c] = fma(r3[c] * unscale, qp.scale, ga * (qp.origin[c] - Tp[4 * c + 3]));
+        double* dst = prow + sc * 12 + part * 4;
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+          const double v = fma(m[2], Tp[8 + b2], fma(m[1], Tp[4 + b2], m[0] * Tp[b2]));
+          dst[b2] = poisoned ? (double)NAN : v;
+        }
+        dst[3] = poisoned ? (double)NAN : ga;
+      }
     }
   }
   // {sum loss, count, dL/dw} of the wavefront; the exponent-gradient columns [P, 2P) of this evaluation are zero
@@ -2956,6 +2980,7 @@ using namespace dc;
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
+static std::atomic<int> g_pose_dbg{0};
 static std::atomic<bool> g_pose_three_pass{false};   // dc_set_option(7, 1): pose gradients through the three-kernel general path (A-B, tests)
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
@@ -3346,6 +3371,7 @@ int dc_set_option(int option, int value) {
   if (option == 5) { g_chain_spin.store(value < 0 ? (1 << 22) : value); return DC_OK; }
   if (option == 6) { g_step_var.store(value); return DC_OK; }
   if (option == 7) { g_pose_three_pass.store(value != 0); return DC_OK; }
+  if (option == 99) { g_pose_dbg.store(value); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -3624,7 +3650,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     {
       ProfScope prof(1);
 #define POSE_NS(NS, P) DC_TIMED_LAUNCH((consistency_step_pose_kernel<NS, P>), grid, block, 0, stream, (const int32_t*)d->local_basis, tab, poses, d->n_scans, \
-                                       w, d->n, d->mask, lp, qp, p_fwd, p_bwd)
+                                       w, d->n, d->mask, lp, qp, p_fwd, p_bwd, g_pose_dbg.load())
 #define POSE_P(NS) do { if (n_terms == 2) POSE_NS(NS, 2); else POSE_NS(NS, 1); } while (0)
       if (d->k == 10) POSE_P(10); else if (d->k == 4) POSE_P(4); else if (d->k == 8) POSE_P(8); else POSE_P(16);
 #undef POSE_P

@@ -19,11 +19,15 @@ def main():
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--points', type=int, default=200_000)
     ap.add_argument('--variants', default='grouped,ungrouped')
+    ap.add_argument('--dbg', type=int, default=0)
     args = ap.parse_args()
     from depth_correction_amd.dataset import RoomBoxDataset
     from depth_correction_amd.pipeline import build_sequence
     from depth_correction_amd.plan import KernelTimer
     dev = torch.device('cuda:0')
+    if args.dbg:
+        from depth_correction_amd import _native
+        _native.lib().dc_set_option(99, args.dbg)
     ds = RoomBoxDataset(n_pts=args.points, n_poses=10, seed_base=1000, dtype=np.float32)
     scans = [np.stack([c[f] for f in 'xyz'], axis=1) for c, _ in ds]
     poses = np.stack([p for _, p in ds])
