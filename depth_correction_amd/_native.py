@@ -58,8 +58,8 @@ _SIGNATURES = {
     'dc_block_table_workspace_bytes': (_sz, [_i64]),
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_block_group': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
-    'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
+    'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_own_base': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'dc_block_table_run_capacity': (_i64, [_i64, _i64]),
     'dc_block_table_build_runs': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -112,7 +112,7 @@ class BlockTableDesc(ctypes.Structure):
 
 class PoseTableDesc(ctypes.Structure):
     """dcPoseTable of include/dc_hip.h."""
-    _fields_ = [('blk_ptr', _vp), ('ids', _vp), ('loc', _vp), ('own_pos', _vp), ('row_seg', _vp), ('rt_ptr', _vp), ('rt_lane', _vp)]
+    _fields_ = [('blk_ptr', _vp), ('ids', _vp), ('loc', _vp), ('own_pos', _vp), ('row_seg', _vp), ('row_scan', _vp)]
 
 
 class IcpScan(ctypes.Structure):

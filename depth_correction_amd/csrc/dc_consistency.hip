@@ -2377,14 +2377,16 @@ __global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
 //   * LOCAL basis rows (dc_points_local_basis, once per exponent set): {d0, dir, c_k, scan} in the SENSOR frame -- 32 B, nothing
 //     in them depends on a pose.  Staging forms a row's world point with the CURRENT pose and weights: d' = d0 + sum w_k c_k,
 //     x = R_s (d' dir) + t_s on the q32 grid, u = R_s dir; the sweeps then run as in consistency_step_q32_kernel.
-//   * reverse mode INSIDE the block for the poses: each centre leaves its record {mean, c1, v0, c2} in LDS (32 B, the
-//     general path's Rec8<q32> -- never in global memory), and every staged row j gathers g_j = sum over the block's centres i that
-//     list it of c1_i (v0_i . e) v0_i - c2_i e, e = x_j - mean_i, through a block-local transposed list (dcPoseTable.rt_*: which
-//     lanes reference which staged row -- static, built once from the forward table).  Rows shared by several blocks get a
-//     partial sum in each; the sums over blocks are the reduction's.
+//     The rows are stored PER BLOCK in the order of its list (24 B each, 1.75 x the points at C2; the scan of a row is a byte of
+//     dcPoseTable.row_scan): staging reads them as one contiguous, coalesced stream -- as gathers through the id list they cost
+//     two dependent memory latencies and ~2.3 cycles of the CU's address pipeline per row.
+//   * reverse mode INSIDE the block for the poses: in the second sweep every centre ADDS its edges' gradients
+//     g_ij = c1_i (v0_i . e) v0_i - c2_i e, e = x_j - mean_i, to the staged rows' sums in LDS (chain_term_pose: 64-bit integer
+//     atomics under a per-block power-of-two scale, so the order they land in does not matter).  Rows shared by several blocks
+//     get a partial sum in each; the sums over blocks are the reduction's.
 //   * the block's distinct rows are listed BY SCAN (dcPoseTable.ids: (scan, id) order, row_seg = where each scan starts), so
-//     dL/d[R|t]_s += g_j (x) [x_local_j, 1] runs over contiguous row ranges: (scan, entry) items, fixed order, one row of the
-//     row-major pose partials per block.  Bitwise reproducible like everything else.
+//     dL/d[R|t]_s = (sum_j g_j (x_j - t_s)^T) R_s | sum_j g_j runs over a contiguous row range of the tile: eight lanes per scan,
+//     fixed order, one row of the row-major pose partials per block.  Bitwise reproducible like everything else.
 // 154 us of kernels in three launches -> one launch; see DESIGN 4 for the measured time.
 struct PoseTab {
   const int32_t* __restrict__ blk_ptr;     // [blocks + 1], the forward table's
@@ -2392,26 +2394,22 @@ struct PoseTab {
   const uint16_t* __restrict__ loc;        // [blocks * K][256]: 16 x position in that order, 0xFFFF = empty slot
   const uint16_t* __restrict__ own_pos;    // [N]: 16 x position of the point's own row in its block's list
   const uint16_t* __restrict__ row_seg;    // [blocks][S + 1]: first row of every scan in the block's list; [S] = the row count
-  const uint16_t* __restrict__ rt_ptr;     // [blk_ptr[b] + b + t], t = 0 .. rows of b: offsets into rt_lane + b * 256 * K
-  const uint8_t* __restrict__ rt_lane;     // [blocks * 256 * K]: the lanes (centres of the block) that list row t, ascending
+  const uint8_t* __restrict__ row_scan;    // the scan of every listed row (parallel to ids)
 };
 constexpr int kPoseCap = 512;              // rows of the static tile (the table builder refuses blocks with longer lists)
 
-// Per block: (scan, id) order of its distinct rows, remapped positions, own positions, transposed lists.  info[0] <- 1 when a
+// Per block: (scan, id) order of its distinct rows, remapped positions, own positions.  info[0] <- 1 when a
 // block cannot take the pose kernel (more than kPoseCap rows, or a block whose list misses one of its own rows).
 template <int K>
 __global__ __launch_bounds__(kBlock) void pose_table_kernel(BlockTab tab, const int32_t* __restrict__ own_base,
                                                             const int32_t* __restrict__ scan_id, int64_t n, int n_scans,
                                                             int32_t* __restrict__ ids_out, uint16_t* __restrict__ loc_out,
                                                             uint16_t* __restrict__ own_pos, uint16_t* __restrict__ row_seg,
-                                                            uint16_t* __restrict__ rt_ptr, uint8_t* __restrict__ rt_lane,
-                                                            int32_t* __restrict__ info) {
+                                                            uint8_t* __restrict__ row_scan, int32_t* __restrict__ info) {
   __shared__ int32_t s_id[kPoseCap];
   __shared__ uint8_t s_scan[kPoseCap];
   __shared__ uint16_t s_new[kPoseCap];
   __shared__ int s_start[kMaxBlockScans + 1];
-  __shared__ int s_cnt[kPoseCap + 1], s_fill[kPoseCap];
-  __shared__ uint8_t s_list[kBlock * K];
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
   const int32_t base = tab.blk_ptr[b], nd = tab.blk_ptr[b + 1] - base;
@@ -2420,7 +2418,6 @@ __global__ __launch_bounds__(kBlock) void pose_table_kernel(BlockTab tab, const 
     if (tid == 0) atomicMax(info, 1);
     return;
   }
-  for (int t = tid; t < kPoseCap; t += kBlock) { s_cnt[t] = 0; s_fill[t] = 0; }
   if (tid <= n_scans) s_start[tid] = 0;
   __syncthreads();
   for (int t = tid; t < nd; t += kBlock) {
@@ -2440,70 +2437,50 @@ __global__ __launch_bounds__(kBlock) void pose_table_kernel(BlockTab tab, const 
     const int p = s_start[sc] + rank;
     s_new[t] = (uint16_t)p;
     ids_out[base + p] = s_id[t];
+    row_scan[base + p] = (uint8_t)sc;
   }
   if (tid <= n_scans) row_seg[b * (n_scans + 1) + tid] = (uint16_t)s_start[tid];
   __syncthreads();
   const int64_t i = b * kBlock + tid;
   own_pos[i < n ? i : n - 1] = (uint16_t)(s_new[own + (i < n ? tid : 0)] << 4);
   const uint16_t* lrow = tab.loc + (int64_t)tab.slot_ptr[b] * kBlock + tid;
-  uint16_t np[K];
 #pragma unroll
   for (int q = 0; q < K; ++q) {
     const uint16_t l = lrow[q * kBlock];
-    np[q] = l == 0xFFFF ? (uint16_t)0xFFFF : (uint16_t)(s_new[l >> 4] << 4);
-    loc_out[((int64_t)b * K + q) * kBlock + tid] = np[q];
-    if (np[q] != 0xFFFF) atomicAdd(&s_cnt[(np[q] >> 4) + 1], 1);
+    loc_out[((int64_t)b * K + q) * kBlock + tid] = l == 0xFFFF ? (uint16_t)0xFFFF : (uint16_t)(s_new[l >> 4] << 4);
   }
-  __syncthreads();
-  if (tid == 0) for (int t = 0; t < nd; ++t) s_cnt[t + 1] += s_cnt[t];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < K; ++q) {
-    if (np[q] != 0xFFFF) {
-      const int p = np[q] >> 4;
-      s_list[s_cnt[p] + atomicAdd(&s_fill[p], 1)] = (uint8_t)tid;
-    }
-  }
-  __syncthreads();
-  for (int t = tid; t < nd; t += kBlock) {               // every row's lanes ascending: the order g_j is summed in, whatever the atomics did
-    const int lo = s_cnt[t], hi = s_cnt[t + 1];
-    for (int a = lo + 1; a < hi; ++a) {
-      const uint8_t v = s_list[a];
-      int c = a;
-      while (c > lo && s_list[c - 1] > v) { s_list[c] = s_list[c - 1]; --c; }
-      s_list[c] = v;
-    }
-  }
-  __syncthreads();
-  for (int t = tid; t <= nd; t += kBlock) rt_ptr[base + b + t] = (uint16_t)s_cnt[t];
-  for (int e = tid; e < kBlock * K; e += kBlock) rt_lane[(int64_t)b * kBlock * K + e] = e < s_cnt[nd] ? s_list[e] : (uint8_t)0;
 }
 
-// {d0, dir, c_k, scan}: the pose-independent part of a ray (sensor frame; viewpoints at the sensor origin), 8 words
+// {d0, dir, c_0, c_1}: the pose-independent part of a ray (sensor frame; viewpoints at the sensor origin), 6 words.  One workgroup
+// per block of the pose table writes the rows of the block's list, in its order, at rows [blk_ptr[b], blk_ptr[b + 1]).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void points_local_basis_kernel(PointInputs in, int64_t n, int32_t* __restrict__ rows) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+__global__ __launch_bounds__(kBlock) void points_local_basis_kernel(PointInputs in, PoseTab tab, int32_t* __restrict__ rows) {
+  const int64_t b = blockIdx.x;
+  const int32_t base = tab.blk_ptr[b], nd = tab.blk_ptr[b + 1] - base;
   ModelParams mp;
   load_model(in, mp);
-  const T* dp = (const T*)in.dirs + i * 3;
-  const double d = (double)((const T*)in.depth)[i];
-  const bool lm = in.lmask ? in.lmask[i] != 0 : true;
-  const bool on = mp.kind != DC_MODEL_NONE && lm;
-  const double inc = on ? (double)((const T*)in.inc)[i] : 0.0;
-  const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;
-  float c[2] = {0.0f, 0.0f};
+  for (int t = threadIdx.x; t < nd; t += kBlock) {
+    const int64_t i = tab.ids[base + t];
+    const T* dp = (const T*)in.dirs + i * 3;
+    const double d = (double)((const T*)in.depth)[i];
+    const bool lm = in.lmask ? in.lmask[i] != 0 : true;
+    const bool on = mp.kind != DC_MODEL_NONE && lm;
+    const double inc = on ? (double)((const T*)in.inc)[i] : 0.0;
+    const double d0 = (on && mp.kind == DC_MODEL_LINEAR) ? 0.0 : d;
+    float c[2] = {0.0f, 0.0f};
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (k < mp.n_terms && on) {
-      const double dk = mp.kind > DC_MODEL_SCALED_POLYNOMIAL ? model_dw_other(mp, k, d, inc)
-                                                             : (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
-      c[k] = (float)dk;
+    for (int k = 0; k < 2; ++k) {
+      if (k < mp.n_terms && on) {
+        const double dk = mp.kind > DC_MODEL_SCALED_POLYNOMIAL ? model_dw_other(mp, k, d, inc)
+                                                               : (mp.kind == DC_MODEL_SCALED_POLYNOMIAL ? -d : -1.0) * pow_term(inc, mp.e[k]);
+        c[k] = (float)dk;
+      }
     }
+    int2* r = reinterpret_cast<int2*>(rows) + 3 * (int64_t)(base + t);
+    r[0] = make_int2(__float_as_int((float)d0), __float_as_int((float)dp[0]));
+    r[1] = make_int2(__float_as_int((float)dp[1]), __float_as_int((float)dp[2]));
+    r[2] = make_int2(__float_as_int(c[0]), __float_as_int(c[1]));
   }
-  int4* r = reinterpret_cast<int4*>(rows) + 2 * i;
-  r[0] = make_int4(__float_as_int((float)d0), __float_as_int((float)dp[0]), __float_as_int((float)dp[1]), __float_as_int((float)dp[2]));
-  r[1] = make_int4(__float_as_int(c[0]), __float_as_int(c[1]), in.scan_id ? in.scan_id[i] : 0, 0);
 }
 
 // second sweep of the pose kernel, one neighbour: chain_term_q32 plus the edge's gradient g_ij = al v0 - c2 e_j ADDED to the
@@ -2512,7 +2489,7 @@ __global__ __launch_bounds__(kBlock) void points_local_basis_kernel(PointInputs 
 // double(g) + 1.5 2^52 holds round(g) in its mantissa: the bit pattern minus that of 1.5 2^52 (low word zero) IS the integer.
 template <int P, int CAP>
 __device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long long* s_g, uint32_t off, bool have, const Pt<q32>::Raw& ci,
-                                                const float* cmf, const float* vs, const float* vu, float c2f, float* gw, int dbg) {
+                                                const float* cmf, const float* vs, const float* vu, float c2f, float* gw) {
   const char* row = reinterpret_cast<const char*>(tile) + (have ? off : 0u);
   const int4 p0 = *reinterpret_cast<const int4*>(row);
   const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)CAP * 16);
@@ -2530,7 +2507,7 @@ __device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long 
   } else {
     gw[0] = fmaf(tj, __int_as_float(p1.z), gw[0]);
   }
-  if (have && !(dbg & 2)) {
+  if (have) {
     constexpr double kMagic = 6755399441055744.0;                                      // 1.5 2^52
     unsigned long long* cell = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(s_g) + (off >> 1));
     const float gg[3] = {g0, g1, g2};
@@ -2548,9 +2525,9 @@ __device__ __forceinline__ void chain_term_pose(const int4* tile, unsigned long 
 // (chain_term_pose); the rows of one scan are contiguous in the block's list (dc_pose_table_build), so dL/d[R|t]_s of the block
 // is a sum over a row range: one row [12 S] of the row-major pose partials per block, summed by reduce_eval_kernel.
 template <int NS, int P>
-__global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
+__global__ __launch_bounds__(kBlock, 4) void consistency_step_pose_kernel(
     const int32_t* __restrict__ lrows, PoseTab tab, const double* __restrict__ poses, int n_scans, const double* __restrict__ w,
-    int64_t n, const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd, int dbg) {
+    int64_t n, const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
   constexpr int CAP = kPoseCap;
   __shared__ int4 tile[2 * CAP];                            // piece 0 {X, u0} | piece 1 {u1, u2, c0, c1}
   __shared__ unsigned long long s_g[3 * CAP];               // three planes: the rows' gradient sums (64-bit integers)
@@ -2559,13 +2536,16 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
   const int tid = threadIdx.x;
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
   const int64_t blk = xcd_block(nblocks);
-  const int64_t rs = (int64_t)gridDim.x * kWavesPerBlock;
-  double* prow = p_bwd + 2 * P * rs + (int64_t)blockIdx.x * 12 * n_scans;        // this block's row of the row-major pose partials
+  // one partial row per block in every column: {sum loss, count} at p_fwd, dL/dw, zeros for dL/de, the 12 S pose sums at p_bwd.  The
+  // eight rows of a 64-byte line are blocks of ONE XCD (blockIdx & 7), so the line is completed in that XCD's L2, and the
+  // reduction reads every column as one contiguous run.
+  const int64_t rs = (int64_t)gridDim.x;
+  double* pcol = p_bwd + 2 * P * rs + (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) gw[k] = 0.0;
   if (blk < 0) {                                            // padding block of the last round (block-uniform): zero rows
-    for (int item = tid; item < 12 * n_scans; item += kBlock) prow[item] = 0.0;
+    for (int item = tid; item < 12 * n_scans; item += kBlock) pcol[item * rs] = 0.0;
   } else {
     for (int t = tid; t < n_scans * 12; t += kBlock) s_pose[t] = poses[t];
     double wq[P];
@@ -2580,17 +2560,16 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
     for (int q = 0; q < NS; ++q) pre[q] = live ? (uint32_t)lrow[q * kBlock] : kNoLoc;
     const uint32_t own = live ? (uint32_t)tab.own_pos[i] : 0u;
     const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
-    // the (at most two) rows this thread stages: both ids, then both local basis rows, in flight before the first barrier
-    static_assert(CAP <= 2 * kBlock, "two staged rows per thread");
-    int32_t sid[2];
-    int4 ra[2], rb[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) sid[j] = tid + j * kBlock < nd ? tab.ids[base + tid + j * kBlock] : -1;
+    // the (at most two) rows this thread stages, in flight before anything else: the block's rows are one contiguous stream
+    static_assert(CAP == 2 * kBlock, "two staged rows per thread");
+    int2 rw[2][3];
+    int rsc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int64_t id = sid[j] < 0 ? 0 : sid[j];
-      ra[j] = reinterpret_cast<const int4*>(lrows)[2 * id];
-      rb[j] = reinterpret_cast<const int4*>(lrows)[2 * id + 1];
+      const int t = tid + j * kBlock < nd ? tid + j * kBlock : 0;
+      const int2* src = reinterpret_cast<const int2*>(lrows) + 3 * (int64_t)(base + t);
+      rw[j][0] = src[0]; rw[j][1] = src[1]; rw[j][2] = src[2];
+      rsc[j] = tab.row_scan[base + t];
     }
     for (int t = tid; t < 3 * CAP; t += kBlock) s_g[t] = 0ull;
     __syncthreads();                                        // the poses are in LDS
@@ -2598,13 +2577,12 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int t = tid + j * kBlock;
-      if (sid[j] < 0) continue;
-      const int4 r0 = ra[j], r1 = rb[j];
-      const float c0 = __int_as_float(r1.x), c1f = __int_as_float(r1.y);
-      const int sc = r1.z;
-      double dp = (double)__int_as_float(r0.x) + wq[0] * (double)c0;
+      if (t >= nd) continue;
+      const float c0 = __int_as_float(rw[j][2].x), c1f = __int_as_float(rw[j][2].y);
+      const int sc = rsc[j];
+      double dp = (double)__int_as_float(rw[j][0].x) + wq[0] * (double)c0;
       if constexpr (P > 1) dp += wq[1] * (double)c1f;
-      const double dl[3] = {(double)__int_as_float(r0.y), (double)__int_as_float(r0.z), (double)__int_as_float(r0.w)};
+      const double dl[3] = {(double)__int_as_float(rw[j][0].y), (double)__int_as_float(rw[j][1].x), (double)__int_as_float(rw[j][1].y)};
       const double* Tp = s_pose + sc * 12;
       double u[3], x[3];
 #pragma unroll
@@ -2614,11 +2592,11 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
       }
       tile[t] = make_int4(quantize(x[0], qp.origin[0], qp.inv_scale, qp.flag), quantize(x[1], qp.origin[1], qp.inv_scale, qp.flag),
                           quantize(x[2], qp.origin[2], qp.inv_scale, qp.flag), __float_as_int((float)u[0]));
-      tile[CAP + t] = make_int4(__float_as_int((float)u[1]), __float_as_int((float)u[2]), r1.x, r1.y);
+      tile[CAP + t] = make_int4(__float_as_int((float)u[1]), __float_as_int((float)u[2]), rw[j][2].x, rw[j][2].y);
     }
     __syncthreads();
     // ---- the centre: moments, smallest eigenpair, loss (as consistency_step_q32_kernel) and a bound of its edges' gradients ----
-    const bool work = live && (!mask || __any((int)in_mask)) && !(dbg & 16);
+    const bool work = live && (!mask || __any((int)in_mask));
     Pt<q32>::Raw ci;
     double cm[3] = {0.0, 0.0, 0.0}, v0[3] = {0.0, 0.0, 0.0}, c1 = 0.0, c2 = 0.0;
     float bound = 0.0f;
@@ -2659,7 +2637,7 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
     }
     const double S = ldexp(1.0, sh), invS = ldexp(1.0, -sh);
     // ---- second sweep: dL/dw of the centre, and its edges' gradients into the rows' planes ----
-    if (work && !poisoned && !(dbg & 4)) {
+    if (work && !poisoned) {
       float cmf[3], vs[3], vu[3], gwf[P];
       const double c1s = c1 * S;
 #pragma unroll
@@ -2671,7 +2649,7 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           if (q % 4 == 0 && q > 0) __builtin_amdgcn_sched_barrier(0);
-          chain_term_pose<P, CAP>(tile, s_g, pre[q], pre[q] != kNoLoc && (c1 != 0.0 || c2 != 0.0), ci, cmf, vs, vu, c2f, gwf, dbg);
+          chain_term_pose<P, CAP>(tile, s_g, pre[q], pre[q] != kNoLoc && (c1 != 0.0 || c2 != 0.0), ci, cmf, vs, vu, c2f, gwf);
         }
       }
 #pragma unroll
@@ -2687,7 +2665,7 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
       const uint16_t* seg = tab.row_seg + blk * (n_scans + 1);
       const int sc = tid >> 3, part = tid & 7;
       const bool mine = sc < n_scans;
-      const int end = (mine && !(dbg & 1)) ? (int)seg[sc + 1] : 0;
+      const int end = mine ? (int)seg[sc + 1] : 0;
       // slot (p & 1) 6 + (p >> 1) 3 + c ends on lane p of the eight: lanes 0..2 get {sum g_a q_c}, a = p; lane 3 {sum g_a}
       double sacc[12];
 #pragma unroll
@@ -2721,22 +2699,19 @@ __global__ __launch_bounds__(kBlock, 5) void consistency_step_pose_kernel(
         double m[3];                                        // row a of sum_j g_j (x_j - t)^T
 #pragma unroll
         for (int c = 0; c < 3; ++c) m[c] = fma(r3[c] * unscale, qp.scale, ga * (qp.origin[c] - Tp[4 * c + 3]));
-        double* dst = prow + sc * 12 + part * 4;
+        double* dst = pcol + (sc * 12 + part * 4) * rs;
 #pragma unroll
         for (int b2 = 0; b2 < 3; ++b2) {
           const double v = fma(m[2], Tp[8 + b2], fma(m[1], Tp[4 + b2], m[0] * Tp[b2]));
-          dst[b2] = poisoned ? (double)NAN : v;
+          dst[b2 * rs] = poisoned ? (double)NAN : v;
         }
-        dst[3] = poisoned ? (double)NAN : ga;
+        dst[3 * rs] = poisoned ? (double)NAN : ga;
       }
     }
   }
   // {sum loss, count, dL/dw} of the wavefront; the exponent-gradient columns [P, 2P) of this evaluation are zero
-  step_partials<P, true>(acc2, gw, p_fwd, p_bwd);
-  {
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    if (lane < P) p_bwd[(P + lane) * rs + (int64_t)blockIdx.x * kWavesPerBlock + wave] = 0.0;
-  }
+  if (tid < P) p_bwd[(P + tid) * rs + blockIdx.x] = 0.0;
+  step_partials<P, true>(acc2, gw, p_fwd, p_bwd, true, 0);
 }
 
 // Backward in basis form over a run table: the point itself and the chain to the weights come from the basis rows.
@@ -2873,20 +2848,22 @@ constexpr int kRedBlock = 1024;
 // Sum of p[threadIdx.x], p[threadIdx.x + 1024], ... in a fixed order with 32 loads in flight per lane: the rows were
 // written by blocks on every XCD, so each read is a trip to the fabric, and with four in flight the ~31 rows per lane
 // (N = 2 M) took eight dependent round trips.
-__device__ __forceinline__ double strided_sum(const double* __restrict__ p, int64_t n_rows, int64_t stride = 1) {
+constexpr int kPoseRedCols = 8;          // columns of the row-major pose partials a block of reduce_eval_kernel sums: one 64-byte line
+__device__ __forceinline__ double strided_sum(const double* __restrict__ p, int64_t n_rows, int64_t stride = 1, int first = -1,
+                                              int step = kRedBlock) {
   constexpr int U = 32;                  // 32 k rows (N = 2 M: one row per wavefront) in ONE round trip per lane
   double acc[U];
 #pragma unroll
   for (int u_ = 0; u_ < U; ++u_) acc[u_] = 0.0;
-  int64_t r = threadIdx.x;
-  for (; r + (U - 1) * kRedBlock < n_rows; r += U * kRedBlock) {
+  int64_t r = first < 0 ? (int)threadIdx.x : first;        // this lane's rows: r, r + step, ...
+  for (; r + (int64_t)(U - 1) * step < n_rows; r += (int64_t)U * step) {
 #pragma unroll
-    for (int u_ = 0; u_ < U; ++u_) acc[u_] += p[(r + u_ * kRedBlock) * stride];
+    for (int u_ = 0; u_ < U; ++u_) acc[u_] += p[(r + (int64_t)u_ * step) * stride];
   }
   {
     double last[U];                      // the tail's loads are issued together, too
 #pragma unroll
-    for (int u_ = 0; u_ < U; ++u_) last[u_] = (r + u_ * kRedBlock < n_rows) ? p[(r + u_ * kRedBlock) * stride] : 0.0;
+    for (int u_ = 0; u_ < U; ++u_) last[u_] = (r + (int64_t)u_ * step < n_rows) ? p[(r + (int64_t)u_ * step) * stride] : 0.0;
 #pragma unroll
     for (int u_ = 0; u_ < U; ++u_) acc[u_] += last[u_];
   }
@@ -2922,21 +2899,37 @@ __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __
                                                                 const int32_t* __restrict__ status, int pose_first = -1,
                                                                 int pose_cols = 0) {
   // pose_first >= 0: the accumulators from 2 + pose_first on (the pose slots) were written ROW-major [rows_bwd / 4][pose_cols]
-  // behind the column-major ones (the grouped backward: one row per block)
-  __shared__ double lds[kRedBlock / kWave];
-  const int a = blockIdx.x;                // grid = 2 + n_red blocks: only the sums that were asked for get a block
+  // behind the column-major ones (one row per block of the backward / pose kernel).  A block of this kernel then sums EIGHT
+  // neighbouring columns -- one 64-byte line of every row: lane & 7 is the column, the other lane bits the row -- so every line is
+  // fetched once, by one XCD (a block per column fetched each line eight times: 16 us at N = 2 M, 20 scans, against 4).
+  __shared__ double lds[kRedBlock / kWave * kPoseRedCols];
+  const int a = blockIdx.x;                // grid = red_grid(): only the sums that were asked for get a block
   if (a == 0)                              // block 0 also clears the slots of gradients that were not requested
     for (int z = 2 + n_red + threadIdx.x; z < n_out; z += kRedBlock) out[z] = 0.0;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (pose_first >= 0 && a >= 2 + pose_first) {
+    const int col = (a - 2 - pose_first) * kPoseRedCols + (threadIdx.x & (kPoseRedCols - 1));
+    const bool have = col < pose_cols;
+    const double* p = p_bwd + (int64_t)pose_first * rows_bwd + (have ? col : 0);
+    double s = strided_sum(p, have ? rows_bwd / kWavesPerBlock : 0, pose_cols, threadIdx.x / kPoseRedCols, kRedBlock / kPoseRedCols);
+#pragma unroll
+    for (int o = kPoseRedCols; o < kWave; o <<= 1) s += __shfl_xor(s, o, kWave);
+    if (lane < kPoseRedCols) lds[wave * kPoseRedCols + lane] = s;
+    __syncthreads();
+    if (threadIdx.x < kPoseRedCols && have) {
+      double t = 0.0;
+      for (int wv = 0; wv < kRedBlock / kWave; ++wv) t += lds[wv * kPoseRedCols + threadIdx.x];
+      out[2 + pose_first + col] = t;
+    }
+    return;
+  }
   const bool flagged = a == 0 && threadIdx.x == 0 && status && *status != 0;      // requested before the rows, not after
-  const bool pose_row = pose_first >= 0 && a >= 2 + pose_first;
-  const int64_t n_rows = a < 2 ? rows_fwd : (pose_row ? rows_bwd / kWavesPerBlock : rows_bwd);
-  const double* p = a < 2 ? p_fwd + (int64_t)a * rows_fwd
-                          : (pose_row ? p_bwd + (int64_t)pose_first * rows_bwd + (a - 2 - pose_first) : p_bwd + (int64_t)(a - 2) * rows_bwd);
+  const int64_t n_rows = a < 2 ? rows_fwd : rows_bwd;
+  const double* p = a < 2 ? p_fwd + (int64_t)a * rows_fwd : p_bwd + (int64_t)(a - 2) * rows_bwd;
   const bool step = adam.p && a >= 2 && a - 2 < adam.n && threadIdx.x == 0;
   double p0 = 0.0, m0 = 0.0, v0 = 0.0;
   if (step) { p0 = adam.p[a - 2]; m0 = adam.m[a - 2]; v0 = adam.v[a - 2]; }      // in flight together with the partial rows
-  const double s = wave_sum(strided_sum(p, n_rows, pose_row ? pose_cols : 1));
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const double s = wave_sum(strided_sum(p, n_rows));
   if (lane == 0) lds[wave] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2947,6 +2940,12 @@ __global__ __launch_bounds__(kRedBlock) void reduce_eval_kernel(const double* __
     out[a] = t;
     if (step) adam_apply(adam, a - 2, t, p0, m0, v0);
   }
+}
+
+// blocks of reduce_eval_kernel: one per column-major sum, one per kPoseRedCols columns of row-major pose partials
+static inline unsigned red_grid(int n_red, int pose_first, int pose_cols) {
+  if (pose_first < 0 || n_red <= pose_first) return 2u + (unsigned)n_red;
+  return 2u + (unsigned)pose_first + (unsigned)((pose_cols + kPoseRedCols - 1) / kPoseRedCols);
 }
 
 __global__ void adam_kernel(const double* __restrict__ grad, AdamArgs adam) {
@@ -2980,7 +2979,6 @@ using namespace dc;
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
-static std::atomic<int> g_pose_dbg{0};
 static std::atomic<bool> g_pose_three_pass{false};   // dc_set_option(7, 1): pose gradients through the three-kernel general path (A-B, tests)
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
@@ -3127,30 +3125,31 @@ int dc_points_basis(const void* vps, const void* dirs, const void* depth, const 
 }
 
 int dc_points_local_basis(const void* dirs, const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
-                          int model_kind, int n_terms, const double* e, int64_t n, int dtype, void* rows_out, hipStream_t stream) {
+                          int model_kind, int n_terms, const double* e, int64_t n, int dtype, const dcPoseTable* table, void* rows_out,
+                          hipStream_t stream) {
   if (n == 0) return DC_OK;
-  if (n < 0 || !dirs || !depth || !rows_out || n_terms < 1 || n_terms > 2) return DC_ERR_ARG;
+  if (n < 0 || !dirs || !depth || !rows_out || n_terms < 1 || n_terms > 2 || !table || !table->blk_ptr || !table->ids) return DC_ERR_ARG;
   if (dtype != DC_F32) return DC_ERR_DTYPE;                  // float32 clouds (q32 points): what the pose kernel takes
   int rc = check_model(model_kind, n_terms, inc, e, e);
   if (rc || model_kind == DC_MODEL_NONE) return rc ? rc : DC_ERR_ARG;
   PointInputs in = make_inputs(nullptr, dirs, depth, inc, lmask, scan_id, nullptr, 1, model_kind, n_terms, e, e);
-  hipLaunchKernelGGL((points_local_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, n, (int32_t*)rows_out);
+  PoseTab tab{table->blk_ptr, table->ids, table->loc, table->own_pos, table->row_seg, table->row_scan};
+  hipLaunchKernelGGL((points_local_basis_kernel<float>), dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, in, tab, (int32_t*)rows_out);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }
 
 int dc_pose_table_build(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int k, int32_t* ids_out,
-                        uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint16_t* rt_ptr, uint8_t* rt_lane, int32_t* info,
-                        hipStream_t stream) {
+                        uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint8_t* row_scan, int32_t* info, hipStream_t stream) {
   if (!fwd || fwd->layout != DC_TABLE_SLOTS || !fwd->blk_ptr || !fwd->blk_ids || !fwd->slot_ptr || !fwd->loc || !fwd->own_base) return DC_ERR_ARG;
-  if (n < 1 || n_scans < 1 || n_scans > kMaxBlockScans || !ids_out || !loc_out || !own_pos || !row_seg || !rt_ptr || !rt_lane || !info) return DC_ERR_ARG;
+  if (n < 1 || n_scans < 1 || n_scans > kMaxBlockScans || !ids_out || !loc_out || !own_pos || !row_seg || !row_scan || !info) return DC_ERR_ARG;
   if (k != 4 && k != 8 && k != 10 && k != 16) return DC_ERR_UNSUPPORTED;
   hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), stream);
   if (err != hipSuccess) return (int)err;
   BlockTab tab{fwd->blk_ptr, fwd->blk_ids, fwd->slot_ptr, fwd->loc};
   const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
 #define PT_K(KK) hipLaunchKernelGGL((pose_table_kernel<KK>), grid, block, 0, stream, tab, fwd->own_base, scan_id, n, n_scans, ids_out, loc_out, own_pos, \
-                                    row_seg, rt_ptr, rt_lane, info)
+                                    row_seg, row_scan, info)
   if (k == 10) PT_K(10); else if (k == 4) PT_K(4); else if (k == 8) PT_K(8); else PT_K(16);
 #undef PT_K
   DC_CHECK_LAUNCH();
@@ -3371,7 +3370,6 @@ int dc_set_option(int option, int value) {
   if (option == 5) { g_chain_spin.store(value < 0 ? (1 << 22) : value); return DC_OK; }
   if (option == 6) { g_step_var.store(value); return DC_OK; }
   if (option == 7) { g_pose_three_pass.store(value != 0); return DC_OK; }
-  if (option == 99) { g_pose_dbg.store(value); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -3644,21 +3642,22 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp, d->status);
     if (rc) return rc;
     const dcPoseTable* pt = d->pose_table;
-    PoseTab tab{pt->blk_ptr, pt->ids, pt->loc, pt->own_pos, pt->row_seg, pt->rt_ptr, pt->rt_lane};
+    PoseTab tab{pt->blk_ptr, pt->ids, pt->loc, pt->own_pos, pt->row_seg, pt->row_scan};
     const LossParams lp = make_loss_params(d->loss_kind & ~DC_LOSS_RAW_POINTWISE, d->normalization, d->sqrt_);
     const dim3 grid((unsigned)xcd_grid(n_blocks(d->n))), block(kBlock);
     {
       ProfScope prof(1);
 #define POSE_NS(NS, P) DC_TIMED_LAUNCH((consistency_step_pose_kernel<NS, P>), grid, block, 0, stream, (const int32_t*)d->local_basis, tab, poses, d->n_scans, \
-                                       w, d->n, d->mask, lp, qp, p_fwd, p_bwd, g_pose_dbg.load())
+                                       w, d->n, d->mask, lp, qp, p_fwd, p_bwd)
 #define POSE_P(NS) do { if (n_terms == 2) POSE_NS(NS, 2); else POSE_NS(NS, 1); } while (0)
       if (d->k == 10) POSE_P(10); else if (d->k == 4) POSE_P(4); else if (d->k == 8) POSE_P(8); else POSE_P(16);
 #undef POSE_P
 #undef POSE_NS
     }
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows, rows, n_acc, 2 + n_acc, out, adam,
-                       (const int32_t*)d->status, 2 * n_terms, 12 * d->n_scans);
+    const int64_t rows_b = xcd_grid(n_blocks(d->n));         // one row per block, every column contiguous
+    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_b, rows_b, n_acc, 2 + n_acc, out, adam,
+                       (const int32_t*)d->status, -1, 0);
     DC_CHECK_LAUNCH();
     return DC_OK;
   }
@@ -3681,8 +3680,9 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   if (rc) return rc;
   // (as consistency_bwd_impl decides: the grouped backward leaves the pose slots row-major, one row per block)
   const bool grouped = want_grad && want_pose_grad && d->scan_seg && !d->lane_perm && d->n_scans <= kMaxBlockScans;
-  hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_red), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows,
-                     n_red, 2 + n_acc, out, adam, (const int32_t*)d->status, grouped ? 2 * n_terms : -1, 12 * d->n_scans);
+  hipLaunchKernelGGL(reduce_eval_kernel, dim3(red_grid(n_red, grouped ? 2 * n_terms : -1, 12 * d->n_scans)), dim3(kRedBlock), 0, stream, p_fwd, p_bwd,
+                     xcd_grid(n_blocks(n_rows)) * kWavesPerBlock, rows, n_red, 2 + n_acc, out, adam, (const int32_t*)d->status,
+                     grouped ? 2 * n_terms : -1, 12 * d->n_scans);
   DC_CHECK_LAUNCH();
   return DC_OK;
 }

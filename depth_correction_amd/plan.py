@@ -303,9 +303,11 @@ class SequencePlan:
         lb = self._local_basis
         if lb is None or lb[0] != key:
             ps = self.ps
-            rows = torch.empty((self.n, 8), dtype=torch.int32, device=self.device)
+            # per block of the pose table, in the order of its list: 24 B per listed row
+            rows = torch.empty((max(self._pose_table[1]['ids'].numel(), 1), 6), dtype=torch.int32, device=self.device)
             check(lib().dc_points_local_basis(ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id), d.model_kind, nt,
-                                              ptr(exponent), self.n, nv.DC_F32, ptr(rows), stream_ptr()), 'dc_points_local_basis')
+                                              ptr(exponent), self.n, nv.DC_F32, ctypes.byref(self._pose_table[0]), ptr(rows),
+                                              stream_ptr()), 'dc_points_local_basis')
             self._local_basis = lb = (key, rows, exponent)
         d.pose_table = ctypes.cast(ctypes.pointer(self._pose_table[0]), ctypes.c_void_p)
         d.local_basis = lb[1].data_ptr()
@@ -318,16 +320,15 @@ class SequencePlan:
                  loc=torch.empty((nb * self.k * 256,), dtype=torch.uint16, device=dev),
                  own_pos=torch.empty((self.n,), dtype=torch.uint16, device=dev),
                  row_seg=torch.empty((nb * (self.n_scans + 1),), dtype=torch.uint16, device=dev),
-                 rt_ptr=torch.empty((total + nb,), dtype=torch.uint16, device=dev),
-                 rt_lane=torch.empty((nb * 256 * self.k,), dtype=torch.uint8, device=dev))
+                 row_scan=torch.empty((max(total, 1),), dtype=torch.uint8, device=dev))
         info = torch.zeros((1,), dtype=torch.int32, device=dev)
         check(lib().dc_pose_table_build(ft.ref(), ptr(self.ps.scan_id), self.n, self.n_scans, self.k, ptr(t['ids']), ptr(t['loc']),
-                                        ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['rt_ptr']), ptr(t['rt_lane']), ptr(info), stream_ptr()),
+                                        ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['row_scan']), ptr(info), stream_ptr()),
               'dc_pose_table_build')
         if int(info.item()) != 0:
             return False
-        desc = nv.PoseTableDesc(ptr(ft.blk_ptr), ptr(t['ids']), ptr(t['loc']), ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['rt_ptr']),
-                                ptr(t['rt_lane']))
+        desc = nv.PoseTableDesc(ptr(ft.blk_ptr), ptr(t['ids']), ptr(t['loc']), ptr(t['own_pos']), ptr(t['row_seg']),
+                                ptr(t['row_scan']))
         return desc, t
 
     def _set_basis(self, d, w, exponent, poses12, want_exponent, want_pose):

@@ -385,27 +385,27 @@ int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, con
 /* ---- pose mode in one pass (round 4; train.py:300-312 with pose corrections, eval.py:68-82) ---------------------------------
  * dcPoseTable: per 256-point block, derived once from the forward block table of a [rows, K] neighbour table (K = 4 / 8 / 10 / 16):
  * its distinct rows listed by (scan, id), the references' positions in that order, every point's own position, where each
- * scan's rows start, and which lanes of the block list each row (block-local transposed lists).  dc_pose_table_build fills
- * caller-allocated arrays: ids int32 [blk_ptr[blocks]], loc uint16 [blocks * K * 256], own_pos uint16 [n], row_seg uint16
- * [blocks * (n_scans + 1)], rt_ptr uint16 [blk_ptr[blocks] + blocks], rt_lane uint8 [blocks * 256 * K]; info int32 [1] <- 1 when
- * some block cannot take the pose kernel (more than 512 distinct rows, or a block whose list misses one of its own rows). */
+ * scan's rows start and the scan of every listed row.  dc_pose_table_build fills caller-allocated arrays: ids int32
+ * [blk_ptr[blocks]], loc uint16 [blocks * K * 256], own_pos uint16 [n], row_seg uint16 [blocks * (n_scans + 1)], row_scan uint8
+ * [blk_ptr[blocks]]; info int32 [1] <- 1 when some block cannot take the pose kernel (more than 512 distinct rows, or a block
+ * whose list misses one of its own rows). */
 typedef struct dcPoseTable {
-  const int32_t* blk_ptr;
+  const int32_t* blk_ptr;          /* the forward table's */
   const int32_t* ids;
   const uint16_t* loc;
   const uint16_t* own_pos;
   const uint16_t* row_seg;
-  const uint16_t* rt_ptr;
-  const uint8_t* rt_lane;
+  const uint8_t* row_scan;
 } dcPoseTable;
 int dc_pose_table_build(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int k, int32_t* ids_out,
-                        uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint16_t* rt_ptr, uint8_t* rt_lane, int32_t* info,
-                        dcStream_t stream);
-/* Pose-independent rows of the rays (sensor frame, viewpoints at the sensor origin): {d0, dir, c_k = dd'/dw_k, scan} as 8 words
- * per point for float32 clouds and models of one or two weights (model.py:113-349 are affine in their weights); valid for the
- * exponents `e`.  rows_out int32 [n, 8]. */
+                        uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint8_t* row_scan, int32_t* info, dcStream_t stream);
+/* Pose-independent rows of the rays (sensor frame, viewpoints at the sensor origin): {d0, dir, c_k = dd'/dw_k} as 6 float32 words
+ * per row for float32 clouds and models of one or two weights (model.py:113-349 are affine in their weights); valid for the
+ * exponents `e`.  Stored per block of `table`, in the order of its list: rows_out [blk_ptr[blocks], 6], block b's row t at
+ * blk_ptr[b] + t -- the pose kernel stages them as one contiguous stream. */
 int dc_points_local_basis(const void* dirs, const void* depth, const void* inc, const uint8_t* lmask, const int32_t* scan_id,
-                          int model_kind, int n_terms, const double* e, int64_t n, int dtype, void* rows_out, dcStream_t stream);
+                          int model_kind, int n_terms, const double* e, int64_t n, int dtype, const dcPoseTable* table, void* rows_out,
+                          dcStream_t stream);
 
 typedef struct dcSequenceDesc {
   int64_t n;

@@ -19,15 +19,15 @@ def main():
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--points', type=int, default=200_000)
     ap.add_argument('--variants', default='grouped,ungrouped')
-    ap.add_argument('--dbg', type=int, default=0)
+    ap.add_argument('--option', default='', help='dc_set_option pairs, e.g. 7=1 (three-kernel path)')
     args = ap.parse_args()
     from depth_correction_amd.dataset import RoomBoxDataset
     from depth_correction_amd.pipeline import build_sequence
     from depth_correction_amd.plan import KernelTimer
     dev = torch.device('cuda:0')
-    if args.dbg:
+    for kv in filter(None, args.option.split(',')):
         from depth_correction_amd import _native
-        _native.lib().dc_set_option(99, args.dbg)
+        _native.lib().dc_set_option(*[int(v) for v in kv.split('=')])
     ds = RoomBoxDataset(n_pts=args.points, n_poses=10, seed_base=1000, dtype=np.float32)
     scans = [np.stack([c[f] for f in 'xyz'], axis=1) for c, _ in ds]
     poses = np.stack([p for _, p in ds])
