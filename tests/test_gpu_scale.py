@@ -75,10 +75,14 @@ def test_fused_loss_2m_properties(room):
     base = run(plan)
     assert base[1] == plan.count and 0.3 * plan.n < base[1] < plan.n
     flat = SequencePlan(info['clouds'], T, info['neighbors'], info['mask'], spatial_sort=False)
-    np.testing.assert_allclose(run(flat)[:2], base[:2], rtol=1e-11)               # same numbers in any point order
-    # pose mode on the sorted layout hands dL/dx to the scan-major pass in the points' dtype (fp32 here)
-    np.testing.assert_allclose(run(flat)[2:4], base[2:4], rtol=1e-8)
-    np.testing.assert_allclose(run(flat)[6:], base[6:], rtol=1e-6, atol=1e-9 * np.abs(base[6:]).max())
+    # same numbers in any point order.  (The sorted plan's pose evaluation is the one-launch kernel, whose rows carry dd'/dw_k
+    # rounded to float32 like the basis rows of the model-only step: d' moves by ~1e-9 m, a few points round to the next q32
+    # grid value (4.7e-8 m), the loss moves by parts in 1e10; the scan-major plan runs the general path.)
+    np.testing.assert_allclose(run(flat)[:2], base[:2], rtol=2e-9)
+    # the pose kernel's second sweep is float32 (as the model-only step's): parts in 1e8 on dL/dw
+    np.testing.assert_allclose(run(flat)[2:4], base[2:4], rtol=1e-6)
+    # (the small entries of a scan's 3 x 4 gradient are differences of large sums of float32 edge terms, summed in different orders)
+    np.testing.assert_allclose(run(flat)[6:], base[6:], rtol=1e-6, atol=1e-6 * np.abs(base[6:]).max())
     f32 = SequencePlan(info['clouds'], T, info['neighbors'], info['mask'], point_format='float')
     np.testing.assert_allclose(run(f32)[:2], base[:2], rtol=1e-5)                  # fp32 points: the 1e-5 bar
     # rigid motion of the whole map leaves the loss and dL/dw unchanged
@@ -433,6 +437,60 @@ def test_c2_full_size_pose_gradients_vs_oracle(room):
         np.testing.assert_allclose(got_T[s], ref_T[s], rtol=1e-5, atol=1e-5 * np.abs(ref_T[s]).max(), err_msg='scan %d [R|t]' % s)
         np.testing.assert_allclose(got_d[s], ref_d[s], rtol=1e-5, atol=1e-5 * np.abs(ref_d[s]).max(), err_msg='scan %d deltas' % s)
     assert np.abs(ref_d).max() > 0 and np.abs(got_T[:, :, 3].sum(0)).max() <= 1e-6 * np.abs(got_T[:, :, 3]).sum()
+
+
+@pytest.mark.parametrize('k, n_terms, loss, normalization, sqrt', [
+    (10, 2, 'min_eigval_loss', True, False),
+    (10, 1, 'min_eigval_loss', False, True),
+    (4, 2, 'trace_loss', False, False),
+    (16, 1, 'min_eigval_loss', True, True),
+])
+def test_pose_kernel_equals_three_kernel_path(room, k, n_terms, loss, normalization, sqrt):
+    """The one-launch pose evaluation (consistency_step_pose_kernel: rows from the local basis, gradients of the staged rows summed
+    in LDS as integers, per-scan sums in the world frame) against the general path (dc_points_fwd + forward + backward over the
+    transposed table, dc_set_option(7, 1)) on the same plan: loss, count, dL/dw and dL/d[R|t] of every scan, for perturbed poses,
+    a ragged last block and every table width the kernel is built for.  Both compute the sweeps in float32 on the q32 grid, in
+    different orders: 1e-6 of each scan's largest entry."""
+    from depth_correction_amd import _native as nv
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import KernelTimer
+    scans, poses = room
+    plan, info = build_sequence([s[:30_011] for s in scans[:4]], poses[:4], k=k, dtype=torch.float32, loss=loss,
+                                normalization=normalization, sqrt=sqrt, min_valid_neighbors=min(5, k - 1))
+    dev = plan.device
+    rng = np.random.default_rng(k)
+    w = torch.tensor([1e-3, 2e-3][:n_terms], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0][:n_terms], dtype=torch.float64, device=dev)
+    from depth_correction_amd.transform import corrected_poses
+    deltas = torch.as_tensor(rng.normal(size=(plan.n_scans, 6)) * 2e-3, dtype=torch.float64, device=dev)
+    P = plan.poses12(corrected_poses(info['poses'], deltas))
+    res = []
+    for three in (0, 1):
+        nv.check(nv.lib().dc_set_option(7, three), 'dc_set_option')
+        try:
+            out = torch.zeros(2 + 2 * n_terms + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+            with KernelTimer(every=1) as kt:
+                plan.eval_native(w, e, P, out, want_pose=True)
+                torch.cuda.synchronize()
+                names = kt.kernels()
+            assert ('consistency_step_pose_kernel<%d, %d>' % (k, n_terms) in names['consistency_fwd']) == (three == 0), names
+            res.append(npy(out).copy())
+        finally:
+            nv.check(nv.lib().dc_set_option(7, 0), 'dc_set_option')
+    a, b = res
+    assert a[1] == b[1] and a[1] > 1000
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-8)           # (a few points land on the next q32 grid value: see test_fused_loss_2m_properties)
+    np.testing.assert_allclose(a[2:2 + n_terms], b[2:2 + n_terms], rtol=1e-6, atol=1e-7 * np.abs(b[2:2 + n_terms]).max())
+    assert not a[2 + n_terms:2 + 2 * n_terms].any()
+    ga, gb = a[2 + 2 * n_terms:].reshape(-1, 3, 4), b[2 + 2 * n_terms:].reshape(-1, 3, 4)
+    assert np.abs(gb).max() > 0
+    for s_ in range(plan.n_scans):
+        np.testing.assert_allclose(ga[s_], gb[s_], rtol=1e-6, atol=1e-6 * np.abs(gb[s_]).max(), err_msg='scan %d' % s_)
+    # bit-reproducible: the integer sums do not depend on the order the wavefronts' atomics land in
+    out2 = torch.zeros_like(out)
+    plan.eval_native(w, e, P, out2, want_pose=True)
+    plan.eval_native(w, e, P, out, want_pose=True)
+    assert torch.equal(out, out2)
 
 
 def test_chained_wait_that_expires_is_reported_not_just_nan(room):
