@@ -220,6 +220,12 @@ def load_profile_table():
         return json.load(f)
 
 
+def profile_key(kernel, n):
+    """Key of profiles/traffic.json: the instantiation as rocprofv3 prints it (the library reports a named template constant by
+    its name: kStepVar = 7, csrc/dc_consistency.hip) / problem size."""
+    return '%s/N%d' % (kernel.replace('kStepVar', '7'), n)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -478,7 +484,7 @@ def main():
             ms64 = (time.perf_counter() - t0) / 200 * 1e3
             k64 = kt64.kernels().get('consistency_fwd')
             kms64 = kt64.read().get('consistency_fwd', (None, 0))[0]
-        prof64 = load_profile_table().get('%s/N%d' % (k64, plan64.n))
+        prof64 = load_profile_table().get(profile_key(k64, plan64.n))
         extras['fp64_cloud_step'] = {'ms_per_step': ms64, 'kernel': k64, 'kernel_ms': kms64, 'points_per_s': plan64.n / (ms64 * 1e-3),
                                      'hbm_bytes': prof64['hbm_bytes'] if prof64 else None,
                                      'hbm_frac': (prof64['hbm_bytes'] / (kms64 * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (prof64 and kms64) else None,
@@ -630,7 +636,7 @@ def main():
             for name in ('points_fwd', 'consistency_fwd', 'consistency_bwd'):
                 if name not in ms:
                     continue
-                prof = table.get('%s/N%d' % (kernel_names.get(name, ''), n_local))
+                prof = table.get(profile_key(kernel_names.get(name, ''), n_local))
                 t_s = ms[name] * 1e-3
                 traffic = prof['hbm_bytes'] if prof else None
                 insts = prof['valu_insts_per_point'] if prof else None

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--cases', default='0.2:0.4,0.2:0.25,0.1:0.25')
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--points', type=int, default=200_000)
+    ap.add_argument('--degree-sort', type=int, default=0)
     args = ap.parse_args()
     from depth_correction_amd import ops
     from depth_correction_amd.dataset import RoomBoxDataset
@@ -37,12 +38,17 @@ def main():
         kept = [filter_grid(s, grid, keep='random', rng=rng) for s in scans]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        plan, info = build_sequence(kept, poses, k=None, r=r, dtype=torch.float32, device=dev)
+        plan, info = build_sequence(kept, poses, k=None, r=r, dtype=torch.float32, device=dev, degree_sort=bool(args.degree_sort))
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - t0) * 1e3
         nbr = info['neighbors']
         deg = (nbr >= 0).sum(1)
         x0 = info['points0']
+        # lanes of a wavefront run to its longest row: useful share of the slots the wavefronts walk
+        dl = deg[plan.order] if plan.order is not None else deg
+        dpad = torch.zeros(((dl.numel() + 63) // 64) * 64, dtype=dl.dtype, device=dl.device)
+        dpad[:dl.numel()] = dl
+        wave_eff = float(dl.sum()) / float((dpad.reshape(-1, 64).max(1).values * 64).sum())
         for _ in range(2):
             ops.radius_neighbors(x0, r)
         torch.cuda.synchronize()
@@ -66,7 +72,7 @@ def main():
         out[case] = {'points': plan.n, 'kmax': int(nbr.shape[1]), 'mean_degree': float(deg.double().mean()),
                      'pairs': int(deg.sum()), 'step_us': step_us, 'chained': bool(tr.chained),
                      'kernel_us': {k: round(v[0] * 1e3, 1) for k, v in ks.items()}, 'kernel': names.get('consistency_fwd'),
-                     'ps_per_pair': step_us * 1e6 / float(deg.sum()), 'radius_search_ms': search_ms, 'setup_ms': setup_ms,
+                     'wavefront_slot_efficiency': wave_eff, 'ps_per_pair': step_us * 1e6 / float(deg.sum()), 'radius_search_ms': search_ms, 'setup_ms': setup_ms,
                      'fused_table': plan.fwd_table is not None, 'max_rows_per_block': None if plan.fwd_table is None else plan.fwd_table.max_rows, 'loss': float(sums[0] / sums[1])}
         del plan, info, tr
         torch.cuda.empty_cache()
