@@ -42,7 +42,7 @@ class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
-                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True):
+                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True, degree_group=False):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -123,22 +123,30 @@ class SequencePlan:
                 sb = torch.arange(self.n, device=dev) // self.kMaskGroup
                 order = order[torch.argsort(sb * 2 + (~mask[order]).long(), stable=True)]
                 mark('plan_mask_first')
-            if scan_group and not degree_sort and self.n_scans <= 64:
+            # ball neighbourhoods, no pose gradients expected: (mask, row length) instead of (mask, scan) -- the lanes of a wavefront of
+            # the ragged one-pass kernel run to its longest row, so rows of similar length share wavefronts (64 bins of the
+            # longest row; 112 -> 106 us at r = 0.4 m).  No scan ranges then: pose gradients take the un-grouped backward
+            by_degree = bool(degree_group) and scan_group and not degree_sort
+            if scan_group and not degree_sort and (self.n_scans <= 64 or by_degree):
                 # inside every block of 256 Morton-consecutive points: the points inside the loss mask first, then those outside;
                 # each group ordered by scan (stable: Morton order inside a (mask, scan) segment).  Which 256 points share a block
                 # does not change -- the LDS-staged gathers do not care about the lane order -- but (a) a block's points of one scan
                 # become contiguous lane ranges known from now on, which is what the pose-gradient sums of the backward need, and
                 # (b) its masked-out points fill whole wavefronts at its end, which the one-pass kernels skip (they add nothing to
                 # the loss, the count or dL/dw).  dcSequenceDesc.scan_seg: [blocks, 2 S + 1]
-                nb, S = (self.n + 255) // 256, self.n_scans
+                nb, S = (self.n + 255) // 256, (64 if by_degree else self.n_scans)
+                group_key = scan_id
+                if by_degree:
+                    deg = (nbr >= 0).sum(1)
+                    group_key = (deg * 63 // deg.max().clamp(min=1)).to(torch.int32).contiguous()
                 order32 = order.to(torch.int32).contiguous()
                 grouped = torch.empty_like(order32)
                 seg16 = torch.empty((nb, 2 * S + 1), dtype=torch.uint16, device=dev)
                 m8 = None if mask is None else mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-                check(lib().dc_block_group(ptr(order32), ptr(scan_id), ptr(m8), self.n, S, ptr(grouped), ptr(seg16), stream_ptr()),
+                check(lib().dc_block_group(ptr(order32), ptr(group_key), ptr(m8), self.n, S, ptr(grouped), ptr(seg16), stream_ptr()),
                       'dc_block_group')
                 order = grouped.long()
-                self.scan_seg = seg16
+                self.scan_seg = None if by_degree else seg16
                 seg = seg16.view(torch.int16).long() & 0xFFFF
                 # share of the wavefronts (64 lanes) whose centres are all outside the mask: what the one-pass kernels skip
                 inside = seg[:, S]                                                                 # masked-in points per block
