@@ -1435,6 +1435,84 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
   return DC_OK;
 }
 
+
+// ---- several scans in one build (the set-up's local feature clouds, preproc.py:35-64 per scan) ---------------------------------
+// The scans are set side by side on a lattice -- scan s shifted by an integer offset per axis, two box widths apart -- so that one
+// k-NN build serves all of them.  The result equals the per-scan builds bit for bit when every shifted coordinate is exact in fp64
+// (every difference, distance and tie is then what it was) and no neighbourhood crosses scans; both are checked, not assumed.
+constexpr int kLatticeScans = 64;
+
+// One block: the box of all scans -> the pitch per axis (an integer: 2 x extent + 1, rounded up) -> the lattice (nx, ny, nz) whose
+// longest side is shortest -> the offset of every scan.  info |= 1 when the box is not finite.
+__global__ void lattice_setup_kernel(const double* __restrict__ part, int n_part, int n_scans, double* __restrict__ offsets,
+                                     int32_t* __restrict__ info) {
+  __shared__ double tot[kBoxVals];
+  combine_box_partials(part, n_part, tot);
+  if (threadIdx.x != 0) return;
+  double pitch[3];
+  bool ok = true;
+  for (int a = 0; a < 3; ++a) {
+    pitch[a] = ceil(2.0 * (tot[3 + a] - tot[a]) + 1.0);
+    ok = ok && isfinite(pitch[a]) && pitch[a] >= 1.0 && pitch[a] < 1e9;
+  }
+  if (!ok) { atomicOr(info, 1); pitch[0] = pitch[1] = pitch[2] = 1.0; }
+  int best[3] = {n_scans, 1, 1};
+  double best_side = INFINITY;
+  for (int nx = 1; nx <= n_scans; ++nx) {
+    for (int ny = 1; nx * (ny - 1) < n_scans; ++ny) {
+      const int nz = (n_scans + nx * ny - 1) / (nx * ny);
+      const double side = fmax(fmax(nx * pitch[0], ny * pitch[1]), nz * pitch[2]);
+      if (side < best_side) { best_side = side; best[0] = nx; best[1] = ny; best[2] = nz; }
+    }
+  }
+  for (int s = 0; s < n_scans; ++s) {
+    offsets[3 * s + 0] = (double)(s % best[0]) * pitch[0];
+    offsets[3 * s + 1] = (double)((s / best[0]) % best[1]) * pitch[1];
+    offsets[3 * s + 2] = (double)(s / (best[0] * best[1])) * pitch[2];
+  }
+}
+
+__device__ __forceinline__ int scan_of_row(const int64_t* __restrict__ scan_ptr, int n_scans, int64_t i) {
+  int lo = 0, hi = n_scans;                       // scan_ptr[lo] <= i < scan_ptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (scan_ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lattice_shift_kernel(const T* __restrict__ xyz, int64_t n, const int64_t* __restrict__ scan_ptr,
+                                                               int n_scans, const double* __restrict__ offsets,
+                                                               double* __restrict__ shifted, int32_t* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int s = scan_of_row(scan_ptr, n_scans, i);
+  bool exact = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double x = (double)xyz[i * 3 + a], o = offsets[3 * s + a];
+    const double y = x + o;
+    exact = exact && (y - o == x);                // also false for NaN
+    shifted[i * 3 + a] = y;
+  }
+  if (!exact) atomicOr(info, 1);
+}
+
+// Row i of the table built over the shifted scans -> indices inside its own scan; info |= 2 when a neighbour lies in another scan.
+__global__ __launch_bounds__(kBlock) void lattice_localize_kernel(int32_t* __restrict__ nbr, int64_t n, int k, const int64_t* __restrict__ scan_ptr,
+                                                                  int n_scans, int32_t* __restrict__ info) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n * k) return;
+  const int64_t i = e / k;
+  const int s = scan_of_row(scan_ptr, n_scans, i);
+  const int32_t v = nbr[e];
+  if (v < 0) return;
+  const int64_t b = scan_ptr[s], en = scan_ptr[s + 1];
+  if (v < b || v >= en) { atomicOr(info, 2); return; }
+  nbr[e] = (int32_t)(v - b);
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -1677,6 +1755,35 @@ int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32
   DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, ids, order_out, (size_t)n, 0, 63, stream));
   DC_HIP(hipGetLastError());
   return DC_OK;
+}
+
+// ---- several scans in one k-NN build ---------------------------------------------------------------------------------------------
+size_t dc_scan_lattice_workspace_bytes(int n_scans) { return (size_t)(kBoxBlocks * kBoxVals + 3 * (n_scans > 0 ? n_scans : 1)) * sizeof(double); }
+
+int dc_scan_lattice_shift(const void* points, int dtype, int64_t n, const int64_t* scan_ptr, int n_scans, double* shifted, int32_t* info,
+                          void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!points || n < 1 || !scan_ptr || n_scans < 1 || n_scans > kLatticeScans || !shifted || !info || !ws) return DC_ERR_ARG;
+  if (ws_bytes < dc_scan_lattice_workspace_bytes(n_scans)) return DC_ERR_WORKSPACE;
+  double* part = (double*)ws;
+  double* offsets = part + kBoxBlocks * kBoxVals;
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  if (dtype == DC_F32) hipLaunchKernelGGL((bbox_partial_kernel<float>), dim3(kBoxBlocks), block, 0, stream, (const float*)points, 3, n, part);
+  else if (dtype == DC_F64) hipLaunchKernelGGL((bbox_partial_kernel<double>), dim3(kBoxBlocks), block, 0, stream, (const double*)points, 3, n, part);
+  else return DC_ERR_DTYPE;
+  hipLaunchKernelGGL(lattice_setup_kernel, dim3(1), block, 0, stream, part, kBoxBlocks, n_scans, offsets, info);
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((lattice_shift_kernel<float>), grid, block, 0, stream, (const float*)points, n, scan_ptr, n_scans, offsets, shifted, info);
+  else
+    hipLaunchKernelGGL((lattice_shift_kernel<double>), grid, block, 0, stream, (const double*)points, n, scan_ptr, n_scans, offsets, shifted, info);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int dc_scan_lattice_localize(int32_t* nbr, int64_t n, int k, const int64_t* scan_ptr, int n_scans, int32_t* info, hipStream_t stream) {
+  if (!nbr || n < 1 || k < 1 || !scan_ptr || n_scans < 1 || !info) return DC_ERR_ARG;
+  hipLaunchKernelGGL(lattice_localize_kernel, dim3((unsigned)((n * k + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, nbr, n, k, scan_ptr, n_scans, info);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
 }
 
 }  // extern "C"

@@ -9,9 +9,11 @@ import numpy as np
 import torch
 
 from . import ops
+from ._native import check, dtype_code, lib, ptr, stream_ptr
+from .ops import _ws
 from .plan import SequencePlan
 
-__all__ = ['local_features', 'global_neighborhoods', 'global_mask', 'build_sequence', 'on_streams', 'DEFAULT_RATIO_BOUNDS']
+__all__ = ['local_features', 'local_features_batch', 'global_neighborhoods', 'global_mask', 'build_sequence', 'on_streams', 'DEFAULT_RATIO_BOUNDS']
 
 # config.py:218 default eigenvalue_ratio_bounds
 DEFAULT_RATIO_BOUNDS = [[0, 1, 0.0, 0.25], [1, 2, 0.25, 1.0]]
@@ -48,6 +50,54 @@ def local_features(xyz, k=None, r=None, vps=None, eigenvalue_bounds=None,
     _eig_masks(mask, f['eigvals'], eigenvalue_bounds, eigenvalue_ratio_bounds)
     return dict(vps=vps_t, dirs=dirs, depth=depth, inc_angles=f['inc_angles'], mask=mask, normals=f['normals'],
                 eigvals=f['eigvals'], neighbors=nbr, points=x)
+
+
+def local_features_batch(scans, k, r=None, eigenvalue_bounds=None, eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, dtype=None,
+                         device='cuda:0'):
+    """local_features of several scans (viewpoints at the sensor origin, k nearest neighbours) in ONE pass: one k-NN build, one
+    feature launch, one set of masks over the concatenated scans instead of one each (ten 200 k-point scans: 4.2 -> ~2 ms).
+
+    The scans are set side by side on a lattice (dc_scan_lattice_shift: scan s shifted by an integer offset per axis, two box
+    widths apart) so that no neighbourhood crosses scans.  The result is the per-scan result bit for bit when (a) every shifted
+    coordinate is exact in fp64 (then every difference, distance and tie is what it was: the k-NN orders equal distances by index)
+    and (b) every neighbour of every point lies in its own scan; both are checked on the device, and None is returned when either
+    fails (the caller then runs the scans one by one)."""
+    pts = torch.cat([torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x, device=device) for x in scans])
+    if dtype is not None:
+        pts = pts.to(dtype)
+    pts = pts.contiguous()
+    dev = pts.device
+    sizes = [len(x) for x in scans]
+    if min(sizes) <= k:
+        return None
+    vps_t = torch.zeros_like(pts)
+    depth = pts.norm(dim=-1, keepdim=True)
+    dirs = torch.where(depth > 0, pts / depth, pts).contiguous()
+    x = ops.points_fwd(ops.PointSet(vps_t, dirs, depth))                    # update_points
+    if len(scans) > 64:
+        return None
+    scan_ptr = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64), device=dev)
+    info = torch.zeros((1,), dtype=torch.int32, device=dev)
+    xs = torch.empty((len(pts), 3), dtype=torch.float64, device=dev)
+    nbytes = lib().dc_scan_lattice_workspace_bytes(len(scans))
+    check(lib().dc_scan_lattice_shift(ptr(x), dtype_code(x), len(pts), ptr(scan_ptr), len(scans), ptr(xs), ptr(info), ptr(_ws(nbytes, dev)),
+                                      nbytes, stream_ptr()), 'dc_scan_lattice_shift')
+    _, nbr = ops.knn(xs, k, r=r, want_dist=False)                            # update_neighbors, all scans at once
+    nbr_global = nbr.clone()
+    check(lib().dc_scan_lattice_localize(ptr(nbr), len(pts), k, ptr(scan_ptr), len(scans), ptr(info), stream_ptr()), 'dc_scan_lattice_localize')
+    if int(info.item()) != 0:
+        return None
+    f = ops.features_fwd(x, nbr_global, dirs=dirs, want=('eigvals', 'normals', 'inc_angles'))
+    mask = torch.ones((len(pts),), dtype=torch.bool, device=dev)
+    _eig_masks(mask, f['eigvals'], eigenvalue_bounds, eigenvalue_ratio_bounds)
+    nbr_local = nbr
+    out, a = [], 0
+    for n_ in sizes:
+        sl = slice(a, a + n_)
+        out.append(dict(vps=vps_t[sl], dirs=dirs[sl], depth=depth[sl], inc_angles=f['inc_angles'][sl], mask=mask[sl],
+                        normals=f['normals'][sl], eigvals=f['eigvals'][sl], neighbors=nbr_local[sl], points=x[sl]))
+        a += n_
+    return out
 
 
 def global_cloud_arrays(clouds, poses):
@@ -150,7 +200,7 @@ def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='
                    eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, vp_dispersion_bounds=None, model_kind='ScaledPolynomial',
                    loss='min_eigval_loss', normalization=True, sqrt=False, spatial_sort=True, point_format='auto',
                    active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs', stage_times=False, basis=True,
-                   local_streams=4, scan_group=True, mask_first=False, degree_group=None):
+                   local_streams=4, scan_group=True, mask_first=False, degree_group=None, batch_local=True):
     """Everything train.py does before its loop for one sequence; returns (plan, info).  ``stage_times``: info['setup_ms']
     = wall-clock milliseconds per stage (device synchronised between stages)."""
     st = _Stages(stage_times, device)
@@ -158,8 +208,12 @@ def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='
     st.mark('upload')
     # the scans are independent and one 200 k-point scan does not fill the chip (782 blocks for > 1024 resident): their
     # pipelines go to a few streams side by side
-    clouds = on_streams([lambda xyz=xyz: local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype,
-                                                          device=device) for xyz in uploaded], device, n_streams=local_streams)
+    clouds = None
+    if k and batch_local and len(uploaded) > 1:
+        clouds = local_features_batch(uploaded, k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype, device=device)
+    if clouds is None:
+        clouds = on_streams([lambda xyz=xyz: local_features(xyz, k=k, r=r, eigenvalue_ratio_bounds=eigenvalue_ratio_bounds, dtype=dtype,
+                                                              device=device) for xyz in uploaded], device, n_streams=local_streams)
     st.mark('local_feature_clouds')
     poses_t = torch.as_tensor(np.asarray(poses), dtype=torch.float64, device=device)
     x0, vps0, dirs0, _ = global_cloud_arrays(clouds, poses_t)

@@ -90,6 +90,17 @@ int dc_radius_fill_query(int64_t n, int64_t n_query, double r, int kmax, int32_t
  * nbr int32 [n,k] with values in [0, n_dst) (n_dst <= 0: n_dst = n); csr_ptr int32 [n_dst+1], csr_src int32 [n*k]
  * (first csr_ptr[n_dst] entries valid, ascending row index). */
 size_t dc_knn_transpose_workspace_bytes(int64_t n, int k);
+/* Several scans in ONE k-NN build (the set-up's local feature clouds: preproc.py:35-64 once per scan, cKDTree per scan).
+ * dc_scan_lattice_shift sets the scans (rows scan_ptr[s] .. scan_ptr[s + 1] of `points` [n,3], scan_ptr a DEVICE int64 [n_scans + 1],
+ * n_scans <= 64) side by side on a lattice: scan s is shifted by an integer offset per axis, two box widths from its neighbours;
+ * shifted fp64 [n,3] is what dc_knn_build then takes.  dc_scan_lattice_localize turns the rows of that table into indices inside
+ * each row's own scan (in place).  info (device int32, zeroed by the caller): bit 0 <- some shifted coordinate is not exact in fp64
+ * (or not finite), bit 1 <- some neighbour lies in another scan.  With info == 0 the table equals the per-scan tables bit for bit
+ * (equal distances are ordered by index); otherwise the caller builds the scans one by one. */
+size_t dc_scan_lattice_workspace_bytes(int n_scans);
+int dc_scan_lattice_shift(const void* points, int dtype, int64_t n, const int64_t* scan_ptr, int n_scans, double* shifted, int32_t* info,
+                          void* ws, size_t ws_bytes, dcStream_t stream);
+int dc_scan_lattice_localize(int32_t* nbr, int64_t n, int k, const int64_t* scan_ptr, int n_scans, int32_t* info, dcStream_t stream);
 int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int64_t n_dst, int32_t* csr_ptr, int32_t* csr_src, void* ws,
                      size_t ws_bytes, dcStream_t stream);
 

@@ -56,6 +56,32 @@ def test_knn_2m_properties(room):
         assert all(jj in nb[i] for i in s[p[jj]:p[jj + 1]])
 
 
+def test_local_features_batch_equals_per_scan(room):
+    """The set-up's local feature clouds in one pass (pipeline.local_features_batch: the scans side by side on a lattice, one
+    k-NN build, one feature launch) against the scans one by one: every array bit for bit -- and None (the caller's cue to
+    run them one by one) when the batch cannot be proven identical: a neighbourhood that would reach into another scan, a
+    coordinate the shift would round."""
+    from depth_correction_amd.pipeline import local_features, local_features_batch
+    scans = [s[:40_000 + 1_111 * i] for i, s in enumerate(room[0][:5])]
+    got = local_features_batch(scans, 10, dtype=torch.float32)
+    assert got is not None and len(got) == len(scans)
+    for xyz, g in zip(scans, got):
+        ref = local_features(xyz, k=10, dtype=torch.float32)
+        assert set(ref) == set(g)
+        for name in ref:
+            assert torch.equal(ref[name], g[name]), name
+    # two clusters a kilometre apart in a flat scan: the k nearest of a point reach across, and another scan's copy (stacked along
+    # the thin axis) would be nearer
+    rng = np.random.default_rng(0)
+    flat = np.concatenate([rng.normal(size=(6, 3)) * [1, 1, 0.01], rng.normal(size=(6, 3)) * [1, 1, 0.01] + [1000.0, 0, 0]]).astype(np.float32)
+    assert local_features_batch([flat, flat + np.float32(0.5)], 8, dtype=torch.float32) is None
+    # coordinates that vanish next to the shift (1e-12 + 9.0 is not exact), whichever axis the scans are stacked along: not
+    # provably identical
+    tiny = scans[0].copy()
+    tiny[7] = [1e-12, 2e-12, 3e-12]
+    assert local_features_batch([scans[1], tiny], 10, dtype=torch.float32) is None
+
+
 def test_fused_loss_2m_properties(room):
     """Config 2 shape.  Layout independence (Morton-sorted vs scan-major, q32 vs fp32 points), rigid-motion
     invariance, and the hand-derived dL/dw against central differences of the loss, all on the 2 M-point cloud."""
