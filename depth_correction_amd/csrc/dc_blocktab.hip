@@ -214,6 +214,23 @@ __global__ __launch_bounds__(kBlock) void bt_block_group_kernel(const int32_t* _
 static inline int64_t blocks_of(int64_t n) { return (n + kBlock - 1) / kBlock; }
 static inline unsigned grid_of(int64_t n) { return (unsigned)(n > 0 ? (n + kBlock - 1) / kBlock : 1); }
 
+// The neighbour table in a new point order: out[i][q] = rank[nbr[order[i]][q]] (-1 stays -1); rank = the inverse of order.  One pass
+// instead of a chain of index / clamp / where passes over [n, k] 64-bit intermediates (the set-up's permute stage: 1.2 -> 0.4 ms).
+__global__ __launch_bounds__(kBlock) void bt_inverse_order_kernel(const int64_t* __restrict__ order, int64_t n, int32_t* __restrict__ rank) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) rank[order[i]] = (int32_t)i;
+}
+__global__ __launch_bounds__(kBlock) void bt_table_permute_kernel(const int32_t* __restrict__ nbr, const int64_t* __restrict__ order,
+                                                                  const int32_t* __restrict__ rank, int64_t n, int k,
+                                                                  int32_t* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n * k) return;
+  const int64_t i = e / k;
+  const int q = (int)(e - i * k);
+  const int32_t v = nbr[order[i] * k + q];
+  out[e] = v >= 0 ? rank[v] : v;
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -312,6 +329,15 @@ int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_
   if (n == 0) return DC_OK;
   hipLaunchKernelGGL(bt_block_group_kernel, dim3((unsigned)blocks_of(n)), dim3(kBlock), 0, stream, order_in, scan_id, mask, n, n_scans,
                      order_out, seg_out);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+int dc_table_permute(const int32_t* nbr, int64_t n, int k, const int64_t* order, int32_t* rank_out, int32_t* nbr_out, hipStream_t stream) {
+  if (n < 0 || k < 1 || !nbr || !order || !rank_out || !nbr_out || nbr == nbr_out) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  hipLaunchKernelGGL(bt_inverse_order_kernel, dim3((unsigned)blocks_of(n)), dim3(kBlock), 0, stream, order, n, rank_out);
+  hipLaunchKernelGGL(bt_table_permute_kernel, dim3((unsigned)blocks_of(n * k)), dim3(kBlock), 0, stream, nbr, order, rank_out, n, k, nbr_out);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

@@ -155,10 +155,17 @@ class SequencePlan:
                 if mask is not None:
                     self.blk_skip = (inside == 0).to(torch.uint8).contiguous()
                 mark('plan_scan_groups')
-            rank = torch.empty_like(order)
-            rank[order] = torch.arange(self.n, device=dev)
-            nbr_l = nbr.long()[order]
-            nbr = torch.where(nbr_l >= 0, rank[nbr_l.clamp(min=0)], nbr_l).to(torch.int32).contiguous()
+            if nbr.numel():
+                rank32 = torch.empty((self.n,), dtype=torch.int32, device=dev)
+                nbr_in = nbr.to(torch.int32).contiguous()
+                nbr = torch.empty_like(nbr_in)
+                check(lib().dc_table_permute(ptr(nbr_in), self.n, nbr_in.shape[1], ptr(order.contiguous()), ptr(rank32), ptr(nbr),
+                                             stream_ptr()), 'dc_table_permute')
+                rank = rank32.long()
+            else:
+                rank = torch.empty_like(order)
+                rank[order] = torch.arange(self.n, device=dev)
+                nbr = nbr[order].to(torch.int32).contiguous()
             vps, dirs, depth = vps[order].contiguous(), dirs[order].contiguous(), depth[order].contiguous()
             inc = None if inc is None else inc[order].contiguous()
             lmask = None if lmask is None else lmask[order].contiguous()

@@ -237,6 +237,9 @@ int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int6
  * [ceil(n / 256), 2 n_scans + 1].  n_scans <= 64.  (No reference counterpart: the reference keeps scans one after the other.) */
 int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_t* mask, int64_t n, int n_scans, int32_t* order_out,
                    uint16_t* seg_out, dcStream_t stream);
+/* The neighbour table in a new point order (`order` int64 [n], a permutation: new row i = old row order[i]): rank_out[order[i]] = i,
+ * nbr_out[i][q] = rank_out[nbr[order[i]][q]], -1 stays -1.  (The layout step of a sequence: Morton order of the global cloud.) */
+int dc_table_permute(const int32_t* nbr, int64_t n, int k, const int64_t* order, int32_t* rank_out, int32_t* nbr_out, dcStream_t stream);
 int64_t dc_block_table_run_capacity(int64_t n_rows, int64_t n_refs);
 int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int64_t n_refs, int32_t* run_ptr,
                               int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes,
