@@ -512,6 +512,30 @@ def main():
                 finally:
                     nv.check(nv.lib().dc_set_option(opt, 0), 'dc_set_option')
             extras['same_step_other_forms'] = abl
+            # pose mode (train() with pose corrections: train.py:300-312, eval.py:68-82): loss, dL/dw and dL/d[R|t] of every scan per
+            # evaluation -- one launch of consistency_step_pose_kernel + the reduction; and the same through the general path
+            wv, ev_ = torch.tensor(w0, dtype=torch.float64, device=dev), torch.tensor(e0, dtype=torch.float64, device=dev)
+            pose_out = torch.zeros((2 + 2 * len(w0) + 12 * plan.n_scans,), dtype=torch.float64, device=dev)
+            P12 = plan.poses12(poses_t)
+            pose = {}
+            for name, three in (('one_launch', 0), ('three_kernel_path', 1)):
+                nv.check(nv.lib().dc_set_option(7, three), 'dc_set_option')
+                try:
+                    for _ in range(100):
+                        plan.eval_native(wv, ev_, P12, pose_out, want_grad=True, want_pose=True)
+                    torch.cuda.synchronize()
+                    with KernelTimer(every=8) as ktp:
+                        t0 = time.perf_counter()
+                        for _ in range(200):
+                            plan.eval_native(wv, ev_, P12, pose_out, want_grad=True, want_pose=True)
+                        torch.cuda.synchronize()
+                        pose[name + '_ms'] = (time.perf_counter() - t0) / 200 * 1e3
+                        if not three:
+                            pose['kernel'] = ktp.kernels().get('consistency_fwd')
+                            pose['kernel_ms'] = ktp.read().get('consistency_fwd', (None, 0))[0]
+                finally:
+                    nv.check(nv.lib().dc_set_option(7, 0), 'dc_set_option')
+            extras['pose_mode_evaluation'] = pose
 
         # the reference-API loop itself: train() (train.py:220-322) with its default callbacks on this very workload, wall clock
         # per iteration from two runs of different length (set-up cancels); see tools/train_bench.py for the C4 shape
