@@ -546,6 +546,124 @@ __global__ __launch_bounds__(kBlock) void pose_correct_kernel(const double* __re
   }
 }
 
+
+// ---- one training iteration with pose corrections, finished in one launch (train.py:300-322 after the loss: backward through
+// eval.create_corrected_poses, the first pose kept fixed, optimizer.step() on the model weights and on the pose corrections) --------
+// `sums` = {sum loss, count, dL/dw [P], dL/de [P], dL/d[R|t] of every pose [12 S]} of dc_sequence_eval with the corrected poses
+// `T_used`.  The mean loss sum / count is what train() back-propagates: every gradient is scaled by 1 / count.  One block; thread p
+// takes pose p: the adjoint of T = T0 X(delta) (pose_chain_bwd), Adam on delta_p -- torch.optim.Adam's single-tensor update,
+// step t = *step + 1 -- and the corrected pose of the NEXT iteration from the updated correction; threads 0 .. P - 1 take the
+// weights.  `record` (optional) <- {sums, the weights, corrections and corrected poses [12 S] this iteration USED}: what a
+// checkpoint of the iteration holds.
+struct PoseTrainArgs {
+  const double* sums;
+  int n_terms, n_scans, n_deltas, zero_first;
+  double *w, *w_m, *w_v;                 // w == nullptr: the model is not optimised (validation sequences)
+  const double* T0;                      // [S, 16]
+  double *delta, *d_m, *d_v;             // [n_deltas, 6]
+  int64_t* step;
+  double lr_w, lr_d, b1, b2, eps;
+  const double* T_used;                  // [S, 16]
+  double* record;                        // or nullptr: a ring of ring_rows records; this iteration's is row *step mod ring_rows
+  int ring_rows;
+  double* T_next;                        // [S, 16]
+  double* P12_next;                      // [S, 12]
+};
+
+__device__ __forceinline__ double adam_one(double p0, double& m, double& v, double g, double lr, double b1, double b2, double eps,
+                                           double bias1, double bias2_sqrt) {
+  m = m + (g - m) * (1.0 - b1);                         // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * b2 + (1.0 - b2) * g * g;                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const double denom = sqrt(v) / bias2_sqrt + eps;
+  return p0 + (-(lr / bias1)) * (m / denom);
+}
+
+__global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs a) {
+  __shared__ double lds[(kBlock / kWave) * 6];
+  const int S = a.n_scans, P = a.n_terms, tid = threadIdx.x;
+  const int n_sums = 2 + 2 * P + 12 * S;
+  if (a.record) {
+    double* r = a.record + (*a.step % a.ring_rows) * (int64_t)(n_sums + P + 6 * a.n_deltas + 12 * S);
+    for (int q = tid; q < n_sums; q += kBlock) r[q] = a.sums[q];
+    r += n_sums;
+    for (int q = tid; q < P; q += kBlock) r[q] = a.w ? a.w[q] : 0.0;
+    r += P;
+    for (int q = tid; q < 6 * a.n_deltas; q += kBlock) r[q] = a.delta[q];
+    r += 6 * a.n_deltas;
+    for (int q = tid; q < 12 * S; q += kBlock) r[q] = a.T_used[(q / 12) * 16 + q % 12];
+  }
+  const double t = (double)(*a.step + 1);
+  const double bias1 = 1.0 - pow(a.b1, t), bias2_sqrt = sqrt(1.0 - pow(a.b2, t));
+  const double gscale = 1.0 / a.sums[1];
+  const double* gT = a.sums + 2 + 2 * P;
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int p = tid; p < S; p += kBlock) {
+    const double* d6 = a.delta + (a.n_deltas == 1 ? 0 : (int64_t)p * 6);
+    const double* A = a.T0 + (int64_t)p * 16;
+    const double* G = gT + (int64_t)p * 12;                    // rows 0..2 of dL/dT (its last row is zero)
+    double R[9], gR[9], g6[6];
+    PoseChain c;
+    pose_chain_fwd(d6, R, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) gR[i * 3 + b] = (A[i] * G[b] + A[4 + i] * G[4 + b] + A[8 + i] * G[8 + b]) * gscale;
+      g6[i] = (A[i] * G[3] + A[4 + i] * G[7] + A[8 + i] * G[11]) * gscale;
+    }
+    pose_chain_bwd(d6, c, gR, g6 + 3);
+    if (a.zero_first && p == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) g6[q] = 0.0;
+    }
+    if (a.n_deltas == 1) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[q] += g6[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int64_t i = (int64_t)p * 6 + q;
+        double m = a.d_m[i], v = a.d_v[i];
+        a.delta[i] = adam_one(a.delta[i], m, v, g6[q], a.lr_d, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+        a.d_m[i] = m; a.d_v[i] = v;
+      }
+    }
+  }
+  if (a.n_deltas == 1) {                                       // one correction for the whole sequence: its gradient is the sum
+    block_sum<6>(acc, lds);                                      // (the totals are thread 0's)
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        double m = a.d_m[q], v = a.d_v[q];
+        a.delta[q] = adam_one(a.delta[q], m, v, acc[q], a.lr_d, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+        a.d_m[q] = m; a.d_v[q] = v;
+      }
+    }
+  }
+  if (a.w && tid < P) {
+    double m = a.w_m[tid], v = a.w_v[tid];
+    a.w[tid] = adam_one(a.w[tid], m, v, a.sums[2 + tid] * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+    a.w_m[tid] = m; a.w_v[tid] = v;
+  }
+  __syncthreads();                                             // the corrections are updated; the step counter and T_used have been read
+  if (tid == 0) *a.step = (int64_t)t;
+  for (int p = tid; p < S; p += kBlock) {
+    const double* d6 = a.delta + (a.n_deltas == 1 ? 0 : (int64_t)p * 6);
+    const double* A = a.T0 + (int64_t)p * 16;
+    double R[9];
+    PoseChain c;
+    pose_chain_fwd(d6, R, c);
+    double* o = a.T_next + (int64_t)p * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) o[i * 4 + b] = A[i * 4] * R[b] + A[i * 4 + 1] * R[3 + b] + A[i * 4 + 2] * R[6 + b];
+      o[i * 4 + 3] = A[i * 4] * d6[0] + A[i * 4 + 1] * d6[1] + A[i * 4 + 2] * d6[2] + A[i * 4 + 3];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) a.P12_next[(int64_t)p * 12 + q] = o[q];
+  }
+}
+
 }  // namespace dc
 
 extern "C" {
@@ -567,6 +685,21 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
   if (n_poses == 0) return (int)hipMemsetAsync(grad_deltas, 0, (size_t)n_deltas * 6 * sizeof(double), stream);
   hipLaunchKernelGGL(dc::pose_correct_kernel, dim3(1), dim3(dc::kBlock), 0, stream, poses, deltas, n_poses, n_deltas,
                      (double*)nullptr, grad_poses, grad_deltas);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int dc_pose_train_finish(const double* sums, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
+                         double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
+                         double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
+                         double* poses12_next, hipStream_t stream) {
+  if (!sums || n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || n_scans < 1 || (n_deltas != 1 && n_deltas != n_scans) || !poses0 || !deltas ||
+      !d_m || !d_v || !step || !poses_used || !poses_next || !poses12_next || (w && (!w_m || !w_v)) || (record && ring_rows < 1))
+    return DC_ERR_ARG;
+  if (!(lr_w >= 0.0) || !(lr_d >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return DC_ERR_ARG;
+  dc::PoseTrainArgs a{sums, n_terms, n_scans, n_deltas, zero_first, w, w_m, w_v, poses0, deltas, d_m, d_v, step, lr_w, lr_d, beta1, beta2, eps,
+                      poses_used, record, ring_rows, poses_next, poses12_next};
+  hipLaunchKernelGGL(dc::pose_train_finish_kernel, dim3(1), dim3(dc::kBlock), 0, stream, a);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
 }

@@ -763,6 +763,63 @@ class KernelTimer:
         return out
 
 
+class PoseSequenceTrainer:
+    """One sequence of train()'s loop WITH pose corrections (train.py:300-322; scripts/model_poses_learning:71) on the library's own
+    launches: per iteration ``evaluate`` = dc_sequence_eval with the corrected poses (one launch of consistency_step_pose_kernel +
+    the reduction where the plan qualifies) and ``finish`` = dc_pose_train_finish -- the adjoint of the pose chain, the first pose
+    kept fixed, torch.optim.Adam's update on the corrections (and on the model weights when given), the corrected poses of the next
+    iteration and the iteration's record, in ONE launch.  The corrections are kept in fp64 (``delta``; the caller's tensor is
+    written back by ``store``): Adam on float32 corrections differs from this in the rounding of every update."""
+
+    @on_device
+    def __init__(self, plan, poses0, deltas, zero_first, lr, betas=(0.9, 0.999), eps=1e-8, n_terms=2):
+        dev = plan.device
+        S = plan.n_scans
+        self.plan, self.S, self.nt = plan, S, int(n_terms)
+        self.T0 = poses0.detach().to(device=dev, dtype=torch.float64).reshape(S, 16).contiguous()
+        self.delta = deltas.detach().to(device=dev, dtype=torch.float64).contiguous().clone()
+        self.nd = self.delta.shape[0]
+        assert self.delta.shape == (self.nd, 6) and self.nd in (1, S)
+        self.d_m, self.d_v = torch.zeros_like(self.delta), torch.zeros_like(self.delta)
+        self.step = torch.zeros((), dtype=torch.int64, device=dev)
+        self.zero_first, self.lr, self.betas, self.eps = int(bool(zero_first)), float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.T = torch.empty((S, 16), dtype=torch.float64, device=dev)         # the corrected poses of the current iteration
+        self.P12 = torch.empty((S, 12), dtype=torch.float64, device=dev)
+        self.out = torch.zeros((2 + 2 * self.nt + 12 * S,), dtype=torch.float64, device=dev)
+        check(lib().dc_pose_correct_fwd(ptr(self.T0), ptr(self.delta), S, self.nd, ptr(self.T), stream_ptr()), 'dc_pose_correct_fwd')
+        self.P12.copy_(self.T[:, :12])
+
+    @property
+    def record_len(self):
+        return 2 + 2 * self.nt + 12 * self.S + self.nt + 6 * self.nd + 12 * self.S
+
+    def evaluate(self, w, exponent):
+        """Loss sums and gradients of the sum (dL/dw, dL/d[R|t]) for the current corrected poses -> self.out."""
+        self.plan.eval_native(w, exponent, self.P12, self.out, want_grad=True, want_pose=True)
+        return self.out
+
+    @on_device
+    def finish(self, w=None, w_m=None, w_v=None, lr_w=0.0, ring=None):
+        """Backward through the pose chain, the optimiser steps, the next iteration's poses (in place); row (step mod rows) of
+        ``ring`` [rows, record_len] <- {sums, weights, corrections, corrected poses} of THIS iteration.  Every pointer is the same
+        from call to call (the ring slot follows the device step counter): a captured iteration replays correctly."""
+        check(lib().dc_pose_train_finish(ptr(self.out), self.nt, self.S, ptr(w), ptr(w_m), ptr(w_v), ptr(self.T0), ptr(self.delta),
+                                         ptr(self.d_m), ptr(self.d_v), self.nd, self.zero_first, ptr(self.step), float(lr_w), self.lr,
+                                         self.betas[0], self.betas[1], self.eps, ptr(self.T), ptr(ring), 0 if ring is None else ring.shape[0],
+                                         ptr(self.T), ptr(self.P12), stream_ptr()), 'dc_pose_train_finish')
+
+    def split_record(self, row):
+        """(sums, weights, corrections [nd,6], corrected poses [S,4,4]) of a record row (a CPU tensor)."""
+        a = 2 + 2 * self.nt + 12 * self.S
+        sums, w = row[:a], row[a:a + self.nt]
+        d = row[a + self.nt:a + self.nt + 6 * self.nd].reshape(self.nd, 6)
+        P = row[a + self.nt + 6 * self.nd:].reshape(self.S, 3, 4)
+        T = torch.zeros((self.S, 4, 4), dtype=row.dtype)
+        T[:, :3, :] = P
+        T[:, 3, 3] = 1.0
+        return sums, w, d, T
+
+
 class SequenceTrainer:
     """The per-iteration body of train.py:220-312 for ball neighbourhoods and the min-eigenvalue / trace loss,
     without Python in the loop: dc_sequence_eval (fwd + bwd) and dc_adam_step (torch.optim.Adam semantics) on

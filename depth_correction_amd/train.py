@@ -233,6 +233,12 @@ def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
             ran, best = _native_loop(cfg, model, optimizer, native[0], native[1], train_poses, val_poses, batch)
             if ran:
                 return best
+        native = _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, train_poses, train_masks, train_ns,
+                                        train_pose_deltas, val_clouds, val_poses, val_masks, val_ns, val_pose_deltas) \
+            if getattr(cfg, 'loop_native', True) else None
+        if native is not None:
+            return _native_pose_loop(cfg, model, optimizer, val_optimizer, native[0], native[1], train_poses, val_poses,
+                                     train_pose_deltas, val_pose_deltas, batch)
         return _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch,
                              lambda: evaluate(train_clouds, train_poses, train_pose_deltas, train_masks, train_ns),
                              lambda: evaluate(val_clouds, val_poses, val_pose_deltas, val_masks, val_ns))
@@ -319,7 +325,9 @@ class _Bookkeeper(object):
     def __init__(self, cfg, model):
         import copy
         self.cfg, self.min_val, self.best, self._last = cfg, np.inf, None, None
-        self.shadow = copy.deepcopy(model).cpu()                 # formats the progress line from a recorded state, on the host
+        # formats the progress line from a recorded state, on the host.  .to() and not .cpu(): the models move their plain tensor
+        # attributes (fixed exponents) in to() only, and a progress line that reads a device tensor waits for every queued iteration
+        self.shadow = copy.deepcopy(model).to('cpu')
         self.shadow_sd = self.shadow.state_dict()
 
     def record(self, it, tl, vl, sd, deltas, poses):
@@ -332,10 +340,26 @@ class _Bookkeeper(object):
             self.shadow_sd[k].copy_(v)
         print('It. %03i: train loss: %.9f, val.: %.9f. Model %s %s.' % (it, tl, vl, self.shadow, 'saved' if saved else 'not saved'))
 
+    def record_fast(self, it, tl, vl, key, value, payload):
+        """record() for the loops that log into a device ring: only the tensor ``key`` of the model's state changes from
+        iteration to iteration (``value``: a NumPy row), and what a checkpoint needs -- (state dict, corrections, poses) -- is built
+        by ``payload()`` only for the iteration whose files are written at the end of the batch."""
+        saved = tl < np.inf and vl < self.min_val
+        if saved:
+            self.min_val = vl
+            self._last = (it, vl, payload)
+        t = self.shadow_sd[key]
+        t.copy_(torch.from_numpy(np.ascontiguousarray(value)).reshape(t.shape))
+        print('It. %03i: train loss: %.9f, val.: %.9f. Model %s %s.' % (it, tl, vl, self.shadow, 'saved' if saved else 'not saved'))
+
     def end_batch(self):
         if self._last is None:
             return
-        it, vl, sd, deltas, poses = self._last
+        if len(self._last) == 3:
+            it, vl, payload = self._last
+            sd, deltas, poses = payload()
+        else:
+            it, vl, sd, deltas, poses = self._last
         self._last = None
         cfg = self.cfg
         stem = '%s/%03i_%.6g' % (cfg.log_dir, it, vl)
@@ -466,6 +490,164 @@ def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_p
     return book.best
 
 
+def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, train_poses, train_masks, train_ns, train_pose_deltas,
+                           val_clouds, val_poses, val_masks, val_ns, val_pose_deltas):
+    """(train plan, [validation plans]) when the loop WITH per-pose / per-sequence corrections can run on plan.PoseSequenceTrainer --
+    one training sequence and at most one validation sequence through the fused min-eigenvalue / trace loss without inlier
+    gating, the weights of a polynomial model and the corrections optimised by Adam as train() builds it -- else None."""
+    from .eval import _plan_for, fused_supported
+    from .optim import Adam
+    kw = cfg.loss_kwargs
+    w = getattr(model, 'w', None)
+    if not (cfg.pose_correction in (PoseCorrection.pose, PoseCorrection.sequence) and len(train_clouds) == 1 and len(val_clouds) <= 1
+            and isinstance(optimizer, Adam) and (val_optimizer is None or isinstance(val_optimizer, Adam))
+            and fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
+            and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
+            and not kw.get('only_finite') and not kw.get('skip_nans')
+            and isinstance(w, torch.nn.Parameter) and [id(p) for p in model.parameters()] == [id(w)]
+            and w.is_cuda and w.dtype == torch.float64 and w.is_contiguous() and 1 <= w.numel() <= 3
+            and model.kernel_params()[0] is w and not model.kernel_params()[1].requires_grad
+            and train_pose_deltas[0] is not None and all(d is not None for d in val_pose_deltas)
+            and (bool(val_clouds) == (val_optimizer is not None))):
+        return None
+    groups = optimizer.param_groups
+    want = ([[id(w)]] if cfg.optimize_model else []) + [[id(d) for d in train_pose_deltas]]
+    if [[id(p) for p in g['params']] for g in groups] != want:
+        return None
+    vgroups = val_optimizer.param_groups if val_optimizer is not None else []
+    if any(g['weight_decay'] != 0.0 or g['betas'] != groups[0]['betas'] or g['eps'] != groups[0]['eps'] for g in list(groups) + list(vgroups)):
+        return None
+    if any(m is None for m in list(train_masks) + list(val_masks)):
+        return None
+    plan = _plan_for(train_clouds[0], train_poses[0], train_ns[0], train_masks[0], model, cfg)
+    vplans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(val_clouds, val_poses, val_ns, val_masks)]
+    return plan, vplans
+
+
+def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_poses, val_poses, train_pose_deltas, val_pose_deltas,
+                      batch):
+    """train()'s loop with pose corrections on the library's own launches (plan.PoseSequenceTrainer): per iteration and sequence
+    one evaluation (the pose kernel + its reduction) and ONE finishing launch that back-propagates through the pose chain, keeps
+    the first pose fixed, takes both Adam updates, forms the next iteration's poses and writes the iteration's record into the
+    log's ring -- against ~35 small launches of tensor glue per iteration around the same evaluation otherwise (0.26 -> 0.11 ms
+    at C2).  Bookkeeping as in _batched_loop: one synchronisation per ``batch`` iterations.  The corrections are optimised in
+    fp64 and written back to the caller's tensors (whatever their dtype) at every synchronisation."""
+    from .plan import PoseSequenceTrainer
+    dev = torch.device(cfg.device)
+    n_it, R = cfg.n_opt_iters, batch
+    groups = optimizer.param_groups
+    w_param = model.w
+    w = w_param.detach().reshape(-1)                               # (a view: the updates land in the parameter's storage)
+    e = model.kernel_params()[1].detach().reshape(-1).contiguous()
+    nt = w.numel()
+    g_d = groups[-1]
+    zero_first = cfg.pose_correction == PoseCorrection.pose
+    tr = PoseSequenceTrainer(plan, train_poses[0], train_pose_deltas[0], zero_first, g_d['lr'], g_d['betas'], g_d['eps'], n_terms=nt)
+    vtr = [PoseSequenceTrainer(vp, T, d, zero_first, val_optimizer.param_groups[0]['lr'], g_d['betas'], g_d['eps'], n_terms=nt)
+           for vp, T, d in zip(vplans, val_poses, val_pose_deltas)]
+    lr_w = groups[0]['lr'] if cfg.optimize_model else 0.0
+    w_m, w_v = (torch.zeros_like(w), torch.zeros_like(w)) if cfg.optimize_model else (None, None)
+    ring = torch.zeros((R, tr.record_len), dtype=torch.float64, device=dev)
+    vrings = [torch.zeros((R, v.record_len), dtype=torch.float64, device=dev) for v in vtr]
+    sd_const = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
+    d_dtype, T_dtype = train_pose_deltas[0].dtype, train_poses[0].dtype
+    book = _Bookkeeper(cfg, model)
+
+    def fetch():
+        """The ring on the host (synchronises: every launched iteration has finished)."""
+        return ring.cpu(), [v.cpu() for v in vrings], plan.status_bits()
+
+    def bookkeep(fetched, first, upto):
+        h, hv, bits = fetched
+        if bits & plan.STATUS_OVERFLOW:
+            warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
+                          'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
+                          % (first, upto - 1))
+        H, HV = h.numpy(), [v.numpy() for v in hv]
+        a0 = 2 + 2 * nt + 12 * plan.n_scans
+
+        def payload_of(row):
+            def build():
+                _, w_used, d_used, T_used = tr.split_record(torch.from_numpy(row))
+                sd = dict(sd_const)
+                sd[w_key] = w_used.reshape(w_param.shape).to(w_param.dtype).clone()
+                return sd, [d_used.to(d_dtype).clone()], [T_used.to(T_dtype).clone()]
+            return build
+
+        for it in range(first, upto):
+            row = H[it % R]
+            tl = float(row[0] / row[1]) if row[1] > 0 else float('nan')
+            vl = tl
+            if vtr:
+                vrow = HV[0][it % R]
+                vl = float(vrow[0] / vrow[1]) if vrow[1] > 0 else float('nan')
+            book.record_fast(it, tl, vl, w_key, row[a0:a0 + nt], payload_of(row.copy()))
+        book.end_batch()
+
+    def body():
+        tr.evaluate(w, e)
+        for v in vtr:
+            v.evaluate(w, e)                                         # validation with the weights of THIS iteration
+        tr.finish(w if cfg.optimize_model else None, w_m, w_v, lr_w, ring)
+        for v, vr in zip(vtr, vrings):
+            v.finish(None, None, None, 0.0, vr)
+
+    state = dict(launched=0, graph=None, tried=False)
+
+    def run_one():
+        if state['launched'] >= 3 and not state['tried'] and n_it - state['launched'] >= 4 and getattr(cfg, 'loop_graph', True):
+            # every launch of an iteration takes the same pointers (the record's ring slot follows the device step counter): the
+            # iteration is captured once, after three eager ones (pose tables built, allocator warm), and replayed -- one graph
+            # launch per iteration instead of the host path of three library calls
+            state['tried'] = True
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            try:
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=side):
+                    body()
+                state['graph'] = g_
+            except Exception as ex:                                   # not capturable here: keep launching eagerly
+                print('train(): the iteration could not be captured as a graph (%s); running eagerly' % (ex,))
+            torch.cuda.current_stream(dev).wait_stream(side)
+        if state['graph'] is not None:
+            state['graph'].replay()
+        else:
+            body()
+        state['launched'] += 1
+
+    # batches of R iterations: the records of a batch are fetched (one synchronisation) BEFORE the next batch is launched into the
+    # same ring, and replayed through the reference's bookkeeping WHILE the device runs that next batch
+    prev, start = None, 0
+    try:
+        while start < n_it:
+            end = min(start + R, n_it)
+            fetched = fetch() if prev is not None else None
+            for _ in range(start, end):
+                run_one()
+            if prev is not None:
+                bookkeep(fetched, *prev)
+            prev, start = (start, end), end
+        if prev is not None:
+            bookkeep(fetch(), *prev)
+            prev = None
+    except BaseException:
+        try:                                                          # an interrupted run keeps the batch it had finished
+            if prev is not None and state['launched'] == prev[1]:
+                bookkeep(fetch(), *prev)
+        except Exception:
+            pass
+        raise
+    finally:
+        with torch.no_grad():                                         # the caller's tensors follow the optimisation
+            train_pose_deltas[0].copy_(tr.delta)
+            for d, v in zip(val_pose_deltas, vtr):
+                d.copy_(v.delta)
+        torch.autograd.graph.increment_version(w_param)            # written through its pointer
+    return book.best
+
+
 def _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_masks, train_ns, val_clouds, val_poses, val_masks, val_ns):
     """(train plan, [validation plans]) when the whole loop can run on plan.SequenceTrainer's chained steps -- only the weights
     of a polynomial model are optimised, with Adam as train() builds it, over ONE training sequence through the fused
@@ -527,9 +709,13 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
             vl = vs / vc if vc > 0 else float('nan')
         else:
             vl = tl
-        sd = dict(sd_const)
-        sd[w_key] = w_used.reshape(w_param.shape).to(w_param.dtype).clone()
-        book.record(it, tl, vl, sd, [], poses_cpu)
+        w_row = np.array(w_used, dtype=np.float64, copy=True)
+
+        def payload():
+            sd = dict(sd_const)
+            sd[w_key] = torch.from_numpy(w_row).reshape(w_param.shape).to(w_param.dtype).clone()
+            return sd, [], poses_cpu
+        book.record_fast(it, tl, vl, w_key, w_row, payload)
 
     def plain_iterations(first):
         """Iterations first .. n_it - 1 with ordinary (two-launch) steps and one synchronisation each: where the loop goes on
@@ -540,7 +726,7 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
             w_used = tr.w.clone()
             vs = [vp.eval_native(tr.w, tr.exponent, P, vr[0], want_grad=False).cpu() for vp, P, vr in zip(vplans, vP, vrings)]
             sums = tr.step().cpu()
-            record(it, sums, w_used.cpu(), vs)
+            record(it, sums.numpy(), w_used.cpu().numpy(), [v.numpy() for v in vs])
             book.end_batch()
 
     def drain(upto):
@@ -568,9 +754,10 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
             warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
                           'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
                           % (done, upto - 1))
+        H, HW, HV = h.numpy(), hw.numpy(), [v.numpy() for v in hv]
         for it in range(done, upto):
             sl = it % R
-            record(it, h[sl], hw[sl], [v[sl] for v in hv])
+            record(it, H[sl], HW[sl], [v[sl] for v in HV])
         book.end_batch()
         done = upto
         snap = snapshot()

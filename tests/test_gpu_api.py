@@ -1038,6 +1038,52 @@ def test_train_batched_graph_loop_equals_plain_loop(golden, tmp_path, capsys, mo
     assert n_plain == sum(f0) and 1 <= n_fast <= 3
 
 
+@pytest.mark.parametrize('correction, float_type, with_val', [('pose', 'float64', True), ('pose', 'float32', False), ('sequence', 'float64', True)])
+def test_train_native_pose_loop_equals_plain_loop(golden, tmp_path, capsys, monkeypatch, correction, float_type, with_val):
+    """train() with per-pose / per-sequence corrections on the map-consistency loss (scripts/model_poses_learning:71) runs on
+    train._native_pose_loop: per iteration the evaluation and ONE finishing launch (dc_pose_train_finish: pose-chain adjoint, first
+    pose fixed, both Adam updates, next poses, the record).  Against cfg.loop_batch = 1 (the reference's loop, train.py:220-322,
+    through autograd and the tensor-level optimisers): the same progress lines and the same checkpoint -- weights, corrections,
+    corrected poses.  float64 clouds: both optimise in fp64 (1e-9); float32: the corrections of the plain loop are float32
+    tensors, the native loop keeps them in fp64 (1e-5)."""
+    from depth_correction_amd import train as train_mod
+    took = []
+    for name in ('_native_loop', '_native_pose_loop', '_batched_loop'):
+        fn = getattr(train_mod, name)
+        monkeypatch.setattr(train_mod, name, (lambda f, n: (lambda *a, **k: (took.append(n), f(*a, **k))[1]))(fn, name))
+    g = golden('room_k10')
+    mk = lambda d, **kw: _cfg(g, n_opt_iters=11, lr=2e-3, log_dir=str(d), pose_correction=correction, float_type=float_type,
+                              model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
+    ds = list(zip(_scan_arrays(g), g['poses']))
+    tr_ds, va_ds = [ds], ([ds[:2]] if with_val else [])
+    (tmp_path / 'plain').mkdir()
+    (tmp_path / 'fast').mkdir()
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), tr_ds, va_ds, capsys)
+    assert took == []
+    b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'fast', loop_batch=4), tr_ds, va_ds, capsys)
+    assert took == ['_native_pose_loop'], took
+    tol = 1e-9 if float_type == 'float64' else 1e-5
+    assert len(l0) == len(l1) == 11 and f0 == f1 and any(f0)
+    np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=tol, atol=1e-12)
+    assert v0[-1][0] != v0[0][0]
+    sa, sb = torch.load(b0.model_state_dict), torch.load(b1.model_state_dict)
+    for k in sa:
+        np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=tol, atol=1e-12)
+    da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
+    assert len(da) == len(db) == 1 and da[0].shape == db[0].shape and da[0].dtype == db[0].dtype
+    scale = np.abs(da[0].cpu().numpy()).max()
+    assert scale > 0
+    # (float32: the plain loop's Adam rounds moments and corrections to float32 at every step)
+    dtol = 1e-7 if float_type == 'float64' else 1e-4
+    np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=dtol, atol=dtol * scale)
+    if correction == 'pose':
+        assert not db[0][0].any()                                      # the first pose stays where it is (train.py:309-311)
+    pa = torch.load(b0.model_state_dict.replace('_state_dict.pth', '_poses_upd.pth'))
+    pb = torch.load(b1.model_state_dict.replace('_state_dict.pth', '_poses_upd.pth'))
+    assert len(pa) == len(pb) == 1 and pa[0].shape == pb[0].shape
+    np.testing.assert_allclose(pb[0].cpu().numpy(), pa[0].cpu().numpy(), rtol=0, atol=dtol * 10)
+
+
 def test_train_native_loop_recovers_from_a_chain_timeout(golden, tmp_path, capsys, monkeypatch):
     """train._native_loop reads the plan's status word at every drain: a chained launch whose wait for its weights
     ran out (forced here: dc_set_option(5, 0), every wait gives up at once) poisons the sums and, through Adam, the weights.

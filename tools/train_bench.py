@@ -56,6 +56,14 @@ def main():
         cfg.loop_batch = batch
         ms, raw = timed_train(cfg, [seq], 50, 50 + args.c2_iters)
         out['c2_train_iteration_ms' + ('' if batch > 1 else '_loop_batch_1')] = ms
+    # ---- C2 with per-pose corrections (scripts/model_poses_learning:71): the map-consistency loss, model + poses optimised
+    from depth_correction_amd.plan import KernelTimer
+    cfgp = cfg.copy()
+    cfgp.pose_correction, cfgp.loop_batch = PoseCorrection.pose, args.loop_batch
+    with KernelTimer(every=16) as kt:
+        ms, raw = timed_train(cfgp, [seq], 50, 50 + args.c2_iters)
+        out['c2_pose_train_kernels'] = kt.kernels()
+    out['c2_pose_train_iteration_ms'] = ms
     if not args.skip_c4:
         cfg4 = Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2, min_depth=5.0,
                       max_depth=25.0, vp_dispersion_bounds=[], lr=1e-3, device='cuda:0', loop_batch=args.loop_batch,
