@@ -696,8 +696,7 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
     w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
     poses_cpu = [train_poses[0].detach().cpu().clone()]
     book = _Bookkeeper(cfg, model)
-    done = 0
-    snap = None                      # optimiser state after iteration done - 1: where a batch can be started again
+    snap = None                      # optimiser state after the last fetched iteration: where a batch can be started again
 
     def snapshot():
         return tr.w.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.t
@@ -729,12 +728,10 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
             record(it, sums.numpy(), w_used.cpu().numpy(), [v.numpy() for v in vs])
             book.end_batch()
 
-    def drain(upto):
-        """Bookkeeping of iterations done .. upto - 1; False when the chain had to be abandoned (the rest of the run has then
-        been done by plain_iterations)."""
-        nonlocal done, snap
-        if upto <= done:
-            return True
+    def fetch(first, upto):
+        """The records of iterations first .. upto - 1 on the host (ONE synchronisation), or None when the chain had to be abandoned
+        (the rest of the run has then been done by plain_iterations)."""
+        nonlocal snap
         # iteration upto - 1 is still pending in the chain: its weights are the current ones, its sums come with the flush
         ring_w[(upto - 1) % R].copy_(tr.w)
         tr.flush(out=ring[(upto - 1) % R])
@@ -743,43 +740,63 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
         bits = plan.status_bits()                                   # (free: the copies above have synchronised)
         if bits & plan.STATUS_CHAIN_TIMEOUT:
             warnings.warn('train(): a chained step gave up waiting for its weights (iterations %d..%d); repeating them and '
-                          'finishing the run with ordinary steps' % (done, upto - 1))
+                          'finishing the run with ordinary steps' % (first, upto - 1))
             plan.clear_status()
             w0_, m0_, v0_, t0_ = snap
             tr.w.copy_(w0_); tr.exp_avg.copy_(m0_); tr.exp_avg_sq.copy_(v0_); tr.t = t0_
-            plain_iterations(done)
-            done = n_it
-            return False
+            plain_iterations(first)
+            return None
         if bits & plan.STATUS_OVERFLOW:
             warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
                           'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
-                          % (done, upto - 1))
-        H, HW, HV = h.numpy(), hw.numpy(), [v.numpy() for v in hv]
-        for it in range(done, upto):
+                          % (first, upto - 1))
+        snap = snapshot()                                           # the optimiser after iteration upto - 1: where a batch can restart
+        return h.numpy(), hw.numpy(), [v.numpy() for v in hv]
+
+    def bookkeep(fetched, first, upto):
+        H, HW, HV = fetched
+        for it in range(first, upto):
             sl = it % R
             record(it, H[sl], HW[sl], [v[sl] for v in HV])
         book.end_batch()
-        done = upto
-        snap = snapshot()
-        return True
 
+    # batches of R iterations: the records of a batch are fetched (one synchronisation) BEFORE the next batch is launched into the
+    # same ring, and replayed through the reference's bookkeeping WHILE the device runs that next batch
     snap = snapshot()
+    prev, fetched, start, launched = None, None, 0, 0
     try:
-        for it in range(n_it):
-            if it - done >= R and not drain(it):
-                break
-            prev = (it - 1) % R
-            if tr.step(out_prev=ring[prev], w_used_prev=ring_w[prev], require_chain=True) is None:
-                assert it == 0
-                return False, None                                 # this plan does not chain; nothing was launched
-            for vp, P, vr in zip(vplans, vP, vrings):                # validation with the weights of THIS iteration
-                vp.eval_native(tr.w, tr.exponent, P, vr[it % R], want_grad=False)
-        drain(n_it)
+        while start < n_it:
+            end = min(start + R, n_it)
+            if prev is not None:
+                fetched = fetch(*prev)
+                if fetched is None:
+                    prev = None
+                    break
+            for it in range(start, end):
+                slot = (it - 1) % R
+                if tr.step(out_prev=ring[slot], w_used_prev=ring_w[slot], require_chain=True) is None:
+                    assert it == 0
+                    return False, None                             # this plan does not chain; nothing was launched
+                for vp, P, vr in zip(vplans, vP, vrings):            # validation with the weights of THIS iteration
+                    vp.eval_native(tr.w, tr.exponent, P, vr[it % R], want_grad=False)
+                launched = it + 1
+            if prev is not None:
+                bookkeep(fetched, *prev)
+                fetched = None
+            prev, start = (start, end), end
+        if prev is not None:
+            fetched = fetch(*prev)
+            if fetched is not None:
+                bookkeep(fetched, *prev)
+            prev = fetched = None
     except BaseException:
-        # an interrupted run keeps the iterations it finished: their records are in the ring (best.yaml, checkpoint)
+        # an interrupted run keeps the batch it had finished: its records are on the host already, or still whole in the ring
         try:
-            if tr.t > done:
-                drain(min(tr.t, n_it))
+            if prev is not None:
+                if fetched is None and launched == prev[1]:
+                    fetched = fetch(*prev)
+                if fetched is not None:
+                    bookkeep(fetched, *prev)
         except Exception:
             pass
         raise
