@@ -548,19 +548,30 @@ def main():
             tcfg = _Cfg(nn_k=args.k, nn_r=None, min_depth=0.0, max_depth=float('inf'), grid_res=0.0, vp_dispersion_bounds=[], lr=1e-3,
                         float_type=args.dtype, device=str(dev), model_kwargs={'w': w0, 'exponent': e0})
             seq = [(c, p) for c, p in ds]
-            wall = {}
-            for n_it in (40, 40, 440):
-                c = tcfg.copy()
-                c.n_opt_iters, c.log_dir = n_it, tempfile.mkdtemp()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                with contextlib.redirect_stdout(io.StringIO()):
-                    _train(c, train_datasets=[seq], val_datasets=[])
-                torch.cuda.synchronize()
-                wall[n_it] = time.perf_counter() - t0            # (the first 40-iteration run pays the process's one-time costs)
-            extras['train_iteration_ms'] = (wall[440] - wall[40]) / 400 * 1e3
+
+            def train_ms(cfg_):
+                wall = {}
+                for n_it in (40, 40, 440):
+                    c = cfg_.copy()
+                    c.n_opt_iters, c.log_dir = n_it, tempfile.mkdtemp()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        _train(c, train_datasets=[seq], val_datasets=[])
+                    torch.cuda.synchronize()
+                    wall[n_it] = time.perf_counter() - t0            # (the first 40-iteration run pays the process's one-time costs)
+                return (wall[440] - wall[40]) / 400 * 1e3
+            extras['train_iteration_ms'] = train_ms(tcfg)
             extras['train_iteration_note'] = ('depth_correction_amd.train.train() itself, default callbacks, cfg.loop_batch = %d: model-only runs '
-                                              'go to the chained native step, one launch per iteration' % tcfg.loop_batch)
+                                              'go to the chained native step, one launch per iteration; the bookkeeping of a batch runs '
+                                              'while the device works on the next' % tcfg.loop_batch)
+            # the same with per-pose corrections (scripts/model_poses_learning:71): model weights and nine poses optimised
+            from depth_correction_amd.config import PoseCorrection as _PC
+            pcfg = tcfg.copy()
+            pcfg.pose_correction = _PC.pose
+            extras['train_pose_iteration_ms'] = train_ms(pcfg)
+            extras['train_pose_iteration_note'] = ('train() with PoseCorrection.pose: per iteration the pose kernel, its reduction and one '
+                                                   'finishing launch (dc_pose_train_finish), replayed as a graph')
 
         # BASELINE config 1 (one 200k-point scan, nn_k = 10, covariance + eig forward only, all DepthCloud features written):
         # 220 launches, each timed by the library's dispatch stamps (the host call takes longer than the kernel, so stream events
