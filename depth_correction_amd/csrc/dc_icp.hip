@@ -557,6 +557,7 @@ __global__ __launch_bounds__(kBlock) void pose_correct_kernel(const double* __re
 // checkpoint of the iteration holds.
 struct PoseTrainArgs {
   const double* sums;
+  int n_sums, count_index, grad_w_off, grad_T_off;      // layout of `sums`; count_index < 0: the gradients are those of the loss itself
   int n_terms, n_scans, n_deltas, zero_first;
   double *w, *w_m, *w_v;                 // w == nullptr: the model is not optimised (validation sequences)
   const double* T0;                      // [S, 16]
@@ -581,7 +582,7 @@ __device__ __forceinline__ double adam_one(double p0, double& m, double& v, doub
 __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs a) {
   __shared__ double lds[(kBlock / kWave) * 6];
   const int S = a.n_scans, P = a.n_terms, tid = threadIdx.x;
-  const int n_sums = 2 + 2 * P + 12 * S;
+  const int n_sums = a.n_sums;
   if (a.record) {
     double* r = a.record + (*a.step % a.ring_rows) * (int64_t)(n_sums + P + 6 * a.n_deltas + 12 * S);
     for (int q = tid; q < n_sums; q += kBlock) r[q] = a.sums[q];
@@ -594,8 +595,8 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
   }
   const double t = (double)(*a.step + 1);
   const double bias1 = 1.0 - pow(a.b1, t), bias2_sqrt = sqrt(1.0 - pow(a.b2, t));
-  const double gscale = 1.0 / a.sums[1];
-  const double* gT = a.sums + 2 + 2 * P;
+  const double gscale = a.count_index >= 0 ? 1.0 / a.sums[a.count_index] : 1.0;
+  const double* gT = a.sums + a.grad_T_off;
   double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int p = tid; p < S; p += kBlock) {
     const double* d6 = a.delta + (a.n_deltas == 1 ? 0 : (int64_t)p * 6);
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
   }
   if (a.w && tid < P) {
     double m = a.w_m[tid], v = a.w_v[tid];
-    a.w[tid] = adam_one(a.w[tid], m, v, a.sums[2 + tid] * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+    a.w[tid] = adam_one(a.w[tid], m, v, a.sums[a.grad_w_off + tid] * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
     a.w_m[tid] = m; a.w_v[tid] = v;
   }
   __syncthreads();                                             // the corrections are updated; the step counter and T_used have been read
@@ -689,7 +690,7 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
   return err == hipSuccess ? DC_OK : (int)err;
 }
 
-int dc_pose_train_finish(const double* sums, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
+int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
                          double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
                          double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
                          double* poses12_next, hipStream_t stream) {
@@ -697,7 +698,11 @@ int dc_pose_train_finish(const double* sums, int n_terms, int n_scans, double* w
       !d_m || !d_v || !step || !poses_used || !poses_next || !poses12_next || (w && (!w_m || !w_v)) || (record && ring_rows < 1))
     return DC_ERR_ARG;
   if (!(lr_w >= 0.0) || !(lr_d >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return DC_ERR_ARG;
-  dc::PoseTrainArgs a{sums, n_terms, n_scans, n_deltas, zero_first, w, w_m, w_v, poses0, deltas, d_m, d_v, step, lr_w, lr_d, beta1, beta2, eps,
+  if (layout != 0 && layout != 1) return DC_ERR_ARG;
+  // layout 0: dc_sequence_eval {sum, count, d/dw, d/de, d/d[R|t]}; 1: dc_p2plane_sequence / dc_p2point_sequence {loss, d/dw, d/de, d/d[R|t]}
+  const int head = layout == 0 ? 2 : 1;
+  dc::PoseTrainArgs a{sums, head + 2 * n_terms + 12 * n_scans, layout == 0 ? 1 : -1, head, head + 2 * n_terms,
+                      n_terms, n_scans, n_deltas, zero_first, w, w_m, w_v, poses0, deltas, d_m, d_v, step, lr_w, lr_d, beta1, beta2, eps,
                       poses_used, record, ring_rows, poses_next, poses12_next};
   hipLaunchKernelGGL(dc::pose_train_finish_kernel, dim3(1), dim3(dc::kBlock), 0, stream, a);
   hipError_t err = hipGetLastError();

@@ -772,10 +772,15 @@ class PoseSequenceTrainer:
     written back by ``store``): Adam on float32 corrections differs from this in the rounding of every update."""
 
     @on_device
-    def __init__(self, plan, poses0, deltas, zero_first, lr, betas=(0.9, 0.999), eps=1e-8, n_terms=2):
+    def __init__(self, plan, poses0, deltas, zero_first, lr, betas=(0.9, 0.999), eps=1e-8, n_terms=2, icp_model_kind=None):
+        """``plan``: a SequencePlan (map-consistency loss) or, with ``icp_model_kind`` (the model's kernel kind, '' for none), an
+        ops.IcpSequence (point-to-plane / point-to-point ICP loss of the sequence's scan pairs)."""
         dev = plan.device
         S = plan.n_scans
         self.plan, self.S, self.nt = plan, S, int(n_terms)
+        self.icp = icp_model_kind is not None
+        self.icp_kind = icp_model_kind or None
+        self.head = 1 if self.icp else 2
         self.T0 = poses0.detach().to(device=dev, dtype=torch.float64).reshape(S, 16).contiguous()
         self.delta = deltas.detach().to(device=dev, dtype=torch.float64).contiguous().clone()
         self.nd = self.delta.shape[0]
@@ -785,32 +790,41 @@ class PoseSequenceTrainer:
         self.zero_first, self.lr, self.betas, self.eps = int(bool(zero_first)), float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.T = torch.empty((S, 16), dtype=torch.float64, device=dev)         # the corrected poses of the current iteration
         self.P12 = torch.empty((S, 12), dtype=torch.float64, device=dev)
-        self.out = torch.zeros((2 + 2 * self.nt + 12 * S,), dtype=torch.float64, device=dev)
+        self.out = torch.zeros((self.head + 2 * self.nt + 12 * S,), dtype=torch.float64, device=dev)
         check(lib().dc_pose_correct_fwd(ptr(self.T0), ptr(self.delta), S, self.nd, ptr(self.T), stream_ptr()), 'dc_pose_correct_fwd')
         self.P12.copy_(self.T[:, :12])
 
     @property
     def record_len(self):
-        return 2 + 2 * self.nt + 12 * self.S + self.nt + 6 * self.nd + 12 * self.S
+        return self.head + 2 * self.nt + 12 * self.S + self.nt + 6 * self.nd + 12 * self.S
 
     def evaluate(self, w, exponent):
-        """Loss sums and gradients of the sum (dL/dw, dL/d[R|t]) for the current corrected poses -> self.out."""
-        self.plan.eval_native(w, exponent, self.P12, self.out, want_grad=True, want_pose=True)
+        """Loss (sums) and gradients (dL/dw, dL/d[R|t]) for the current corrected poses -> self.out."""
+        if self.icp:
+            self.plan.eval(self.P12, self.icp_kind, w if self.icp_kind else None, exponent if self.icp_kind else None, out=self.out)
+        else:
+            self.plan.eval_native(w, exponent, self.P12, self.out, want_grad=True, want_pose=True)
         return self.out
+
+    def loss_of(self, row):
+        """The mean loss train() reports, from a record row."""
+        if self.icp:
+            return float(row[0])
+        return float(row[0] / row[1]) if row[1] > 0 else float('nan')
 
     @on_device
     def finish(self, w=None, w_m=None, w_v=None, lr_w=0.0, ring=None):
         """Backward through the pose chain, the optimiser steps, the next iteration's poses (in place); row (step mod rows) of
         ``ring`` [rows, record_len] <- {sums, weights, corrections, corrected poses} of THIS iteration.  Every pointer is the same
         from call to call (the ring slot follows the device step counter): a captured iteration replays correctly."""
-        check(lib().dc_pose_train_finish(ptr(self.out), self.nt, self.S, ptr(w), ptr(w_m), ptr(w_v), ptr(self.T0), ptr(self.delta),
+        check(lib().dc_pose_train_finish(ptr(self.out), 1 if self.icp else 0, self.nt, self.S, ptr(w), ptr(w_m), ptr(w_v), ptr(self.T0), ptr(self.delta),
                                          ptr(self.d_m), ptr(self.d_v), self.nd, self.zero_first, ptr(self.step), float(lr_w), self.lr,
                                          self.betas[0], self.betas[1], self.eps, ptr(self.T), ptr(ring), 0 if ring is None else ring.shape[0],
                                          ptr(self.T), ptr(self.P12), stream_ptr()), 'dc_pose_train_finish')
 
     def split_record(self, row):
         """(sums, weights, corrections [nd,6], corrected poses [S,4,4]) of a record row (a CPU tensor)."""
-        a = 2 + 2 * self.nt + 12 * self.S
+        a = self.head + 2 * self.nt + 12 * self.S
         sums, w = row[:a], row[a:a + self.nt]
         d = row[a + self.nt:a + self.nt + 6 * self.nd].reshape(self.nd, 6)
         P = row[a + self.nt + 6 * self.nd:].reshape(self.S, 3, 4)

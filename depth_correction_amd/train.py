@@ -499,11 +499,19 @@ def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, t
     from .optim import Adam
     kw = cfg.loss_kwargs
     w = getattr(model, 'w', None)
+    icp = cfg.loss == 'icp_loss'
+    if icp:
+        # icp_loss's own fused path (loss.icp_loss): precomputed correspondences, normals for point to plane, a kernel model
+        plane = bool(kw['icp_point_to_plane'])
+        ok_loss = (all(m is not None for m in list(train_masks) + list(val_masks))
+                   and all(c.dirs.is_cuda and (not plane or c.normals is not None) for seq in list(train_clouds) + list(val_clouds) for c in seq)
+                   and getattr(model, 'kernel_kind', None) is not None)
+    else:
+        ok_loss = (fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
+                   and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
+                   and not kw.get('only_finite') and not kw.get('skip_nans'))
     if not (cfg.pose_correction in (PoseCorrection.pose, PoseCorrection.sequence) and len(train_clouds) == 1 and len(val_clouds) <= 1
-            and isinstance(optimizer, Adam) and (val_optimizer is None or isinstance(val_optimizer, Adam))
-            and fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
-            and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
-            and not kw.get('only_finite') and not kw.get('skip_nans')
+            and isinstance(optimizer, Adam) and (val_optimizer is None or isinstance(val_optimizer, Adam)) and ok_loss
             and isinstance(w, torch.nn.Parameter) and [id(p) for p in model.parameters()] == [id(w)]
             and w.is_cuda and w.dtype == torch.float64 and w.is_contiguous() and 1 <= w.numel() <= 3
             and model.kernel_params()[0] is w and not model.kernel_params()[1].requires_grad
@@ -519,6 +527,11 @@ def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, t
         return None
     if any(m is None for m in list(train_masks) + list(val_masks)):
         return None
+    if icp:
+        from .loss import _icp_sequence_plan
+        plan = _icp_sequence_plan(train_clouds[0], train_masks[0], True, plane)
+        vplans = [_icp_sequence_plan(c, m, True, plane) for c, m in zip(val_clouds, val_masks)]
+        return plan, vplans
     plan = _plan_for(train_clouds[0], train_poses[0], train_ns[0], train_masks[0], model, cfg)
     vplans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(val_clouds, val_poses, val_ns, val_masks)]
     return plan, vplans
@@ -542,8 +555,11 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_
     nt = w.numel()
     g_d = groups[-1]
     zero_first = cfg.pose_correction == PoseCorrection.pose
-    tr = PoseSequenceTrainer(plan, train_poses[0], train_pose_deltas[0], zero_first, g_d['lr'], g_d['betas'], g_d['eps'], n_terms=nt)
-    vtr = [PoseSequenceTrainer(vp, T, d, zero_first, val_optimizer.param_groups[0]['lr'], g_d['betas'], g_d['eps'], n_terms=nt)
+    icp_kind = model.kernel_kind if cfg.loss == 'icp_loss' else None
+    tr = PoseSequenceTrainer(plan, train_poses[0], train_pose_deltas[0], zero_first, g_d['lr'], g_d['betas'], g_d['eps'], n_terms=nt,
+                             icp_model_kind=icp_kind)
+    vtr = [PoseSequenceTrainer(vp, T, d, zero_first, val_optimizer.param_groups[0]['lr'], g_d['betas'], g_d['eps'], n_terms=nt,
+                               icp_model_kind=icp_kind)
            for vp, T, d in zip(vplans, val_poses, val_pose_deltas)]
     lr_w = groups[0]['lr'] if cfg.optimize_model else 0.0
     w_m, w_v = (torch.zeros_like(w), torch.zeros_like(w)) if cfg.optimize_model else (None, None)
@@ -556,16 +572,16 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_
 
     def fetch():
         """The ring on the host (synchronises: every launched iteration has finished)."""
-        return ring.cpu(), [v.cpu() for v in vrings], plan.status_bits()
+        return ring.cpu(), [v.cpu() for v in vrings], (plan.status_bits() if hasattr(plan, 'status_bits') else 0)
 
     def bookkeep(fetched, first, upto):
         h, hv, bits = fetched
-        if bits & plan.STATUS_OVERFLOW:
+        if bits and bits & plan.STATUS_OVERFLOW:
             warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
                           'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
                           % (first, upto - 1))
         H, HV = h.numpy(), [v.numpy() for v in hv]
-        a0 = 2 + 2 * nt + 12 * plan.n_scans
+        a0 = tr.head + 2 * nt + 12 * plan.n_scans
 
         def payload_of(row):
             def build():
@@ -577,11 +593,8 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_
 
         for it in range(first, upto):
             row = H[it % R]
-            tl = float(row[0] / row[1]) if row[1] > 0 else float('nan')
-            vl = tl
-            if vtr:
-                vrow = HV[0][it % R]
-                vl = float(vrow[0] / vrow[1]) if vrow[1] > 0 else float('nan')
+            tl = tr.loss_of(row)
+            vl = vtr[0].loss_of(HV[0][it % R]) if vtr else tl
             book.record_fast(it, tl, vl, w_key, row[a0:a0 + nt], payload_of(row.copy()))
         book.end_batch()
 

@@ -299,16 +299,17 @@ int dc_pose_correct_fwd(const double* poses, const double* deltas, int n_poses, 
 int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, int n_deltas, const double* grad_poses,
                         double* grad_deltas, dcStream_t stream);
 /* The rest of a training iteration with pose corrections in ONE launch (train.py:300-322 after the loss: loss.backward() through
- * eval.create_corrected_poses, the first pose kept fixed -- train.py:309-311 --, optimizer.step()).  `sums` fp64 [2 + 2 P + 12 S] is
- * what dc_sequence_eval wrote for the corrected poses `poses_used` [S,16]; the mean loss sums[0] / sums[1] is what train()
- * back-propagates, so every gradient is scaled by 1 / sums[1].  torch.optim.Adam's single-tensor update (step = *step + 1, written
+ * eval.create_corrected_poses, the first pose kept fixed -- train.py:309-311 --, optimizer.step()).  layout 0: `sums` fp64
+ * [2 + 2 P + 12 S] is what dc_sequence_eval wrote for the corrected poses `poses_used` [S,16]; the mean loss sums[0] / sums[1] is
+ * what train() back-propagates, so every gradient is scaled by 1 / sums[1].  layout 1: `sums` fp64 [1 + 2 P + 12 S] is the output of
+ * dc_p2plane_sequence / dc_p2point_sequence (the ICP loss of the sequence and its gradients as they are).  torch.optim.Adam's single-tensor update (step = *step + 1, written
  * back) on the corrections `deltas` [n_deltas, 6] (n_deltas = S: PoseCorrection.pose; 1: sequence) with moments d_m / d_v, and on
  * the weights `w` [P] with w_m / w_v unless w is NULL (validation sequences: only the corrections move).  Then poses_next [S,16] /
  * poses12_next [S,12] <- poses0 corrected by the UPDATED deltas: the poses of the next evaluation (poses_next may be poses_used:
  * it is read first).  record (or NULL): a ring of ring_rows rows of fp64 [2 + 2 P + 12 S | P | 6 n_deltas | 12 S]; row (*step mod
  * ring_rows) <- sums, and the weights, corrections and corrected poses (rows [R|t]) this iteration used -- the slot follows the
  * device counter, so a captured iteration replays into the right one.  All arrays device fp64. */
-int dc_pose_train_finish(const double* sums, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
+int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
                          double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
                          double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
                          double* poses12_next, dcStream_t stream);

@@ -1006,7 +1006,8 @@ def test_train_batched_graph_loop_equals_plain_loop(golden, tmp_path, capsys, mo
         from depth_correction_amd.preproc import filtered_cloud
         mk = lambda d, **kw: Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2,
                                     min_depth=5.0, max_depth=12.0, vp_dispersion_bounds=[], n_opt_iters=13, lr=2e-3,
-                                    log_dir=str(d), model_kwargs={'w': [1e-3, -1e-3], 'exponent': [2.0, 4.0]}).from_dict(kw)
+                                    log_dir=str(d), loop_native=False,        # (the native loop: test_train_native_icp_pose_loop_...)
+                                    model_kwargs={'w': [1e-3, -1e-3], 'exponent': [2.0, 4.0]}).from_dict(kw)
         c0 = mk(tmp_path)
         seq = [(filtered_cloud(cloud, c0), pose) for cloud, pose in KittiLikeDataset(n_poses=3, n_rings=96, n_azimuth=384)]
         tr_ds, va_ds = [seq], []
@@ -1082,6 +1083,44 @@ def test_train_native_pose_loop_equals_plain_loop(golden, tmp_path, capsys, monk
     pb = torch.load(b1.model_state_dict.replace('_state_dict.pth', '_poses_upd.pth'))
     assert len(pa) == len(pb) == 1 and pa[0].shape == pb[0].shape
     np.testing.assert_allclose(pb[0].cpu().numpy(), pa[0].cpu().numpy(), rtol=0, atol=dtol * 10)
+
+
+@pytest.mark.parametrize('plane', [True, False])
+def test_train_native_icp_pose_loop_equals_plain_loop(tmp_path, capsys, monkeypatch, plane):
+    """The C4 shape -- ICP loss over consecutive scan pairs (point to plane / point to point), model weights and per-pose corrections
+    optimised (scripts/model_poses_learning_icp) -- on train._native_pose_loop: dc_p2plane_sequence / dc_p2point_sequence +
+    dc_pose_train_finish (layout 1) per iteration, against the reference's loop with cfg.loop_batch = 1."""
+    from depth_correction_amd import train as train_mod
+    from depth_correction_amd.config import Config, Loss, PoseCorrection
+    from depth_correction_amd.dataset import KittiLikeDataset
+    from depth_correction_amd.preproc import filtered_cloud
+    took = []
+    for name in ('_native_loop', '_native_pose_loop', '_batched_loop'):
+        fn = getattr(train_mod, name)
+        monkeypatch.setattr(train_mod, name, (lambda f, n: (lambda *a, **k: (took.append(n), f(*a, **k))[1]))(fn, name))
+    def mk(d, **kw):
+        c = Config(loss=Loss.icp_loss, pose_correction=PoseCorrection.pose, nn_k=0, nn_r=0.4, grid_res=0.2, min_depth=5.0, max_depth=12.0,
+                   vp_dispersion_bounds=[], n_opt_iters=11, lr=2e-3, log_dir=str(d), float_type='float64',
+                   model_kwargs={'w': [1e-3, -1e-3], 'exponent': [2.0, 4.0]}).from_dict(kw)
+        c.loss_kwargs['icp_point_to_plane'] = plane
+        return c
+    c0 = mk(tmp_path)
+    seq = [(filtered_cloud(cloud, c0), pose) for cloud, pose in KittiLikeDataset(n_poses=3, n_rings=96, n_azimuth=384)]
+    (tmp_path / 'plain').mkdir()
+    (tmp_path / 'fast').mkdir()
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), [seq], [], capsys)
+    assert took == []
+    b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'fast', loop_batch=4), [seq], [], capsys)
+    assert took == ['_native_pose_loop'], took
+    assert len(l0) == len(l1) == 11 and f0 == f1 and any(f0)
+    np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-8, atol=1e-12)
+    assert v0[-1][0] != v0[0][0]
+    sa, sb = torch.load(b0.model_state_dict), torch.load(b1.model_state_dict)
+    for k in sa:
+        np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-8, atol=1e-13)
+    da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
+    assert not db[0][0].any()                                        # (the checkpoint is the best iteration's: possibly the first)
+    np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=1e-7, atol=1e-10)
 
 
 def test_train_native_loop_recovers_from_a_chain_timeout(golden, tmp_path, capsys, monkeypatch):
