@@ -289,7 +289,15 @@ def main():
                                         point_format=args.point_format, active_only=args.active_only,
                                         degree_sort=args.degree_sort, block_tables=not args.no_block_tables,
                                         bwd_layout=args.bwd_layout, basis=not args.no_basis, **kw)
+    # (apart from it: the device context with torch's first kernel, and dlopen of the library -- what any GPU program pays)
+    t0 = time.perf_counter()
+    torch.zeros(1, device=dev)
     torch.cuda.synchronize()
+    device_init_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    from depth_correction_amd import _native as _nv0
+    _nv0.lib()
+    library_load_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     plan, info = build()
     torch.cuda.synchronize()
@@ -724,7 +732,7 @@ def main():
                                        'and skip the moments, the eigen-solve and the second sweep (every term they would add carries the mask); '
                                        'the plan groups masked-out points at the end of every 256-point block', 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
-                       'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s,
+                       'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s, 'device_init_s': device_init_s, 'library_load_s': library_load_s,
                        'setup_note': 'setup_ms: the whole set-up phase (upload, 10 local feature clouds, global k-NN, masks, Morton '
                                      'order, transpose, block tables) rebuilt in a warm process; setup_first_call_s additionally '
                                      'holds the one-time code-object load and allocator warm-up'},
