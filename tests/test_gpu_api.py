@@ -1085,6 +1085,28 @@ def test_train_native_pose_loop_equals_plain_loop(golden, tmp_path, capsys, monk
     np.testing.assert_allclose(pb[0].cpu().numpy(), pa[0].cpu().numpy(), rtol=0, atol=dtol * 10)
 
 
+@pytest.mark.parametrize('n_it, batch, graph', [(1, 4, True), (2, 2, True), (7, 2, True), (7, 3, False)])
+def test_train_native_pose_loop_short_runs_and_small_batches(golden, tmp_path, capsys, monkeypatch, n_it, batch, graph):
+    """train._native_pose_loop at its edges: runs shorter than the three eager iterations before the capture, rings smaller than
+    that, an uncaptured loop (cfg.loop_graph = False) -- the same progress lines as the reference's loop."""
+    from depth_correction_amd import train as train_mod
+    took = []
+    fn = train_mod._native_pose_loop
+    monkeypatch.setattr(train_mod, '_native_pose_loop', lambda *a, **k: (took.append(1), fn(*a, **k))[1])
+    g = golden('room_k10')
+    mk = lambda d, **kw: _cfg(g, n_opt_iters=n_it, lr=2e-3, log_dir=str(d), pose_correction='pose', float_type='float64',
+                              loop_graph=graph, model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
+    ds = list(zip(_scan_arrays(g), g['poses']))
+    (tmp_path / 'plain').mkdir()
+    (tmp_path / 'fast').mkdir()
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), [ds], [], capsys)
+    b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'fast', loop_batch=batch), [ds], [], capsys)
+    assert took == [1] and len(l0) == len(l1) == n_it and f0 == f1
+    np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-9, atol=1e-12)
+    da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
+    np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=1e-7, atol=1e-10)
+
+
 @pytest.mark.parametrize('plane', [True, False])
 def test_train_native_icp_pose_loop_equals_plain_loop(tmp_path, capsys, monkeypatch, plane):
     """The C4 shape -- ICP loss over consecutive scan pairs (point to plane / point to point), model weights and per-pose corrections
