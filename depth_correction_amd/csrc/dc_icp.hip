@@ -217,7 +217,7 @@ struct IcpSeqReduce {
   int n_pairs;
 };
 __global__ __launch_bounds__(kBlock) void p2plane_reduce_all_kernel(const double* __restrict__ partials, IcpSeqReduce rq, int n_terms,
-                                                                    double* __restrict__ out) {
+                                                                    double* __restrict__ out, int first, int n_scans) {
   __shared__ double lds[2 * (kBlock / kWave)];
   const int a = blockIdx.x;
   const int pw = 2, pe = 2 + DC_MAX_MODEL_TERMS, pa = 2 + 2 * DC_MAX_MODEL_TERMS, pb = pa + 12;
@@ -228,27 +228,56 @@ __global__ __launch_bounds__(kBlock) void p2plane_reduce_all_kernel(const double
     const int k = (a - 1) % DC_MAX_MODEL_TERMS;
     if (k >= n_terms) return;
   }
-  for (int p = 0; p < rq.n_pairs; ++p) {
-    double v[2] = {0.0, 0.0};
-    const double* rows = partials + (int64_t)rq.row0[p] * kIcpAcc;
-    for (int r = threadIdx.x; r < rq.rows[p]; r += kBlock) {
-      v[0] += rows[(int64_t)r * kIcpAcc + col0];
-      if (col1 >= 0) v[1] += rows[(int64_t)r * kIcpAcc + col1];
-    }
-    block_sum<2>(v, lds);
-    if (threadIdx.x == 0) {
-      const double wt = rq.weight[p];
-      if (a == 0) out[0] += wt * (v[0] + v[1]);
-      else if (!pose) {
-        const int k = (a - 1) % DC_MAX_MODEL_TERMS;
-        out[1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + k] += wt * v[0];
-      } else {
-        out[1 + 2 * n_terms + 12 * rq.scan_a[p] + j] += wt * v[0];
-        out[1 + 2 * n_terms + 12 * rq.scan_b[p] + j] += wt * v[1];
+  // the first launch of a sequence also clears the slots this block adds to (instead of a memset in front: two launches fewer in
+  // an iteration that is a chain of short ones); the same thread adds to them below
+  if (first && threadIdx.x == 0) {
+    if (a == 0) out[0] = 0.0;
+    else if (!pose) out[1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + (a - 1) % DC_MAX_MODEL_TERMS] = 0.0;
+    else for (int sc = 0; sc < n_scans; ++sc) out[1 + 2 * n_terms + 12 * sc + j] = 0.0;
+  }
+  // every pair's rows are requested before anything is added (a pair after the other cost a round trip to the fabric and two
+  // barriers each: 14 us for nine pairs); the sums of a pair are formed in the same order as before and added pair after pair
+  __shared__ double s_pair[kBlock / kWave][2 * kIcpSeqPairs];
+  double v[kIcpSeqPairs][2];
+#pragma unroll
+  for (int p = 0; p < kIcpSeqPairs; ++p) {
+    v[p][0] = v[p][1] = 0.0;
+    if (p < rq.n_pairs) {
+      const double* rows = partials + (int64_t)rq.row0[p] * kIcpAcc;
+      for (int r = threadIdx.x; r < rq.rows[p]; r += kBlock) {
+        v[p][0] += rows[(int64_t)r * kIcpAcc + col0];
+        if (col1 >= 0) v[p][1] += rows[(int64_t)r * kIcpAcc + col1];
       }
     }
-    __syncthreads();
   }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int p = 0; p < kIcpSeqPairs; ++p) {
+    if (p < rq.n_pairs) {                                                // (uniform)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double t = wave_sum(v[p][c]);                              // (as block_sum: the same order of additions as before)
+        if (lane == 0) s_pair[wave][2 * p + c] = t;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int p = 0; p < rq.n_pairs; ++p) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int wv = 0; wv < kBlock / kWave; ++wv) { t0 += s_pair[wv][2 * p]; t1 += s_pair[wv][2 * p + 1]; }
+      const double wt = rq.weight[p];
+      if (a == 0) out[0] += wt * (t0 + t1);
+      else if (!pose) {
+        const int k = (a - 1) % DC_MAX_MODEL_TERMS;
+        out[1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + k] += wt * t0;
+      } else {
+        out[1 + 2 * n_terms + 12 * rq.scan_a[p] + j] += wt * t0;
+        out[1 + 2 * n_terms + 12 * rq.scan_b[p] + j] += wt * t1;
+      }
+    }
+  }
+  (void)lds;
   (void)pw; (void)pe;
 }
 
@@ -375,7 +404,8 @@ static int icp_sequence_impl(bool plane, const dcIcpScan* scans, int n_scans, co
       if (!c.dirs || !c.depth || (plane && !c.normals) || (model_kind != DC_MODEL_NONE && !c.inc)) return DC_ERR_ARG;
     }
   }
-  hipError_t err = hipMemsetAsync(out, 0, (size_t)(1 + 2 * n_terms + 12 * n_scans) * sizeof(double), stream);
+  hipError_t err = hipSuccess;
+  bool launched = false;
   if (err != hipSuccess) return (int)err;
   // chunks of up to kIcpSeqPairs pairs: one pair launch + one reduction launch per chunk (the workspace holds the rows of the
   // largest chunk: dc_p2plane_sequence_partial_count)
@@ -407,7 +437,13 @@ static int icp_sequence_impl(bool plane, const dcIcpScan* scans, int n_scans, co
     if (dtype == DC_F32) { if (plane) ICP_SEQ(float, true); else ICP_SEQ(float, false); }
     else { if (plane) ICP_SEQ(double, true); else ICP_SEQ(double, false); }
 #undef ICP_SEQ
-    hipLaunchKernelGGL(p2plane_reduce_all_kernel, dim3(1 + 2 * DC_MAX_MODEL_TERMS + 12), dim3(kBlock), 0, stream, partials_ws, rq, n_terms, out);
+    hipLaunchKernelGGL(p2plane_reduce_all_kernel, dim3(1 + 2 * DC_MAX_MODEL_TERMS + 12), dim3(kBlock), 0, stream, partials_ws, rq, n_terms, out,
+                       launched ? 0 : 1, n_scans);
+    launched = true;
+  }
+  if (!launched) {                                                      // no correspondences at all: the sums are zero
+    err = hipMemsetAsync(out, 0, (size_t)(1 + 2 * n_terms + 12 * n_scans) * sizeof(double), stream);
+    if (err != hipSuccess) return (int)err;
   }
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;

@@ -369,8 +369,34 @@ class _Bookkeeper(object):
         best = cfg.copy()
         best.model_state_dict = stem + '_state_dict.pth'
         best.train_pose_deltas = stem + '_pose_deltas.pth'
-        best.to_yaml(os.path.join(cfg.log_dir, 'best.yaml'))
+        self._write_yaml(best, os.path.join(cfg.log_dir, 'best.yaml'))
         self.best = best
+
+    def _write_yaml(self, best, path):
+        """best.to_yaml(path), re-serialising only the entries that changed since the last call: a block-style dump of a mapping is
+        the concatenation of the dumps of its entries in key order (checked on the first call), and of ~60 entries two change
+        from checkpoint to checkpoint (2.5 ms -> 0.3 ms per checkpoint, which is per batch of the ring-logged loops)."""
+        import copy
+        import yaml
+        d = best.to_dict()
+        cache = getattr(self, '_yaml_cache', None)
+        if cache is None:
+            full = yaml.safe_dump(d)
+            parts = {k: yaml.safe_dump({k: v}) for k, v in d.items()}
+            if ''.join(parts[k] for k in sorted(d)) != full:
+                self._yaml_cache = False                         # not a plain block mapping after all: always dump in full
+            else:
+                self._yaml_cache = {k: (copy.deepcopy(v), parts[k]) for k, v in d.items()}
+            text = full
+        elif cache is False or set(cache) != set(d):
+            text = yaml.safe_dump(d)
+        else:
+            for k, v in d.items():
+                if cache[k][0] != v:
+                    cache[k] = (copy.deepcopy(v), yaml.safe_dump({k: v}))
+            text = ''.join(cache[k][1] for k in sorted(d))
+        with open(path, 'w') as f:
+            f.write(text)
 
 
 def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch, eval_train, eval_val):
