@@ -490,7 +490,7 @@ int dc_p2point_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pa
 namespace dc {
 
 struct PoseChain {
-  double q[4], s, k, theta;
+  double q[4], s, k, theta, sh, ch;      // sh, ch: sin / cos of theta / 2 (one sincos; the adjoint needs them again)
   bool small;
 };
 
@@ -498,8 +498,9 @@ __device__ __forceinline__ void pose_chain_fwd(const double* d6, double* R, Pose
   const double a0 = d6[3], a1 = d6[4], a2 = d6[5];
   c.theta = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
   c.small = fabs(c.theta) < 1e-6;
-  c.k = c.small ? 0.5 - c.theta * c.theta / 48.0 : sin(0.5 * c.theta) / c.theta;
-  c.q[0] = cos(0.5 * c.theta); c.q[1] = a0 * c.k; c.q[2] = a1 * c.k; c.q[3] = a2 * c.k;
+  sincos(0.5 * c.theta, &c.sh, &c.ch);
+  c.k = c.small ? 0.5 - c.theta * c.theta / 48.0 : c.sh / c.theta;
+  c.q[0] = c.ch; c.q[1] = a0 * c.k; c.q[2] = a1 * c.k; c.q[3] = a2 * c.k;
   const double r = c.q[0], i = c.q[1], j = c.q[2], k = c.q[3];
   c.s = 2.0 / (r * r + i * i + j * j + k * k);
   const double s = c.s;
@@ -525,9 +526,9 @@ __device__ __forceinline__ void pose_chain_bwd(const double* d6, const PoseChain
   dr += 2.0 * r * dn; di += 2.0 * i * dn; dj += 2.0 * j * dn; dk += 2.0 * k * dn;
   const double a0 = d6[3], a1 = d6[4], a2 = d6[5];
   const double dkk = a0 * di + a1 * dj + a2 * dk;            // through q_vec = a * k
-  double dtheta = -0.5 * sin(0.5 * c.theta) * dr;            // through q0 = cos(theta / 2)
+  double dtheta = -0.5 * c.sh * dr;                          // through q0 = cos(theta / 2)
   dtheta += c.small ? -(c.theta / 24.0) * dkk
-                    : (0.5 * cos(0.5 * c.theta) / c.theta - sin(0.5 * c.theta) / (c.theta * c.theta)) * dkk;
+                    : (0.5 * c.ch / c.theta - c.sh / (c.theta * c.theta)) * dkk;
   const double inv = c.theta > 0.0 ? 1.0 / c.theta : 0.0;     // d|a|/da = a / |a|, zero at the origin
   g_aa[0] = c.k * di + a0 * inv * dtheta;
   g_aa[1] = c.k * dj + a1 * inv * dtheta;

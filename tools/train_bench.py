@@ -3,7 +3,7 @@
 workload (10 x 200k-point room scans, K = 10, ScaledPolynomial, min-eigenvalue loss, model weights only) and on the C4 shape
 (ring scans, pre-filters, radius neighbourhoods, point-to-plane ICP, model + per-pose corrections).
 
-    python3 tools/train_bench.py [--c2-iters 400] [--c4-iters 200] [--loop-batch 16]"""
+    python3 tools/train_bench.py [--c2-iters 2000] [--c4-iters 2000] [--loop-batch 64]"""
 import argparse
 import contextlib
 import io
@@ -37,8 +37,8 @@ def timed_train(cfg, train_ds, n_short, n_long):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--c2-iters', type=int, default=400)
-    ap.add_argument('--c4-iters', type=int, default=200)
+    ap.add_argument('--c2-iters', type=int, default=2000)
+    ap.add_argument('--c4-iters', type=int, default=2000)
     ap.add_argument('--loop-batch', type=int, default=64)
     ap.add_argument('--skip-c4', action='store_true')
     args = ap.parse_args()
@@ -54,7 +54,7 @@ def main():
     seq = [(c, p) for c, p in ds]
     for batch in (args.loop_batch, 1):
         cfg.loop_batch = batch
-        ms, raw = timed_train(cfg, [seq], 50, 50 + args.c2_iters)
+        ms, raw = timed_train(cfg, [seq], 50, 50 + (args.c2_iters if batch > 1 else min(args.c2_iters, 400)))
         out['c2_train_iteration_ms' + ('' if batch > 1 else '_loop_batch_1')] = ms
     # ---- C2 with per-pose corrections (scripts/model_poses_learning:71): the map-consistency loss, model + poses optimised
     from depth_correction_amd.plan import KernelTimer
@@ -72,7 +72,7 @@ def main():
         out['c4_points'] = int(sum(len(c) for c, _ in seq4))
         for batch in (args.loop_batch, 1):
             cfg4.loop_batch = batch
-            ms, raw = timed_train(cfg4, [seq4], 30, 30 + args.c4_iters)
+            ms, raw = timed_train(cfg4, [seq4], 30, 30 + (args.c4_iters if batch > 1 else min(args.c4_iters, 200)))
             out['c4_train_iteration_ms' + ('' if batch > 1 else '_loop_batch_1')] = ms
     print(json.dumps(out))
 
