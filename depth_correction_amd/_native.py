@@ -61,7 +61,8 @@ _SIGNATURES = {
     'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_pose_train_finish': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f64, _f64, _f64, _f64, _f64,
-                                    _vp, _vp, _i32, _vp, _vp, _vp]),
+                                    _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    'dc_pose_train_combine': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     'dc_table_permute': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'dc_scan_lattice_workspace_bytes': (_sz, [_i32]),
     'dc_scan_lattice_shift': (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -595,6 +595,7 @@ __global__ __launch_bounds__(kBlock) void pose_correct_kernel(const double* __re
 struct PoseTrainArgs {
   const double* sums;
   int n_sums, count_index, grad_w_off, grad_T_off;      // layout of `sums`; count_index < 0: the gradients are those of the loss itself
+  const double* totals;                                 // or nullptr: {loss, divisor, dL/dw [P]} over ALL sequences of the loss (dc_pose_train_combine)
   int n_terms, n_scans, n_deltas, zero_first;
   double *w, *w_m, *w_v;                 // w == nullptr: the model is not optimised (validation sequences)
   const double* T0;                      // [S, 16]
@@ -607,6 +608,27 @@ struct PoseTrainArgs {
   double* T_next;                        // [S, 16]
   double* P12_next;                      // [S, 12]
 };
+
+// {loss, divisor, dL/dw} of a loss over several sequences (eval.py:85-112 sums the sequences' sums and counts; icp_loss averages the
+// sequences' losses, loss.py:403): layout 0: {sum of sums, sum of counts, ...}; layout 1: {sum of losses, number of sequences, ...}.
+constexpr int kTrainSeqs = 16;
+struct PoseCombineArgs {
+  const double* outs[kTrainSeqs];
+  int n_seq, layout, n_terms;
+  double* totals;
+};
+__global__ void pose_train_combine_kernel(PoseCombineArgs a) {
+  const int q = threadIdx.x;                     // 0: loss, 1: divisor, 2 + k: dL/dw_k
+  if (q >= 2 + a.n_terms) return;
+  const int head = a.layout == 0 ? 2 : 1;
+  double s = 0.0;
+  for (int i = 0; i < a.n_seq; ++i) {            // fixed order
+    if (q == 0) s += a.outs[i][0];
+    else if (q == 1) s += a.layout == 0 ? a.outs[i][1] : 1.0;
+    else s += a.outs[i][head + (q - 2)];
+  }
+  a.totals[q] = s;
+}
 
 __device__ __forceinline__ double adam_one(double p0, double& m, double& v, double g, double lr, double b1, double b2, double eps,
                                            double bias1, double bias2_sqrt) {
@@ -632,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
   }
   const double t = (double)(*a.step + 1);
   const double bias1 = 1.0 - pow(a.b1, t), bias2_sqrt = sqrt(1.0 - pow(a.b2, t));
-  const double gscale = a.count_index >= 0 ? 1.0 / a.sums[a.count_index] : 1.0;
+  const double gscale = a.totals ? 1.0 / a.totals[1] : (a.count_index >= 0 ? 1.0 / a.sums[a.count_index] : 1.0);
   const double* gT = a.sums + a.grad_T_off;
   double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int p = tid; p < S; p += kBlock) {
@@ -679,7 +701,8 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
   }
   if (a.w && tid < P) {
     double m = a.w_m[tid], v = a.w_v[tid];
-    a.w[tid] = adam_one(a.w[tid], m, v, a.sums[a.grad_w_off + tid] * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+    const double gw = a.totals ? a.totals[2 + tid] : a.sums[a.grad_w_off + tid];
+    a.w[tid] = adam_one(a.w[tid], m, v, gw * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
     a.w_m[tid] = m; a.w_v[tid] = v;
   }
   __syncthreads();                                             // the corrections are updated; the step counter and T_used have been read
@@ -727,10 +750,24 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
   return err == hipSuccess ? DC_OK : (int)err;
 }
 
+int dc_pose_train_combine(const double* const* outs, int n_seq, int layout, int n_terms, double* totals, hipStream_t stream) {
+  if (!outs || n_seq < 1 || n_seq > dc::kTrainSeqs || (layout != 0 && layout != 1) || n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !totals)
+    return DC_ERR_ARG;
+  dc::PoseCombineArgs a{};
+  for (int i = 0; i < n_seq; ++i) {
+    if (!outs[i]) return DC_ERR_ARG;
+    a.outs[i] = outs[i];
+  }
+  a.n_seq = n_seq; a.layout = layout; a.n_terms = n_terms; a.totals = totals;
+  hipLaunchKernelGGL(dc::pose_train_combine_kernel, dim3(1), dim3(64), 0, stream, a);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
 int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
                          double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
                          double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
-                         double* poses12_next, hipStream_t stream) {
+                         double* poses12_next, const double* totals, hipStream_t stream) {
   if (!sums || n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || n_scans < 1 || (n_deltas != 1 && n_deltas != n_scans) || !poses0 || !deltas ||
       !d_m || !d_v || !step || !poses_used || !poses_next || !poses12_next || (w && (!w_m || !w_v)) || (record && ring_rows < 1))
     return DC_ERR_ARG;
@@ -738,7 +775,7 @@ int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scan
   if (layout != 0 && layout != 1) return DC_ERR_ARG;
   // layout 0: dc_sequence_eval {sum, count, d/dw, d/de, d/d[R|t]}; 1: dc_p2plane_sequence / dc_p2point_sequence {loss, d/dw, d/de, d/d[R|t]}
   const int head = layout == 0 ? 2 : 1;
-  dc::PoseTrainArgs a{sums, head + 2 * n_terms + 12 * n_scans, layout == 0 ? 1 : -1, head, head + 2 * n_terms,
+  dc::PoseTrainArgs a{sums, head + 2 * n_terms + 12 * n_scans, layout == 0 ? 1 : -1, head, head + 2 * n_terms, totals,
                       n_terms, n_scans, n_deltas, zero_first, w, w_m, w_v, poses0, deltas, d_m, d_v, step, lr_w, lr_d, beta1, beta2, eps,
                       poses_used, record, ring_rows, poses_next, poses12_next};
   hipLaunchKernelGGL(dc::pose_train_finish_kernel, dim3(1), dim3(dc::kBlock), 0, stream, a);

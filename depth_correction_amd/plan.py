@@ -777,7 +777,7 @@ class PoseSequenceTrainer:
         ops.IcpSequence (point-to-plane / point-to-point ICP loss of the sequence's scan pairs)."""
         dev = plan.device
         S = plan.n_scans
-        self.plan, self.S, self.nt = plan, S, int(n_terms)
+        self.plan, self.S, self.nt, self.device = plan, S, int(n_terms), dev
         self.icp = icp_model_kind is not None
         self.icp_kind = icp_model_kind or None
         self.head = 1 if self.icp else 2
@@ -813,14 +813,25 @@ class PoseSequenceTrainer:
         return float(row[0] / row[1]) if row[1] > 0 else float('nan')
 
     @on_device
-    def finish(self, w=None, w_m=None, w_v=None, lr_w=0.0, ring=None):
+    def finish(self, w=None, w_m=None, w_v=None, lr_w=0.0, ring=None, totals=None):
         """Backward through the pose chain, the optimiser steps, the next iteration's poses (in place); row (step mod rows) of
         ``ring`` [rows, record_len] <- {sums, weights, corrections, corrected poses} of THIS iteration.  Every pointer is the same
         from call to call (the ring slot follows the device step counter): a captured iteration replays correctly."""
         check(lib().dc_pose_train_finish(ptr(self.out), 1 if self.icp else 0, self.nt, self.S, ptr(w), ptr(w_m), ptr(w_v), ptr(self.T0), ptr(self.delta),
                                          ptr(self.d_m), ptr(self.d_v), self.nd, self.zero_first, ptr(self.step), float(lr_w), self.lr,
                                          self.betas[0], self.betas[1], self.eps, ptr(self.T), ptr(ring), 0 if ring is None else ring.shape[0],
-                                         ptr(self.T), ptr(self.P12), stream_ptr()), 'dc_pose_train_finish')
+                                         ptr(self.T), ptr(self.P12), ptr(totals), stream_ptr()), 'dc_pose_train_finish')
+
+    @staticmethod
+    @on_device
+    def combine(trainers, totals):
+        """totals [2 + P] <- {loss, divisor, dL/dw} over the sequences of one loss (dc_pose_train_combine); the trainers have
+        evaluated.  Several sequences: every finish() of the group then takes ``totals``."""
+        t0 = trainers[0]
+        arr = (ctypes.c_void_p * len(trainers))(*[t.out.data_ptr() for t in trainers])
+        check(lib().dc_pose_train_combine(ctypes.cast(arr, ctypes.c_void_p), len(trainers), 1 if t0.icp else 0, t0.nt, ptr(totals),
+                                          stream_ptr()), 'dc_pose_train_combine')
+        return totals
 
     def split_record(self, row):
         """(sums, weights, corrections [nd,6], corrected poses [S,4,4]) of a record row (a CPU tensor)."""

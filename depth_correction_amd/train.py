@@ -518,9 +518,10 @@ def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_p
 
 def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, train_poses, train_masks, train_ns, train_pose_deltas,
                            val_clouds, val_poses, val_masks, val_ns, val_pose_deltas):
-    """(train plan, [validation plans]) when the loop WITH per-pose / per-sequence corrections can run on plan.PoseSequenceTrainer --
-    one training sequence and at most one validation sequence through the fused min-eigenvalue / trace loss without inlier
-    gating, the weights of a polynomial model and the corrections optimised by Adam as train() builds it -- else None."""
+    """([train plans], [validation plans]) when the loop WITH per-pose / per-sequence corrections can run on plan.PoseSequenceTrainer
+    -- up to sixteen training and validation sequences through the fused min-eigenvalue / trace loss without inlier gating, or
+    through the ICP losses; the weights of a polynomial model and the corrections optimised by Adam as train() builds it -- else
+    None."""
     from .eval import _plan_for, fused_supported
     from .optim import Adam
     kw = cfg.loss_kwargs
@@ -536,12 +537,12 @@ def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, t
         ok_loss = (fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
                    and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
                    and not kw.get('only_finite') and not kw.get('skip_nans'))
-    if not (cfg.pose_correction in (PoseCorrection.pose, PoseCorrection.sequence) and len(train_clouds) == 1 and len(val_clouds) <= 1
+    if not (cfg.pose_correction in (PoseCorrection.pose, PoseCorrection.sequence) and 1 <= len(train_clouds) <= 16 and len(val_clouds) <= 16
             and isinstance(optimizer, Adam) and (val_optimizer is None or isinstance(val_optimizer, Adam)) and ok_loss
             and isinstance(w, torch.nn.Parameter) and [id(p) for p in model.parameters()] == [id(w)]
             and w.is_cuda and w.dtype == torch.float64 and w.is_contiguous() and 1 <= w.numel() <= 3
             and model.kernel_params()[0] is w and not model.kernel_params()[1].requires_grad
-            and train_pose_deltas[0] is not None and all(d is not None for d in val_pose_deltas)
+            and all(d is not None for d in list(train_pose_deltas) + list(val_pose_deltas))
             and (bool(val_clouds) == (val_optimizer is not None))):
         return None
     groups = optimizer.param_groups
@@ -555,22 +556,25 @@ def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, t
         return None
     if icp:
         from .loss import _icp_sequence_plan
-        plan = _icp_sequence_plan(train_clouds[0], train_masks[0], True, plane)
+        plans = [_icp_sequence_plan(c, m, True, plane) for c, m in zip(train_clouds, train_masks)]
         vplans = [_icp_sequence_plan(c, m, True, plane) for c, m in zip(val_clouds, val_masks)]
-        return plan, vplans
-    plan = _plan_for(train_clouds[0], train_poses[0], train_ns[0], train_masks[0], model, cfg)
+        return plans, vplans
+    plans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(train_clouds, train_poses, train_ns, train_masks)]
     vplans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(val_clouds, val_poses, val_ns, val_masks)]
-    return plan, vplans
+    return plans, vplans
 
 
-def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_poses, val_poses, train_pose_deltas, val_pose_deltas,
+def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train_poses, val_poses, train_pose_deltas, val_pose_deltas,
                       batch):
     """train()'s loop with pose corrections on the library's own launches (plan.PoseSequenceTrainer): per iteration and sequence
     one evaluation (the pose kernel + its reduction) and ONE finishing launch that back-propagates through the pose chain, keeps
     the first pose fixed, takes both Adam updates, forms the next iteration's poses and writes the iteration's record into the
     log's ring -- against ~35 small launches of tensor glue per iteration around the same evaluation otherwise (0.26 -> 0.11 ms
-    at C2).  Bookkeeping as in _batched_loop: one synchronisation per ``batch`` iterations.  The corrections are optimised in
-    fp64 and written back to the caller's tensors (whatever their dtype) at every synchronisation."""
+    at C2).  Several sequences: their sums are joined on the device (dc_pose_train_combine: the loss of eval.py:85-112 divides the
+    sum of the sequences' sums by the sum of their counts, icp_loss averages their losses) and every finishing launch scales by
+    the joint divisor; the first sequence's also steps the weights.  Bookkeeping as in _batched_loop: one synchronisation per
+    ``batch`` iterations.  The corrections are optimised in fp64 and written back to the caller's tensors (whatever their dtype)
+    when the loop ends."""
     from .plan import PoseSequenceTrainer
     dev = torch.device(cfg.device)
     n_it, R = cfg.n_opt_iters, batch
@@ -582,55 +586,77 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_
     g_d = groups[-1]
     zero_first = cfg.pose_correction == PoseCorrection.pose
     icp_kind = model.kernel_kind if cfg.loss == 'icp_loss' else None
-    tr = PoseSequenceTrainer(plan, train_poses[0], train_pose_deltas[0], zero_first, g_d['lr'], g_d['betas'], g_d['eps'], n_terms=nt,
-                             icp_model_kind=icp_kind)
+    trs = [PoseSequenceTrainer(p_, T, d, zero_first, g_d['lr'], g_d['betas'], g_d['eps'], n_terms=nt, icp_model_kind=icp_kind)
+           for p_, T, d in zip(plans, train_poses, train_pose_deltas)]
+    tr, plan = trs[0], plans[0]
     vtr = [PoseSequenceTrainer(vp, T, d, zero_first, val_optimizer.param_groups[0]['lr'], g_d['betas'], g_d['eps'], n_terms=nt,
                                icp_model_kind=icp_kind)
            for vp, T, d in zip(vplans, val_poses, val_pose_deltas)]
     lr_w = groups[0]['lr'] if cfg.optimize_model else 0.0
     w_m, w_v = (torch.zeros_like(w), torch.zeros_like(w)) if cfg.optimize_model else (None, None)
-    ring = torch.zeros((R, tr.record_len), dtype=torch.float64, device=dev)
+    rings = [torch.zeros((R, t_.record_len), dtype=torch.float64, device=dev) for t_ in trs]
     vrings = [torch.zeros((R, v.record_len), dtype=torch.float64, device=dev) for v in vtr]
+    # several sequences in a loss: their sums joined on the device, every finishing launch scaled by the joint divisor
+    totals = torch.zeros((2 + nt,), dtype=torch.float64, device=dev) if len(trs) > 1 else None
+    vtotals = torch.zeros((2 + nt,), dtype=torch.float64, device=dev) if len(vtr) > 1 else None
     sd_const = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
     d_dtype, T_dtype = train_pose_deltas[0].dtype, train_poses[0].dtype
+    all_plans = list(plans) + list(vplans)
     book = _Bookkeeper(cfg, model)
 
     def fetch():
         """The ring on the host (synchronises: every launched iteration has finished)."""
-        return ring.cpu(), [v.cpu() for v in vrings], (plan.status_bits() if hasattr(plan, 'status_bits') else 0)
+        bits = 0
+        hs, hv = [r_.cpu() for r_ in rings], [v.cpu() for v in vrings]          # synchronises
+        for p_ in all_plans:
+            bits |= p_.status_bits() if hasattr(p_, 'status_bits') else 0
+        return hs, hv, bits
 
     def bookkeep(fetched, first, upto):
-        h, hv, bits = fetched
+        hs, hv, bits = fetched
         if bits and bits & plan.STATUS_OVERFLOW:
             warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
                           'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
                           % (first, upto - 1))
-        H, HV = h.numpy(), [v.numpy() for v in hv]
+        HS, HV = [h.numpy() for h in hs], [v.numpy() for v in hv]
         a0 = tr.head + 2 * nt + 12 * plan.n_scans
 
-        def payload_of(row):
+        def joint_loss(group, rows):
+            if tr.icp:                                                # icp_loss: the mean of the sequences' losses (loss.py:403)
+                return float(sum(r_[0] for r_ in rows) / len(rows))
+            cnt = float(sum(r_[1] for r_ in rows))                    # eval.py:85-112: sum of the sums / sum of the counts
+            return float(sum(r_[0] for r_ in rows)) / cnt if cnt > 0 else float('nan')
+
+        def payload_of(rows):
             def build():
-                _, w_used, d_used, T_used = tr.split_record(torch.from_numpy(row))
+                parts = [t_.split_record(torch.from_numpy(r_)) for t_, r_ in zip(trs, rows)]
                 sd = dict(sd_const)
-                sd[w_key] = w_used.reshape(w_param.shape).to(w_param.dtype).clone()
-                return sd, [d_used.to(d_dtype).clone()], [T_used.to(T_dtype).clone()]
+                sd[w_key] = parts[0][1].reshape(w_param.shape).to(w_param.dtype).clone()
+                return sd, [p_[2].to(d_dtype).clone() for p_ in parts], [p_[3].to(T_dtype).clone() for p_ in parts]
             return build
 
         for it in range(first, upto):
-            row = H[it % R]
-            tl = tr.loss_of(row)
-            vl = vtr[0].loss_of(HV[0][it % R]) if vtr else tl
-            book.record_fast(it, tl, vl, w_key, row[a0:a0 + nt], payload_of(row.copy()))
+            rows = [H[it % R] for H in HS]
+            tl = joint_loss(trs, rows)
+            vl = joint_loss(vtr, [V[it % R] for V in HV]) if vtr else tl
+            book.record_fast(it, tl, vl, w_key, rows[0][a0:a0 + nt], payload_of([r_.copy() for r_ in rows]))
         book.end_batch()
 
     def body():
-        tr.evaluate(w, e)
+        for t_ in trs:
+            t_.evaluate(w, e)
         for v in vtr:
             v.evaluate(w, e)                                         # validation with the weights of THIS iteration
-        tr.finish(w if cfg.optimize_model else None, w_m, w_v, lr_w, ring)
+        if totals is not None:
+            PoseSequenceTrainer.combine(trs, totals)
+        if vtotals is not None:
+            PoseSequenceTrainer.combine(vtr, vtotals)
+        for q, (t_, r_) in enumerate(zip(trs, rings)):               # the first sequence's launch also steps the weights
+            first = q == 0 and cfg.optimize_model
+            t_.finish(w if first else None, w_m if first else None, w_v if first else None, lr_w if first else 0.0, r_, totals)
         for v, vr in zip(vtr, vrings):
-            v.finish(None, None, None, 0.0, vr)
+            v.finish(None, None, None, 0.0, vr, vtotals)
 
     state = dict(launched=0, graph=None, tried=False)
 
@@ -680,9 +706,8 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plan, vplans, train_
         raise
     finally:
         with torch.no_grad():                                         # the caller's tensors follow the optimisation
-            train_pose_deltas[0].copy_(tr.delta)
-            for d, v in zip(val_pose_deltas, vtr):
-                d.copy_(v.delta)
+            for d, t_ in zip(list(train_pose_deltas) + list(val_pose_deltas), trs + vtr):
+                d.copy_(t_.delta)
         torch.autograd.graph.increment_version(w_param)            # written through its pointer
     return book.best
 

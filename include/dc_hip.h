@@ -308,11 +308,17 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
  * poses12_next [S,12] <- poses0 corrected by the UPDATED deltas: the poses of the next evaluation (poses_next may be poses_used:
  * it is read first).  record (or NULL): a ring of ring_rows rows of fp64 [2 + 2 P + 12 S | P | 6 n_deltas | 12 S]; row (*step mod
  * ring_rows) <- sums, and the weights, corrections and corrected poses (rows [R|t]) this iteration used -- the slot follows the
- * device counter, so a captured iteration replays into the right one.  All arrays device fp64. */
+ * device counter, so a captured iteration replays into the right one.  totals (or NULL): the loss runs over SEVERAL sequences
+ * (eval.py:85-112 divides the sum of the sequences' sums by the sum of their counts; icp_loss averages their losses, loss.py:403) --
+ * dc_pose_train_combine's {loss, divisor, dL/dw [P]} over all of them: gradients are then scaled by 1 / totals[1] and the weights
+ * step with totals[2..] (pass w for ONE sequence of the group only).  All arrays device fp64. */
 int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
                          double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
                          double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
-                         double* poses12_next, dcStream_t stream);
+                         double* poses12_next, const double* totals, dcStream_t stream);
+/* totals fp64 [2 + P] <- {sum of outs[i][0], layout 0: sum of outs[i][1] (the counts) / layout 1: n_seq, sum of the sequences'
+ * dL/dw}; outs: HOST array of n_seq <= 16 device pointers (the `sums` of every sequence of the loss), fixed order. */
+int dc_pose_train_combine(const double* const* outs, int n_seq, int layout, int n_terms, double* totals, dcStream_t stream);
 
 /* Scan-shadow filter: filters.filter_shadow_points filters.py:257-309 on the direction neighbourhoods of
  * DepthCloud.update_dir_neighbors depth_cloud.py:217-224 (radius search on the unit directions: dc_radius_*).

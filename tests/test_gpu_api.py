@@ -1039,7 +1039,8 @@ def test_train_batched_graph_loop_equals_plain_loop(golden, tmp_path, capsys, mo
     assert n_plain == sum(f0) and 1 <= n_fast <= 3
 
 
-@pytest.mark.parametrize('correction, float_type, with_val', [('pose', 'float64', True), ('pose', 'float32', False), ('sequence', 'float64', True)])
+@pytest.mark.parametrize('correction, float_type, with_val', [('pose', 'float64', True), ('pose', 'float32', False), ('sequence', 'float64', True),
+                                                              ('pose', 'float64', 'multi'), ('sequence', 'float64', 'multi')])
 def test_train_native_pose_loop_equals_plain_loop(golden, tmp_path, capsys, monkeypatch, correction, float_type, with_val):
     """train() with per-pose / per-sequence corrections on the map-consistency loss (scripts/model_poses_learning:71) runs on
     train._native_pose_loop: per iteration the evaluation and ONE finishing launch (dc_pose_train_finish: pose-chain adjoint, first
@@ -1057,6 +1058,8 @@ def test_train_native_pose_loop_equals_plain_loop(golden, tmp_path, capsys, monk
                               model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
     ds = list(zip(_scan_arrays(g), g['poses']))
     tr_ds, va_ds = [ds], ([ds[:2]] if with_val else [])
+    if with_val == 'multi':                  # several sequences in both losses: sums joined on the device (dc_pose_train_combine)
+        tr_ds, va_ds = [ds, ds[1:]], [ds[:2], ds[2:]]
     (tmp_path / 'plain').mkdir()
     (tmp_path / 'fast').mkdir()
     b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), tr_ds, va_ds, capsys)
@@ -1071,18 +1074,21 @@ def test_train_native_pose_loop_equals_plain_loop(golden, tmp_path, capsys, monk
     for k in sa:
         np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=tol, atol=1e-12)
     da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
-    assert len(da) == len(db) == 1 and da[0].shape == db[0].shape and da[0].dtype == db[0].dtype
-    scale = np.abs(da[0].cpu().numpy()).max()
-    assert scale > 0
+    assert len(da) == len(db) == len(tr_ds)
     # (float32: the plain loop's Adam rounds moments and corrections to float32 at every step)
     dtol = 1e-7 if float_type == 'float64' else 1e-4
-    np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=dtol, atol=dtol * scale)
-    if correction == 'pose':
-        assert not db[0][0].any()                                      # the first pose stays where it is (train.py:309-311)
     pa = torch.load(b0.model_state_dict.replace('_state_dict.pth', '_poses_upd.pth'))
     pb = torch.load(b1.model_state_dict.replace('_state_dict.pth', '_poses_upd.pth'))
-    assert len(pa) == len(pb) == 1 and pa[0].shape == pb[0].shape
-    np.testing.assert_allclose(pb[0].cpu().numpy(), pa[0].cpu().numpy(), rtol=0, atol=dtol * 10)
+    assert len(pa) == len(pb) == len(tr_ds)
+    for q in range(len(tr_ds)):
+        assert da[q].shape == db[q].shape and da[q].dtype == db[q].dtype
+        scale = np.abs(da[q].cpu().numpy()).max()
+        assert scale > 0
+        np.testing.assert_allclose(db[q].cpu().numpy(), da[q].cpu().numpy(), rtol=dtol, atol=dtol * scale)
+        if correction == 'pose':
+            assert not db[q][0].any()                                  # the first pose stays where it is (train.py:309-311)
+        assert pa[q].shape == pb[q].shape
+        np.testing.assert_allclose(pb[q].cpu().numpy(), pa[q].cpu().numpy(), rtol=0, atol=dtol * 10)
 
 
 @pytest.mark.parametrize('n_it, batch, graph', [(1, 4, True), (2, 2, True), (7, 2, True), (7, 3, False)])
@@ -1107,8 +1113,8 @@ def test_train_native_pose_loop_short_runs_and_small_batches(golden, tmp_path, c
     np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize('plane', [True, False])
-def test_train_native_icp_pose_loop_equals_plain_loop(tmp_path, capsys, monkeypatch, plane):
+@pytest.mark.parametrize('plane, multi', [(True, False), (False, False), (True, True)])
+def test_train_native_icp_pose_loop_equals_plain_loop(tmp_path, capsys, monkeypatch, plane, multi):
     """The C4 shape -- ICP loss over consecutive scan pairs (point to plane / point to point), model weights and per-pose corrections
     optimised (scripts/model_poses_learning_icp) -- on train._native_pose_loop: dc_p2plane_sequence / dc_p2point_sequence +
     dc_pose_train_finish (layout 1) per iteration, against the reference's loop with cfg.loop_batch = 1."""
@@ -1128,11 +1134,12 @@ def test_train_native_icp_pose_loop_equals_plain_loop(tmp_path, capsys, monkeypa
         return c
     c0 = mk(tmp_path)
     seq = [(filtered_cloud(cloud, c0), pose) for cloud, pose in KittiLikeDataset(n_poses=3, n_rings=96, n_azimuth=384)]
+    seqs = [seq, seq[1:]] if multi else [seq]                        # (several sequences: icp_loss averages their losses)
     (tmp_path / 'plain').mkdir()
     (tmp_path / 'fast').mkdir()
-    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), [seq], [], capsys)
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), seqs, [], capsys)
     assert took == []
-    b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'fast', loop_batch=4), [seq], [], capsys)
+    b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'fast', loop_batch=4), seqs, [], capsys)
     assert took == ['_native_pose_loop'], took
     assert len(l0) == len(l1) == 11 and f0 == f1 and any(f0)
     np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-8, atol=1e-12)
@@ -1141,8 +1148,10 @@ def test_train_native_icp_pose_loop_equals_plain_loop(tmp_path, capsys, monkeypa
     for k in sa:
         np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-8, atol=1e-13)
     da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
-    assert not db[0][0].any()                                        # (the checkpoint is the best iteration's: possibly the first)
-    np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=1e-7, atol=1e-10)
+    assert len(da) == len(db) == len(seqs)
+    for q in range(len(seqs)):
+        assert not db[q][0].any()                                    # (the checkpoint is the best iteration's: possibly the first)
+        np.testing.assert_allclose(db[q].cpu().numpy(), da[q].cpu().numpy(), rtol=1e-7, atol=1e-10)
 
 
 def test_train_native_loop_recovers_from_a_chain_timeout(golden, tmp_path, capsys, monkeypatch):
