@@ -1212,16 +1212,24 @@ __global__ __launch_bounds__(kBlock) void radius_sort_rows_kernel(int32_t* __res
   if (rowi >= n) return;
   int32_t* s = s_all + wave * N;
   int32_t* row = idx + rowi * kmax;
+  int mine = 0;
   for (int t = lane; t < N; t += kWave) {
     const int32_t id = t < kmax ? row[t] : -1;
     s[t] = id < 0 ? 0x7fffffff : id;
+    mine += id >= 0 ? 1 : 0;
   }
+  // the network of THIS row: the power of two that holds its entries (the template argument is the longest row of the table:
+  // at r = 0.4 m on 0.2 m voxels 290, i.e. 512, while most rows fit 256 -- 45 stages over 256 pairs against 36 over 128)
+  for (int off = kWave / 2; off > 0; off >>= 1) mine += __shfl_xor(mine, off, kWave);
+  const int len = __builtin_amdgcn_readfirstlane(mine);
+  int nr = kWave;
+  while (nr < len) nr <<= 1;
   wave_sync();
 #pragma unroll 1
-  for (int k = 2; k <= N; k <<= 1) {
+  for (int k = 2; k <= nr; k <<= 1) {
 #pragma unroll 1
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < N / 2; t += kWave) {
+      for (int t = lane; t < nr / 2; t += kWave) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // pair t: i and i | j
         const int32_t a = s[i], c = s[i | j];
         const bool up = (i & k) == 0;
