@@ -519,6 +519,43 @@ def test_pose_kernel_equals_three_kernel_path(room, k, n_terms, loss, normalizat
     assert torch.equal(out, out2)
 
 
+def test_ball_neighbourhood_plan_grouped_by_row_length(room):
+    """Ball neighbourhoods (nn_r): SequencePlan(degree_group=True) orders every block's points by (mask, row length) so that rows of
+    similar length share wavefronts of the ragged one-pass kernel -- a pure re-ordering: the same loss, count and dL/dw as the
+    (mask, scan) grouping through the chained step, and the same pose gradients (which then take the un-grouped backward: no scan
+    ranges in such a plan)."""
+    from depth_correction_amd.filters import filter_grid
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import KernelTimer
+    scans, poses = room
+    rng = np.random.default_rng(3)
+    kept = [filter_grid(s[:60_000], 0.15, keep='random', rng=rng) for s in scans[:4]]
+    res = {}
+    for by_degree in (True, False):
+        plan, info = build_sequence(kept, poses[:4], k=None, r=0.3, dtype=torch.float32, degree_group=by_degree)
+        assert (plan.scan_seg is None) == by_degree and plan.fwd_table is not None
+        dev = plan.device
+        w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+        e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+        P = plan.poses12(info['poses'])
+        out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+        with KernelTimer(every=1) as kt:
+            plan.eval_native(w, e, P, out, want_grad=True, want_pose=False)
+            torch.cuda.synchronize()
+            assert kt.kernels()['consistency_fwd'].startswith('consistency_step_ragged_q32_kernel'), kt.kernels()
+        model_only = npy(out).copy()
+        plan.eval_native(w, e, P, out, want_grad=True, want_pose=True)
+        res[by_degree] = (model_only, npy(out).copy())
+    (m1, p1), (m0, p0) = res[True], res[False]
+    assert m1[1] == m0[1] > 1000
+    np.testing.assert_allclose(m1[0], m0[0], rtol=1e-11)
+    np.testing.assert_allclose(m1[2:4], m0[2:4], rtol=1e-6)
+    np.testing.assert_allclose(p1[:2], p0[:2], rtol=1e-9)
+    g1, g0 = p1[6:].reshape(-1, 3, 4), p0[6:].reshape(-1, 3, 4)
+    for s_ in range(4):
+        np.testing.assert_allclose(g1[s_], g0[s_], rtol=1e-6, atol=1e-6 * np.abs(g0[s_]).max())
+
+
 def test_chained_wait_that_expires_is_reported_not_just_nan(room):
     """A chained launch whose blocks give up waiting for their weights (forced: zero polls) must not pass as a number and
     must not look like a q32 overflow: NaN sums AND bit 1 of the status word (SequencePlan.chain_timed_out)."""
