@@ -1521,6 +1521,20 @@ __global__ __launch_bounds__(kBlock) void lattice_localize_kernel(int32_t* __res
   nbr[e] = (int32_t)(v - b);
 }
 
+// Bounding box of a cloud: out[0..2] = min, out[3..5] = max per axis (non-finite coordinates are skipped by the partial kernel's
+// min / max; an empty cloud gives +inf / -inf).
+__global__ void extent_finish_kernel(const double* __restrict__ part, int n_part, double* __restrict__ out) {
+  __shared__ double tot[kBoxVals];
+  combine_box_partials(part, n_part, tot);
+  if (threadIdx.x < 6) out[threadIdx.x] = tot[threadIdx.x];
+}
+
+// out[i] = the scan of row i (scan_ptr: [n_scans + 1] ascending row offsets)
+__global__ __launch_bounds__(kBlock) void scan_ids_kernel(const int64_t* __restrict__ scan_ptr, int n_scans, int64_t n, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = scan_of_row(scan_ptr, n_scans, i);
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -1790,6 +1804,28 @@ int dc_scan_lattice_shift(const void* points, int dtype, int64_t n, const int64_
 int dc_scan_lattice_localize(int32_t* nbr, int64_t n, int k, const int64_t* scan_ptr, int n_scans, int32_t* info, hipStream_t stream) {
   if (!nbr || n < 1 || k < 1 || !scan_ptr || n_scans < 1 || !info) return DC_ERR_ARG;
   hipLaunchKernelGGL(lattice_localize_kernel, dim3((unsigned)((n * k + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, nbr, n, k, scan_ptr, n_scans, info);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+size_t dc_points_extent_workspace_bytes(void) { return (size_t)kBoxBlocks * kBoxVals * sizeof(double); }
+
+int dc_points_extent(const void* points, int stride, int dtype, int64_t n, double* out6, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!points || n < 1 || (stride != 3 && stride != 4) || !out6 || !ws) return DC_ERR_ARG;
+  if (ws_bytes < dc_points_extent_workspace_bytes()) return DC_ERR_WORKSPACE;
+  double* part = (double*)ws;
+  if (dtype == DC_F32) hipLaunchKernelGGL((bbox_partial_kernel<float>), dim3(kBoxBlocks), dim3(kBlock), 0, stream, (const float*)points, stride, n, part);
+  else if (dtype == DC_F64) hipLaunchKernelGGL((bbox_partial_kernel<double>), dim3(kBoxBlocks), dim3(kBlock), 0, stream, (const double*)points, stride, n, part);
+  else return DC_ERR_DTYPE;
+  hipLaunchKernelGGL(extent_finish_kernel, dim3(1), dim3(kBlock), 0, stream, part, kBoxBlocks, out6);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+int dc_scan_ids(const int64_t* scan_ptr, int n_scans, int64_t n, int32_t* out, hipStream_t stream) {
+  if (!scan_ptr || n_scans < 1 || n < 0 || (n > 0 && !out)) return DC_ERR_ARG;
+  if (n == 0) return DC_OK;
+  hipLaunchKernelGGL(scan_ids_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, scan_ptr, n_scans, n, out);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
 }

@@ -16,7 +16,7 @@ __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'table_to_csr', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
     'IcpSequence', 'shadow_mask', 'shadow_filter', 'correct_depth', 'cloud_from_points',
-    'as_index32',
+    'as_index32', 'scan_ids', 'points_extent',
 ]
 
 
@@ -56,6 +56,36 @@ def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
                              float(r) if r else 0.0, float(cell_hint), ptr(idx), ptr(dist), ptr(ws), nbytes,
                              stream_ptr()), 'dc_knn_build')
     return dist, idx
+
+
+def scan_ids(sizes, device):
+    """int32 [sum(sizes)]: the scan of every row of scans concatenated in order (torch.repeat_interleave(arange(S), sizes) in one
+    small launch: dc_scan_ids)."""
+    import numpy as _np
+    n = int(sum(sizes))
+    out = torch.empty((n,), dtype=torch.int32, device=device)
+    if n == 0:
+        return out
+    scan_ptr = torch.as_tensor(_np.concatenate([[0], _np.cumsum(sizes)]).astype(_np.int64), device=device)
+    with torch.cuda.device(out.device):
+        check(lib().dc_scan_ids(ptr(scan_ptr), len(sizes), n, ptr(out), stream_ptr()), 'dc_scan_ids')
+    return out
+
+
+@on_device
+def points_extent(points):
+    """(lo, hi): per-axis minimum and maximum of a cloud [n, 3 | 4] (float32 / float64) as Python lists -- ONE synchronisation
+    (dc_points_extent; the extent the q32 point format is sized for)."""
+    need(points, (None, None), name='points')
+    n, stride = points.shape
+    if n == 0:
+        return [float('inf')] * 3, [float('-inf')] * 3
+    out = torch.empty((6,), dtype=torch.float64, device=points.device)
+    nbytes = lib().dc_points_extent_workspace_bytes()
+    check(lib().dc_points_extent(ptr(points), stride, dtype_code(points), n, ptr(out), ptr(_ws(nbytes, points.device)), nbytes,
+                                 stream_ptr()), 'dc_points_extent')
+    v = out.tolist()
+    return v[:3], v[3:]
 
 
 @on_device

@@ -104,8 +104,7 @@ def global_cloud_arrays(clouds, poses):
     """preproc.global_cloud (preproc.py:80-119) without a model: (points, vps, dirs) of the concatenated cloud."""
     dev = clouds[0]['dirs'].device
     sizes = [len(c['dirs']) for c in clouds]
-    scan_id = torch.repeat_interleave(torch.arange(len(clouds), dtype=torch.int32, device=dev),
-                                      torch.as_tensor(sizes, device=dev))
+    scan_id = ops.scan_ids(sizes, dev)
     cat = lambda f: torch.cat([c[f].reshape(len(c['dirs']), -1) for c in clouds]).contiguous()
     ps = ops.PointSet(cat('vps'), cat('dirs'), cat('depth'), None, None, scan_id)
     P = torch.as_tensor(poses, device=dev).to(torch.float64)[:, :3, :].reshape(len(clouds), 12).contiguous()

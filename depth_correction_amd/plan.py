@@ -78,8 +78,7 @@ class SequencePlan:
         dev = dirs.device
         sizes = [len(get(c, 'dirs')) for c in clouds]
         lmask = None if lms[0] is None else torch.cat(lms).contiguous()
-        scan_id = torch.repeat_interleave(torch.arange(len(clouds), dtype=torch.int32, device=dev),
-                                          torch.as_tensor(sizes, device=dev))
+        scan_id = ops.scan_ids(sizes, dev)
         self.n, self.n_scans, self.device, self.dtype = dirs.shape[0], len(clouds), dev, dirs.dtype
         self._poses_key = self._poses12 = self._poses_ref = None
         self.sizes = sizes
@@ -220,7 +219,7 @@ class SequencePlan:
         self.qfmt = None
         self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
         if point_format in ('auto', 'q32') and self.dtype == torch.float32:
-            lo, hi = (v.tolist() for v in torch.aminmax(x0, dim=0))          # one reduction, one synchronisation
+            lo, hi = ops.points_extent(x0)                                   # one small reduction, one synchronisation
             qfmt = ops.QFormat.for_extent(lo, hi)
             if point_format == 'q32' or qfmt.scale <= ops.QFormat.MAX_AUTO_SCALE:
                 self.qfmt = qfmt

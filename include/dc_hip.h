@@ -101,6 +101,12 @@ size_t dc_scan_lattice_workspace_bytes(int n_scans);
 int dc_scan_lattice_shift(const void* points, int dtype, int64_t n, const int64_t* scan_ptr, int n_scans, double* shifted, int32_t* info,
                           void* ws, size_t ws_bytes, dcStream_t stream);
 int dc_scan_lattice_localize(int32_t* nbr, int64_t n, int k, const int64_t* scan_ptr, int n_scans, int32_t* info, dcStream_t stream);
+/* Bounding box of a cloud [n, stride] (stride 3 or 4): out6 device fp64 <- {min x, y, z, max x, y, z} (the extent a fixed-point point
+ * format is sized for: torch.aminmax over dim 0 of an [n,3] tensor took 1.1 ms at n = 2 M; this takes 0.03).  dc_scan_ids: out[i] =
+ * the scan of row i for rows partitioned by scan_ptr (device int64 [n_scans + 1]): torch.repeat_interleave(arange(S), sizes). */
+size_t dc_points_extent_workspace_bytes(void);
+int dc_points_extent(const void* points, int stride, int dtype, int64_t n, double* out6, void* ws, size_t ws_bytes, dcStream_t stream);
+int dc_scan_ids(const int64_t* scan_ptr, int n_scans, int64_t n, int32_t* out, dcStream_t stream);
 int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int64_t n_dst, int32_t* csr_ptr, int32_t* csr_src, void* ws,
                      size_t ws_bytes, dcStream_t stream);
 
@@ -227,6 +233,9 @@ typedef struct dcBlockTable {
 int dc_block_table_slots(const int32_t* row_ptr, int64_t n_rows, int k, int32_t* slot_cnt_ws, int32_t* slot_ptr,
                          dcStream_t stream);
 size_t dc_block_table_workspace_bytes(int64_t n_refs);
+/* A-B switch (measurements, tests; process-wide, not thread-safe like dc_set_option): 0 = [rows, K] tables through the radix-sort
+ * build as well; returns the previous setting.  Default 1: K = 4 / 8 / 10 / 16 tables are built block by block in LDS. */
+int dc_block_table_set_lds_build(int on);
 int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
                          const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
                          int32_t* info, void* ws, size_t ws_bytes, dcStream_t stream);

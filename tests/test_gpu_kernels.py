@@ -413,6 +413,37 @@ def test_p2plane_golden(golden, dev):
     np.testing.assert_allclose(npy(pd.grad), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize('k', [4, 8, 10, 16])
+def test_block_table_lds_build_equals_radix_build(dev, k):
+    """[rows, K] tables are built block by block in LDS (bt_block_unique_kernel: hash table, bitonic sort of the distinct rows);
+    dc_block_table_set_lds_build(0) sends them through the radix-sort build: identical arrays -- distinct rows ascending per block,
+    positions, own rows -- for every K the LDS build takes, with missing entries, a ragged last block, and blocks whose 256 K
+    references are nearly all distinct."""
+    from depth_correction_amd import ops, _native as nv
+    rng = np.random.default_rng(k)
+    n = 256 * 37 + 91
+    base = np.arange(n)[:, None] + rng.integers(-300, 300, size=(n, k))
+    base[:, 0] = np.arange(n)
+    nbr = np.clip(base, 0, n - 1).astype(np.int32)
+    nbr[256 * 5:256 * 6] = rng.integers(0, n, size=(256, k))            # a block of scattered references (up to 256 K distinct rows)
+    nbr[rng.random((n, k)) < 0.03] = -1
+    nbr[17] = -1                                                       # an empty row
+    x = t(nbr, dev)
+    tabs = []
+    for lds in (1, 0):
+        prev = nv.lib().dc_block_table_set_lds_build(lds)
+        try:
+            tabs.append(ops.block_table(nbr=x))
+        finally:
+            nv.lib().dc_block_table_set_lds_build(prev)
+    a, b = tabs
+    assert a.max_rows == b.max_rows and a.n_rows == b.n_rows
+    for f in ('blk_ptr', 'blk_ids', 'slot_ptr', 'own_base'):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    nslots = int(a.slot_ptr[-1]) * 256
+    assert torch.equal(a.loc[:nslots], b.loc[:nslots])
+
+
 def test_block_table_structure(golden, dev):
     """dc_block_table_build(_runs) against a direct numpy construction: per block of 256 rows the sorted distinct
     references and every reference's position in that list (stored as 16 x position, 0xFFFF = empty), slot-major for a
