@@ -20,6 +20,7 @@ DC_TABLE_SLOTS, DC_TABLE_RUNS = 0, 1
 LOSS_KINDS = {'min_eigval_loss': 0, 'trace_loss': 1}
 DC_LOSS_RAW_POINTWISE, DC_LOSS_SKIP_NANS, DC_LOSS_ONLY_FINITE = 0x100, 0x200, 0x400      # OR-ed into a loss kind (include/dc_hip.h)
 LOSS_RAW_POINTWISE = 0x100
+DC_ERR_ARG, DC_ERR_DTYPE, DC_ERR_WORKSPACE, DC_ERR_UNSUPPORTED = -1, -2, -3, -4       # include/dc_hip.h / csrc/dc_common.h
 DC_ERR_BACKWARD_TABLES = -5
 MODEL_KINDS = {None: 0, 'BaseModel': 0, 'Polynomial': 1, 'ScaledPolynomial': 2, 'Linear': 3, 'InvCos': 4, 'ScaledInvCos': 5}
 MAX_MODEL_TERMS = 8

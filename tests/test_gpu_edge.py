@@ -1,6 +1,8 @@
 """Edge cases of the domain on the GPU: empty and tiny clouds, k larger than the cloud, ragged radius neighbourhoods,
 neighbourhoods with one / zero valid members, duplicate points, non-finite coordinates, sizes around the block and
 window boundaries, the widest k the builder supports."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -433,3 +435,52 @@ def test_knn_row_per_query_kernel_shapes_and_sizes(shape):
             nv.check(nv.lib().dc_knn_set_shell_budget(1000), 'budget')
         d1, i1 = ops.knn(x, 9)
         assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+def test_round4_entry_points_reject_bad_arguments():
+    """Status codes of the C ABI (include/dc_hip.h: 0 ok, < 0 invalid argument, nothing launched): the entry points added in round 4
+    refuse what they cannot serve instead of faulting -- layouts, counts and sizes outside their ranges, missing arrays, in-place
+    calls that would race."""
+    from depth_correction_amd import _native as nv
+    lib, ptr = nv.lib(), nv.ptr
+    dev = torch.device(DEV)
+    f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
+    S, P = 3, 2
+    sums, w, m, v = f64(2 + 2 * P + 12 * S), f64(P), f64(P), f64(P)
+    T0, d, dm, dv, T, P12 = f64(S, 16), f64(S, 6), f64(S, 6), f64(S, 6), f64(S, 16), f64(S, 12)
+    step = torch.zeros((), dtype=torch.int64, device=dev)
+    args = lambda **kw: [kw.get('sums', ptr(sums)), kw.get('layout', 0), kw.get('nt', P), kw.get('ns', S), ptr(w), ptr(m), ptr(v), ptr(T0),
+                         ptr(d), ptr(dm), ptr(dv), kw.get('nd', S), 1, ptr(step), 1e-3, 1e-3, kw.get('b1', 0.9), 0.999, 1e-8, ptr(T),
+                         kw.get('rec', None), kw.get('rows', 0), ptr(T), ptr(P12), None, nv.stream_ptr()]
+    assert lib.dc_pose_train_finish(*args()) == 0
+    for bad in (dict(layout=2), dict(sums=None), dict(nt=0), dict(nt=99), dict(ns=0), dict(nd=2), dict(b1=1.0),
+                dict(rec=ptr(f64(4, 200)), rows=0)):
+        assert lib.dc_pose_train_finish(*args(**bad)) == nv.DC_ERR_ARG, bad
+    outs = (ctypes.c_void_p * 17)(*([sums.data_ptr()] * 17))
+    tot = f64(2 + P)
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    assert lib.dc_pose_train_combine(cast(outs), 2, 0, P, ptr(tot), nv.stream_ptr()) == 0
+    for n_seq, layout, nt in ((0, 0, P), (17, 0, P), (2, 3, P), (2, 0, 0)):
+        assert lib.dc_pose_train_combine(cast(outs), n_seq, layout, nt, ptr(tot), nv.stream_ptr()) == nv.DC_ERR_ARG
+    pts = torch.zeros((10, 3), dtype=torch.float32, device=dev)
+    sp = torch.tensor([0, 4, 10], dtype=torch.int64, device=dev)
+    xs, info = f64(10, 3), i32(1)
+    nb = lib.dc_scan_lattice_workspace_bytes(2)
+    ws = torch.zeros((nb,), dtype=torch.uint8, device=dev)
+    assert lib.dc_scan_lattice_shift(ptr(pts), nv.DC_F32, 10, ptr(sp), 2, ptr(xs), ptr(info), ptr(ws), nb, nv.stream_ptr()) == 0
+    assert lib.dc_scan_lattice_shift(ptr(pts), nv.DC_F32, 10, ptr(sp), 65, ptr(xs), ptr(info), ptr(ws), nb, nv.stream_ptr()) == nv.DC_ERR_ARG
+    assert lib.dc_scan_lattice_shift(ptr(pts), nv.DC_F32, 10, ptr(sp), 2, ptr(xs), ptr(info), ptr(ws), 8, nv.stream_ptr()) == nv.DC_ERR_WORKSPACE
+    assert lib.dc_scan_lattice_shift(ptr(pts), 7, 10, ptr(sp), 2, ptr(xs), ptr(info), ptr(ws), nb, nv.stream_ptr()) == nv.DC_ERR_DTYPE
+    nbr = i32(10, 4)
+    assert lib.dc_scan_lattice_localize(ptr(nbr), 10, 0, ptr(sp), 2, ptr(info), nv.stream_ptr()) == nv.DC_ERR_ARG
+    out6 = f64(6)
+    nb6 = lib.dc_points_extent_workspace_bytes()
+    ws6 = torch.zeros((nb6,), dtype=torch.uint8, device=dev)
+    assert lib.dc_points_extent(ptr(pts), 5, nv.DC_F32, 10, ptr(out6), ptr(ws6), nb6, nv.stream_ptr()) == nv.DC_ERR_ARG
+    assert lib.dc_points_extent(ptr(pts), 3, nv.DC_F32, 10, ptr(out6), ptr(ws6), 16, nv.stream_ptr()) == nv.DC_ERR_WORKSPACE
+    order = torch.arange(10, dtype=torch.int64, device=dev)
+    rank = i32(10)
+    assert lib.dc_table_permute(ptr(nbr), 10, 4, ptr(order), ptr(rank), ptr(nbr), nv.stream_ptr()) == nv.DC_ERR_ARG      # in place
+    assert lib.dc_scan_ids(None, 2, 10, ptr(rank), nv.stream_ptr()) == nv.DC_ERR_ARG
+    torch.cuda.synchronize()
