@@ -616,7 +616,7 @@ def main():
         # the gathers: N K rows of 12 B, each its own cache line when the scan's points are in no spatial order (these rays are
         # drawn at random) -- the kernel is bound by the CUs' vector-memory address pipelines (one line look-up per lane and
         # gather), neither by bytes nor by instructions: tools/ubench/gather_rows.hip measures that floor by itself
-        c1['roofline'] = {'bound': 'L1 line look-ups of the random row gathers (neither roofline: see note)',
+        c1['roofline'] = {'bound': 'hbm', 'limiter': 'L1 line look-ups of the random row gathers (neither roofline: see note)',
                           'achieved': (traffic or comp1) / t_s / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': hbm_frac,
                           'traffic': traffic, 'compulsory_bytes': comp1,
                           'traffic_source': (load_profile_table().get('_paths') or {}).get('source') if prof else
@@ -696,8 +696,10 @@ def main():
                     'algorithmic_GBps': ab[name] * n_local / t_s / 1e9}
             dom = max((n_ for n_ in ('consistency_fwd', 'consistency_bwd') if n_ in ms), key=lambda n_: ms[n_])
             d = per_kernel[dom]
-            bound = 'valu' if (d['valu_frac'] or 0.0) > d['hbm_frac'] else 'hbm'
-            roofline = {'bound': bound, 'kernel': 'dc_sequence_step (one-pass loss + dL/dw kernel)' if one_pass else 'dc_' + dom,
+            # `bound` names the roofline achieved / peak / frac are quoted against (bytes over HBM); `limiter` what the counters say
+            # actually limits the kernel: the vector ALUs' issue rate (fp64 / int VALU work, not MFMA) or the bytes
+            limiter = 'valu' if (d['valu_frac'] or 0.0) > d['hbm_frac'] else 'hbm'
+            roofline = {'bound': 'hbm', 'limiter': limiter, 'kernel': 'dc_sequence_step (one-pass loss + dL/dw kernel)' if one_pass else 'dc_' + dom,
                         'instantiation': d['kernel'],
                         'achieved': d['hbm_GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': d['hbm_frac'],
                         'traffic': d['traffic'],
