@@ -3233,9 +3233,12 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
   RunTab rtab{};
   size_t lds_bytes = 0;
   int lds_rows = 0;
-  // the pose variants hold 16 KB of static LDS for the per-scan sums: keep the staged records within 44 KB
+  // the pose variants hold up to 16 KB of static LDS for the per-scan sums: staged records within 44 KB fit the default 64 KB of a
+  // workgroup; longer lists (ball neighbourhoods: 1 500 centres reference a block at r = 0.4 m) take the run kernel with a larger
+  // dynamic allocation (hipFuncSetAttribute below) -- one or two blocks per CU, but gathers from LDS: un-staged, the backward of the
+  // r = 0.4 m table took 535 us
   const uint32_t rec_row = point_fmt == DC_F64 ? 64u : 32u;
-  const bool by_runs = !lane_perm && use_table(table, DC_TABLE_RUNS, stride, rec_row, 1, 44 * 1024, &lds_bytes, &lds_rows);
+  const bool by_runs = !lane_perm && use_table(table, DC_TABLE_RUNS, stride, rec_row, 1, 128 * 1024, &lds_bytes, &lds_rows);
   const bool staged = by_runs || (!lane_perm && use_table(table, DC_TABLE_SLOTS, stride, rec_row, 1, 44 * 1024, &lds_bytes, &lds_rows));
   if (by_runs) rtab = RunTab{table->blk_ptr, table->blk_ids, table->run_ptr, table->loc};
   else if (staged) tab = BlockTab{table->blk_ptr, table->blk_ids, table->slot_ptr, table->loc};
@@ -3299,6 +3302,23 @@ static int consistency_bwd_impl(const void* points, int stride, int dtype, int p
       else DC_TIMED_LAUNCH((consistency_bwd_kernel<T, PT, S, false, false>), grid, block, 0, stream, BWD_ARGS(T, PT)); \
     } \
   } while (0)
+  if (by_runs && lds_bytes > 44 * 1024) {
+    int attr_rc = DC_OK;
+#define BIG_LDS(T, PT, S) \
+  do { \
+    if (S == 4) { \
+      hipError_t e_; \
+      if (want_pose_grad && want_exponent_grad) e_ = hipFuncSetAttribute((const void*)consistency_bwd_runs_kernel<T, PT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      else if (want_pose_grad) e_ = hipFuncSetAttribute((const void*)consistency_bwd_runs_kernel<T, PT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      else if (want_exponent_grad) e_ = hipFuncSetAttribute((const void*)consistency_bwd_runs_kernel<T, PT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      else e_ = hipFuncSetAttribute((const void*)consistency_bwd_runs_kernel<T, PT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      if (e_ != hipSuccess) attr_rc = (int)e_; \
+    } \
+  } while (0)
+    DC_DISPATCH_FMT(dtype, point_fmt, stride, BIG_LDS);
+#undef BIG_LDS
+    if (attr_rc) return attr_rc;
+  }
   { ProfScope prof(2); DC_DISPATCH_FMT(dtype, point_fmt, stride, LAUNCH); }
 #undef LAUNCH
   DC_CHECK_LAUNCH();

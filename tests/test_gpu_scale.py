@@ -556,6 +556,45 @@ def test_ball_neighbourhood_plan_grouped_by_row_length(room):
         np.testing.assert_allclose(g1[s_], g0[s_], rtol=1e-6, atol=1e-6 * np.abs(g0[s_]).max())
 
 
+def test_ball_pose_backward_with_large_lds_tiles(room):
+    """Pose gradients on ball neighbourhoods of r = 0.4 m (0.2 m voxels: 185 neighbours per point, ~1 500 centres reference a block):
+    the backward's record tile exceeds a workgroup's default LDS and takes the run kernel with a larger dynamic allocation
+    (consistency_bwd_impl) -- the same loss and gradients as the un-staged kernels (dc_set_option(0, 1): gathers from global memory)."""
+    from depth_correction_amd import _native as nv
+    from depth_correction_amd.filters import filter_grid
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import KernelTimer
+    scans, poses = room
+    rng = np.random.default_rng(135)
+    kept = [filter_grid(s, 0.2, keep='random', rng=rng) for s in scans]
+    plan, info = build_sequence(kept, poses, k=None, r=0.4, dtype=torch.float32, degree_group=False)
+    dev = plan.device
+    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
+    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
+    P = plan.poses12(info['poses'])
+    res = []
+    for no_tab in (0, 1):
+        nv.check(nv.lib().dc_set_option(0, no_tab), 'dc_set_option')
+        try:
+            out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+            with KernelTimer(every=1) as kt:
+                plan.eval_native(w, e, P, out, want_grad=True, want_pose=True)
+                torch.cuda.synchronize()
+                name = kt.kernels()['consistency_bwd']
+            assert name.startswith('consistency_bwd_runs_kernel') == (no_tab == 0), name
+            res.append(npy(out).copy())
+        finally:
+            nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
+    assert plan.bwd_table.max_rows * 32 > 44 * 1024                    # the case this test is about
+    a, b = res
+    assert a[1] == b[1] > 10000
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-11)
+    np.testing.assert_allclose(a[2:4], b[2:4], rtol=1e-7)
+    ga, gb = a[6:].reshape(-1, 3, 4), b[6:].reshape(-1, 3, 4)
+    for s_ in range(plan.n_scans):
+        np.testing.assert_allclose(ga[s_], gb[s_], rtol=1e-6, atol=1e-7 * np.abs(gb[s_]).max())
+
+
 def test_chained_wait_that_expires_is_reported_not_just_nan(room):
     """A chained launch whose blocks give up waiting for their weights (forced: zero polls) must not pass as a number and
     must not look like a q32 overflow: NaN sums AND bit 1 of the status word (SequencePlan.chain_timed_out)."""
