@@ -58,7 +58,7 @@ _SIGNATURES = {
     'dc_block_table_slots': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_block_table_workspace_bytes': (_sz, [_i64]),
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'dc_block_group': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'dc_block_group': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_pose_train_finish': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f64, _f64, _f64, _f64, _f64,

@@ -22,7 +22,7 @@
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include "dc_hostutil.h"
-#include <rocprim/rocprim.hpp>
+#include "dc_sort.h"
 
 namespace dc {
 
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kBlock) void bt_info_kernel(const int32_t* __restri
 constexpr int kMaxGroupKeys = 2 * 64 + 1;
 __global__ __launch_bounds__(kBlock) void bt_block_group_kernel(const int32_t* __restrict__ order_in, const int32_t* __restrict__ scan_id,
                                                                 const uint8_t* __restrict__ mask, int64_t n, int n_scans,
-                                                                int32_t* __restrict__ order_out, uint16_t* __restrict__ seg) {
+                                                                int32_t* __restrict__ order_out, uint16_t* __restrict__ seg,
+                                                                uint8_t* __restrict__ blk_skip, int32_t* __restrict__ skipped) {
   constexpr int NW = kBlock / kWave;
   __shared__ int s_cnt[NW][kMaxGroupKeys];
   __shared__ int s_start[kMaxGroupKeys + 1];
@@ -205,6 +206,13 @@ __global__ __launch_bounds__(kBlock) void bt_block_group_kernel(const int32_t* _
   }
   __syncthreads();
   if (tid <= V) seg[(int64_t)blockIdx.x * (V + 1) + tid] = (uint16_t)s_start[tid];
+  if (tid == 0 && (blk_skip || skipped)) {
+    // the block's points inside the mask come first (keys below n_scans): a block without any is skipped by the one-pass kernels,
+    // and of a mixed block the wavefronts behind its last inside point are
+    const int inside = s_start[n_scans], cnt = s_start[V];
+    if (blk_skip) blk_skip[blockIdx.x] = inside == 0 ? 1 : 0;
+    if (skipped) atomicAdd(skipped, (cnt + kWave - 1) / kWave - (inside + kWave - 1) / kWave);
+  }
   if (valid) {
     int pos = s_start[key] + rank_in_wave;
     for (int w = 0; w < wave; ++w) pos += s_cnt[w][key];
@@ -369,10 +377,7 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs) {
   Carver c(nullptr);
   c.take<uint64_t>(ne); c.take<uint64_t>(ne); c.take<uint32_t>(ne); c.take<uint32_t>(ne);
   c.take<uint32_t>(ne); c.take<uint32_t>(ne); c.take<int32_t>(ne);
-  size_t sb = 0, cb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  ne, 0, 64, (hipStream_t)0);
-  (void)rocprim::inclusive_scan(nullptr, cb, (uint32_t*)nullptr, (uint32_t*)nullptr, ne, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  const size_t sb = sort_pairs_bytes(ne, 64), cb = scan_bytes(ne);
   c.take<char>(sb > cb ? sb : cb);
   return c.off + 256;
 }
@@ -415,11 +420,7 @@ static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, in
   uint32_t* heads = c.take<uint32_t>(n_refs);
   uint32_t* rank1 = c.take<uint32_t>(n_refs);
   int32_t* row_of = c.take<int32_t>(n_refs);
-  size_t sb = 0, cb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (size_t)n_refs, 0, 64, (hipStream_t)0);
-  (void)rocprim::inclusive_scan(nullptr, cb, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_refs, rocprim::plus<uint32_t>(),
-                                (hipStream_t)0);
+  const size_t sb = sort_pairs_bytes((size_t)n_refs, 64), cb = scan_bytes((size_t)n_refs);
   void* tmp = c.take<char>(sb > cb ? sb : cb);
   const dim3 block(kBlock);
   if (row_ptr) {
@@ -433,9 +434,9 @@ static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, in
   // references sort behind all blocks, and the sort runs 6 radix passes instead of 8
   unsigned key_bits = 33;
   while (key_bits < 64 && (((uint64_t)1 << (key_bits - 32)) - 1) < (uint64_t)nb) ++key_bits;
-  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, vals, svals, (size_t)n_refs, 0, key_bits, stream));
+  DC_HIP(sort_pairs_u64(tmp, sb, keys, skeys, vals, svals, (size_t)n_refs, 0, key_bits, stream));
   hipLaunchKernelGGL(bt_heads_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, n_refs, heads);
-  DC_HIP(rocprim::inclusive_scan(tmp, cb, heads, rank1, (size_t)n_refs, rocprim::plus<uint32_t>(), stream));
+  DC_HIP(inclusive_scan_32(tmp, cb, heads, rank1, (size_t)n_refs, stream));
   hipLaunchKernelGGL(bt_blk_ptr_kernel, dim3(grid_of(nb + 1)), block, 0, stream, skeys, rank1, n_refs, nb, blk_ptr);
   hipLaunchKernelGGL(bt_scatter_kernel, dim3(grid_of(n_refs)), block, 0, stream, skeys, svals, heads, rank1, rows, row_ptr,
                      n_refs, k, blk_ptr, slot_ptr, run_ptr, blk_ids, loc, info);
@@ -455,11 +456,12 @@ int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int6
 }
 
 int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_t* mask, int64_t n, int n_scans, int32_t* order_out,
-                   uint16_t* seg_out, hipStream_t stream) {
+                   uint16_t* seg_out, uint8_t* blk_skip_out, int32_t* skipped_out, hipStream_t stream) {
   if (n < 0 || n_scans < 1 || n_scans > 64 || !order_in || !scan_id || !order_out || !seg_out || order_in == order_out) return DC_ERR_ARG;
+  if (skipped_out) DC_HIP(hipMemsetAsync(skipped_out, 0, sizeof(int32_t), stream));
   if (n == 0) return DC_OK;
   hipLaunchKernelGGL(bt_block_group_kernel, dim3((unsigned)blocks_of(n)), dim3(kBlock), 0, stream, order_in, scan_id, mask, n, n_scans,
-                     order_out, seg_out);
+                     order_out, seg_out, blk_skip_out, skipped_out);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
@@ -496,13 +498,11 @@ int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_
   // run_ptr = exclusive scan of ceil(length / 4); the scan's scratch and input live in the (not yet used) workspace
   Carver c(ws);
   int32_t* len = c.take<int32_t>((size_t)n_rows + 1);
-  size_t cb = 0;
-  (void)rocprim::exclusive_scan(nullptr, cb, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n_rows + 1, rocprim::plus<int32_t>(),
-                                (hipStream_t)0);
+  const size_t cb = scan_bytes((size_t)n_rows + 1);
   void* tmp = c.take<char>(cb);
   if (c.off > ws_bytes) return DC_ERR_WORKSPACE;
   hipLaunchKernelGGL(bt_run_len_kernel, dim3(grid_of(n_rows + 1)), dim3(kBlock), 0, stream, row_ptr, n_rows, len);
-  DC_HIP(rocprim::exclusive_scan(tmp, cb, len, run_ptr, 0, (size_t)n_rows + 1, rocprim::plus<int32_t>(), stream));
+  DC_HIP(exclusive_scan_32(tmp, cb, len, run_ptr, (size_t)n_rows + 1, stream));
   return block_table_build_impl(row_ptr, ids, n_rows, 0, n_refs, nullptr, run_ptr, dc_block_table_run_capacity(n_rows, n_refs) * 4,
                                 blk_ptr, blk_ids, loc, info, ws, ws_bytes, stream);
 }

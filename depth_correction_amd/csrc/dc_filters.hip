@@ -8,7 +8,7 @@
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
+#include "dc_sort.h"
 
 namespace dc {
 
@@ -268,10 +268,7 @@ static size_t voxel_ws(void* base, int64_t n, int32_t** vox, int32_t** box, uint
   *vals = (int32_t*)take(m * 4); *svals = (int32_t*)take(m * 4);
   *head = (int32_t*)take(m * 4); *run_id = (int32_t*)take(m * 4);
   *skey = (int32_t*)take(m * 4); *surv = (int32_t*)take(m * 4); *skey2 = (int32_t*)take(m * 4);
-  size_t a = 0, b = 0, c = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 63, (hipStream_t)0);
-  (void)rocprim::radix_sort_pairs(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 32, (hipStream_t)0);
-  (void)rocprim::inclusive_scan(nullptr, c, (int32_t*)nullptr, (int32_t*)nullptr, m, rocprim::plus<int32_t>(), (hipStream_t)0);
+  const size_t a = sort_pairs_bytes(m, 64), b = sort_pairs_bytes(m, 32), c = scan_bytes(m);
   *tmp_bytes = a > b ? (a > c ? a : c) : (b > c ? b : c);
   *tmp = take(*tmp_bytes);
   return off + 256;
@@ -344,13 +341,13 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
     hipLaunchKernelGGL((voxel_coords_kernel<double>), grid, block, 0, stream, (const double*)points, stride, n, grid_res, vox, box, box + 4, status_out);
   else return DC_ERR_DTYPE;
   hipLaunchKernelGGL(voxel_keys_kernel, grid, block, 0, stream, vox, seq, n, box, box + 4, status_out, keys, vals);
-  err = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, vals, svals, (size_t)n, 0, 63, stream);
+  err = sort_pairs_u64(tmp, tmp_bytes, keys, skeys, vals, svals, (size_t)n, 0, 63, stream);
   if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL(run_heads_kernel, grid, block, 0, stream, skeys, n, head);
-  err = rocprim::inclusive_scan(tmp, tmp_bytes, head, run_id, (size_t)n, rocprim::plus<int32_t>(), stream);
+  err = inclusive_scan_32(tmp, tmp_bytes, head, run_id, (size_t)n, stream);
   if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL(run_emit_kernel, grid, block, 0, stream, skeys, svals, run_id, seq, n, preserve_order, skey, surv, count_out);
-  err = rocprim::radix_sort_pairs(tmp, tmp_bytes, skey, skey2, surv, out_idx, (size_t)n, 0, 32, stream);
+  err = sort_pairs_u32(tmp, tmp_bytes, skey, skey2, surv, out_idx, (size_t)n, 0, 32, stream);      // (keys never negative)
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;

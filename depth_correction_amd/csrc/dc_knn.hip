@@ -21,7 +21,7 @@
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include "dc_hostutil.h"
-#include <rocprim/rocprim.hpp>
+#include "dc_sort.h"
 
 namespace dc {
 
@@ -1370,9 +1370,8 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
   g.qf64 = c.take<double>(3 * n_query_extra);
   g.pending = c.take<int32_t>(n > n_query_extra ? n : n_query_extra);      // queries the query kernels hand to knn_tail_kernel
   g.n_pending = c.take<int32_t>(16);
-  g.sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, g.sort_bytes, (GridKey*)nullptr, (GridKey*)nullptr, (int32_t*)nullptr,
-                            (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0, kGridKeyBits, (hipStream_t)0);
+  static_assert(sizeof(GridKey) == 4, "the grid keys sort as 32-bit words");
+  g.sort_bytes = sort_pairs_bytes((size_t)(n > 0 ? n : 1), 32);
   g.sort_tmp = c.take<char>(g.sort_bytes);
   g.total = c.off + 256;
   return g;
@@ -1385,7 +1384,7 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   hipLaunchKernelGGL((bbox_partial_kernel<T>), dim3(kBoxBlocks), dim3(kBlock), 0, st, xyz, stride, n, w.part);
   hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(kBlock), 0, st, w.part, kBoxBlocks, n, k, cell_hint, w.grid);
   hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.grid, w.keys, w.ids);
-  DC_HIP(rocprim::radix_sort_pairs(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, kGridKeyBits, st));
+  DC_HIP(sort_pairs_u32(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, kGridKeyBits, st));
   DC_HIP(hipMemsetAsync(w.tab_key, 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
   hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp, w.tab_key, w.tab_n - 1);
   hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, w.tab_key, w.tab_s, w.tab_n - 1);
@@ -1699,9 +1698,7 @@ size_t dc_knn_transpose_workspace_bytes(int64_t n, int k) {
   const int64_t ne = n * k;
   Carver c(nullptr);
   c.take<uint32_t>(ne); c.take<uint32_t>(ne); c.take<int32_t>(ne);
-  size_t sb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                            (size_t)(ne > 0 ? ne : 1), 0, 32, (hipStream_t)0);
+  const size_t sb = sort_pairs_bytes((size_t)(ne > 0 ? ne : 1), 32);
   c.take<char>(sb);
   return c.off + 256;
 }
@@ -1721,15 +1718,13 @@ int dc_knn_transpose(const int32_t* nbr, int64_t n, int k, int64_t n_dst, int32_
   uint32_t* keys = c.take<uint32_t>(ne);
   uint32_t* skeys = c.take<uint32_t>(ne);
   int32_t* src = c.take<int32_t>(ne);
-  size_t sb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                            (size_t)ne, 0, 32, (hipStream_t)0);
+  const size_t sb = sort_pairs_bytes((size_t)ne, 32);
   void* tmp = c.take<char>(sb);
   int bits = 1;
   while (((int64_t)1 << bits) <= n_dst) ++bits;
   const dim3 block(kBlock);
   hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)((ne + kBlock - 1) / kBlock)), block, 0, stream, nbr, ne, k, (int32_t)n_dst, keys, src);
-  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, src, csr_src, (size_t)ne, 0, (unsigned)bits, stream));
+  DC_HIP(sort_pairs_u32(tmp, sb, keys, skeys, src, csr_src, (size_t)ne, 0, (unsigned)bits, stream));
   hipLaunchKernelGGL(csr_ptr_kernel, dim3((unsigned)((n_dst + 1 + kBlock - 1) / kBlock)), block, 0, stream, skeys, ne, (int32_t)n_dst, csr_ptr);
   DC_HIP(hipGetLastError());
   return DC_OK;
@@ -1739,9 +1734,7 @@ size_t dc_spatial_order_workspace_bytes(int64_t n) {
   if (n < 0) return 0;
   Carver c(nullptr);
   c.take<double>(kBoxBlocks * kBoxVals); c.take<double>(4); c.take<uint64_t>(n); c.take<uint64_t>(n); c.take<int32_t>(n);
-  size_t sb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                            (size_t)(n > 0 ? n : 1), 0, 63, (hipStream_t)0);
+  const size_t sb = sort_pairs_bytes((size_t)(n > 0 ? n : 1), 64);
   c.take<char>(sb);
   return c.off + 256;
 }
@@ -1760,9 +1753,7 @@ int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32
   uint64_t* keys = c.take<uint64_t>(n);
   uint64_t* skeys = c.take<uint64_t>(n);
   int32_t* ids = c.take<int32_t>(n);
-  size_t sb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sb, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                            (size_t)n, 0, 63, (hipStream_t)0);
+  const size_t sb = sort_pairs_bytes((size_t)n, 64);
   void* tmp = c.take<char>(sb);
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
   if (dtype == DC_F32) {
@@ -1774,7 +1765,7 @@ int dc_spatial_order(const void* points, int stride, int dtype, int64_t n, int32
     hipLaunchKernelGGL(box_finish_kernel, dim3(1), dim3(kBlock), 0, stream, part, kBoxBlocks, box);
     hipLaunchKernelGGL((fine_keys_kernel<double>), grid, block, 0, stream, (const double*)points, stride, n, box, keys, ids);
   } else return DC_ERR_DTYPE;
-  DC_HIP(rocprim::radix_sort_pairs(tmp, sb, keys, skeys, ids, order_out, (size_t)n, 0, 63, stream));
+  DC_HIP(sort_pairs_u64(tmp, sb, keys, skeys, ids, order_out, (size_t)n, 0, 63, stream));
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

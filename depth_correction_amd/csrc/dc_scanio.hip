@@ -16,7 +16,7 @@
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include "dc_hostutil.h"
-#include <rocprim/rocprim.hpp>
+#include "dc_sort.h"
 
 namespace dc {
 
@@ -89,8 +89,7 @@ size_t dc_cloud_from_points_workspace_bytes(int64_t n) {
   const size_t ne = (size_t)(n > 0 ? n : 1);
   Carver c(nullptr);
   c.take<int32_t>(ne); c.take<int32_t>(ne);
-  size_t cb = 0;
-  (void)rocprim::exclusive_scan(nullptr, cb, (int32_t*)nullptr, (int32_t*)nullptr, 0, ne, rocprim::plus<int32_t>(), (hipStream_t)0);
+  const size_t cb = scan_bytes(ne);
   c.take<char>(cb);
   return c.off + 256;
 }
@@ -106,8 +105,7 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
   Carver c(ws);
   int32_t* keep = c.take<int32_t>((size_t)n);
   int32_t* pos = c.take<int32_t>((size_t)n);
-  size_t cb = 0;
-  (void)rocprim::exclusive_scan(nullptr, cb, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n, rocprim::plus<int32_t>(), (hipStream_t)0);
+  const size_t cb = scan_bytes((size_t)n);
   void* tmp = c.take<char>(cb);
   const double lo = (min_depth == min_depth) ? min_depth : -INFINITY, hi = (max_depth == max_depth) ? max_depth : INFINITY;   // NaN = unbounded
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
@@ -115,7 +113,7 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
   do {                                                                                                                       \
     hipLaunchKernelGGL((scan_flags_kernel<TI, TO>), grid, block, 0, stream, (const TI*)points, stride, (const TI*)vps, n,     \
                        (TI)ego_box, (TI)lo, (TI)hi, keep);                                                                   \
-    DC_HIP(rocprim::exclusive_scan(tmp, cb, keep, pos, 0, (size_t)n, rocprim::plus<int32_t>(), stream));                     \
+    DC_HIP(exclusive_scan_32(tmp, cb, keep, pos, (size_t)n, stream));                                                        \
     hipLaunchKernelGGL((scan_compact_kernel<TI, TO>), grid, block, 0, stream, (const TI*)points, stride, (const TI*)vps, n,   \
                        keep, pos, (TO*)dirs_out, (TO*)depth_out, (TO*)vps_out, index_out, count_out);                        \
   } while (0)

@@ -142,17 +142,17 @@ class SequencePlan:
                 grouped = torch.empty_like(order32)
                 seg16 = torch.empty((nb, 2 * S + 1), dtype=torch.uint16, device=dev)
                 m8 = None if mask is None else mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-                check(lib().dc_block_group(ptr(order32), ptr(group_key), ptr(m8), self.n, S, ptr(grouped), ptr(seg16), stream_ptr()),
-                      'dc_block_group')
+                # (the skipped-wavefront count and the blocks without a point inside the mask come from the same kernel: as tensor
+                #  expressions over seg16 they were eight more torch kernels to load in the first set-up of a process)
+                skip8 = torch.empty((nb,), dtype=torch.uint8, device=dev) if mask is not None else None
+                nskip = torch.zeros((1,), dtype=torch.int32, device=dev)
+                check(lib().dc_block_group(ptr(order32), ptr(group_key), ptr(m8), self.n, S, ptr(grouped), ptr(seg16), ptr(skip8), ptr(nskip),
+                                           stream_ptr()), 'dc_block_group')
                 order = grouped.long()
                 self.scan_seg = None if by_degree else seg16
-                seg = seg16.view(torch.int16).long() & 0xFFFF
                 # share of the wavefronts (64 lanes) whose centres are all outside the mask: what the one-pass kernels skip
-                inside = seg[:, S]                                                                 # masked-in points per block
-                skipped = (4 - ((inside + 63) // 64)).clamp(min=0).sum() - (nb * 4 - (self.n + 63) // 64)
-                self.skipped_wavefronts = float(skipped) / max((self.n + 63) // 64, 1)
-                if mask is not None:
-                    self.blk_skip = (inside == 0).to(torch.uint8).contiguous()
+                self.skipped_wavefronts = float(nskip.item()) / max((self.n + 63) // 64, 1)
+                self.blk_skip = skip8
                 mark('plan_scan_groups')
             if nbr.numel():
                 rank32 = torch.empty((self.n,), dtype=torch.int32, device=dev)

@@ -243,9 +243,11 @@ int dc_block_table_own_base(const int32_t* blk_ptr, const int32_t* blk_ids, int6
 /* The layout step behind dcSequenceDesc.scan_seg: inside every block of 256 consecutive entries of `order_in` (point indices in the
  * plan's order) the points inside `mask` (uint8 [n] in the ORIGINAL order, or NULL: all) first, by scan id (`scan_id` int32 [n],
  * original order), then those outside, by scan id; stable.  order_out int32 [n] (not order_in), seg_out uint16
- * [ceil(n / 256), 2 n_scans + 1].  n_scans <= 64.  (No reference counterpart: the reference keeps scans one after the other.) */
+ * [ceil(n / 256), 2 n_scans + 1].  n_scans <= 64.  Optional: blk_skip_out uint8 [ceil(n / 256)] <- 1 for blocks without a point inside
+ * the mask (dcSequenceDesc.blk_skip), skipped_out int32 [1] <- the number of 64-lane wavefronts with no point inside the mask.
+ * (No reference counterpart: the reference keeps scans one after the other.) */
 int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_t* mask, int64_t n, int n_scans, int32_t* order_out,
-                   uint16_t* seg_out, dcStream_t stream);
+                   uint16_t* seg_out, uint8_t* blk_skip_out, int32_t* skipped_out, dcStream_t stream);
 /* The neighbour table in a new point order (`order` int64 [n], a permutation: new row i = old row order[i]): rank_out[order[i]] = i,
  * nbr_out[i][q] = rank_out[nbr[order[i]][q]], -1 stays -1.  (The layout step of a sequence: Morton order of the global cloud.) */
 int dc_table_permute(const int32_t* nbr, int64_t n, int k, const int64_t* order, int32_t* rank_out, int32_t* nbr_out, dcStream_t stream);
