@@ -65,6 +65,7 @@ _SIGNATURES = {
                                     _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'dc_pose_train_combine': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     'dc_table_permute': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'dc_gather_rows': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     'dc_points_extent_workspace_bytes': (_sz, []),
     'dc_points_extent': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _sz, _vp]),
     'dc_scan_ids': (_i32, [_vp, _i32, _i64, _vp, _vp]),
@@ -72,6 +73,7 @@ _SIGNATURES = {
     'dc_scan_lattice_shift': (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     'dc_scan_lattice_localize': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp]),
     'dc_block_table_set_lds_build': (_i32, [_i32]),
+    'dc_block_table_slots_workspace_bytes': (_sz, [_i64, _i32]),
     'dc_block_table_own_base': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'dc_block_table_run_capacity': (_i64, [_i64, _i64]),
     'dc_block_table_build_runs': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

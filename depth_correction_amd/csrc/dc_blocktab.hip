@@ -329,6 +329,21 @@ __global__ __launch_bounds__(kBlock) void bt_pack_unique_kernel(const int32_t* _
   for (int p = threadIdx.x; p < n; p += kBlock) blk_ids[lo + p] = uniq[b * (int64_t)stride + p];
 }
 
+// dst row i = src row order[i], rows of `words` 32-bit words (or `bytes` single bytes when words == 0): the plan's permutation of its
+// per-point arrays in one kernel family (as tensor indexing every dtype / shape loads its own torch kernel in a fresh process).
+__global__ __launch_bounds__(kBlock) void bt_gather_rows_kernel(const uint32_t* __restrict__ src, const int64_t* __restrict__ order,
+                                                                int64_t n, int words, uint32_t* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n * words) return;
+  const int64_t i = e / words;
+  dst[e] = src[order[i] * words + (e - i * words)];
+}
+__global__ __launch_bounds__(kBlock) void bt_gather_bytes_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ order,
+                                                                 int64_t n, uint8_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) dst[i] = src[order[i]];
+}
+
 static inline int64_t blocks_of(int64_t n) { return (n + kBlock - 1) / kBlock; }
 static inline unsigned grid_of(int64_t n) { return (unsigned)(n > 0 ? (n + kBlock - 1) / kBlock : 1); }
 
@@ -382,6 +397,20 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs) {
   return c.off + 256;
 }
 
+// A [rows, K] table with K = 4 / 8 / 10 / 16 is built block by block in LDS and needs only the blocks' scratch rows (one int32 per
+// reference slot) -- a tenth of the radix build's keys, values and sort storage (800 MB for the C2 table: its allocation alone took
+// 0.2 s of the first set-up of a process).
+size_t dc_block_table_slots_workspace_bytes(int64_t n_rows, int k) {
+  if (n_rows < 0 || k < 1) return 0;
+  if ((k == 4 || k == 8 || k == 10 || k == 16) && g_bt_lds.load()) {
+    const size_t nb = (size_t)blocks_of(n_rows);
+    Carver c(nullptr);
+    c.take<int32_t>((nb > 0 ? nb : 1) * kBlock * (size_t)k); c.take<int32_t>(nb + 1);
+    return c.off + 256;
+  }
+  return dc_block_table_workspace_bytes(n_rows * (int64_t)k);
+}
+
 // loc_entries: number of uint16 entries of loc (all set to 0xFFFF first); run_ptr != NULL selects the run layout
 static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
                                   const int32_t* slot_ptr, const int32_t* run_ptr, int64_t loc_entries, int32_t* blk_ptr,
@@ -395,8 +424,9 @@ static int block_table_build_impl(const int32_t* row_ptr, const int32_t* ids, in
   if (!ids || (!slot_ptr && !run_ptr) || !blk_ids || !loc || !ws) return DC_ERR_ARG;
   if (!row_ptr && n_refs != n_rows * (int64_t)k) return DC_ERR_ARG;
   if (n_refs >= (int64_t)0x7fffffff || n_slot_rows * kBlock >= ((int64_t)1 << 40)) return DC_ERR_UNSUPPORTED;
-  if (ws_bytes < dc_block_table_workspace_bytes(n_refs)) return DC_ERR_WORKSPACE;
-  if (!row_ptr && !run_ptr && (k == 4 || k == 8 || k == 10 || k == 16) && g_bt_lds.load()) {
+  const bool lds_build = !row_ptr && !run_ptr && (k == 4 || k == 8 || k == 10 || k == 16) && g_bt_lds.load();
+  if (ws_bytes < (lds_build ? dc_block_table_slots_workspace_bytes(n_rows, k) : dc_block_table_workspace_bytes(n_refs))) return DC_ERR_WORKSPACE;
+  if (lds_build) {
     // a [rows, K] table: every block on its own in LDS (bt_block_unique_kernel); the workspace holds the blocks' scratch rows
     Carver c2(ws);
     int32_t* uniq = c2.take<int32_t>((size_t)nb * kBlock * k);       // (<= n_refs + 255 k entries: inside the radix build's arrays)
@@ -462,6 +492,19 @@ int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_
   if (n == 0) return DC_OK;
   hipLaunchKernelGGL(bt_block_group_kernel, dim3((unsigned)blocks_of(n)), dim3(kBlock), 0, stream, order_in, scan_id, mask, n, n_scans,
                      order_out, seg_out, blk_skip_out, skipped_out);
+  DC_HIP(hipGetLastError());
+  return DC_OK;
+}
+
+int dc_gather_rows(const void* src, int row_bytes, const int64_t* order, int64_t n, void* dst, hipStream_t stream) {
+  if (n < 0 || row_bytes < 1 || (n > 0 && (!src || !order || !dst || src == dst))) return DC_ERR_ARG;
+  if (row_bytes != 1 && (row_bytes & 3)) return DC_ERR_UNSUPPORTED;
+  if (n == 0) return DC_OK;
+  if (row_bytes == 1)
+    hipLaunchKernelGGL(bt_gather_bytes_kernel, dim3((unsigned)blocks_of(n)), dim3(kBlock), 0, stream, (const uint8_t*)src, order, n, (uint8_t*)dst);
+  else
+    hipLaunchKernelGGL(bt_gather_rows_kernel, dim3((unsigned)blocks_of(n * (row_bytes / 4))), dim3(kBlock), 0, stream, (const uint32_t*)src, order, n,
+                       row_bytes / 4, (uint32_t*)dst);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }

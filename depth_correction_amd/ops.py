@@ -16,7 +16,7 @@ __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'table_to_csr', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
     'IcpSequence', 'shadow_mask', 'shadow_filter', 'correct_depth', 'cloud_from_points',
-    'as_index32', 'scan_ids', 'points_extent',
+    'as_index32', 'scan_ids', 'points_extent', 'gather_rows', 'cat_rows',
 ]
 
 
@@ -56,6 +56,39 @@ def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
                              float(r) if r else 0.0, float(cell_hint), ptr(idx), ptr(dist), ptr(ws), nbytes,
                              stream_ptr()), 'dc_knn_build')
     return dist, idx
+
+
+@on_device
+def gather_rows(src, order):
+    """src[order] for a contiguous per-point array [n, ...] and an int64 permutation (dc_gather_rows: one kernel family for every
+    dtype and row shape)."""
+    row_bytes = src.element_size() * (src[0].numel() if src.shape[0] else 1)
+    if not (src.is_contiguous() and order.dtype == torch.int64 and order.is_contiguous() and (row_bytes == 1 or row_bytes % 4 == 0)):
+        return src[order].contiguous()
+    out = torch.empty((order.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    check(lib().dc_gather_rows(ptr(src), row_bytes, ptr(order), order.shape[0], ptr(out), stream_ptr()), 'dc_gather_rows')
+    return out
+
+
+def cat_rows(parts):
+    """torch.cat(parts) -- without a copy when the parts are consecutive row ranges of ONE contiguous tensor (the clouds of
+    pipeline.local_features_batch are slices of the arrays it built for all scans at once)."""
+    first = parts[0]
+    if len(parts) > 1 and all(p.is_contiguous() and p.dtype == first.dtype and p.shape[1:] == first.shape[1:] for p in parts):
+        base = getattr(first, '_base', None)
+        row = first.element_size() * (first[0].numel() if first.shape[0] else 1)
+        at = first.data_ptr()
+        ok = base is not None and base.is_contiguous() and row > 0
+        for p_ in parts:
+            ok = ok and getattr(p_, '_base', None) is base and p_.data_ptr() == at
+            at += p_.shape[0] * row
+        if ok:
+            n = sum(p_.shape[0] for p_ in parts)
+            start = (first.data_ptr() - base.data_ptr()) // row
+            flat = base.reshape((base.shape[0],) + tuple(first.shape[1:])) if base.dim() == first.dim() else None
+            if flat is not None and flat.shape[1:] == first.shape[1:] and start + n <= flat.shape[0]:
+                return flat[start:start + n]
+    return torch.cat(list(parts)).contiguous()
 
 
 def scan_ids(sizes, device):
@@ -199,7 +232,10 @@ def block_table(nbr=None, csr=None, layout=None, own_rows=True):
     blk_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
     blk_ids = torch.empty((max(n_refs, 1),), dtype=torch.int32, device=dev)
     info = torch.empty((4,), dtype=torch.int32, device=dev)
-    nbytes = lib().dc_block_table_workspace_bytes(max(n_refs, n_rows + 1))
+    if nbr is not None:
+        nbytes = lib().dc_block_table_slots_workspace_bytes(n_rows, k)      # (the LDS build: a tenth of the radix build's)
+    else:
+        nbytes = lib().dc_block_table_workspace_bytes(max(n_refs, n_rows + 1))
     ws = _ws(nbytes, dev)
     slot_ptr = run_ptr = None
     if layout == 'runs':
@@ -211,7 +247,8 @@ def block_table(nbr=None, csr=None, layout=None, own_rows=True):
         slot_ptr = torch.empty((nb + 1,), dtype=torch.int32, device=dev)
         if row_ptr is None:
             # a table [rows, K]: every block has K slots, known without asking the device
-            slot_ptr.copy_(torch.arange(nb + 1, dtype=torch.int32, device=dev) * k)
+            import numpy as _np
+            slot_ptr = torch.as_tensor(_np.arange(nb + 1, dtype=_np.int32) * _np.int32(k), device=dev)      # (a copy from the host: no kernel)
             n_slot_rows = nb * k
         else:
             cnt = torch.empty((max(nb, 1),), dtype=torch.int32, device=dev)

@@ -105,7 +105,7 @@ def global_cloud_arrays(clouds, poses):
     dev = clouds[0]['dirs'].device
     sizes = [len(c['dirs']) for c in clouds]
     scan_id = ops.scan_ids(sizes, dev)
-    cat = lambda f: torch.cat([c[f].reshape(len(c['dirs']), -1) for c in clouds]).contiguous()
+    cat = lambda f: ops.cat_rows([c[f].reshape(len(c['dirs']), -1) for c in clouds])
     ps = ops.PointSet(cat('vps'), cat('dirs'), cat('depth'), None, None, scan_id)
     P = torch.as_tensor(poses, device=dev).to(torch.float64)[:, :3, :].reshape(len(clouds), 12).contiguous()
     return ops.points_fwd(ps, P, want_parts=True)

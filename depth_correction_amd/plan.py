@@ -26,6 +26,8 @@ from __future__ import annotations
 
 import ctypes
 
+import numpy as np
+
 import torch
 
 from . import ops
@@ -69,15 +71,15 @@ class SequencePlan:
         """
         mark = stages.mark if stages is not None else (lambda name: None)
         get = (lambda c, f: c[f]) if isinstance(clouds[0], dict) else getattr
-        vps = torch.cat([get(c, 'vps') for c in clouds]).contiguous()
-        dirs = torch.cat([get(c, 'dirs') for c in clouds]).contiguous()
-        depth = torch.cat([get(c, 'depth').reshape(-1) for c in clouds]).contiguous()
+        vps = ops.cat_rows([get(c, 'vps') for c in clouds])
+        dirs = ops.cat_rows([get(c, 'dirs') for c in clouds])
+        depth = ops.cat_rows([get(c, 'depth') for c in clouds]).reshape(-1)
         incs = [get(c, 'inc_angles') for c in clouds]
-        inc = None if incs[0] is None else torch.cat([i.reshape(-1) for i in incs]).contiguous()
+        inc = None if incs[0] is None else ops.cat_rows(incs).reshape(-1)
         lms = [get(c, 'mask') for c in clouds]
         dev = dirs.device
         sizes = [len(get(c, 'dirs')) for c in clouds]
-        lmask = None if lms[0] is None else torch.cat(lms).contiguous()
+        lmask = None if lms[0] is None else ops.cat_rows(lms)
         scan_id = ops.scan_ids(sizes, dev)
         self.n, self.n_scans, self.device, self.dtype = dirs.shape[0], len(clouds), dev, dirs.dtype
         self._poses_key = self._poses12 = self._poses_ref = None
@@ -165,11 +167,8 @@ class SequencePlan:
                 rank = torch.empty_like(order)
                 rank[order] = torch.arange(self.n, device=dev)
                 nbr = nbr[order].to(torch.int32).contiguous()
-            vps, dirs, depth = vps[order].contiguous(), dirs[order].contiguous(), depth[order].contiguous()
-            inc = None if inc is None else inc[order].contiguous()
-            lmask = None if lmask is None else lmask[order].contiguous()
-            scan_id = scan_id[order].contiguous()
-            mask = None if mask is None else mask[order].contiguous()
+            gat = lambda t_: None if t_ is None else ops.gather_rows(t_.contiguous(), order)
+            vps, dirs, depth, inc, lmask, scan_id, mask = (gat(t_) for t_ in (vps, dirs, depth, inc, lmask, scan_id, mask))
             self.order, self.rank = order, rank
             mark('plan_permute')
         else:
@@ -206,9 +205,10 @@ class SequencePlan:
                 self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None)
         self.fwd_rows_active = 0
         if self.fwd_table is not None and getattr(self, 'blk_skip', None) is not None and self.centre_idx is None:
-            rows_per_block = self.fwd_table.blk_ptr[1:] - self.fwd_table.blk_ptr[:-1]
-            keep = self.blk_skip == 0
-            self.fwd_rows_active = int(rows_per_block[keep].max().item()) if bool(keep.any()) else 0
+            # (on the host: two copies of a few kilobytes -- as tensor expressions, six more torch kernels to load in a fresh process)
+            rows_per_block = np.diff(self.fwd_table.blk_ptr.cpu().numpy())
+            keep = self.blk_skip.cpu().numpy() == 0
+            self.fwd_rows_active = int(rows_per_block[keep].max()) if keep.any() else 0
         mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 

@@ -236,6 +236,9 @@ size_t dc_block_table_workspace_bytes(int64_t n_refs);
 /* A-B switch (measurements, tests; process-wide, not thread-safe like dc_set_option): 0 = [rows, K] tables through the radix-sort
  * build as well; returns the previous setting.  Default 1: K = 4 / 8 / 10 / 16 tables are built block by block in LDS. */
 int dc_block_table_set_lds_build(int on);
+/* Workspace of dc_block_table_build for a table [n_rows, k] (row_ptr NULL): the LDS build's scratch rows where it applies, else
+ * dc_block_table_workspace_bytes(n_rows * k). */
+size_t dc_block_table_slots_workspace_bytes(int64_t n_rows, int k);
 int dc_block_table_build(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int k, int64_t n_refs,
                          const int32_t* slot_ptr, int64_t n_slot_rows, int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc,
                          int32_t* info, void* ws, size_t ws_bytes, dcStream_t stream);
@@ -251,6 +254,8 @@ int dc_block_group(const int32_t* order_in, const int32_t* scan_id, const uint8_
 /* The neighbour table in a new point order (`order` int64 [n], a permutation: new row i = old row order[i]): rank_out[order[i]] = i,
  * nbr_out[i][q] = rank_out[nbr[order[i]][q]], -1 stays -1.  (The layout step of a sequence: Morton order of the global cloud.) */
 int dc_table_permute(const int32_t* nbr, int64_t n, int k, const int64_t* order, int32_t* rank_out, int32_t* nbr_out, dcStream_t stream);
+/* dst row i = src row order[i] for rows of row_bytes bytes (1, or a multiple of 4): a per-point array into the plan's order. */
+int dc_gather_rows(const void* src, int row_bytes, const int64_t* order, int64_t n, void* dst, dcStream_t stream);
 int64_t dc_block_table_run_capacity(int64_t n_rows, int64_t n_refs);
 int dc_block_table_build_runs(const int32_t* row_ptr, const int32_t* ids, int64_t n_rows, int64_t n_refs, int32_t* run_ptr,
                               int32_t* blk_ptr, int32_t* blk_ids, uint16_t* loc, int32_t* info, void* ws, size_t ws_bytes,
