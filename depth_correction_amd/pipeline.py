@@ -36,9 +36,9 @@ def local_features(xyz, k=None, r=None, vps=None, eigenvalue_bounds=None,
         pts = pts.to(dtype)
     pts = pts.contiguous()
     vps_t = torch.zeros_like(pts) if vps is None else torch.as_tensor(vps, dtype=pts.dtype, device=pts.device).expand_as(pts).contiguous()
-    dirs = pts - vps_t
-    depth = dirs.norm(dim=-1, keepdim=True)
-    dirs = torch.where(depth > 0, dirs / depth, dirs).contiguous()
+    # rays of the points (DepthCloud.from_points, depth_cloud.py:592-638) by the kernel the package's from_points uses: depth = |p - vp|,
+    # dirs = (p - vp) / depth, zero-depth rays left un-normalised
+    _, dirs, depth, _ = ops.cloud_from_points(pts, vps=None if vps is None else vps_t)
     ps = ops.PointSet(vps_t, dirs, depth)
     x = ops.points_fwd(ps)                                            # update_points
     if k:
@@ -62,8 +62,8 @@ def local_features_batch(scans, k, r=None, eigenvalue_bounds=None, eigenvalue_ra
     coordinate is exact in fp64 (then every difference, distance and tie is what it was: the k-NN orders equal distances by index)
     and (b) every neighbour of every point lies in its own scan; both are checked on the device, and None is returned when either
     fails (the caller then runs the scans one by one)."""
-    pts = torch.cat([torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x, device=device) for x in scans])
-    if dtype is not None:
+    pts = ops.cat_rows([torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x, device=device) for x in scans])
+    if dtype is not None and pts.dtype != dtype:
         pts = pts.to(dtype)
     pts = pts.contiguous()
     dev = pts.device
@@ -71,8 +71,7 @@ def local_features_batch(scans, k, r=None, eigenvalue_bounds=None, eigenvalue_ra
     if min(sizes) <= k:
         return None
     vps_t = torch.zeros_like(pts)
-    depth = pts.norm(dim=-1, keepdim=True)
-    dirs = torch.where(depth > 0, pts / depth, pts).contiguous()
+    _, dirs, depth, _ = ops.cloud_from_points(pts)                           # as local_features: the rays of the points
     x = ops.points_fwd(ops.PointSet(vps_t, dirs, depth))                    # update_points
     if len(scans) > 64:
         return None
@@ -203,7 +202,19 @@ def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='
     """Everything train.py does before its loop for one sequence; returns (plan, info).  ``stage_times``: info['setup_ms']
     = wall-clock milliseconds per stage (device synchronised between stages)."""
     st = _Stages(stage_times, device)
-    uploaded = [torch.as_tensor(np.ascontiguousarray(xyz) if isinstance(xyz, np.ndarray) else xyz, device=device) for xyz in scans_xyz]
+    if all(isinstance(xyz, np.ndarray) and xyz.ndim == 2 and xyz.dtype == scans_xyz[0].dtype and xyz.shape[1] == scans_xyz[0].shape[1]
+           for xyz in scans_xyz):
+        # all scans into ONE device array (a copy from the host each): the per-scan clouds are then row ranges of it and nothing
+        # concatenates them again (pipeline.local_features_batch, ops.cat_rows)
+        sizes_ = [len(xyz) for xyz in scans_xyz]
+        buf = torch.empty((sum(sizes_), scans_xyz[0].shape[1]), dtype=torch.from_numpy(scans_xyz[0][:0]).dtype, device=device)
+        uploaded, a_ = [], 0
+        for xyz, n_ in zip(scans_xyz, sizes_):
+            buf[a_:a_ + n_].copy_(torch.from_numpy(np.ascontiguousarray(xyz)))
+            uploaded.append(buf[a_:a_ + n_])
+            a_ += n_
+    else:
+        uploaded = [torch.as_tensor(np.ascontiguousarray(xyz) if isinstance(xyz, np.ndarray) else xyz, device=device) for xyz in scans_xyz]
     st.mark('upload')
     # the scans are independent and one 200 k-point scan does not fill the chip (782 blocks for > 1024 resident): their
     # pipelines go to a few streams side by side
