@@ -71,24 +71,22 @@ def gather_rows(src, order):
 
 
 def cat_rows(parts):
-    """torch.cat(parts) -- without a copy when the parts are consecutive row ranges of ONE contiguous tensor (the clouds of
-    pipeline.local_features_batch are slices of the arrays it built for all scans at once)."""
+    """torch.cat(parts) -- without a copy when the parts are consecutive row ranges of ONE contiguous allocation (the clouds of
+    pipeline.local_features_batch are slices of the arrays it built for all scans at once): a view over all of them."""
+    parts = list(parts)
     first = parts[0]
-    if len(parts) > 1 and all(p.is_contiguous() and p.dtype == first.dtype and p.shape[1:] == first.shape[1:] for p in parts):
-        base = getattr(first, '_base', None)
-        row = first.element_size() * (first[0].numel() if first.shape[0] else 1)
-        at = first.data_ptr()
-        ok = base is not None and base.is_contiguous() and row > 0
+    if len(parts) > 1 and first.dim() >= 1 and all(p.is_contiguous() and p.dtype == first.dtype and p.device == first.device
+                                                   and p.shape[1:] == first.shape[1:] for p in parts):
+        row = first.element_size() * (first[0].numel() if first.shape[0] else 0)
+        store = first.untyped_storage().data_ptr()
+        at, ok = first.data_ptr(), row > 0
         for p_ in parts:
-            ok = ok and getattr(p_, '_base', None) is base and p_.data_ptr() == at
+            ok = ok and p_.untyped_storage().data_ptr() == store and p_.data_ptr() == at
             at += p_.shape[0] * row
         if ok:
             n = sum(p_.shape[0] for p_ in parts)
-            start = (first.data_ptr() - base.data_ptr()) // row
-            flat = base.reshape((base.shape[0],) + tuple(first.shape[1:])) if base.dim() == first.dim() else None
-            if flat is not None and flat.shape[1:] == first.shape[1:] and start + n <= flat.shape[0]:
-                return flat[start:start + n]
-    return torch.cat(list(parts)).contiguous()
+            return torch.as_strided(first, (n,) + tuple(first.shape[1:]), first.stride())
+    return torch.cat(parts).contiguous()
 
 
 def scan_ids(sizes, device):

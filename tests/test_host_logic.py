@@ -387,3 +387,24 @@ def test_caller_script_imports_resolve_under_install_as():
     finally:
         for k in [k for k in sys.modules if k == 'depth_correction' or k.startswith('depth_correction.')]:
             del sys.modules[k]
+
+
+def test_cat_rows_views_consecutive_slices_and_copies_the_rest():
+    """ops.cat_rows (the plan's concatenation of per-scan arrays): consecutive row ranges of one contiguous tensor come back as a
+    view of it -- no copy, same storage -- anything else as torch.cat."""
+    import torch
+    from depth_correction_amd import ops
+    base = torch.arange(60, dtype=torch.float32).reshape(20, 3)
+    parts = [base[0:7], base[7:12], base[12:20]]
+    out = ops.cat_rows(parts)
+    assert out.data_ptr() == base.data_ptr() and out.shape == (20, 3) and torch.equal(out, base)
+    mid = ops.cat_rows([base[7:12], base[12:20]])
+    assert mid.data_ptr() == base[7:].data_ptr() and torch.equal(mid, base[7:])
+    col = torch.arange(20, dtype=torch.float32).reshape(20, 1)
+    assert ops.cat_rows([col[:5], col[5:]]).reshape(-1).data_ptr() == col.data_ptr()
+    flat = torch.arange(20)
+    assert ops.cat_rows([flat[:5], flat[5:]]).data_ptr() == flat.data_ptr()
+    # not consecutive, different bases, a gap, a single part, a non-contiguous part: copies with the right content
+    for bad in ([base[7:12], base[0:7]], [base[0:7], base.clone()[7:12]], [base[0:7], base[8:12]], [base[3:9]], [base[:, :2][0:4], base[:, :2][4:8]]):
+        got = ops.cat_rows(bad)
+        assert torch.equal(got, torch.cat(bad)) and (len(bad) == 1 or got.data_ptr() not in [b.data_ptr() for b in bad])
