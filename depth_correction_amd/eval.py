@@ -128,15 +128,16 @@ def _plan_for(seq_clouds, poses, nn, mask, model, cfg):
     nan_policy = 'only_finite' if kw.get('only_finite') else ('skip_nans' if kw.get('skip_nans') else None)     # loss.py:125-137
     # ball neighbourhoods (a ragged table) and no pose corrections: rows of similar length share wavefronts (SequencePlan.degree_group)
     by_degree = bool(getattr(cfg, 'nn_r', None)) and not getattr(cfg, 'nn_k', None) and str(getattr(cfg, 'pose_correction', 'none')).endswith('none')
+    ball = bool(getattr(cfg, 'nn_r', None)) and not getattr(cfg, 'nn_k', None)       # rows of different lengths: SequencePlan.heavy_first
     flags = (cfg.loss, bool(kw.get('normalization', False)), bool(kw.get('sqrt', False)),
-             getattr(model, 'kernel_kind', None) if model is not None else None, nan_policy, by_degree)
+             getattr(model, 'kernel_kind', None) if model is not None else None, nan_policy, by_degree, ball)
     tensors = [t for c in seq_clouds for t in (c.vps, c.dirs, c.depth, c.inc_angles, c.mask)] + [neighbors, mask]
 
     def build():
         return SequencePlan(seq_clouds, poses.detach(), neighbors, None if mask is None else mask.to(neighbors.device),
                             model_kind=flags[3] or 'ScaledPolynomial', loss=cfg.loss,
                             normalization=flags[1] and cfg.loss == 'min_eigval_loss', sqrt=flags[2], nan_policy=nan_policy,
-                            degree_group=by_degree)
+                            degree_group=by_degree, heavy_first=ball)
     return _plans.get(tensors, flags, build)
 
 

@@ -26,6 +26,8 @@ from __future__ import annotations
 
 import ctypes
 
+import os
+
 import numpy as np
 
 import torch
@@ -44,7 +46,7 @@ class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
-                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True, degree_group=False):
+                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True, degree_group=False, heavy_first=False):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -64,6 +66,9 @@ class SequencePlan:
                            measured at C2 the remaining blocks then draw their neighbours from a third more distinct rows --
                            larger LDS tiles, fewer resident blocks -- and the step got SLOWER (44 -> 55 us); the two-kernel
                            forms lose more.  Results are the same either way.
+        :param degree_group: ball neighbourhoods without pose gradients: lanes of a block ordered by (mask, row length) instead of
+                             (mask, scan).
+        :param heavy_first: ball neighbourhoods: the blocks with the longest rows first in the grid (see below).
         :param scan_group: group the points of every 256-point block by scan (contiguous per-scan lane ranges for the pose-gradient
                            sums; the set of points per block, hence every other kernel's work, is unchanged).
         :param active_only: evaluate only the masked points as neighbourhood centres (the others contribute neither to
@@ -128,6 +133,26 @@ class SequencePlan:
             # the ragged one-pass kernel run to its longest row, so rows of similar length share wavefronts (64 bins of the
             # longest row; 112 -> 106 us at r = 0.4 m).  No scan ranges then: pose gradients take the un-grouped backward
             by_degree = bool(degree_group) and scan_group and not degree_sort
+            deg = None
+            if heavy_first and scan_group and not degree_sort and self.n // 256 > 8:
+                # rows of different lengths (ball neighbourhoods): the blocks with the longest rows go out first.  The grid is a
+                # handful of blocks per CU (1 103 blocks with 32-49 KB tiles at r = 0.25-0.4 m) and a block lasts as long as its
+                # longest row, so in Morton order the launch ended whenever the last heavy block to start did: 107.7 -> 92.0 us
+                # (r = 0.4 m), 52.8 -> 47.9 (0.25 m), 386 -> 293 (grid 0.1 m).  Block b of the grid is logical block
+                # (b % 8) * per + b / 8 (xcd_block_of); a last, partly filled block keeps its place.  Which points share a block
+                # is unchanged.  (Fixed K, weight = wavefronts inside the mask: slower, 43.2 -> 45.7 us at C2 -- the blocks of
+                # an XCD no longer share rows in its L2 -- so not done there.)
+                deg = (nbr >= 0).sum(1)
+                nbf, per = self.n // 256, ((self.n + 255) // 256 + 7) // 8
+                b = torch.arange(per * 8, device=dev)
+                logical = (b % 8) * per + b // 8
+                logical = logical[logical < nbf]
+                dblk = deg[order[:nbf * 256]].reshape(nbf, 256)
+                heavy = torch.argsort(dblk.max(1).values * 1024 + dblk.sum(1) // 256, descending=True, stable=True)
+                src = torch.empty_like(heavy)
+                src[logical] = heavy
+                order = torch.cat([order[:nbf * 256].reshape(nbf, 256)[src].reshape(-1), order[nbf * 256:]])
+                mark('plan_heavy_first')
             if scan_group and not degree_sort and (self.n_scans <= 64 or by_degree):
                 # inside every block of 256 Morton-consecutive points: the points inside the loss mask first, then those outside;
                 # each group ordered by scan (stable: Morton order inside a (mask, scan) segment).  Which 256 points share a block
@@ -138,7 +163,7 @@ class SequencePlan:
                 nb, S = (self.n + 255) // 256, (64 if by_degree else self.n_scans)
                 group_key = scan_id
                 if by_degree:
-                    deg = (nbr >= 0).sum(1)
+                    deg = (nbr >= 0).sum(1) if deg is None else deg
                     group_key = (deg * 63 // deg.max().clamp(min=1)).to(torch.int32).contiguous()
                 order32 = order.to(torch.int32).contiguous()
                 grouped = torch.empty_like(order32)

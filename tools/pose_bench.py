@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--points', type=int, default=200_000)
     ap.add_argument('--variants', default='grouped,ungrouped')
     ap.add_argument('--option', default='', help='dc_set_option pairs, e.g. 7=1 (three-kernel path)')
+    ap.add_argument('--heavy-first', type=int, default=1, help='ball neighbourhoods: blocks with the longest rows first (SequencePlan.heavy_first)')
     ap.add_argument('--radius', default='', help='grid:radius in metres: ball neighbourhoods on voxel-filtered scans instead of k = 10')
     args = ap.parse_args()
     from depth_correction_amd.dataset import RoomBoxDataset
@@ -41,7 +42,7 @@ def main():
             rng = np.random.default_rng(135)
             kept = [filter_grid(s_, grid, keep='random', rng=rng) for s_ in scans]
             plan, info = build_sequence(kept, poses, k=None, r=r, dtype=torch.float32, device=dev, scan_group=(name == 'grouped'),
-                                        degree_group=False)
+                                        degree_group=False, heavy_first=bool(args.heavy_first))
         else:
             plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32, device=dev, scan_group=(name == 'grouped'))
         w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)

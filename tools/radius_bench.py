@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--points', type=int, default=200_000)
     ap.add_argument('--degree-sort', type=int, default=0)
+    ap.add_argument('--heavy-first', type=int, default=1, help='blocks with the longest rows first in the grid (SequencePlan.heavy_first)')
     args = ap.parse_args()
     from depth_correction_amd import ops
     from depth_correction_amd.dataset import RoomBoxDataset
@@ -38,7 +39,8 @@ def main():
         kept = [filter_grid(s, grid, keep='random', rng=rng) for s in scans]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        plan, info = build_sequence(kept, poses, k=None, r=r, dtype=torch.float32, device=dev, degree_sort=bool(args.degree_sort))
+        plan, info = build_sequence(kept, poses, k=None, r=r, dtype=torch.float32, device=dev, degree_sort=bool(args.degree_sort),
+                                    heavy_first=bool(args.heavy_first))
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - t0) * 1e3
         nbr = info['neighbors']
