@@ -2211,7 +2211,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
 // The second sweep accumulates float32 per trip and fp64 across trips.  Same sums as the slots kernel to the rounding of that
 // order of additions.
 template <int P, int CAP>
-__global__ __launch_bounds__(kBlock) void consistency_step_ragged_q32_kernel(
+__global__ __launch_bounds__(kBlock, (CAP <= 1024 ? 5 : 4)) void consistency_step_ragged_q32_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, const int32_t* __restrict__ row_ptr, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
     StepChain ch) {

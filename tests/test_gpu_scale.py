@@ -530,10 +530,12 @@ def test_ball_neighbourhood_plan_grouped_by_row_length(room):
     scans, poses = room
     rng = np.random.default_rng(3)
     kept = [filter_grid(s[:60_000], 0.15, keep='random', rng=rng) for s in scans[:4]]
-    res = {}
-    for by_degree in (True, False):
-        plan, info = build_sequence(kept, poses[:4], k=None, r=0.3, dtype=torch.float32, degree_group=by_degree)
+    res, blocks = {}, {}
+    for by_degree, heavy in ((True, True), (False, True), (True, False)):
+        plan, info = build_sequence(kept, poses[:4], k=None, r=0.3, dtype=torch.float32, degree_group=by_degree, heavy_first=heavy)
         assert (plan.scan_seg is None) == by_degree and plan.fwd_table is not None
+        nbf = plan.n // 256
+        blocks[by_degree, heavy] = torch.sort(plan.order[:nbf * 256].reshape(nbf, 256), dim=1).values.cpu().numpy()
         dev = plan.device
         w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
         e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
@@ -545,8 +547,19 @@ def test_ball_neighbourhood_plan_grouped_by_row_length(room):
             assert kt.kernels()['consistency_fwd'].startswith('consistency_step_ragged_q32_kernel'), kt.kernels()
         model_only = npy(out).copy()
         plan.eval_native(w, e, P, out, want_grad=True, want_pose=True)
-        res[by_degree] = (model_only, npy(out).copy())
-    (m1, p1), (m0, p0) = res[True], res[False]
+        res[by_degree, heavy] = (model_only, npy(out).copy())
+    # heavy_first: the same blocks of 256 points (as sets), numbered so that the grid starts with the longest rows; the blocks
+    # after the first ones of the eight XCDs hold shorter and shorter longest rows
+    a, b = blocks[True, True], blocks[True, False]
+    assert a.shape == b.shape and not np.array_equal(a, b)
+    assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+    deg = npy((info['neighbors'] >= 0).sum(1))
+    nb = (len(deg) + 255) // 256
+    per = (nb + 7) // 8
+    longest = [deg[a[(g % 8) * per + g // 8]].max() for g in range(per * 8) if (g % 8) * per + g // 8 < len(a)]
+    assert all(x >= y for x, y in zip(longest, longest[1:]))
+    np.testing.assert_allclose(res[True, True][0], res[True, False][0], rtol=1e-9)
+    (m1, p1), (m0, p0) = res[True, True], res[False, True]
     assert m1[1] == m0[1] > 1000
     np.testing.assert_allclose(m1[0], m0[0], rtol=1e-11)
     np.testing.assert_allclose(m1[2:4], m0[2:4], rtol=1e-6)
