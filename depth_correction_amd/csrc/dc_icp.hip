@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kBlock) void p2plane_pair_kernel(ScanView A, ScanVi
 // belongs to the pair whose row range holds it.  (One launch per pair left a C4-shaped iteration -- nine pairs of ~15 k
 // correspondences -- with eighteen dependent launches of ~50 blocks each: 0.22 of its 0.29 ms.)
 constexpr int kIcpSeqPairs = 16;
+constexpr int kIcpDstScans = 1024;      // scans whose pose-gradient entries p2plane_reduce_all_kernel keeps in LDS (more: global adds)
 struct IcpSeqPair {
   ScanView A, B;
   const int32_t* idxA; const int32_t* idxB;
@@ -228,13 +229,16 @@ __global__ __launch_bounds__(kBlock) void p2plane_reduce_all_kernel(const double
     const int k = (a - 1) % DC_MAX_MODEL_TERMS;
     if (k >= n_terms) return;
   }
-  // the first launch of a sequence also clears the slots this block adds to (instead of a memset in front: two launches fewer in
-  // an iteration that is a chain of short ones); the same thread adds to them below
-  if (first && threadIdx.x == 0) {
-    if (a == 0) out[0] = 0.0;
-    else if (!pose) out[1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + (a - 1) % DC_MAX_MODEL_TERMS] = 0.0;
-    else for (int sc = 0; sc < n_scans; ++sc) out[1 + 2 * n_terms + 12 * sc + j] = 0.0;
-  }
+  // the first launch of a sequence starts its slots from zero (instead of a memset in front: two launches fewer in an iteration
+  // that is a chain of short ones).  A pose block keeps its entry of every scan in LDS while the pairs are added and writes all of
+  // them once at the end; the other blocks have one destination, kept in a register: the additions happen in the order they
+  // always did, but none of them is a dependent read-modify-write of global memory any more (C4 train() iteration 48 -> 45.8 us)
+  __shared__ double s_dst[kIcpDstScans];
+  const bool dst_lds = pose && n_scans <= kIcpDstScans;
+  if (dst_lds)
+    for (int sc = threadIdx.x; sc < n_scans; sc += kBlock) s_dst[sc] = first ? 0.0 : out[1 + 2 * n_terms + 12 * sc + j];
+  else if (pose && first && threadIdx.x == 0)
+    for (int sc = 0; sc < n_scans; ++sc) out[1 + 2 * n_terms + 12 * sc + j] = 0.0;
   // every pair's rows are requested before anything is added (a pair after the other cost a round trip to the fabric and two
   // barriers each: 14 us for nine pairs); the sums of a pair are formed in the same order as before and added pair after pair
   __shared__ double s_pair[kBlock / kWave][2 * kIcpSeqPairs];
@@ -263,19 +267,27 @@ __global__ __launch_bounds__(kBlock) void p2plane_reduce_all_kernel(const double
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const int slot = a == 0 ? 0 : 1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + (a - 1) % DC_MAX_MODEL_TERMS;     // (not a pose block)
+    double x = (pose || first) ? 0.0 : out[slot];
     for (int p = 0; p < rq.n_pairs; ++p) {
       double t0 = 0.0, t1 = 0.0;
       for (int wv = 0; wv < kBlock / kWave; ++wv) { t0 += s_pair[wv][2 * p]; t1 += s_pair[wv][2 * p + 1]; }
       const double wt = rq.weight[p];
-      if (a == 0) out[0] += wt * (t0 + t1);
-      else if (!pose) {
-        const int k = (a - 1) % DC_MAX_MODEL_TERMS;
-        out[1 + (a - 1 < DC_MAX_MODEL_TERMS ? 0 : n_terms) + k] += wt * t0;
+      if (a == 0) x += wt * (t0 + t1);
+      else if (!pose) x += wt * t0;
+      else if (dst_lds) {
+        s_dst[rq.scan_a[p]] += wt * t0;
+        s_dst[rq.scan_b[p]] += wt * t1;
       } else {
         out[1 + 2 * n_terms + 12 * rq.scan_a[p] + j] += wt * t0;
         out[1 + 2 * n_terms + 12 * rq.scan_b[p] + j] += wt * t1;
       }
     }
+    if (!pose) out[slot] = x;
+  }
+  if (dst_lds) {
+    __syncthreads();
+    for (int sc = threadIdx.x; sc < n_scans; sc += kBlock) out[1 + 2 * n_terms + 12 * sc + j] = s_dst[sc];
   }
   (void)lds;
   (void)pw; (void)pe;
