@@ -1961,6 +1961,21 @@ __device__ __forceinline__ void chain_term_q32(const int4* tile, uint32_t off, b
 
 // (six wavefronts per SIMD: left alone the kernel takes 81 VGPRs -- one allocation granule over the 80 of six wavefronts, i.e. FIVE per SIMD;
 //  at 79 + 12 B of scratch a step takes 44.4 instead of 47.2 us.  Seven -- 71 VGPRs, 44 B of scratch -- take 50.9 us.)
+// Diagnostic build only (-DDC_BLOCK_TRACE, tools/block_trace.py): every block of the two one-pass step kernels records where and
+// when it ran -- {XCC | HW_ID, start, end} on the 100 MHz constant clock -- so that the schedule of a launch can be drawn (which
+// CU got how many blocks, when each CU ran dry).  The product library is built without it: the macros expand to nothing.
+#ifdef DC_BLOCK_TRACE
+__device__ unsigned long long* g_block_trace = nullptr;
+#define DC_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime()
+#define DC_TRACE_END() do { if (threadIdx.x == 0 && g_block_trace) { \
+    unsigned long long* tr_ = g_block_trace + 4 * (size_t)blockIdx.x; \
+    tr_[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
+    tr_[1] = trace_t0; tr_[2] = __builtin_amdgcn_s_memrealtime(); tr_[3] = 1; } } while (0)
+#else
+#define DC_TRACE_BEGIN() do {} while (0)
+#define DC_TRACE_END() do {} while (0)
+#endif
+
 template <int NS, int P, int CAP>
 __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, const int32_t* __restrict__ centre_idx, int64_t n,
@@ -1973,6 +1988,7 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
   __shared__ double s_front[kWavesPerBlock];
   __shared__ double s_comb[kWavesPerBlock * NP2];
   __shared__ int s_ok[2];
+  DC_TRACE_BEGIN();
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
@@ -2090,6 +2106,7 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
     if (q < 2) p_fwd[q * rs + row] = tot;
     else if (q < NV) p_bwd[(q - 2) * rs + row] = tot;
   }
+  DC_TRACE_END();
 }
 
 // the same for any slot count (radius neighbourhoods): run-time slot loops, as consistency_fwd_basis_slots_kernel
@@ -2220,6 +2237,7 @@ __global__ __launch_bounds__(kBlock, (CAP <= 1024 ? 5 : 4)) void consistency_ste
   __shared__ double s_w[DC_MAX_MODEL_TERMS];
   __shared__ int s_ok;
   __shared__ double s_front[kBlock / kWave];
+  DC_TRACE_BEGIN();
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
@@ -2365,6 +2383,7 @@ __global__ __launch_bounds__(kBlock, (CAP <= 1024 ? 5 : 4)) void consistency_ste
   }
   if (timed_out) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
   step_partials<P, true>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
+  DC_TRACE_END();
 }
 
 // ================================================================================================
@@ -3382,6 +3401,12 @@ int dc_points_bwd(const void* grad_points, const int32_t* perm, int stride, int 
 }
 
 // option 0: 1 = ignore block tables and gather from global memory (ablation / A-B measurements), 0 = default.
+#ifdef DC_BLOCK_TRACE
+int dc_debug_block_trace(void* buf) {        // diagnostic build only: [4 x grid] uint64 (or null to stop recording)
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dc::g_block_trace), &p, sizeof(p));
+}
+#endif
 int dc_set_option(int option, int value) {
   if (option == 0) { g_no_tab.store(value != 0); return DC_OK; }
   if (option == 1) { g_fwd_generic.store(value); return DC_OK; }
