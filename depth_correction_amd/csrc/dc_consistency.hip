@@ -1355,6 +1355,7 @@ __device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double gra
 struct StepChain {
   int32_t* ready;            // [2], zero before the first launch of a chain; nullptr: ordinary launch (per-wavefront rows)
   int parity, has_prev, n_front, n_out;
+  int reverse;               // this launch walks every XCD's share of the blocks backwards (chain_block_of)
   const double* prev;        // the previous launch's rows [(2 + P)][prev_rows]
   int64_t prev_rows;
   const double* grad_sum;    // or: the previous evaluation's dL/dw already summed (over the ranks: an all-reduce ran in between);
@@ -1369,6 +1370,20 @@ struct StepChain {
 };
 constexpr int32_t kStatusChainTimeout = 2;     // (bit 0: q32 overflow, raised by quantize())
 constexpr int kChainFront = 8;             // leading blocks of a chained launch (a multiple of the XCD count)
+
+// The logical block of this workgroup (xcd_block_of); -1: padding.  Every other launch of a chain of fixed-K steps walks its XCD's
+// share of the blocks BACKWARDS: the basis rows are the same in every step, an XCD's 4 MB of L2 still holds the rows of the last
+// ~260 blocks it finished, and a launch's first round -- 1 536 blocks that all start by fetching rows -- is its slowest
+// (profiles/r04_block_trace.md: 12 us per block against 7.7 later on).  Walking back, the first round finds its rows in L2:
+// C2 step 42.8 -> 41.4 us.  Block -> row of the partial sums is by grid position either way, so the order of the final
+// additions differs between the two directions by rounding only (deterministic: the direction is the launch's parity).
+__device__ __forceinline__ int64_t chain_block_of(const StepChain& ch, bool chained, int64_t nblocks) {
+  const int64_t b = (int64_t)blockIdx.x - (chained ? ch.n_front : 0);
+  if (!(chained && ch.reverse)) return xcd_block_of(b, nblocks);
+  const int64_t per = (nblocks + kXcds - 1) / kXcds;
+  const int64_t logical = (b % kXcds) * per + (per - 1 - b / kXcds);
+  return logical < nblocks ? logical : -1;
+}
 
 template <int P>
 __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* lds /* [kBlock / kWave] in LDS */) {
@@ -1803,7 +1818,7 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  int64_t blk = chain_block_of(ch, chained, nblocks);
   if (blk >= 0 && ch.blk_skip && ch.blk_skip[blk]) blk = -1;            // no centre of this block is inside the loss mask
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
@@ -1992,7 +2007,7 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
   const bool chained = ch.ready != nullptr;
   if (chained && (int)blockIdx.x < ch.n_front) { chain_front_block<P>(ch, s_front); return; }
   const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  int64_t blk = xcd_block_of((int64_t)blockIdx.x - (chained ? ch.n_front : 0), nblocks);
+  int64_t blk = chain_block_of(ch, chained, nblocks);
   if (blk >= 0 && ch.blk_skip && ch.blk_skip[blk]) blk = -1;            // no centre of this block is inside the loss mask
   double acc2[2] = {0.0, 0.0}, gw[P];
 #pragma unroll
@@ -2998,6 +3013,7 @@ using namespace dc;
 
 static inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 // dc_set_option(0, 1): ignore block tables, gather from global memory (A-B measurements); process-wide, read per launch
+static std::atomic<bool> g_no_reverse{false};        // dc_set_option(8, 1): every launch of a chain walks the blocks forwards (A-B, chain_block_of)
 static std::atomic<bool> g_pose_three_pass{false};   // dc_set_option(7, 1): pose gradients through the three-kernel general path (A-B, tests)
 static std::atomic<bool> g_no_tab{false};
 static std::atomic<int> g_fwd_generic{0};
@@ -3415,6 +3431,7 @@ int dc_set_option(int option, int value) {
   if (option == 5) { g_chain_spin.store(value < 0 ? (1 << 22) : value); return DC_OK; }
   if (option == 6) { g_step_var.store(value); return DC_OK; }
   if (option == 7) { g_pose_three_pass.store(value != 0); return DC_OK; }
+  if (option == 8) { g_no_reverse.store(value != 0); return DC_OK; }
   return DC_ERR_ARG;
 }
 
@@ -3582,6 +3599,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
         ch.out_prev = chain->out_prev; ch.w_prev_out = chain->w_prev_out; ch.status = d->status; ch.spin_limit = g_chain_spin.load(); ch.adam = chain->adam_prev;
         ch.grad_sum = chain->grad_sum;
+        ch.reverse = (chain->parity && !g_no_reverse.load()) ? 1 : 0;
       }
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
       const int var = g_step_var.load();

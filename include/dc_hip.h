@@ -596,6 +596,8 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
  * option 4: value 1 makes basis-form evaluations run the forward and the backward kernel separately instead of the one-pass
  *           loss + dL/dw kernel.
  * option 7: value 1 sends pose-gradient evaluations through the three-kernel general path even when dcSequenceDesc.pose_table is set.
+ * option 8: value 1 makes every launch of a chain of fixed-K steps walk the blocks forwards; by default every other launch walks
+ *           each XCD's share backwards, so that its first blocks find their rows in that XCD's L2 (same sums to rounding).
  * option 5: number of polls a chained launch's blocks make while they wait for the weights its leading blocks publish
  *           (default 2^22, negative restores it).  A wait that runs out yields NaN sums for that evaluation and raises bit 1 of
  *           dcSequenceDesc.status (bit 0: DC_Q32 overflow), so the two causes of a NaN loss can be told apart; tests force 0. */
