@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--radius', default='', help='grid:radius (ball neighbourhoods on voxel-filtered scans); default: C2, k = 10')
     ap.add_argument('--heavy-first', type=int, default=1)
     ap.add_argument('--points', type=int, default=200_000)
+    ap.add_argument('--forwards', type=int, default=0, help='1: dc_set_option(8, 1), every launch of the chain walks the blocks forwards')
     ap.add_argument('--lib', default=os.path.join(ROOT, 'build', 'libdc_hip_trace.so'))
     args = ap.parse_args()
     from depth_correction_amd import _native
@@ -44,6 +45,7 @@ def main():
         plan, info = build_sequence(kept, poses, k=None, r=r, dtype=torch.float32, device=dev, heavy_first=bool(args.heavy_first))
     else:
         plan, info = build_sequence(scans, poses, k=10, dtype=torch.float32, device=dev)
+    _native.lib().dc_set_option(8, int(args.forwards))
     tr = SequenceTrainer([plan], [1e-3, 2e-3], [2.0, 4.0], [info['poses']], lr=1e-3, chained=True)
     for _ in range(300):
         tr.step()
@@ -92,7 +94,10 @@ def main():
         place = {'same_cu_as_block_minus_256': round(ok(cu_of[256:], cu_of[:-256]), 3), 'same_cu_as_block_minus_512': round(ok(cu_of[512:], cu_of[:-512]), 3),
                  'xcc_is_block_mod_8': round(float(np.mean(xcc_of[g] == (g - int(g.min())) % 8)), 3),
                  'first_traced_block': int(g.min()), 'cu_of_first_40': [int(v) for v in cu_of[g.min():g.min() + 40]]}
-        out.append({'blocks_traced': int(len(t)), 'launch_us': round(float(end - begin), 2), 'cus_seen': int(len(ids)),
+        first_round = np.sort(t0)[min(len(t0) - 1, 1535)]
+        out.append({'block_us_started_in_first_round_p50': round(float(np.median(dur[t0 <= first_round])), 2),
+                    'block_us_started_later_p50': round(float(np.median(dur[t0 > first_round])), 2) if (t0 > first_round).any() else None,
+                    'blocks_traced': int(len(t)), 'launch_us': round(float(end - begin), 2), 'cus_seen': int(len(ids)),
                     'block_us_p0_10_50_90_100': q(dur), 'blocks_per_cu_p0_10_50_90_100': q(cnt),
                     'cu_first_start_us': q(first), 'cu_last_end_us': q(last),
                     'cu_busy_block_us_sum': q(busy),
