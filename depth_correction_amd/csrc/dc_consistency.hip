@@ -1353,7 +1353,9 @@ __device__ __forceinline__ void adam_update(const AdamArgs& a, int i, double gra
 // clears the other flag and writes its own partial rows to the other buffer.  The last step of a chain is finished by the
 // ordinary reduction launch (flush).
 struct StepChain {
-  int32_t* ready;            // [2], zero before the first launch of a chain; nullptr: ordinary launch (per-wavefront rows)
+  int32_t* ready;            // 64 bytes, zero before the first launch of a chain (the published weights, chain_publish); nullptr: ordinary
+                             // launch (per-wavefront rows)
+  uint32_t stamp;            // this launch's number: what marks a published word as belonging to it
   int parity, has_prev, n_front, n_out;
   int reverse;               // this launch walks every XCD's share of the blocks backwards (chain_block_of)
   const double* prev;        // the previous launch's rows [(2 + P)][prev_rows]
@@ -1364,6 +1366,7 @@ struct StepChain {
   double* w_prev_out;        // [P] or nullptr <- the weights the previous evaluation used (a training log records them: train.py)
   int32_t* status;           // bit 0: a point left the q32 extent (read); bit 1: a wait for the weights ran out (raised here)
   int spin_limit;            // polls a waiting block makes before it gives up (dc_set_option(5, n); 0: gives up at once)
+  const double* w_now;       // the caller's weights (what a launch with nothing to finish publishes)
   AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
   const uint8_t* blk_skip;   // [blocks] or nullptr: blocks none of whose centres is inside the loss mask (dcSequenceDesc.blk_skip): they add
                              // nothing to the loss, the count or dL/dw and are treated like the padding blocks of the last round
@@ -1385,20 +1388,27 @@ __device__ __forceinline__ int64_t chain_block_of(const StepChain& ch, bool chai
   return logical < nblocks ? logical : -1;
 }
 
+// Weight k of a chained launch, published by the leading block that finished it and picked up by every other block in ONE
+// memory trip: the double travels as two 64-bit words {low half | stamp}, {high half | stamp} (8-byte accesses are single-copy
+// atomic), the stamp being the launch's number -- a word carrying it can only be this launch's.  (Rounds 2-4: a counter raised
+// after a fence, polled, and then the weights loaded: two dependent trips through the fabric in front of every block's staging.)
+__device__ __forceinline__ void chain_publish(const StepChain& ch, int k, double w) {
+  unsigned long long* pub = reinterpret_cast<unsigned long long*>(ch.ready);
+  const unsigned long long st = (unsigned long long)ch.stamp << 32;
+  __hip_atomic_store(pub + 2 * k, st | (unsigned)__double2loint(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(pub + 2 * k + 1, st | (unsigned)__double2hiint(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int P>
 __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* lds /* [kBlock / kWave] in LDS */) {
   const int a = blockIdx.x;
-  if (a == 0) {
-    if (threadIdx.x == 0) __hip_atomic_store(ch.ready + (ch.parity ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ch.has_prev && !ch.grad_sum)
-      for (int z = 2 + P + threadIdx.x; z < ch.n_out; z += kBlock) ch.out_prev[z] = 0.0;
-  }
+  if (a == 0 && ch.has_prev && !ch.grad_sum)
+    for (int z = 2 + P + threadIdx.x; z < ch.n_out; z += kBlock) ch.out_prev[z] = 0.0;
   if (a >= 2 + P) return;
   if (ch.grad_sum) {                     // the sums exist already: weight a - 2's update, then publish
     if (a >= 2 && threadIdx.x == 0) {
       if (ch.has_prev && ch.adam.p) adam_update(ch.adam, a - 2, ch.grad_sum[a - 2]);
-      __threadfence();
-      __hip_atomic_fetch_add(ch.ready + ch.parity, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      chain_publish(ch, a - 2, ch.adam.p ? ch.adam.p[a - 2] : ch.w_now[a - 2]);
     }
     return;
   }
@@ -1438,29 +1448,36 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* l
       ch.out_prev[a] = t;
       if (step) adam_apply(ch.adam, a - 2, t, p0, m0, v0);
     }
-    if (a >= 2) {                        // weight a - 2 is final for this launch
-      __threadfence();
-      __hip_atomic_fetch_add(ch.ready + ch.parity, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // weight a - 2 is final for this launch (the value just stored, or the caller's when there was nothing to finish)
+    if (a >= 2) chain_publish(ch, a - 2, step ? ch.adam.p[a - 2] : ch.w_now[a - 2]);
   }
 }
 
-// wait (bounded) until all P weights of this launch are published; every thread of the block must call it
-__device__ __forceinline__ bool chain_wait(const StepChain& ch, int n_weights, int* s_ok) {
-  if (threadIdx.x == 0) {
-    int ok = 0;
+// s_w[k] <- w_k * w_scale of this launch for the lanes of the block, as soon as its leading blocks have published them
+// (bounded wait); *s_ok <- 0 when a wait ran out.  Every thread of the block calls it; the caller's barrier follows.
+template <int P>
+__device__ __forceinline__ void chain_weights(const StepChain& ch, double w_scale, double* s_w, int* s_ok) {
+  const int tid = threadIdx.x;
+  if (tid == 0) *s_ok = 1;
+  if (tid < 2 * P) {
+    const unsigned long long* pub = reinterpret_cast<const unsigned long long*>(ch.ready) + tid;
+    unsigned long long word = 0;
+    bool ok = false;
     for (int spin = 0; spin < ch.spin_limit; ++spin) {
-      // relaxed: an agent-scope acquire would invalidate this XCD's L2 on every poll; the weights are read with
-      // device-coherent loads afterwards instead
-      if (__hip_atomic_load(ch.ready + ch.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_weights) { ok = 1; break; }
+      // (relaxed: an agent-scope acquire would invalidate this XCD's L2 on every poll -- nothing else is read through it)
+      word = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(word >> 32) == ch.stamp) { ok = true; break; }
       __builtin_amdgcn_s_sleep(2);
     }
+    const int half = (int)(uint32_t)word;
+    const int other = __shfl_xor(half, 1, kWave);                       // lanes 2k / 2k + 1: low / high half of weight k
+    if ((tid & 1) == 0) s_w[tid >> 1] = (ok ? __hiloint2double(other, half) : __longlong_as_double(0x7ff8000000000000ll)) * w_scale;
     // a wait that ran out poisons this launch's sums (NaN) AND says so: the status word tells it apart from a q32 overflow
-    if (!ok && ch.status) atomicOr(ch.status, kStatusChainTimeout);
-    *s_ok = ok;
+    if (!ok) {
+      *s_ok = 0;
+      if (ch.status) atomicOr(ch.status, kStatusChainTimeout);
+    }
   }
-  __syncthreads();
-  return *s_ok != 0;
 }
 
 // ---- loss AND dL/dw in one pass (forward-mode accumulation) -------------------------------------------------------------
@@ -1844,9 +1861,9 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
       const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
       if (t0 < nd) r0 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t0]);
       if (t1 < nd) r1 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t1]);
-      if (!chain_wait(ch, P, &s_ok)) bad = true;
-      stage_weights(pb, s_w, true);
+      chain_weights<P>(ch, pb.w_scale, s_w, &s_ok);
       __syncthreads();
+      if (!s_ok) bad = true;
 #pragma unroll
       for (int k = 0; k < P; ++k) wq[k] = s_w[k];
       if (t0 < nd) StepRow<PT, P>::place(r0, wq, tile, cap, t0);
@@ -1918,10 +1935,6 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
         for (int k = 0; k < P; ++k) gw[k] *= u;            // differences were in grid steps
       }
     }
-  } else {
-    if (chained) chain_wait(ch, P, &s_ok);
-    __syncthreads();
-    __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
   step_partials<P, (VAR & kVarDppSums) != 0>(acc2, gw, p_fwd, p_bwd, chained, chained ? ch.n_front : 0);
@@ -2031,9 +2044,9 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
       const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
       if (t0 < nd) r0 = StepRow<q32, P>::fetch(pb, tab.blk_ids[base + t0]);
       if (t1 < nd) r1 = StepRow<q32, P>::fetch(pb, tab.blk_ids[base + t1]);
-      if (!chain_wait(ch, P, s_ok)) bad = true;
-      stage_weights(pb, s_w, true);
+      chain_weights<P>(ch, pb.w_scale, s_w, s_ok);
       __syncthreads();
+      if (!s_ok[0]) bad = true;
 #pragma unroll
       for (int k = 0; k < P; ++k) wq[k] = s_w[k];
       if (t0 < nd) StepRow<q32, P>::place(r0, wq, tile, cap, t0);
@@ -2092,10 +2105,6 @@ __global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
 #pragma unroll
       for (int k = 0; k < P; ++k) gw[k] = (double)gwf[k] * u;          // differences were in grid steps
     }
-  } else {
-    if (chained) chain_wait(ch, P, s_ok);
-    __syncthreads();
-    __syncthreads();
   }
   if (bad) acc2[0] = acc2[1] = __longlong_as_double(0x7ff8000000000000ll);
   // ---- {sum loss, count, dL/dw} of the wavefront (one row per wavefront; chained: per block), as step_partials
@@ -2165,9 +2174,9 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_slots_kernel(
     const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
     if (t0 < nd) r0 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t0]);
     if (t1 < nd) r1 = StepRow<PT, P>::fetch(pb, tab.blk_ids[base + t1]);
-    timed_out = !chain_wait(ch, P, &s_ok);
-    stage_weights(pb, s_w, true);
+    chain_weights<P>(ch, pb.w_scale, s_w, &s_ok);
     __syncthreads();
+    timed_out = !s_ok;
 #pragma unroll
     for (int k = 0; k < P; ++k) wq[k] = s_w[k];
     if (t0 < nd) StepRow<PT, P>::place(r0, wq, tile, cap, t0);
@@ -2285,9 +2294,9 @@ __global__ __launch_bounds__(kBlock, (CAP <= 1024 ? 5 : 4)) void consistency_ste
     const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
     if (t0 < nd) r0 = Row::fetch(pb, tab.blk_ids[base + t0]);
     if (t1 < nd) r1 = Row::fetch(pb, tab.blk_ids[base + t1]);
-    timed_out = !chain_wait(ch, P, &s_ok);
-    stage_weights(pb, s_w, true);
+    chain_weights<P>(ch, pb.w_scale, s_w, &s_ok);
     __syncthreads();
+    timed_out = !s_ok;
 #pragma unroll
     for (int k = 0; k < P; ++k) wq[k] = s_w[k];
     if (t0 < nd) Row::place(r0, wq, tile, CAP, t0);
@@ -2476,7 +2485,7 @@ __global__ __launch_bounds__(kBlock) void pose_table_kernel(BlockTab tab, const 
   if (tid <= n_scans) row_seg[b * (n_scans + 1) + tid] = (uint16_t)s_start[tid];
   __syncthreads();
   const int64_t i = b * kBlock + tid;
-  own_pos[i < n ? i : n - 1] = (uint16_t)(s_new[own + (i < n ? tid : 0)] << 4);
+  if (i < n) own_pos[i] = (uint16_t)(s_new[own + tid] << 4);
   const uint16_t* lrow = tab.loc + (int64_t)tab.slot_ptr[b] * kBlock + tid;
 #pragma unroll
   for (int q = 0; q < K; ++q) {
@@ -3024,17 +3033,23 @@ static std::atomic<int> g_chain_spin{1 << 22};  // dc_set_option(5, n): polls of
 static std::atomic<bool> g_no_basis{false};    // dc_set_option(3, 1): ignore a sequence's basis rows (general path)    // dc_set_option(1, 1): run-time slot loop instead of the fixed-K forward kernels
 
 // consistency_step_ragged_q32_kernel with a tile of CAP rows: more than 64 KB of LDS per block needs the attribute (once per
-// instantiation and process).  Capacities up to the table's own limit (4095 rows), so every ball-neighbourhood table that can be
+// instantiation, process and device).  Capacities up to the table's own limit (4095 rows), so every ball-neighbourhood table that can be
 // built runs fused -- at one block per CU for the densest (voxel grid 0.1 m, r = 0.25 m: 2 000 distinct rows per block).
 template <int P, int CAP>
 static int ragged_launch(dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const PointBasis& pb, const BlockTab& tab,
                          const dcBlockTable* t, int64_t n_rows, const uint8_t* mask, const LossParams& lp, const QParams& qp, double* p_fwd,
                          double* p_bwd, const StepChain& ch) {
   constexpr size_t bytes = (size_t)StepRow<q32, P>::kPieces * CAP * 16;
-  static std::atomic<bool> attr_set{false};
-  if (bytes > 60 * 1024 && !attr_set.exchange(true)) {
-    hipError_t err = hipFuncSetAttribute((const void*)consistency_step_ragged_q32_kernel<P, CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (err != hipSuccess) { attr_set.store(false); return (int)err; }
+  // function attributes are per device: one bit per device of the process (a second GPU of the same process sets its own)
+  static std::atomic<uint64_t> attr_set{0};
+  if (bytes > 60 * 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.fetch_or(bit) & bit)) {
+      hipError_t err = hipFuncSetAttribute((const void*)consistency_step_ragged_q32_kernel<P, CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (err != hipSuccess) { attr_set.fetch_and(~bit); return (int)err; }
+    }
   }
   hipExtLaunchKernelGGL((consistency_step_ragged_q32_kernel<P, CAP>), grid, dim3(kBlock), bytes, stream, ev0, ev1, 0, pb, tab, t->own_base, t->row_ptr, n_rows,
                         mask, lp, qp, p_fwd, p_bwd, ch);
@@ -3515,6 +3530,7 @@ struct ChainCall {
   const double* grad_sum;    // nullptr: the previous evaluation's rows are summed by this launch
   bool reduce_now;           // also launch the ordinary reduction of THIS evaluation's rows into `out` (no Adam)
   double* w_prev_out = nullptr;
+  uint32_t stamp = 0;        // the launch's number (its step): marks the weights it publishes
 };
 // the two partial-row buffers of a chain: behind the columns ordinary evaluations use, so that an evaluation of the same
 // sequence between two chained steps (a validation pass, a lazily produced loss cloud) cannot overwrite a pending step
@@ -3599,6 +3615,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
         ch.out_prev = chain->out_prev; ch.w_prev_out = chain->w_prev_out; ch.status = d->status; ch.spin_limit = g_chain_spin.load(); ch.adam = chain->adam_prev;
         ch.grad_sum = chain->grad_sum;
+        ch.stamp = chain->stamp; ch.w_now = w;
         ch.reverse = (chain->parity && !g_no_reverse.load()) ? 1 : 0;
       }
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
@@ -3795,6 +3812,7 @@ int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e
   if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1) return DC_ERR_ARG;
   if (has_prev && step < 2) return DC_ERR_ARG;
   ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}, nullptr, false};
+  c.stamp = (uint32_t)step;
   if (has_prev) {
     int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
     if (rc) return rc;
@@ -3809,6 +3827,7 @@ int dc_sequence_step_chained_rec(const dcSequenceDesc* d, double* w, const doubl
   if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1) return DC_ERR_ARG;
   if (has_prev && step < 2) return DC_ERR_ARG;
   ChainCall c{ready, (int)(step & 1), has_prev ? 1 : 0, out_prev, AdamArgs{}, nullptr, false, has_prev ? w_used_prev : nullptr};
+  c.stamp = (uint32_t)step;
   if (has_prev) {
     int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
     if (rc) return rc;
@@ -3839,6 +3858,7 @@ int dc_sequence_eval_after_update(const dcSequenceDesc* d, double* w, const doub
   if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out || step < 1) return DC_ERR_ARG;
   if (grad_sum && step < 2) return DC_ERR_ARG;
   ChainCall c{ready, (int)(step & 1), grad_sum ? 1 : 0, out, AdamArgs{}, grad_sum ? grad_sum : w, true};
+  c.stamp = (uint32_t)step;
   if (grad_sum) {
     int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
     if (rc) return rc;

@@ -664,6 +664,7 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
     r += 6 * a.n_deltas;
     for (int q = tid; q < 12 * S; q += kBlock) r[q] = a.T_used[(q / 12) * 16 + q % 12];
   }
+  __syncthreads();                                             // the record holds what this iteration USED: copied before any update
   const double t = (double)(*a.step + 1);
   const double bias1 = 1.0 - pow(a.b1, t), bias2_sqrt = sqrt(1.0 - pow(a.b2, t));
   const double gscale = a.totals ? 1.0 / a.totals[1] : (a.count_index >= 0 ? 1.0 / a.sums[a.count_index] : 1.0);
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
       }
     }
   }
-  if (a.w && tid < P) {
+  if (a.w && tid < P && a.lr_w != 0.0) {                       // (lr_w = 0: weights that are recorded, not optimised)
     double m = a.w_m[tid], v = a.w_v[tid];
     const double gw = a.totals ? a.totals[2 + tid] : a.sums[a.grad_w_off + tid];
     a.w[tid] = adam_one(a.w[tid], m, v, gw * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);

@@ -457,7 +457,7 @@ class SequencePlan:
             need(w_used_prev, (nt,), dtype=torch.float64, name='w_used_prev', device=self.device)
             for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
                 need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
-            need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
+            need(ready, (16,), dtype=torch.int32, name='ready', device=self.device)
             self._set_basis(d, w, exponent, poses12, False, False)
             rc = lib().dc_sequence_step_chained_rec(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
                                                     int(t), int(bool(has_prev)), float(grad_scale), float(lr), float(betas[0]),
@@ -468,7 +468,7 @@ class SequencePlan:
             check(rc, 'dc_sequence_step_chained_rec')
             self.version += 1
             return True
-        need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
+        need(ready, (16,), dtype=torch.int32, name='ready', device=self.device)
         for name, v in (('w', w), ('exponent', exponent), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
             need(v, (nt,), dtype=torch.float64, name=name, device=self.device)
         self._set_basis(d, w, exponent, poses12, False, False)
@@ -490,7 +490,7 @@ class SequencePlan:
         nt = w.numel()
         d = self.desc(nt)
         need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
-        need(ready, (2,), dtype=torch.int32, name='ready', device=self.device)
+        need(ready, (16,), dtype=torch.int32, name='ready', device=self.device)
         if grad_sum is not None:
             need(grad_sum, (nt,), dtype=torch.float64, name='grad_sum', device=self.device)
         self._set_basis(d, w, exponent, poses12, False, False)
@@ -902,7 +902,7 @@ class SequenceTrainer:
         self.update_in_next = (bool(chained) and not self.fused_step and evaluate is None and adam is None
                                and len(self.plans) >= 1 and self.nt > 0)
         self._pending = False
-        self.ready = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self.ready = torch.zeros((16,), dtype=torch.int32, device=dev)      # 64 bytes: the chain's published weights
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
         self.acc = torch.zeros((2 + self.nt,), dtype=torch.float64, device=dev)       # [sum loss, count, dL/dw]
         self.distributed, self.group = distributed, process_group

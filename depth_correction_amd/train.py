@@ -592,8 +592,10 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
     vtr = [PoseSequenceTrainer(vp, T, d, zero_first, val_optimizer.param_groups[0]['lr'], g_d['betas'], g_d['eps'], n_terms=nt,
                                icp_model_kind=icp_kind)
            for vp, T, d in zip(vplans, val_poses, val_pose_deltas)]
+    # a model that is not optimised still goes into the first sequence's finishing launch, with a zero learning rate: the
+    # iteration's record (progress line, *_state_dict.pth) takes its weights from there
     lr_w = groups[0]['lr'] if cfg.optimize_model else 0.0
-    w_m, w_v = (torch.zeros_like(w), torch.zeros_like(w)) if cfg.optimize_model else (None, None)
+    w_m, w_v = torch.zeros_like(w), torch.zeros_like(w)
     rings = [torch.zeros((R, t_.record_len), dtype=torch.float64, device=dev) for t_ in trs]
     vrings = [torch.zeros((R, v.record_len), dtype=torch.float64, device=dev) for v in vtr]
     # several sequences in a loss: their sums joined on the device, every finishing launch scaled by the joint divisor
@@ -653,7 +655,7 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
         if vtotals is not None:
             PoseSequenceTrainer.combine(vtr, vtotals)
         for q, (t_, r_) in enumerate(zip(trs, rings)):               # the first sequence's launch also steps the weights
-            first = q == 0 and cfg.optimize_model
+            first = q == 0
             t_.finish(w if first else None, w_m if first else None, w_v if first else None, lr_w if first else 0.0, r_, totals)
         for v, vr in zip(vtr, vrings):
             v.finish(None, None, None, 0.0, vr, vtotals)
@@ -724,6 +726,9 @@ def _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_ma
             and isinstance(optimizer, Adam) and len(optimizer.param_groups) == 1
             and fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
             and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
+            # (NaN-dropping reductions divide by the evaluation's OWN count, loss.py:125-137; the chained step scales its gradient
+            #  by the plan's static count)
+            and not kw.get('only_finite') and not kw.get('skip_nans')
             and isinstance(w, torch.nn.Parameter) and [id(p) for p in model.parameters()] == [id(w)]
             and w.is_cuda and w.dtype == torch.float64 and w.is_contiguous() and 1 <= w.numel() <= 3
             and model.kernel_params()[0] is w and not model.kernel_params()[1].requires_grad):

@@ -524,7 +524,8 @@ int dc_sequence_step(const dcSequenceDesc* d, double* w, const double* e, const 
  * t - 1) and take its Adam update, while the other blocks fetch what does not depend on the weights and then wait for them
  * (bounded; a wait that never ends yields NaN sums).  step: this evaluation's number (1, 2, ...; its parity selects the flag
  * and the partial-row buffer), has_prev: evaluation step - 1 is still unfinished (0 for the first launch and after a flush);
- * ready: device int32 [2], zeroed once; dcSequenceDesc.partials must hold dc_partial_rows(n) * (2 + 2 P + 12 S + 2 (2 + P))
+ * ready: device int32 [16] (64 bytes, 8-byte aligned), zeroed once -- the leading blocks publish the launch's weights there,
+ * every word stamped with `step`, and the other blocks pick them up in one trip; dcSequenceDesc.partials must hold dc_partial_rows(n) * (2 + 2 P + 12 S + 2 (2 + P))
  * doubles (the chain's two row buffers sit behind the columns of ordinary evaluations).  dc_sequence_chain_flush finishes evaluation `step` with the ordinary reduction
  * launch (sums -> out, Adam update `step`): the chain's last call. */
 int dc_sequence_step_chained(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,

@@ -636,3 +636,35 @@ def test_chained_wait_that_expires_is_reported_not_just_nan(room):
     tr2.step()
     again = npy(tr2.flush()).copy()
     assert np.isfinite(again).all() and not plan.chain_timed_out()
+
+
+def test_chained_steps_beside_a_busy_stream_finish_with_the_same_bits(room):
+    """The blocks of a chained launch wait (bounded) for the weights its leading blocks publish.  The leading blocks are dispatched
+    first and need nothing from the waiting ones, so the launch completes whatever else occupies the CUs -- here a second stream
+    of matrix products (as another rank's collective or any other kernel would): the steps finish beside it, nothing times out,
+    and sums and weights are bit-identical to the quiet run (fixed-order sums: timing does not enter)."""
+    from depth_correction_amd.pipeline import build_sequence
+    from depth_correction_amd.plan import SequenceTrainer
+    scans, poses = room
+    plan, info = build_sequence([s[:50_000] for s in scans[:3]], poses[:3], k=10, dtype=torch.float32)
+
+    def run(busy):
+        tr = SequenceTrainer([plan], [1e-3, 2e-3], [2.0, 4.0], [info['poses']], lr=1e-3, chained=True)
+        side = torch.cuda.Stream()
+        a = torch.randn((4096, 4096), device='cuda:0')
+        got = []
+        if busy:
+            with torch.cuda.stream(side):
+                for _ in range(40):
+                    a = torch.tanh(a @ a) * 0.5
+        for _ in range(30):
+            got.append(tr.step().clone())
+            assert tr.chained
+        got.append(tr.flush().clone())
+        torch.cuda.synchronize()
+        return [npy(v) for v in got], npy(tr.w).copy()
+
+    quiet, wq = run(False)
+    beside, wb = run(True)
+    assert all(np.array_equal(x, y) for x, y in zip(quiet, beside)) and np.array_equal(wq, wb)
+    assert np.isfinite(quiet[-1]).all() and plan.status_bits() == 0
