@@ -62,8 +62,9 @@ _SIGNATURES = {
     'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_pose_train_finish': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f64, _f64, _f64, _f64, _f64,
-                                    _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     'dc_pose_train_combine': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    'dc_pose_train_combine2': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     'dc_table_permute': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'dc_gather_rows': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     'dc_points_extent_workspace_bytes': (_sz, []),
@@ -88,7 +89,7 @@ _SIGNATURES = {
     'dc_sequence_step': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     'dc_sequence_step_chained': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
     'dc_sequence_step_chained_rec': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
-    'dc_sequence_eval_after_update': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
+    'dc_sequence_eval_after_update': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     'dc_sequence_chain_flush': (_i32, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     'dc_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp]),
     'dc_adam_step_device': (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _vp]),

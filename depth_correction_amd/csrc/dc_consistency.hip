@@ -1408,7 +1408,9 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* l
   if (ch.grad_sum) {                     // the sums exist already: weight a - 2's update, then publish
     if (a >= 2 && threadIdx.x == 0) {
       if (ch.has_prev && ch.adam.p) adam_update(ch.adam, a - 2, ch.grad_sum[a - 2]);
-      chain_publish(ch, a - 2, ch.adam.p ? ch.adam.p[a - 2] : ch.w_now[a - 2]);
+      const double wk = ch.adam.p ? ch.adam.p[a - 2] : ch.w_now[a - 2];
+      chain_publish(ch, a - 2, wk);
+      if (ch.w_prev_out) ch.w_prev_out[a - 2] = wk;      // (this form records the weights THIS evaluation uses: its sums are current)
     }
     return;
   }
@@ -3854,10 +3856,11 @@ int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg,
 
 int dc_sequence_eval_after_update(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
                                   double* exp_avg_sq, int64_t step, const double* grad_sum, double grad_scale, double lr, double beta1,
-                                  double beta2, double eps, double weight_decay, int32_t* ready, double* out, hipStream_t stream) {
+                                  double beta2, double eps, double weight_decay, int32_t* ready, double* out, double* w_used,
+                                  hipStream_t stream) {
   if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out || step < 1) return DC_ERR_ARG;
   if (grad_sum && step < 2) return DC_ERR_ARG;
-  ChainCall c{ready, (int)(step & 1), grad_sum ? 1 : 0, out, AdamArgs{}, grad_sum ? grad_sum : w, true};
+  ChainCall c{ready, (int)(step & 1), grad_sum ? 1 : 0, out, AdamArgs{}, grad_sum ? grad_sum : w, true, w_used};
   c.stamp = (uint32_t)step;
   if (grad_sum) {
     int rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);

@@ -602,8 +602,8 @@ __global__ __launch_bounds__(kBlock) void pose_correct_kernel(const double* __re
 // `T_used`.  The mean loss sum / count is what train() back-propagates: every gradient is scaled by 1 / count.  One block; thread p
 // takes pose p: the adjoint of T = T0 X(delta) (pose_chain_bwd), Adam on delta_p -- torch.optim.Adam's single-tensor update,
 // step t = *step + 1 -- and the corrected pose of the NEXT iteration from the updated correction; threads 0 .. P - 1 take the
-// weights.  `record` (optional) <- {sums, the weights, corrections and corrected poses [12 S] this iteration USED}: what a
-// checkpoint of the iteration holds.
+// weights.  `record` (optional) <- {sums, the weights, corrections and corrected poses [12 S] this iteration USED, then the
+// caller's `rec_extra` doubles}: what a checkpoint of the iteration holds.
 struct PoseTrainArgs {
   const double* sums;
   int n_sums, count_index, grad_w_off, grad_T_off;      // layout of `sums`; count_index < 0: the gradients are those of the loss itself
@@ -619,27 +619,30 @@ struct PoseTrainArgs {
   int ring_rows;
   double* T_next;                        // [S, 16]
   double* P12_next;                      // [S, 12]
+  const double* rec_extra;               // or nullptr: n_rec_extra doubles appended to the record (the joint sums of every loss of the
+  int n_rec_extra;                       // iteration: a rank's log then holds the training AND the validation loss of all ranks)
 };
 
 // {loss, divisor, dL/dw} of a loss over several sequences (eval.py:85-112 sums the sequences' sums and counts; icp_loss averages the
 // sequences' losses, loss.py:403): layout 0: {sum of sums, sum of counts, ...}; layout 1: {sum of losses, number of sequences, ...}.
 constexpr int kTrainSeqs = 16;
 struct PoseCombineArgs {
-  const double* outs[kTrainSeqs];
-  int n_seq, layout, n_terms;
-  double* totals;
+  const double* outs[2 * kTrainSeqs];            // group 0 (n_seq of them), then group 1 (n_seq_b)
+  int n_seq, n_seq_b, layout, n_terms;
+  double* totals;                                // [2 + P], or [2][2 + P] with two groups (block g takes group g)
 };
 __global__ void pose_train_combine_kernel(PoseCombineArgs a) {
   const int q = threadIdx.x;                     // 0: loss, 1: divisor, 2 + k: dL/dw_k
   if (q >= 2 + a.n_terms) return;
+  const int g = blockIdx.x, first = g == 0 ? 0 : a.n_seq, count = g == 0 ? a.n_seq : a.n_seq_b;
   const int head = a.layout == 0 ? 2 : 1;
   double s = 0.0;
-  for (int i = 0; i < a.n_seq; ++i) {            // fixed order
+  for (int i = first; i < first + count; ++i) {  // fixed order
     if (q == 0) s += a.outs[i][0];
     else if (q == 1) s += a.layout == 0 ? a.outs[i][1] : 1.0;
     else s += a.outs[i][head + (q - 2)];
   }
-  a.totals[q] = s;
+  a.totals[g * (2 + a.n_terms) + q] = s;
 }
 
 __device__ __forceinline__ double adam_one(double p0, double& m, double& v, double g, double lr, double b1, double b2, double eps,
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
   const int S = a.n_scans, P = a.n_terms, tid = threadIdx.x;
   const int n_sums = a.n_sums;
   if (a.record) {
-    double* r = a.record + (*a.step % a.ring_rows) * (int64_t)(n_sums + P + 6 * a.n_deltas + 12 * S);
+    double* r = a.record + (*a.step % a.ring_rows) * (int64_t)(n_sums + P + 6 * a.n_deltas + 12 * S + a.n_rec_extra);
     for (int q = tid; q < n_sums; q += kBlock) r[q] = a.sums[q];
     r += n_sums;
     for (int q = tid; q < P; q += kBlock) r[q] = a.w ? a.w[q] : 0.0;
@@ -663,6 +666,8 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
     for (int q = tid; q < 6 * a.n_deltas; q += kBlock) r[q] = a.delta[q];
     r += 6 * a.n_deltas;
     for (int q = tid; q < 12 * S; q += kBlock) r[q] = a.T_used[(q / 12) * 16 + q % 12];
+    r += 12 * S;
+    for (int q = tid; q < a.n_rec_extra; q += kBlock) r[q] = a.rec_extra[q];
   }
   __syncthreads();                                             // the record holds what this iteration USED: copied before any update
   const double t = (double)(*a.step + 1);
@@ -764,15 +769,27 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
 }
 
 int dc_pose_train_combine(const double* const* outs, int n_seq, int layout, int n_terms, double* totals, hipStream_t stream) {
-  if (!outs || n_seq < 1 || n_seq > dc::kTrainSeqs || (layout != 0 && layout != 1) || n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !totals)
+  if (n_seq < 1) return DC_ERR_ARG;
+  return dc_pose_train_combine2(outs, n_seq, nullptr, -1, layout, n_terms, totals, stream);
+}
+
+int dc_pose_train_combine2(const double* const* outs_a, int n_a, const double* const* outs_b, int n_b, int layout, int n_terms,
+                           double* totals, hipStream_t stream) {
+  // n_b < 0: one group, totals [2 + P]; otherwise two groups (either may be empty: zeros), totals [2][2 + P]
+  if (n_a < 0 || n_a > dc::kTrainSeqs || n_b > dc::kTrainSeqs || (n_a > 0 && !outs_a) || (n_b > 0 && !outs_b) || (layout != 0 && layout != 1) ||
+      n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !totals)
     return DC_ERR_ARG;
   dc::PoseCombineArgs a{};
-  for (int i = 0; i < n_seq; ++i) {
-    if (!outs[i]) return DC_ERR_ARG;
-    a.outs[i] = outs[i];
+  for (int i = 0; i < n_a; ++i) {
+    if (!outs_a[i]) return DC_ERR_ARG;
+    a.outs[i] = outs_a[i];
   }
-  a.n_seq = n_seq; a.layout = layout; a.n_terms = n_terms; a.totals = totals;
-  hipLaunchKernelGGL(dc::pose_train_combine_kernel, dim3(1), dim3(64), 0, stream, a);
+  for (int i = 0; i < n_b; ++i) {
+    if (!outs_b[i]) return DC_ERR_ARG;
+    a.outs[n_a + i] = outs_b[i];
+  }
+  a.n_seq = n_a; a.n_seq_b = n_b < 0 ? 0 : n_b; a.layout = layout; a.n_terms = n_terms; a.totals = totals;
+  hipLaunchKernelGGL(dc::pose_train_combine_kernel, dim3(n_b < 0 ? 1 : 2), dim3(64), 0, stream, a);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
 }
@@ -780,7 +797,8 @@ int dc_pose_train_combine(const double* const* outs, int n_seq, int layout, int 
 int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
                          double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
                          double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
-                         double* poses12_next, const double* totals, hipStream_t stream) {
+                         double* poses12_next, const double* totals, const double* record_extra, int n_record_extra, hipStream_t stream) {
+  if (n_record_extra < 0 || (n_record_extra > 0 && !record_extra)) return DC_ERR_ARG;
   if (!sums || n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || n_scans < 1 || (n_deltas != 1 && n_deltas != n_scans) || !poses0 || !deltas ||
       !d_m || !d_v || !step || !poses_used || !poses_next || !poses12_next || (w && (!w_m || !w_v)) || (record && ring_rows < 1))
     return DC_ERR_ARG;
@@ -790,7 +808,7 @@ int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scan
   const int head = layout == 0 ? 2 : 1;
   dc::PoseTrainArgs a{sums, head + 2 * n_terms + 12 * n_scans, layout == 0 ? 1 : -1, head, head + 2 * n_terms, totals,
                       n_terms, n_scans, n_deltas, zero_first, w, w_m, w_v, poses0, deltas, d_m, d_v, step, lr_w, lr_d, beta1, beta2, eps,
-                      poses_used, record, ring_rows, poses_next, poses12_next};
+                      poses_used, record, ring_rows, poses_next, poses12_next, record_extra, n_record_extra};
   hipLaunchKernelGGL(dc::pose_train_finish_kernel, dim3(1), dim3(dc::kBlock), 0, stream, a);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;

@@ -483,10 +483,11 @@ class SequencePlan:
 
     @on_device
     def eval_after_update(self, w, exponent, poses12, out, exp_avg, exp_avg_sq, t, grad_sum, ready, grad_scale, lr, betas, eps,
-                          weight_decay):
+                          weight_decay, w_used=None):
         """Evaluation number ``t`` whose launch first takes Adam update ``t - 1`` from ``grad_sum`` (the previous evaluation's
         dL/dw, already summed over sequences / ranks; None for the first call), then the ordinary reduction of this
-        evaluation into ``out`` (dc_sequence_eval_after_update).  Returns False when this plan / model cannot do that."""
+        evaluation into ``out`` (dc_sequence_eval_after_update); ``w_used`` (fp64 [P], optional) <- the weights this evaluation
+        uses.  Returns False when this plan / model cannot do that."""
         nt = w.numel()
         d = self.desc(nt)
         need(out, (2 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
@@ -496,7 +497,8 @@ class SequencePlan:
         self._set_basis(d, w, exponent, poses12, False, False)
         rc = lib().dc_sequence_eval_after_update(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq),
                                                  int(t), ptr(grad_sum), float(grad_scale), float(lr), float(betas[0]),
-                                                 float(betas[1]), float(eps), float(weight_decay), ptr(ready), ptr(out), stream_ptr())
+                                                 float(betas[1]), float(eps), float(weight_decay), ptr(ready), ptr(out), ptr(w_used),
+                                                 stream_ptr())
         if rc in (-4, nv.DC_ERR_BACKWARD_TABLES):
             return False
         check(rc, 'dc_sequence_eval_after_update')
@@ -823,6 +825,7 @@ class PoseSequenceTrainer:
     def record_len(self):
         return self.head + 2 * self.nt + 12 * self.S + self.nt + 6 * self.nd + 12 * self.S
 
+
     def evaluate(self, w, exponent):
         """Loss (sums) and gradients (dL/dw, dL/d[R|t]) for the current corrected poses -> self.out."""
         if self.icp:
@@ -838,14 +841,16 @@ class PoseSequenceTrainer:
         return float(row[0] / row[1]) if row[1] > 0 else float('nan')
 
     @on_device
-    def finish(self, w=None, w_m=None, w_v=None, lr_w=0.0, ring=None, totals=None):
+    def finish(self, w=None, w_m=None, w_v=None, lr_w=0.0, ring=None, totals=None, rec_extra=None):
         """Backward through the pose chain, the optimiser steps, the next iteration's poses (in place); row (step mod rows) of
-        ``ring`` [rows, record_len] <- {sums, weights, corrections, corrected poses} of THIS iteration.  Every pointer is the same
-        from call to call (the ring slot follows the device step counter): a captured iteration replays correctly."""
+        ``ring`` [rows, record_len (+ len(rec_extra))] <- {sums, weights, corrections, corrected poses} of THIS iteration (then the
+        ``rec_extra`` doubles: the joint sums of the iteration's losses).  Every pointer is the same from call to call (the ring
+        slot follows the device step counter): a captured iteration replays correctly."""
         check(lib().dc_pose_train_finish(ptr(self.out), 1 if self.icp else 0, self.nt, self.S, ptr(w), ptr(w_m), ptr(w_v), ptr(self.T0), ptr(self.delta),
                                          ptr(self.d_m), ptr(self.d_v), self.nd, self.zero_first, ptr(self.step), float(lr_w), self.lr,
                                          self.betas[0], self.betas[1], self.eps, ptr(self.T), ptr(ring), 0 if ring is None else ring.shape[0],
-                                         ptr(self.T), ptr(self.P12), ptr(totals), stream_ptr()), 'dc_pose_train_finish')
+                                         ptr(self.T), ptr(self.P12), ptr(totals), ptr(rec_extra), 0 if rec_extra is None else rec_extra.numel(),
+                                         stream_ptr()), 'dc_pose_train_finish')
 
     @staticmethod
     @on_device
@@ -858,16 +863,36 @@ class PoseSequenceTrainer:
                                           stream_ptr()), 'dc_pose_train_combine')
         return totals
 
+    @staticmethod
+    def combine2(trainers, val_trainers, totals2):
+        """totals2 [2, 2 + P] <- {loss, divisor, dL/dw} of the training sequences' loss and of the validation sequences' loss in
+        ONE launch (dc_pose_train_combine2); either list may be empty (zeros).  With sharded sequences ``totals2`` is what the
+        iteration's one all-reduce sums over the ranks."""
+        return combine_sums([t.out for t in trainers], [v.out for v in val_trainers], totals2,
+                            layout=1 if (list(trainers) + list(val_trainers))[0].icp else 0)
+
     def split_record(self, row):
         """(sums, weights, corrections [nd,6], corrected poses [S,4,4]) of a record row (a CPU tensor)."""
         a = self.head + 2 * self.nt + 12 * self.S
         sums, w = row[:a], row[a:a + self.nt]
         d = row[a + self.nt:a + self.nt + 6 * self.nd].reshape(self.nd, 6)
-        P = row[a + self.nt + 6 * self.nd:].reshape(self.S, 3, 4)
+        P = row[a + self.nt + 6 * self.nd:a + self.nt + 6 * self.nd + 12 * self.S].reshape(self.S, 3, 4)
         T = torch.zeros((self.S, 4, 4), dtype=row.dtype)
         T[:, :3, :] = P
         T[:, 3, 3] = 1.0
         return sums, w, d, T
+
+
+@on_device
+def combine_sums(outs_a, outs_b, totals2, layout=0):
+    """totals2 [2, 2 + P] <- the sums {loss, divisor, dL/dw} of two groups of evaluation outputs (dc_pose_train_combine2)."""
+    nt = totals2.shape[1] - 2
+    need(totals2, (2, 2 + nt), dtype=torch.float64, name='totals2')
+    arr_a = (ctypes.c_void_p * max(len(outs_a), 1))(*[o.data_ptr() for o in outs_a])
+    arr_b = (ctypes.c_void_p * max(len(outs_b), 1))(*[o.data_ptr() for o in outs_b])
+    check(lib().dc_pose_train_combine2(ctypes.cast(arr_a, ctypes.c_void_p), len(outs_a), ctypes.cast(arr_b, ctypes.c_void_p), len(outs_b),
+                                       int(layout), nt, ptr(totals2), stream_ptr()), 'dc_pose_train_combine2')
+    return totals2
 
 
 class SequenceTrainer:
@@ -902,6 +927,7 @@ class SequenceTrainer:
         self.update_in_next = (bool(chained) and not self.fused_step and evaluate is None and adam is None
                                and len(self.plans) >= 1 and self.nt > 0)
         self._pending = False
+        self._grad_prev = None         # update_in_next: the summed gradient of the last step when the caller reduced it (use_sums)
         self.ready = torch.zeros((16,), dtype=torch.int32, device=dev)      # 64 bytes: the chain's published weights
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
         self.acc = torch.zeros((2 + self.nt,), dtype=torch.float64, device=dev)       # [sum loss, count, dL/dw]
@@ -922,8 +948,8 @@ class SequenceTrainer:
         update); returns the sums.  No-op otherwise."""
         buf = self.outs[0] if out is None else out
         if self._pending and self.update_in_next:
-            g = self.acc if len(self.plans) > 1 else self.outs[0]
-            self.adam(g[2:2 + self.nt])                           # the last evaluation's (all-reduced) gradient, step self.t
+            g = self._grad_prev if self._grad_prev is not None else (self.acc if len(self.plans) > 1 else self.outs[0])[2:2 + self.nt]
+            self.adam(g)                                          # the last evaluation's (all-reduced) gradient, step self.t
             self._pending = False
         elif self._pending:
             self.plans[0].chain_flush(self.w, buf, self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
@@ -931,16 +957,24 @@ class SequenceTrainer:
             self._pending = False
         return buf[:2 + self.nt] if len(self.outs) == 1 else self.acc
 
+    def use_sums(self, acc):
+        """``acc`` [2 + P] = {sum loss, count, dL/dw} of the last step over all sequences and ranks (step(defer_reduce=True)): the
+        gradient the next launch's Adam update takes."""
+        need(acc, (2 + self.nt,), dtype=torch.float64, name='acc', device=self.w.device)
+        self._grad_prev = acc[2:]
+
     def _grad_scale(self):
         """1 / number of masked points of all sequences (the mean reduction, loss.py:205-213); no masked point at all:
         NaN, the mean of an empty tensor, as in the reference."""
         return 1.0 / self.count if self.count > 0 else float('nan')
 
-    def step(self, out_prev=None, w_used_prev=None, require_chain=False):
+    def step(self, out_prev=None, w_used_prev=None, require_chain=False, defer_reduce=False):
         """One optimisation step; returns the device tensor [sum loss, count, dL/dw...] summed over sequences / ranks
         (mean loss = acc[0] / acc[1]).  No host synchronisation.  Chained mode only: ``out_prev`` (fp64 [2 + 2P + 12S]) takes
         the PREVIOUS evaluation's sums instead of the trainer's own buffer and ``w_used_prev`` (fp64 [P]) the weights that
-        evaluation used -- a training log's record of an iteration, written by the launch itself."""
+        evaluation used -- a training log's record of an iteration, written by the launch itself.  ``update_in_next`` mode: the
+        sums are current, ``w_used_prev`` takes the weights THIS evaluation uses; ``defer_reduce``: the sequences' sums stay in
+        ``self.outs`` and the caller hands the joint (all-reduced) sums back with use_sums() before the next step."""
         if self.chained:
             buf = self.outs[0] if out_prev is None else out_prev
             ok = self.plans[0].step_chained(self.w, self.exponent, self.poses12[0], buf, self.exp_avg, self.exp_avg_sq,
@@ -964,26 +998,34 @@ class SequenceTrainer:
             several = len(self.plans) > 1
             acc = self.acc if several else self.outs[0][:2 + self.nt]
             # (the launch reads the gradient before the reduction that follows it on the stream overwrites `out`)
+            grad = (self._grad_prev if self._grad_prev is not None else acc[2:]) if self._pending else None
             ok = self.plans[0].eval_after_update(self.w, self.exponent, self.poses12[0], self.outs[0], self.exp_avg, self.exp_avg_sq,
-                                                 self.t + 1, acc[2:] if self._pending else None, self.ready, self._grad_scale(),
-                                                 self.lr, self.betas, self.eps, self.weight_decay)
+                                                 self.t + 1, grad, self.ready, self._grad_scale(),
+                                                 self.lr, self.betas, self.eps, self.weight_decay, w_used=w_used_prev)
             if ok:
+                # the other local sequences follow on the stream: their launches start after the first one has published
+                # the updated weights (kernels of one stream run in order)
+                for plan, P, out in zip(self.plans[1:], self.poses12[1:], self.outs[1:]):
+                    self.evaluate(plan, self.w, self.exponent, P, out)
+                self.t += 1
+                self._pending = True
+                if defer_reduce:
+                    # the caller joins self.outs (with whatever else the iteration's ONE all-reduce carries) and hands the summed
+                    # gradient back through use_sums()
+                    return self.outs
+                self._grad_prev = None
                 if several:
-                    # the other local sequences follow on the stream: their launches start after the first one has published
-                    # the updated weights (kernels of one stream run in order); their sums join the first one's
-                    for plan, P, out in zip(self.plans[1:], self.poses12[1:], self.outs[1:]):
-                        self.evaluate(plan, self.w, self.exponent, P, out)
                     acc.zero_()
                     for o in self.outs:
                         acc += o[:2 + self.nt]
                 if self.distributed:
                     from .distributed import all_reduce_sum
                     all_reduce_sum(acc, self.group)
-                self.t += 1
-                self._pending = True
                 return acc
             self.flush()
             self.update_in_next = False
+            if require_chain:
+                return None                      # (nothing was launched)
         for plan, P, out in zip(self.plans, self.poses12, self.outs):
             self.evaluate(plan, self.w, self.exponent, P, out)
         if len(self.outs) == 1:

@@ -51,6 +51,38 @@ class TrainCallbacks(object):
         pass
 
 
+def _sharding(cfg):
+    """(rank, world, sharded): sequences are dealt over the ranks of an initialised process group unless cfg.distributed is False.
+    DC_FORCE_DIST=1 makes a one-rank group take the sharded code paths too (collectives included): how they are exercised, and
+    timed, on a one-GPU box."""
+    if getattr(cfg, 'distributed', None) is False:
+        return 0, 1, False
+    rank, world = world_info()
+    forced = False
+    if world == 1 and os.environ.get('DC_FORCE_DIST') == '1':
+        import torch.distributed as dist
+        forced = dist.is_available() and dist.is_initialized()
+    return rank, world, world > 1 or forced
+
+
+def _only_watches_the_clock(callbacks):
+    """True when nothing looks at an iteration's tensors while it runs: the callbacks are the no-op base class, or a subclass that
+    overrides ``iteration_started`` only (a host-side hook the native loops call before they launch an iteration)."""
+    return isinstance(callbacks, TrainCallbacks) and all(getattr(type(callbacks), name, None) is getattr(TrainCallbacks, name)
+                                                         for name in ('train_inputs', 'val_inputs', 'train_loss', 'val_loss'))
+
+
+def _agree(code, device):
+    """The same value on every rank: ``code`` when all ranks hold it, else 0 (one small all-reduce at set-up)."""
+    from .distributed import all_reduce_sum
+    import torch.distributed as dist
+    v = torch.tensor([float(code), -float(code)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    hi, lo = float(v[0].item()), -float(v[1].item())
+    return int(hi) if hi == lo else 0
+
+
 def _load_sequences(datasets, cfg):
     all_clouds, all_poses = [], []
     for ds in datasets:
@@ -140,8 +172,7 @@ def train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
 def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
     assert cfg.nn_type == NeighborhoodType.ball
     callbacks = callbacks or TrainCallbacks(cfg)
-    rank, world = world_info() if getattr(cfg, 'distributed', None) is not False else (0, 1)
-    sharded = world > 1
+    rank, world, sharded = _sharding(cfg)
     if sharded and torch.device(cfg.device).type == 'cuda' and torch.device(cfg.device).index is not None:
         # object collectives (the checkpoint gather) and RCCL's own staging use torch's current device: it must be this
         # rank's GPU, whatever the launcher did.  An index-less 'cuda' means "the current device" (the launcher has already
@@ -223,25 +254,36 @@ def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
         return loss * weight if loss is not None else torch.zeros((), dtype=torch.float64, device=cfg.device)
 
     batch = int(getattr(cfg, 'loop_batch', 64) or 1)
-    if (batch > 1 and not sharded and type(callbacks) is TrainCallbacks and torch.device(cfg.device).type == 'cuda'
-            and cfg.n_opt_iters > 0):
-        # nobody looks at an iteration while it runs (the callbacks are the no-op base class): the loop runs without a host
-        # synchronisation per iteration -- see _batched_loop
+    if (batch > 1 and _only_watches_the_clock(callbacks) and torch.device(cfg.device).type == 'cuda' and cfg.n_opt_iters > 0):
+        # nobody looks at an iteration while it runs: the loop runs without a host synchronisation per iteration -- see _batched_loop.
+        # Sharded sequences (one process per GPU): the same loops with the iteration's ONE all-reduce enqueued on the stream between
+        # the evaluations and the finishing launches; every rank must take the same loop, so they agree on it first
+        use_native = getattr(cfg, 'loop_native', True)
+        shard = dict(rank=rank, world=world, n_train=n_train, n_val=n_val) if sharded else None
         native = _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_masks, train_ns, val_clouds, val_poses,
-                                   val_masks, val_ns) if getattr(cfg, 'loop_native', True) else None
-        if native is not None:
-            ran, best = _native_loop(cfg, model, optimizer, native[0], native[1], train_poses, val_poses, batch)
+                                   val_masks, val_ns, sharded) if use_native else None
+        pose_native = None
+        if native is None and use_native:
+            pose_native = _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, train_poses, train_masks, train_ns,
+                                                 train_pose_deltas, val_clouds, val_poses, val_masks, val_ns, val_pose_deltas)
+        code = 1 if native is not None else (2 if pose_native is not None else 0)
+        if sharded:
+            code = _agree(code, cfg.device)
+        if code == 1:
+            if not sharded and len(native[0]) == 1:
+                ran, best = _native_loop(cfg, model, optimizer, native[0][0], native[1], train_poses, val_poses, batch, callbacks)
+            else:
+                ran, best = _native_shared_loop(cfg, model, optimizer, native[0], native[1], train_poses, val_poses, batch, shard, callbacks)
             if ran:
                 return best
-        native = _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, train_poses, train_masks, train_ns,
-                                        train_pose_deltas, val_clouds, val_poses, val_masks, val_ns, val_pose_deltas) \
-            if getattr(cfg, 'loop_native', True) else None
-        if native is not None:
-            return _native_pose_loop(cfg, model, optimizer, val_optimizer, native[0], native[1], train_poses, val_poses,
-                                     train_pose_deltas, val_pose_deltas, batch)
-        return _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch,
-                             lambda: evaluate(train_clouds, train_poses, train_pose_deltas, train_masks, train_ns),
-                             lambda: evaluate(val_clouds, val_poses, val_pose_deltas, val_masks, val_ns))
+            code = 0
+        if code == 2:
+            return _native_pose_loop(cfg, model, optimizer, val_optimizer, pose_native[0], pose_native[1], train_poses, val_poses,
+                                     train_pose_deltas, val_pose_deltas, batch, shard, callbacks)
+        if not sharded:
+            return _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch,
+                                 lambda: evaluate(train_clouds, train_poses, train_pose_deltas, train_masks, train_ns),
+                                 lambda: evaluate(val_clouds, val_poses, val_pose_deltas, val_masks, val_ns), callbacks)
 
     min_train_loss = min_val_loss = np.inf
     best_cfg = None
@@ -322,9 +364,14 @@ class _Bookkeeper(object):
     config), fed with RECORDED iterations in order.  A batch of records ends with ``end_batch``, which writes the files of the
     batch's last improvement."""
 
-    def __init__(self, cfg, model):
+    def __init__(self, cfg, model, shard=None):
+        """shard: None, or dict(rank, world, n_train, n_val) when the sequences are dealt over ranks -- every rank replays the same
+        records (the losses are all-reduced: identical everywhere), rank 0 prints and writes, and a checkpoint gathers the pose
+        corrections / corrected poses of the sequences the other ranks own (one object gather per batch, at its last improvement)."""
         import copy
         self.cfg, self.min_val, self.best, self._last = cfg, np.inf, None, None
+        self.shard = shard
+        self.lead = shard is None or shard['rank'] == 0
         # formats the progress line from a recorded state, on the host.  .to() and not .cpu(): the models move their plain tensor
         # attributes (fixed exponents) in to() only, and a progress line that reads a device tensor waits for every queued iteration
         self.shadow = copy.deepcopy(model).to('cpu')
@@ -336,6 +383,8 @@ class _Bookkeeper(object):
         if saved:
             self.min_val = vl
             self._last = (it, vl, sd, deltas, poses)
+        if not self.lead:
+            return
         for k, v in sd.items():
             self.shadow_sd[k].copy_(v)
         print('It. %03i: train loss: %.9f, val.: %.9f. Model %s %s.' % (it, tl, vl, self.shadow, 'saved' if saved else 'not saved'))
@@ -348,6 +397,8 @@ class _Bookkeeper(object):
         if saved:
             self.min_val = vl
             self._last = (it, vl, payload)
+        if not self.lead:
+            return
         t = self.shadow_sd[key]
         t.copy_(torch.from_numpy(np.ascontiguousarray(value)).reshape(t.shape))
         print('It. %03i: train loss: %.9f, val.: %.9f. Model %s %s.' % (it, tl, vl, self.shadow, 'saved' if saved else 'not saved'))
@@ -363,13 +414,26 @@ class _Bookkeeper(object):
         self._last = None
         cfg = self.cfg
         stem = '%s/%03i_%.6g' % (cfg.log_dir, it, vl)
-        torch.save({k: v.clone() for k, v in sd.items()}, stem + '_state_dict.pth')
-        torch.save([d.clone() for d in deltas], stem + '_pose_deltas.pth')
-        torch.save([p.clone() for p in poses], stem + '_poses_upd.pth')
+        if self.shard is not None:
+            # sequence order: rank r owns sequences r, r + world, ...; every rank takes part in the gather (train.py:232-240 saves
+            # the corrections and corrected poses of ALL training sequences)
+            sh = self.shard
+            by_rank = gather_objects((shard_sequences(sh['n_train'], sh['rank'], sh['world']), [d.clone() for d in deltas],
+                                      [p.clone() for p in poses]), device=cfg.device)
+            deltas, poses = sh['n_train'] * [None], sh['n_train'] * [None]
+            for idx, ds_, ps_ in by_rank:
+                for k, i in enumerate(idx):
+                    deltas[i] = ds_[k] if k < len(ds_) else None
+                    poses[i] = ps_[k] if k < len(ps_) else None
+            deltas, poses = [d for d in deltas if d is not None], [p for p in poses if p is not None]
         best = cfg.copy()
         best.model_state_dict = stem + '_state_dict.pth'
         best.train_pose_deltas = stem + '_pose_deltas.pth'
-        self._write_yaml(best, os.path.join(cfg.log_dir, 'best.yaml'))
+        if self.lead:
+            torch.save({k: v.clone() for k, v in sd.items()}, stem + '_state_dict.pth')
+            torch.save([d.clone() for d in deltas], stem + '_pose_deltas.pth')
+            torch.save([p.clone() for p in poses], stem + '_poses_upd.pth')
+            self._write_yaml(best, os.path.join(cfg.log_dir, 'best.yaml'))
         self.best = best
 
     def _write_yaml(self, best, path):
@@ -399,7 +463,8 @@ class _Bookkeeper(object):
             f.write(text)
 
 
-def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch, eval_train, eval_val):
+def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_pose_deltas, n_val, batch, eval_train, eval_val,
+                  callbacks=None):
     """The loop of train() (train.py:220-322) without a host synchronisation per iteration.
 
     The reference reads ``train_loss.item()`` / ``val_loss.item()`` in every iteration (checkpoint decision and the progress
@@ -480,8 +545,10 @@ def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_p
     warm = min(3, n_it)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
+    started = callbacks.iteration_started if callbacks is not None else (lambda i: None)
     with torch.cuda.stream(side):
         for _ in range(warm):                                # real iterations 0 .. warm - 1, off the default stream as captures ask
+            started(it)
             body()
             it += 1
     torch.cuda.current_stream(dev).wait_stream(side)
@@ -499,6 +566,7 @@ def _batched_loop(cfg, model, optimizer, val_optimizer, train_pose_deltas, val_p
         while it < n_it:
             if it - state['done'] >= R:
                 drain(it)
+            started(it)
             if graph is not None:
                 graph.replay()
             else:
@@ -565,7 +633,7 @@ def _native_pose_loop_plan(cfg, model, optimizer, val_optimizer, train_clouds, t
 
 
 def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train_poses, val_poses, train_pose_deltas, val_pose_deltas,
-                      batch):
+                      batch, shard=None, callbacks=None):
     """train()'s loop with pose corrections on the library's own launches (plan.PoseSequenceTrainer): per iteration and sequence
     one evaluation (the pose kernel + its reduction) and ONE finishing launch that back-propagates through the pose chain, keeps
     the first pose fixed, takes both Adam updates, forms the next iteration's poses and writes the iteration's record into the
@@ -574,7 +642,12 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
     sum of the sequences' sums by the sum of their counts, icp_loss averages their losses) and every finishing launch scales by
     the joint divisor; the first sequence's also steps the weights.  Bookkeeping as in _batched_loop: one synchronisation per
     ``batch`` iterations.  The corrections are optimised in fp64 and written back to the caller's tensors (whatever their dtype)
-    when the loop ends."""
+    when the loop ends.
+    Sharded sequences (``shard``; BASELINE config 4: one KITTI-360-like sequence per GPU): the joint sums of the training and the
+    validation loss -- [2][loss, divisor, dL/dw], one launch (dc_pose_train_combine2) -- go through the iteration's ONE all-reduce,
+    enqueued on the stream between the evaluations and the finishing launches; every rank then takes the identical update of the
+    weights, and the corrections stay with the rank that owns the sequence.  No host synchronisation, no autograd."""
+    from .distributed import all_reduce_sum
     from .plan import PoseSequenceTrainer
     dev = torch.device(cfg.device)
     n_it, R = cfg.n_opt_iters, batch
@@ -596,16 +669,21 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
     # iteration's record (progress line, *_state_dict.pth) takes its weights from there
     lr_w = groups[0]['lr'] if cfg.optimize_model else 0.0
     w_m, w_v = torch.zeros_like(w), torch.zeros_like(w)
-    rings = [torch.zeros((R, t_.record_len), dtype=torch.float64, device=dev) for t_ in trs]
-    vrings = [torch.zeros((R, v.record_len), dtype=torch.float64, device=dev) for v in vtr]
-    # several sequences in a loss: their sums joined on the device, every finishing launch scaled by the joint divisor
-    totals = torch.zeros((2 + nt,), dtype=torch.float64, device=dev) if len(trs) > 1 else None
-    vtotals = torch.zeros((2 + nt,), dtype=torch.float64, device=dev) if len(vtr) > 1 else None
+    # several sequences in a loss (or in other ranks' hands): their sums joined on the device -- both losses in one launch, then one
+    # all-reduce -- and every finishing launch scaled by the joint divisor; every record carries the joint sums of both losses
+    sharded = shard is not None
+    has_val = (shard['n_val'] if sharded else len(vtr)) > 0
+    totals2 = torch.zeros((2, 2 + nt), dtype=torch.float64, device=dev) if (sharded or len(trs) > 1 or len(vtr) > 1) else None
+    totals, vtotals = (totals2[0], totals2[1]) if totals2 is not None else (None, None)
+    extra = totals2.reshape(-1) if totals2 is not None else None
+    n_extra = 0 if extra is None else extra.numel()
+    rings = [torch.zeros((R, t_.record_len + n_extra), dtype=torch.float64, device=dev) for t_ in trs]
+    vrings = [torch.zeros((R, v.record_len + n_extra), dtype=torch.float64, device=dev) for v in vtr]
     sd_const = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
     d_dtype, T_dtype = train_pose_deltas[0].dtype, train_poses[0].dtype
     all_plans = list(plans) + list(vplans)
-    book = _Bookkeeper(cfg, model)
+    book = _Bookkeeper(cfg, model, shard)
 
     def fetch():
         """The ring on the host (synchronises: every launched iteration has finished)."""
@@ -632,7 +710,7 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
 
         def payload_of(rows):
             def build():
-                parts = [t_.split_record(torch.from_numpy(r_)) for t_, r_ in zip(trs, rows)]
+                parts = [t_.split_record(torch.from_numpy(r_[:t_.record_len])) for t_, r_ in zip(trs, rows)]
                 sd = dict(sd_const)
                 sd[w_key] = parts[0][1].reshape(w_param.shape).to(w_param.dtype).clone()
                 return sd, [p_[2].to(d_dtype).clone() for p_ in parts], [p_[3].to(T_dtype).clone() for p_ in parts]
@@ -640,8 +718,13 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
 
         for it in range(first, upto):
             rows = [H[it % R] for H in HS]
-            tl = joint_loss(trs, rows)
-            vl = joint_loss(vtr, [V[it % R] for V in HV]) if vtr else tl
+            if n_extra:                                               # the joint sums over all sequences (and ranks) ride in every record
+                t2 = rows[0][-n_extra:].reshape(2, 2 + nt)
+                tl = float(t2[0, 0] / t2[0, 1]) if t2[0, 1] > 0 else float('nan')
+                vl = (float(t2[1, 0] / t2[1, 1]) if t2[1, 1] > 0 else float('nan')) if has_val else tl
+            else:
+                tl = joint_loss(trs, rows)
+                vl = joint_loss(vtr, [V[it % R] for V in HV]) if vtr else tl
             book.record_fast(it, tl, vl, w_key, rows[0][a0:a0 + nt], payload_of([r_.copy() for r_ in rows]))
         book.end_batch()
 
@@ -650,20 +733,24 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
             t_.evaluate(w, e)
         for v in vtr:
             v.evaluate(w, e)                                         # validation with the weights of THIS iteration
-        if totals is not None:
-            PoseSequenceTrainer.combine(trs, totals)
-        if vtotals is not None:
-            PoseSequenceTrainer.combine(vtr, vtotals)
+        if totals2 is not None:
+            PoseSequenceTrainer.combine2(trs, vtr, totals2)
+            if sharded:
+                all_reduce_sum(totals2)                                  # the iteration's ONE collective
         for q, (t_, r_) in enumerate(zip(trs, rings)):               # the first sequence's launch also steps the weights
             first = q == 0
-            t_.finish(w if first else None, w_m if first else None, w_v if first else None, lr_w if first else 0.0, r_, totals)
+            t_.finish(w if first else None, w_m if first else None, w_v if first else None, lr_w if first else 0.0, r_, totals, extra)
         for v, vr in zip(vtr, vrings):
-            v.finish(None, None, None, 0.0, vr, vtotals)
+            v.finish(None, None, None, 0.0, vr, vtotals, extra)
 
     state = dict(launched=0, graph=None, tried=False)
 
     def run_one():
-        if state['launched'] >= 3 and not state['tried'] and n_it - state['launched'] >= 4 and getattr(cfg, 'loop_graph', True):
+        if callbacks is not None:
+            callbacks.iteration_started(state['launched'])
+        # (sharded: launched eagerly -- a collective inside a captured graph is not something this path relies on)
+        if (state['launched'] >= 3 and not state['tried'] and n_it - state['launched'] >= 4 and getattr(cfg, 'loop_graph', True)
+                and not sharded):
             # every launch of an iteration takes the same pointers (the record's ring slot follows the device step counter): the
             # iteration is captured once, after three eager ones (pose tables built, allocator warm), and replayed -- one graph
             # launch per iteration instead of the host path of three library calls
@@ -701,7 +788,7 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
             prev = None
     except BaseException:
         try:                                                          # an interrupted run keeps the batch it had finished
-            if prev is not None and state['launched'] == prev[1]:
+            if prev is not None and state['launched'] == prev[1] and not sharded:
                 bookkeep(fetch(), *prev)
         except Exception:
             pass
@@ -714,15 +801,16 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
     return book.best
 
 
-def _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_masks, train_ns, val_clouds, val_poses, val_masks, val_ns):
-    """(train plan, [validation plans]) when the whole loop can run on plan.SequenceTrainer's chained steps -- only the weights
-    of a polynomial model are optimised, with Adam as train() builds it, over ONE training sequence through the fused
-    min-eigenvalue / trace loss without inlier gating -- else None."""
+def _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_masks, train_ns, val_clouds, val_poses, val_masks, val_ns,
+                      sharded=False):
+    """([train plans], [validation plans]) when the whole loop can run on plan.SequenceTrainer's native steps -- only the weights
+    of a polynomial model are optimised, with Adam as train() builds it, over up to sixteen (local) training sequences through the
+    fused min-eigenvalue / trace loss without inlier gating -- else None."""
     from .eval import _plan_for, fused_supported
     from .optim import Adam
     kw = cfg.loss_kwargs
     w = getattr(model, 'w', None)
-    if not (cfg.pose_correction == PoseCorrection.none and cfg.optimize_model and len(train_clouds) == 1
+    if not (cfg.pose_correction == PoseCorrection.none and cfg.optimize_model and 1 <= len(train_clouds) <= 16 and len(val_clouds) <= 16
             and isinstance(optimizer, Adam) and len(optimizer.param_groups) == 1
             and fused_supported(train_clouds, model, cfg) and (not val_clouds or fused_supported(val_clouds, model, cfg))
             and kw.get('inlier_ratio', 1.0) >= 1.0 and kw.get('inlier_max_loss') is None
@@ -736,12 +824,119 @@ def _native_loop_plan(cfg, model, optimizer, train_clouds, train_poses, train_ma
     g = optimizer.param_groups[0]
     if g['weight_decay'] != 0.0 or any(m is None for m in list(train_masks) + list(val_masks)):
         return None
-    plan = _plan_for(train_clouds[0], train_poses[0], train_ns[0], train_masks[0], model, cfg)
+    plans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(train_clouds, train_poses, train_ns, train_masks)]
     vplans = [_plan_for(c, p, nn, m, model, cfg) for c, p, nn, m in zip(val_clouds, val_poses, val_ns, val_masks)]
-    return plan, vplans
+    return plans, vplans
 
 
-def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, batch):
+def _native_shared_loop(cfg, model, optimizer, plans, vplans, train_poses, val_poses, batch, shard, callbacks=None):
+    """train()'s model-only loop when the loss runs over SEVERAL training sequences and / or the sequences are dealt over ranks
+    (BASELINE config 3; train.py:166-175 loops over the sequences, eval.py:85-112 divides the sum of their sums by the sum of their
+    counts).  Per iteration, all on the stream and without a host synchronisation:
+
+        evaluation of the first local sequence, whose launch first takes the previous iteration's Adam update from the joint
+        gradient (dc_sequence_eval_after_update: it also records the weights it uses) -> evaluations of the other local training
+        sequences and of the local validation sequences with those weights -> ONE launch that joins the local sums of both
+        losses (dc_pose_train_combine2) -> ONE all-reduce of [training | validation] x {sum, count, dL/dw} over the ranks.
+
+    The joint sums land in the log's ring row; bookkeeping as in _batched_loop (one synchronisation per ``batch`` iterations; rank 0
+    prints and writes).  Returns (ran, best config); ran = False, nothing touched, when the plans cannot take this path."""
+    from .distributed import all_reduce_sum
+    from .plan import SequenceTrainer, combine_sums
+    dev = torch.device(cfg.device)
+    n_it, R = cfg.n_opt_iters, batch
+    sharded = shard is not None
+    g = optimizer.param_groups[0]
+    w_param = model.w
+    e = model.kernel_params()[1].detach()
+    tr = SequenceTrainer(plans, w_param.detach(), e, train_poses, lr=g['lr'], betas=g['betas'], eps=g['eps'], distributed=sharded, chained=True)
+    assert tr.w.data_ptr() == w_param.data_ptr()
+    can = 1 if tr.update_in_next and not any(getattr(p_, 'nan_policy', None) for p_ in list(plans) + list(vplans)) else 0
+    if (sharded and _agree(can, cfg.device) != 1) or not can:
+        return False, None
+    nt = tr.nt
+    has_val = (shard['n_val'] if sharded else len(vplans)) > 0
+    ring = torch.zeros((R, 2, 2 + nt), dtype=torch.float64, device=dev)     # per iteration: the joint sums of both losses
+    ring_w = torch.zeros((R, nt), dtype=torch.float64, device=dev)          # and the weights it used
+    vouts = [torch.zeros((2 + 2 * nt + 12 * vp.n_scans,), dtype=torch.float64, device=dev) for vp in vplans]
+    vP = [vp.poses12(T) for vp, T in zip(vplans, val_poses)]
+    sd_const = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
+    poses_cpu = [T.detach().cpu().clone() for T in train_poses]
+    book = _Bookkeeper(cfg, model, shard)
+    all_plans = list(plans) + list(vplans)
+
+    def launch(it):
+        slot = it % R
+        if callbacks is not None:
+            callbacks.iteration_started(it)
+        if tr.step(w_used_prev=ring_w[slot], require_chain=True, defer_reduce=True) is None:
+            return False
+        for vp, P, vo in zip(vplans, vP, vouts):                     # validation with the weights of THIS iteration
+            vp.eval_native(tr.w, tr.exponent, P, vo, want_grad=False)
+        combine_sums(tr.outs, vouts, ring[slot])
+        if sharded:
+            all_reduce_sum(ring[slot])                                # the iteration's ONE collective
+        tr.use_sums(ring[slot, 0])
+        return True
+
+    def fetch():
+        h, hw = ring.cpu(), ring_w.cpu()                              # synchronises
+        bits = 0
+        for p_ in all_plans:
+            bits |= p_.status_bits()
+        return h.numpy(), hw.numpy(), bits
+
+    def bookkeep(fetched, first, upto):
+        H, HW, bits = fetched
+        if bits & all_plans[0].STATUS_OVERFLOW:
+            warnings.warn('train(): points left the extent of the 32-bit fixed-point format (or are NaN) in iterations %d..%d: '
+                          'their losses are NaN; build the plan with point_format="f64" for maps that grow this much'
+                          % (first, upto - 1))
+        for it in range(first, upto):
+            sums = H[it % R]
+            tl = float(sums[0, 0] / sums[0, 1]) if sums[0, 1] > 0 else float('nan')
+            vl = (float(sums[1, 0] / sums[1, 1]) if sums[1, 1] > 0 else float('nan')) if has_val else tl
+            w_row = np.array(HW[it % R], dtype=np.float64, copy=True)
+
+            def payload(w_row=w_row):
+                sd = dict(sd_const)
+                sd[w_key] = torch.from_numpy(w_row).reshape(w_param.shape).to(w_param.dtype).clone()
+                return sd, [], poses_cpu
+            book.record_fast(it, tl, vl, w_key, w_row, payload)
+        book.end_batch()
+
+    prev, start, launched = None, 0, 0
+    try:
+        while start < n_it:
+            end = min(start + R, n_it)
+            fetched = fetch() if prev is not None else None
+            for it in range(start, end):
+                if not launch(it):
+                    if it or sharded:
+                        raise RuntimeError('train(): a sequence plan refused the native step after the loop had been chosen')
+                    return False, None                             # nothing was launched
+                launched = it + 1
+            if prev is not None:
+                bookkeep(fetched, *prev)
+            prev, start = (start, end), end
+        if prev is not None:
+            bookkeep(fetch(), *prev)
+            prev = None
+        tr.flush()                                                  # the last iteration's Adam update (train.py:312)
+    except BaseException:
+        try:                                                        # an interrupted run keeps the batch it had finished
+            if prev is not None and launched == prev[1] and not sharded:
+                bookkeep(fetch(), *prev)
+        except Exception:
+            pass
+        raise
+    finally:
+        torch.autograd.graph.increment_version(w_param)            # written through its pointer
+    return True, book.best
+
+
+def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, batch, callbacks=None):
     """train()'s loop for the model-only case on the library's own step: ONE launch per iteration (dc_sequence_step_chained_rec:
     the launch of iteration t evaluates loss and dL/dw with the weights Adam update t - 1 left, and its leading blocks first
     finish iteration t - 1 -- sums, update, and the record {sums, weights used} of that iteration straight into the log's ring
@@ -843,6 +1038,8 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
                     break
             for it in range(start, end):
                 slot = (it - 1) % R
+                if callbacks is not None:
+                    callbacks.iteration_started(it)
                 if tr.step(out_prev=ring[slot], w_used_prev=ring_w[slot], require_chain=True) is None:
                     assert it == 0
                     return False, None                             # this plan does not chain; nothing was launched

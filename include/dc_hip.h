@@ -326,15 +326,22 @@ int dc_pose_correct_bwd(const double* poses, const double* deltas, int n_poses, 
  * ring_rows) <- sums, and the weights, corrections and corrected poses (rows [R|t]) this iteration used -- the slot follows the
  * device counter, so a captured iteration replays into the right one.  totals (or NULL): the loss runs over SEVERAL sequences
  * (eval.py:85-112 divides the sum of the sequences' sums by the sum of their counts; icp_loss averages their losses, loss.py:403) --
- * dc_pose_train_combine's {loss, divisor, dL/dw [P]} over all of them: gradients are then scaled by 1 / totals[1] and the weights
- * step with totals[2..] (pass w for ONE sequence of the group only).  All arrays device fp64. */
+ * dc_pose_train_combine's {loss, divisor, dL/dw [P]} over all of them (all-reduced over the ranks when the sequences are sharded,
+ * SURVEY 8e): gradients are then scaled by 1 / totals[1], the weights step with totals[2..] (pass w for ONE sequence of the group
+ * only).  record_extra (or NULL): n_record_extra further doubles copied behind the other fields of the record row (the joint sums
+ * of the iteration's training and validation losses: with sharded sequences every rank's log needs both).  All arrays device fp64. */
 int dc_pose_train_finish(const double* sums, int layout, int n_terms, int n_scans, double* w, double* w_m, double* w_v, const double* poses0,
                          double* deltas, double* d_m, double* d_v, int n_deltas, int zero_first, int64_t* step, double lr_w, double lr_d,
                          double beta1, double beta2, double eps, const double* poses_used, double* record, int ring_rows, double* poses_next,
-                         double* poses12_next, const double* totals, dcStream_t stream);
+                         double* poses12_next, const double* totals, const double* record_extra, int n_record_extra, dcStream_t stream);
 /* totals fp64 [2 + P] <- {sum of outs[i][0], layout 0: sum of outs[i][1] (the counts) / layout 1: n_seq, sum of the sequences'
  * dL/dw}; outs: HOST array of n_seq <= 16 device pointers (the `sums` of every sequence of the loss), fixed order. */
 int dc_pose_train_combine(const double* const* outs, int n_seq, int layout, int n_terms, double* totals, dcStream_t stream);
+/* The same for the TWO losses of an iteration in one launch (training and validation sequences, train.py:250-270): totals fp64
+ * [2][2 + P] <- group a, group b; either group may be empty (zeros: a rank that owns no validation sequence still takes part in the
+ * all-reduce of the totals). */
+int dc_pose_train_combine2(const double* const* outs_a, int n_a, const double* const* outs_b, int n_b, int layout, int n_terms,
+                           double* totals, dcStream_t stream);
 
 /* Scan-shadow filter: filters.filter_shadow_points filters.py:257-309 on the direction neighbourhoods of
  * DepthCloud.update_dir_neighbors depth_cloud.py:217-224 (radius search on the unit directions: dc_radius_*).
@@ -544,10 +551,13 @@ int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg,
  * its update, so a launch cannot sum the previous rows itself): evaluation `step`, whose leading blocks first take Adam update
  * step - 1 from grad_sum (device fp64 [P]: the previous evaluation's dL/dw summed over all ranks; NULL for the first call),
  * followed by the ordinary reduction of THIS evaluation into out -- three launches per multi-rank step (evaluation,
- * reduction, all-reduce) instead of four (+ dc_adam_step).  The last update of a loop is a plain dc_adam_step. */
+ * reduction, all-reduce) instead of four (+ dc_adam_step).  The last update of a loop is a plain dc_adam_step.
+ * w_used (device fp64 [n_terms] or NULL) <- the weights THIS evaluation uses, i.e. after update step - 1: with `out` the record a
+ * training log keeps per iteration (train.py:219-244), written by the launches themselves. */
 int dc_sequence_eval_after_update(const dcSequenceDesc* d, double* w, const double* e, const double* poses, double* exp_avg,
                                   double* exp_avg_sq, int64_t step, const double* grad_sum, double grad_scale, double lr, double beta1,
-                                  double beta2, double eps, double weight_decay, int32_t* ready, double* out, dcStream_t stream);
+                                  double beta2, double eps, double weight_decay, int32_t* ready, double* out, double* w_used,
+                                  dcStream_t stream);
 
 /* torch.optim.Adam step (train.py:139-149,312) on a device fp64 vector; grad is multiplied by grad_scale first
  * (1 / number of masked points of all sequences = the reference's mean reduction, loss.py:205-213). */
