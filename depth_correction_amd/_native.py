@@ -152,7 +152,8 @@ class SequenceDesc(ctypes.Structure):
                 ('loss_kind', ctypes.c_int32), ('normalization', ctypes.c_int32), ('sqrt_', ctypes.c_int32),
                 ('reserved', ctypes.c_int32), ('fwd_table', _vp), ('bwd_table', _vp), ('status', _vp), ('basis', _vp),
                 ('partials_count', ctypes.c_int64), ('scan_seg', _vp), ('blk_skip', _vp), ('fwd_rows_active', ctypes.c_int32),
-                ('reserved2', ctypes.c_int32), ('pose_table', _vp), ('local_basis', _vp)]
+                ('reserved2', ctypes.c_int32), ('pose_table', _vp), ('local_basis', _vp), ('fwd_table_loss', _vp),
+                ('fwd_rows_active_loss', ctypes.c_int32), ('reserved3', ctypes.c_int32)]
 
 
 def lib_path():

@@ -3544,8 +3544,18 @@ static inline double* chain_buffer(const dcSequenceDesc* d, int n_terms, int par
 
 static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const double* e, const double* poses, int want_grad,
                               int want_exponent_grad, int want_pose_grad, double* out, hipStream_t stream,
-                              const AdamArgs& adam, const ChainCall* chain = nullptr) {
+                              const AdamArgs& adam, const ChainCall* chain = nullptr, bool one_pass_only = false) {
   if (!d || !out || !poses || !d->partials) return DC_ERR_ARG;
+  // the one-pass evaluation first tries the table that lists only what the centres INSIDE the mask gather (dcSequenceDesc.fwd_table_loss)
+  if (!one_pass_only && d->fwd_table_loss && d->mask && !d->centre_idx && want_grad && !want_exponent_grad && !want_pose_grad && d->basis &&
+      d->model_kind != DC_MODEL_NONE && d->n_terms >= 1 && d->n_terms <= 3 && d->n > 0) {
+    dcSequenceDesc dd = *d;
+    dd.fwd_table = d->fwd_table_loss;
+    dd.fwd_table_loss = nullptr;
+    dd.fwd_rows_active = d->fwd_rows_active_loss;
+    const int rc = sequence_eval_impl(&dd, w, e, poses, want_grad, want_exponent_grad, want_pose_grad, out, stream, adam, chain, true);
+    if (rc != DC_ERR_UNSUPPORTED) return rc;
+  }
   const int stride = 4;
   const int n_terms = d->model_kind == DC_MODEL_NONE ? 0 : d->n_terms;
   const int n_acc = 2 * n_terms + 12 * d->n_scans;
@@ -3597,7 +3607,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
                      (!want_grad || one_pass || use_table(d->bwd_table, DC_TABLE_RUNS, stride, q32_pts ? 32u : 64u, 1, 44 * 1024, &lds_b, &rows_b));
   const int fixed_k = g_fwd_generic.load() ? 0 : d->k;
   // a chained step exists for the one-pass kernels only: the caller steps without a chain otherwise
-  if (chain && !(basis && one_pass)) return DC_ERR_UNSUPPORTED;
+  if ((chain || one_pass_only) && !(basis && one_pass)) return DC_ERR_UNSUPPORTED;
   if (basis) {
     QParams qp;
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);

@@ -198,7 +198,8 @@ def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='
                    eigenvalue_ratio_bounds=DEFAULT_RATIO_BOUNDS, vp_dispersion_bounds=None, model_kind='ScaledPolynomial',
                    loss='min_eigval_loss', normalization=True, sqrt=False, spatial_sort=True, point_format='auto',
                    active_only=False, degree_sort=False, block_tables=True, bwd_layout='runs', stage_times=False, basis=True,
-                   local_streams=4, scan_group=True, mask_first=False, degree_group=None, batch_local=True, heavy_first=None):
+                   local_streams=4, scan_group=True, mask_first=False, degree_group=None, batch_local=True, heavy_first=None,
+                   wave_pack=None):
     """Everything train.py does before its loop for one sequence; returns (plan, info).  ``stage_times``: info['setup_ms']
     = wall-clock milliseconds per stage (device synchronised between stages)."""
     st = _Stages(stage_times, device)
@@ -239,6 +240,6 @@ def build_sequence(scans_xyz, poses, k=10, r=None, dtype=torch.float32, device='
                         degree_sort=degree_sort, block_tables=block_tables, bwd_layout=bwd_layout, stages=st, basis=basis,
                         scan_group=scan_group, mask_first=mask_first,
                         degree_group=(r is not None) if degree_group is None else degree_group,
-                        heavy_first=(r is not None) if heavy_first is None else heavy_first)
+                        heavy_first=(r is not None) if heavy_first is None else heavy_first, wave_pack=wave_pack)
     st.mark('plan_other')
     return plan, dict(clouds=clouds, poses=poses_t, neighbors=nbr, mask=mask, points0=x0, setup_ms=st.out)

@@ -46,7 +46,8 @@ class SequencePlan:
     def __init__(self, clouds, poses, neighbors, mask=None, model_kind='ScaledPolynomial', loss='min_eigval_loss',
                  normalization=True, sqrt=False, spatial_sort=True, point_format='auto', degree_sort=False,
                  active_only=False, block_tables=True, bwd_layout='runs', stages=None, basis=True, lazy_backward=True,
-                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True, degree_group=False, heavy_first=False):
+                 scan_group=True, mask_first=False, nan_policy=None, pose_kernel=True, degree_group=False, heavy_first=False,
+                 wave_pack=None):
         """
         :param clouds: per-scan dicts / objects with vps [n,3], dirs [n,3], depth [n,1], inc_angles [n,1], mask [n]
                        (local feature clouds, sensor frame), GPU tensors of one dtype.
@@ -67,6 +68,11 @@ class SequencePlan:
                            larger LDS tiles, fewer resident blocks -- and the step got SLOWER (44 -> 55 us); the two-kernel
                            forms lose more; super-blocks of 512 with a 768-row static tile: 19 % skipped, 44.5 against 42.4 us.
                            Results are the same either way.
+        :param wave_pack: form the wavefronts (64 points) from points that are ALL inside or ALL outside the loss mask -- 64 Morton-
+                          consecutive points of either kind -- and lay the wavefronts out in Morton order of their first point; a block
+                          is four consecutive wavefronts.  The one-pass kernels skip a wavefront none of whose centres is inside the
+                          mask, and with whole-block grouping alone only floor(outside / 64) wavefronts of a block qualify (C2: 26 % of
+                          the points are outside, 10.7 % of the wavefronts were skipped).  Default: on for [rows, K] tables with a mask.
         :param degree_group: ball neighbourhoods without pose gradients: lanes of a block ordered by (mask, row length) instead of
                              (mask, scan).
         :param heavy_first: ball neighbourhoods: the blocks with the longest rows first in the grid (see below).
@@ -121,6 +127,39 @@ class SequencePlan:
                 pos = (local + torch.arange(nb, device=dev)[:, None] * 256).reshape(-1)
                 order = order[pos[pos < self.n]]
             self.scan_seg, self.skipped_wavefronts, self.blk_skip = None, 0.0, None
+            if wave_pack is None:
+                wave_pack = nbr.shape[1] <= 16 and not heavy_first and not degree_group
+            if wave_pack and mask is not None and not degree_sort and not active_only and not mask_first and self.n >= 4 * 256:
+                # wavefronts of one kind: the points inside the mask, in Morton order, cut into runs of 64, and likewise the points
+                # outside; the runs merged by the Morton position of their first point.  Every wavefront but the two at the ends of
+                # the lists is all-in or all-out; a block (four consecutive runs) still covers one stretch of the curve -- its
+                # distinct-row list grows by a few per cent, not by the third that whole super-blocks of one kind cost (mask_first)
+                m_o = mask[order]
+                pos = torch.arange(self.n, device=dev)
+                pa, pb = pos[m_o], pos[~m_o]
+                na, nb_ = pa.numel(), pb.numel()
+                big = torch.iinfo(torch.int64).max
+                # (the last, partial run of either kind goes to the very end: every run before it has exactly 64 points)
+                ka = pa[::64].clone()
+                kb = pb[::64].clone()
+                if na % 64 and ka.numel():
+                    ka[-1] = big - 1
+                if nb_ % 64 and kb.numel():
+                    kb[-1] = big
+                keys = torch.cat([ka, kb])
+                runs = torch.argsort(keys, stable=True)                    # run r: kind A when r < len(ka)
+                start = torch.cat([torch.arange(ka.numel(), device=dev) * 64, na + torch.arange(kb.numel(), device=dev) * 64])[runs]
+                length = torch.cat([torch.full((ka.numel(),), 64, device=dev), torch.full((kb.numel(),), 64, device=dev)])
+                if na % 64 and ka.numel():
+                    length[ka.numel() - 1] = na % 64
+                if nb_ % 64 and kb.numel():
+                    length[-1] = nb_ % 64
+                length = length[runs]
+                off = torch.cumsum(length, 0) - length
+                idx = torch.repeat_interleave(start - off, length) + pos      # position in cat([pa, pb]) of every output slot
+                order = order[torch.cat([pa, pb])[idx]]
+                self._wave_packed = True
+                mark('plan_wave_pack')
             if mask_first and mask is not None and not degree_sort and not active_only:
                 # inside every super-block of kMaskGroup Morton-consecutive points: the points inside the loss mask first, then those
                 # outside (Morton order inside each part).  Most blocks of 256 are then all-in or all-out, and the one-pass kernels
@@ -229,12 +268,24 @@ class SequencePlan:
                 self.fwd_table = ops.block_table(csr=ops.table_to_csr(nbr), layout='slots', own_rows='csr' if self.centre_idx is None else False)
             else:
                 self.fwd_table = ops.block_table(nbr=nbr, own_rows=self.centre_idx is None)
-        self.fwd_rows_active = 0
+        self.fwd_rows_active = self.fwd_rows_active_loss = 0
+        self.fwd_table_loss = None
+        if (block_tables and self.fwd_table is not None and mask is not None and self.centre_idx is None and nbr.shape[1] <= 16
+                and nbr.shape[0] > 0 and getattr(self, '_wave_packed', False)):
+            # what the one-pass loss + dL/dw evaluation stages: only the rows the centres INSIDE the mask gather -- the points
+            # outside keep the reference to themselves (a block's own rows stay in its list) and nothing else
+            rows_ = torch.arange(self.n, device=dev, dtype=torch.int32)[:, None]
+            nbr_loss = torch.where(mask[:, None] | (nbr == rows_), nbr, torch.full_like(nbr, -1)).contiguous()
+            self.fwd_table_loss = ops.block_table(nbr=nbr_loss, own_rows=True)
+            del nbr_loss
         if self.fwd_table is not None and getattr(self, 'blk_skip', None) is not None and self.centre_idx is None:
             # (on the host: two copies of a few kilobytes -- as tensor expressions, six more torch kernels to load in a fresh process)
-            rows_per_block = np.diff(self.fwd_table.blk_ptr.cpu().numpy())
             keep = self.blk_skip.cpu().numpy() == 0
+            rows_per_block = np.diff(self.fwd_table.blk_ptr.cpu().numpy())
             self.fwd_rows_active = int(rows_per_block[keep].max()) if keep.any() else 0
+            if self.fwd_table_loss is not None:
+                rows_per_block = np.diff(self.fwd_table_loss.blk_ptr.cpu().numpy())
+                self.fwd_rows_active_loss = int(rows_per_block[keep].max()) if keep.any() else 0
         mark('plan_block_tables')
         self.count = float(nbr.shape[0] if mask is None else int(mask.sum().item()))
 
@@ -308,6 +359,9 @@ class SequencePlan:
             d.nbr, d.csr_ptr, d.csr_src, d.mask = p(self.nbr), p(csr[0]), p(csr[1]), p(self.mask)
             d.lane_perm = p(self.lane_perm)
             d.fwd_table = None if self.fwd_table is None else self.fwd_table.ref()
+            ftl = getattr(self, 'fwd_table_loss', None)
+            d.fwd_table_loss = None if ftl is None else ftl.ref()
+            d.fwd_rows_active_loss = int(getattr(self, 'fwd_rows_active_loss', 0)) if ftl is not None else 0
             d.bwd_table = None if self._bwd_table is None else self._bwd_table.ref()
             d.centre_idx, d.n_centres = p(self.centre_idx), (0 if self.centre_idx is None else self.centre_idx.shape[0])
             d.x, d.rec, d.partials = p(self.x), p(self.rec), p(self.partials)

@@ -507,6 +507,13 @@ typedef struct dcSequenceDesc {
                                       sequence run as ONE launch (consistency_step_pose_kernel) instead of dc_points_fwd + forward +
                                       backward; NULL: the three-kernel path */
   const void* local_basis;         /* dc_points_local_basis rows, valid FOR THE EXPONENTS OF THE CALL, or NULL */
+  const dcBlockTable* fwd_table_loss; /* or NULL: block table of `nbr` in which the rows of the points OUTSIDE `mask` keep only their
+                                      reference to themselves.  A centre outside the mask adds nothing to the loss, the count or
+                                      dL/dw (loss.py:283-284 indexes the pointwise loss by the mask), so the one-pass evaluation
+                                      -- which never produces per-point outputs -- stages only the rows the centres inside the mask
+                                      gather: shorter lists per block.  Every other evaluation keeps reading fwd_table */
+  int32_t fwd_rows_active_loss;    /* fwd_rows_active of fwd_table_loss */
+  int32_t reserved3;
 } dcSequenceDesc;
 
 /* Doubles of dcSequenceDesc.partials for a sequence of n points evaluated with up to n_terms weights and n_scans poses:

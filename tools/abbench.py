@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--k', type=int, default=10)
     ap.add_argument('--dtype', default='float32')
     ap.add_argument('--no-chain', action='store_true')
+    ap.add_argument('--no-wave-pack', action='store_true')
     args = ap.parse_args()
     from depth_correction_amd import _native as nv
     from depth_correction_amd.dataset import RoomBoxDataset
@@ -37,7 +38,8 @@ def main():
                         dtype=np.float32 if dtype == torch.float32 else np.float64)
     scans_xyz = [np.stack([c[f] for f in 'xyz'], axis=1) for c, _ in ds]
     poses = np.stack([p for _, p in ds])
-    plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev)
+    plan, info = build_sequence(scans_xyz, poses, k=args.k, dtype=dtype, device=dev, wave_pack=False if args.no_wave_pack else None)
+    print(json.dumps({'skipped_wavefronts': plan.skipped_wavefronts, 'max_rows': int(plan.fwd_table.max_rows), 'rows_active': plan.fwd_rows_active, 'loss_table_max_rows': None if plan.fwd_table_loss is None else int(plan.fwd_table_loss.max_rows)}))
     w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
     e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
     P12 = plan.poses12(info['poses'])
