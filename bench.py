@@ -77,6 +77,7 @@ def parse():
                          '(one launch per step: each launch also finishes the previous step; dc_sequence_step_chained)')
     ap.add_argument('--two-pass', action='store_true', help='basis form with separate forward and backward kernels (ablation)')
     ap.add_argument('--no-extras', action='store_true', help='skip the C1 / online-correction side measurements')
+    ap.add_argument('--multi-sequences', type=int, default=4, help='extras: sequences of the same shape stepped together on one GPU (0 / 1: skip)')
     ap.add_argument('--step-var', type=int, default=None, help='dc_set_option(6, v): form of the one-pass step kernel (A-B measurements)')
     return ap.parse_args()
 
@@ -97,6 +98,7 @@ def compulsory_bytes(plan):
     """Bytes every hot kernel has to move at least once per launch: the arrays it reads and writes, each counted once
     (what the Morton layout + LDS staging reduce the traffic to; rocprofv3's FETCH_SIZE / WRITE_SIZE agree within ~10 %)."""
     ps, ft = plan.ps, plan.fwd_table
+    ftl = getattr(plan, 'fwd_table_loss', None) or ft          # what the one-pass step stages from
     built = plan._csr is not None            # the backward structures exist only if an evaluation needed them (lazy)
     bt = plan._bwd_table if built else None
     pt_in = nbytes(ps.vps, ps.dirs, ps.depth, ps.inc, ps.lmask, ps.scan_id)
@@ -108,7 +110,7 @@ def compulsory_bytes(plan):
         # consistency_step: the one-pass loss + dL/dw kernel (no record written, no backward launch)
         return dict(points_fwd=0, consistency_fwd=nbytes(basis, plan.mask, plan.rec, ft.own_base) + fwd_tab,
                     consistency_bwd=nbytes(basis, plan.rec) + bwd_tab,
-                    consistency_step=nbytes(basis, plan.mask, ft.own_base) + fwd_tab)
+                    consistency_step=nbytes(basis, plan.mask, ftl.own_base, ftl.blk_ptr, ftl.blk_ids, ftl.slot_ptr, ftl.loc))
     return dict(points_fwd=pt_in + nbytes(plan.x),
                 consistency_fwd=nbytes(plan.x, plan.mask, plan.rec) + fwd_tab,
                 consistency_bwd=nbytes(plan.x, plan.rec) + pt_in + bwd_tab)
@@ -315,12 +317,19 @@ def main():
     if args.step_var is not None:
         nv.check(nv.lib().dc_set_option(6, args.step_var), 'dc_set_option')
     # the k-NN build alone, on the global cloud (reported separately)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
+    # (one untimed call first: the variant without distances is not the one the set-up ran, and a code object's first launch pages
+    # it in -- 11 ms in the round-4 driver line against 1.7 ms for the kernels; then the median of five)
     ops.knn(info['points0'], args.k, want_dist=False)
-    ev1.record()
     torch.cuda.synchronize()
-    knn_ms = ev0.elapsed_time(ev1)
+    knn_all = []
+    for _ in range(5):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        ops.knn(info['points0'], args.k, want_dist=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        knn_all.append(ev0.elapsed_time(ev1))
+    knn_ms = float(np.median(knn_all))
 
     n_local = plan.n
     from depth_correction_amd.plan import SequenceTrainer, KernelTimer
@@ -448,6 +457,7 @@ def main():
     # ---- side measurements, after the timed region (the GPU goes idle between their host-synchronised calls; run before
     # the loop they left it at idle clocks for the first timed steps)
     extras = {}
+    sustained_kernel_ms = sustained_kernel_names = None
     if world == 1 and not args.autograd and not args.no_extras:
         # the same chained step (a) sustained -- 2 000 steps back to back, what a training run of the reference's default length
         # and longer sees -- and (b) cold -- the first `steps` steps after the device has sat idle for a second (clocks down, no
@@ -464,6 +474,15 @@ def main():
         torch.cuda.synchronize()
         extras['sustained_ms_per_step'] = (time.perf_counter() - t0) / 2000 * 1e3
         extras['sustained_steps'] = 2000
+        # the kernel's own duration over the same 2 000 steps (a second pass: stamping every 8th launch costs a few microseconds of
+        # idle device each, so it is kept out of the sustained figure): 250 stamps, what the roofline block is computed from
+        with KernelTimer(every=8) as kt2:
+            for _ in range(2000):
+                tr2.step()
+            tr2.flush()
+            torch.cuda.synchronize()
+            sustained_kernel_ms = kt2.read()
+            sustained_kernel_names = kt2.kernels()
         time.sleep(1.0)
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -499,6 +518,51 @@ def main():
                                      'valu_insts_per_point': prof64['valu_insts_per_point'] if prof64 else None,
                                      'what': 'float64 clouds (the reference default float_type): fp64 points, fp64 basis rows, fp64 second sweep'}
         del tr64, plan64, info64, scans64
+        torch.cuda.empty_cache()
+    if world == 1 and not args.autograd and not args.no_extras and args.multi_sequences > 1 and args.scans * args.points <= 4_000_000:
+        # (d) S sequences of the same shape on ONE GPU, stepped together as train() does for several train_names (train.py:172-175;
+        # eval.py:85-112 pools their sums): S x 118 MB of rows and tables no longer fit the 256 MiB Infinity Cache, so every launch
+        # fetches its working set from HBM -- the number the single-sequence line cannot give
+        S = args.multi_sequences
+        mplans, mposes = [plan], [poses_t]
+        for q in range(1, S):
+            ds_q = RoomBoxDataset(n_pts=args.points, n_poses=args.scans, seed_base=1000 + 7919 * q,
+                                  dtype=np.float32 if dtype == torch.float32 else np.float64)
+            xyz_q = [np.stack([c[f] for f in 'xyz'], axis=1) for c, _ in ds_q]
+            pl_q, info_q = build_sequence(xyz_q, np.stack([p for _, p in ds_q]), k=args.k, dtype=dtype, device=dev)
+            mplans.append(pl_q)
+            mposes.append(info_q['poses'])
+            del ds_q, xyz_q, info_q
+        trm = SequenceTrainer(mplans, w0, e0, mposes, lr=1e-3, chained=not args.no_chain)
+        for _ in range(50):
+            trm.step()
+        trm.flush()
+        torch.cuda.synchronize()
+        n_ms = 300
+        with KernelTimer(every=8) as ktm:
+            t0 = time.perf_counter()
+            for _ in range(n_ms):
+                trm.step()
+            trm.flush()
+            torch.cuda.synchronize()
+            ms_multi = (time.perf_counter() - t0) / n_ms * 1e3
+            km = ktm.read().get('consistency_fwd', (None, 0))
+            kname_m = ktm.kernels().get('consistency_fwd')
+        prof_m = load_profile_table().get(profile_key(kname_m, mplans[0].n) + '/multi%d' % S)
+        comp_m = compulsory_bytes(mplans[0])['consistency_step']
+        extras['multi_sequence_step'] = {
+            'sequences': S, 'points': int(sum(p_.n for p_ in mplans)), 'working_set_bytes': int(sum(compulsory_bytes(p_)['consistency_step'] for p_ in mplans)),
+            'ms_per_step': ms_multi, 'us_per_sequence_step': ms_multi / S * 1e3, 'points_per_s': sum(p_.n for p_ in mplans) / (ms_multi * 1e-3),
+            'kernel': kname_m, 'kernel_ms': km[0], 'timed_launches': km[1],
+            'launches_per_step': '%d evaluations (the first takes the previous Adam update in its launch) + %d reductions + the sum of the sequences\' sums' % (S, S),
+            'design_bytes_per_launch': comp_m,
+            'design_GBps': comp_m / (km[0] * 1e-3) / 1e9 if km[0] else None,
+            'traffic_per_launch': prof_m['hbm_bytes'] if prof_m else None,
+            'hbm_frac': (prof_m['hbm_bytes'] / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (prof_m and km[0]) else None,
+            'traffic_source': prof_m.get('source') if prof_m else 'no committed PMC pass of this configuration',
+            'what': '%d sequences of %d x %dk points stepped round robin on one GPU (a loss over several training sequences); the working '
+                    'set exceeds the 256 MiB Infinity Cache, unlike the single-sequence step' % (S, args.scans, args.points // 1000)}
+        del trm, mplans, mposes
         torch.cuda.empty_cache()
     if world == 1 and not args.no_extras:        # single-process runs only: the other ranks must not wait for rank 0
         # the same step without the loop-invariant hoisting (general path: dc_points_fwd + forward + backward every iteration,
@@ -665,6 +729,12 @@ def main():
                                                'scan resident on the device; median of 5'}
 
     if rank == 0:
+        timed_region_kernel_ms = {name: v[0] for name, v in kernel_ms.items()}
+        stamps_from = 'the timed region (%d steps)' % args.steps
+        if sustained_kernel_ms and 'consistency_fwd' in sustained_kernel_ms and sustained_kernel_ms['consistency_fwd'][1] >= 100:
+            # (three stamps of a 20-step run are not a measurement; the roofline block uses the sustained run's)
+            kernel_ms, kernel_names = sustained_kernel_ms, sustained_kernel_names
+            stamps_from = 'the sustained run (2 000 chained steps after the timed region)'
         ms = {name: v[0] for name, v in kernel_ms.items()}
         ab = algorithmic_bytes(args.k, (plan.count / n_local) if args.active_only else 1.0)
         value = n_local * world * args.steps / elapsed
@@ -708,8 +778,22 @@ def main():
                                  'peak': '%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction' % (N_SIMD, CLOCK_GHZ)},
                         'kernels': per_kernel,
                         'timed_launches': {name: v[1] for name, v in kernel_ms.items()},
-                        'timing': 'HIP events stamped with the dispatch start / end of every %d-th launch inside the timed region' % args.timer_every,
+                        'timing': 'HIP events stamped with the dispatch start / end of every 8th launch of ' + stamps_from,
                         'gpu_kernel_ms_per_step': sum(ms.values()),
+                        'gpu_kernel_ms_per_step_timed_region': sum(timed_region_kernel_ms.values()),
+                        # (c) the two byte models side by side
+                        'model_bytes_8d': ab['path'] * n_local,
+                        'design_bytes': d['compulsory_bytes'],
+                        'bytes_note': 'model_bytes_8d = SURVEY 8(d) / BASELINE.md 3 (584 B per point: every gather and scattered gradient an '
+                                      'HBM access, saved tensors, a backward pass) x N; over the kernel time it exceeds the HBM peak because '
+                                      'this design does not move those bytes: LDS-staged block tables serve the gathers, dL/dw is formed in '
+                                      'forward mode (no record, no backward pass), the pose-invariant basis rows are hoisted.  design_bytes = '
+                                      'every array the kernel touches, once; frac = measured bytes (traffic) / kernel time / peak',
+                        'working_set_fits_mall': bool(d['compulsory_bytes'] < 256 * 2 ** 20),
+                        'mall_note': 'the step re-reads the same ~%d MB every launch and the Infinity Cache holds 256 MiB: the counter bytes '
+                                     '(fabric requests, MALL hits included) are not HBM traffic and 8 TB/s is not the ceiling that applies; '
+                                     'config.multi_sequence_step is the same kernel on a working set that does not fit'
+                                     % (d['compulsory_bytes'] // 2 ** 20),
                         'algorithmic': {'bytes_per_point': ab[dom], 'GBps': d['algorithmic_GBps'],
                                         'path_bytes_per_point': ab['path'], 'path_GBps': ab['path'] * value / world / 1e9,
                                         'note': 'SURVEY 8d accounting: every gather / scatter priced as a 12-B HBM access; the '
@@ -734,7 +818,7 @@ def main():
                        'skipped_wavefronts_share': getattr(plan, 'skipped_wavefronts', 0.0),
                        'skipped_note': 'share of the 64-centre wavefronts whose centres are ALL outside the loss mask: they stage their rows '
                                        'and skip the moments, the eigen-solve and the second sweep (every term they would add carries the mask); '
-                                       'the plan groups masked-out points at the end of every 256-point block', 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
+                                       'the plan forms wavefronts of one kind (64 Morton-consecutive points inside, or outside, the mask)', 'spatial_sort': not args.no_sort, 'final_loss': final_loss,
                        'knn_build_ms': knn_ms, 'knn_points_per_s': n_local / (knn_ms * 1e-3),
                        'setup_ms': setup_ms, 'setup_stages_ms': info['setup_ms'], 'setup_first_call_s': setup_first_s, 'device_init_s': device_init_s, 'library_load_s': library_load_s,
                        'setup_note': 'setup_ms: the whole set-up phase (upload, 10 local feature clouds, global k-NN, masks, Morton '

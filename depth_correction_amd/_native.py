@@ -110,6 +110,7 @@ _SIGNATURES = {
     'dc_p2point_pair': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
                                _i64, _vp, _vp, _vp]),
     'dc_p2point_sequence': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'dc_icp_sequence_step': (_i32, [_i32, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dc_pose_correct_fwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     'dc_pose_correct_bwd': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     'dc_shadow_mask': (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp]),
@@ -139,6 +140,14 @@ class IcpPair(ctypes.Structure):
     """dcIcpPair of include/dc_hip.h."""
     _fields_ = [('scan_a', ctypes.c_int32), ('scan_b', ctypes.c_int32), ('idx_a', _vp), ('idx_b', _vp),
                 ('m', ctypes.c_int64), ('weight', ctypes.c_double)]
+
+
+class PoseTrainStepDesc(ctypes.Structure):
+    """dcPoseTrainStep of include/dc_hip.h."""
+    _fields_ = [('w', _vp), ('w_m', _vp), ('w_v', _vp), ('poses0', _vp), ('deltas', _vp), ('d_m', _vp), ('d_v', _vp),
+                ('n_deltas', ctypes.c_int32), ('zero_first', ctypes.c_int32), ('step', _vp), ('lr_w', _f64), ('lr_d', _f64),
+                ('beta1', _f64), ('beta2', _f64), ('eps', _f64), ('poses_used', _vp), ('record', _vp), ('ring_rows', ctypes.c_int32),
+                ('n_record_extra', ctypes.c_int32), ('record_extra', _vp), ('poses_next', _vp), ('poses12_next', _vp)]
 
 
 class SequenceDesc(ctypes.Structure):

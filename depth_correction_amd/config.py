@@ -122,6 +122,7 @@ class Config(object):
         # one hipGraph
         self.loop_batch = 64
         self.loop_graph = True
+        self.loop_graph_iters = 8      # iterations per captured graph of the loops with pose corrections (train._native_pose_loop)
         self.loop_native = True        # model-only runs: the library's chained step, one launch per iteration (train._native_loop)
         self.keep_plans = False        # train() releases the per-sequence plans it built when it returns; True keeps them cached
         self.from_dict(kwargs)

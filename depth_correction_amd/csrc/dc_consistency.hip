@@ -1757,6 +1757,11 @@ __device__ __forceinline__ void chain_tail(const int4* tile, int cap, const uint
   }
 }
 
+// (Round 5, measured and dropped for float64 rows: loss AND dL/dw from ONE sweep.  t_j is bilinear in (1, cm) x d_j, so with
+//  A_k = sum c_kj u_j, B_k = sum c_kj (d_j . u_j), M_k = sum c_kj u_j d_j^T the second sweep collapses to
+//  c1 (v^T M_k v - (v . cm)(v . A_k)) - c2 (B_k - cm . A_k): every staged row read once, 64 B per neighbour instead of 96.  But the 26
+//  fp64 accumulators beside the moments cost the occupancy the LDS saving was meant to buy: 246 registers = two wavefronts per SIMD and
+//  101 us; held to 168 registers (three per SIMD) 117 us, against 69 us for the two sweeps at 126 registers.)
 // ---- wavefront sums through DPP -------------------------------------------------------------------------------------------
 // One 32-bit half of a double moved by a DPP row operation (quad permutes, rotations inside a row of 16 lanes)
 template <int CTRL>
@@ -1957,7 +1962,8 @@ __global__ __launch_bounds__(kBlock) void consistency_step_basis_kernel(
 // A fp64-difference row format ({x - ref} as doubles: no int -> fp conversions in the sweeps, 80 instructions fewer) was measured
 // and dropped: 48-B rows make the kernel LDS-bound (SQ_LDS_IDX_ACTIVE 87 % of its duration, 56 % of it bank conflicts of the
 // random row reads: 61 us against 52).
-constexpr int kStepQ32Cap = 512;          // rows of the static LDS tile (16 KB + 8 KB for a third piece: six blocks per CU); tables with
+constexpr int kStepQ32Cap = 512;          // rows of the static LDS tile (16 KB + 8 KB for a third piece: six blocks per CU); a second
+                                          // instantiation takes 768 rows (24 KB: still six blocks per CU for one or two weights); tables with
                                           // more distinct rows per block take consistency_step_basis_kernel
 
 // second sweep, one neighbour (float32): gw[k] += c_kj (c1 (v . e_j)(v . u_j) - c2 (e_j . u_j)); vs = c1 v0, vu = v0
@@ -2007,7 +2013,7 @@ __device__ unsigned long long* g_block_trace = nullptr;
 #endif
 
 template <int NS, int P, int CAP>
-__global__ __launch_bounds__(kBlock, 6) void consistency_step_q32_kernel(
+__global__ __launch_bounds__(kBlock, (StepRow<q32, P>::kPieces * CAP * 16 <= 25 * 1024 ? 6 : 4)) void consistency_step_q32_kernel(
     PointBasis pb, BlockTab tab, const int32_t* __restrict__ own_base, const int32_t* __restrict__ centre_idx, int64_t n,
     const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd,
     StepChain ch) {
@@ -3633,7 +3639,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       const dim3 grid((unsigned)(g_blocks + (chain ? kChainFront : 0)));
       const int var = g_step_var.load();
       // float32 clouds with a [rows, K] table: the kernel with fp64 row differences in LDS (48-B rows + its scratch, all dynamic)
-      const bool q32_step = q32_pts && var == 1 && (fixed_k == 10 || fixed_k == 4 || fixed_k == 8 || fixed_k == 16) && rows_s <= kStepQ32Cap;
+      const bool q32_step = q32_pts && var == 1 && (fixed_k == 10 || fixed_k == 4 || fixed_k == 8 || fixed_k == 16) && rows_s <= 768;
       const bool ragged_step = ragged_ok;
       if (ragged_step) {
         ProfScope prof(1);
@@ -3652,10 +3658,12 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
       } else if (q32_step) {
         ProfScope prof(1);
         static_assert(kStepQ32Cap == 512, "the profiler names the instantiation by its literal arguments");
-#define STEPQ_LAUNCH(NS, P) DC_TIMED_LAUNCH((consistency_step_q32_kernel<NS, P, 512>), grid, block, 0, stream, pb, tab, d->fwd_table->own_base, \
-                                            d->centre_idx, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch)
-#define STEPQ_P(NS) do { if (n_terms == 2) STEPQ_LAUNCH(NS, 2); else if (n_terms == 1) STEPQ_LAUNCH(NS, 1); else STEPQ_LAUNCH(NS, 3); } while (0)
-        if (fixed_k == 10) STEPQ_P(10); else if (fixed_k == 4) STEPQ_P(4); else if (fixed_k == 8) STEPQ_P(8); else STEPQ_P(16);
+#define STEPQ_LAUNCH(NS, P, CAP) DC_TIMED_LAUNCH((consistency_step_q32_kernel<NS, P, CAP>), grid, block, 0, stream, pb, tab, d->fwd_table->own_base, \
+                                                 d->centre_idx, n_rows, d->mask, lp, qp, p_fwd, p_bwd, ch)
+#define STEPQ_P(NS, CAP) do { if (n_terms == 2) STEPQ_LAUNCH(NS, 2, CAP); else if (n_terms == 1) STEPQ_LAUNCH(NS, 1, CAP); else STEPQ_LAUNCH(NS, 3, CAP); } while (0)
+#define STEPQ_K(CAP) do { if (fixed_k == 10) STEPQ_P(10, CAP); else if (fixed_k == 4) STEPQ_P(4, CAP); else if (fixed_k == 8) STEPQ_P(8, CAP); else STEPQ_P(16, CAP); } while (0)
+        if (rows_s <= 512) STEPQ_K(512); else STEPQ_K(768);
+#undef STEPQ_K
 #undef STEPQ_P
 #undef STEPQ_LAUNCH
       } else {

@@ -471,7 +471,7 @@ int64_t dc_p2plane_sequence_partial_count(const dcIcpPair* pairs, int n_pairs) {
     ++np;
     best = rows > best ? rows : best;
   }
-  return best * kIcpAcc;
+  return (best + kIcpSeqPairs) * kIcpAcc;      // (+ one row per pair: dc_icp_sequence_step's second level)
 }
 
 int dc_p2plane_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
@@ -653,8 +653,8 @@ __device__ __forceinline__ double adam_one(double p0, double& m, double& v, doub
   return p0 + (-(lr / bias1)) * (m / denom);
 }
 
-__global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs a) {
-  __shared__ double lds[(kBlock / kWave) * 6];
+// (one block of kBlock threads; lds: (kBlock / kWave) * 6 doubles)
+__device__ __forceinline__ void pose_train_finish_block(const PoseTrainArgs& a, double* lds) {
   const int S = a.n_scans, P = a.n_terms, tid = threadIdx.x;
   const int n_sums = a.n_sums;
   if (a.record) {
@@ -743,9 +743,182 @@ __global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs
   }
 }
 
+__global__ __launch_bounds__(kBlock) void pose_train_finish_kernel(PoseTrainArgs a) {
+  __shared__ double lds[(kBlock / kWave) * 6];
+  pose_train_finish_block(a, lds);
+}
+
+// ---- a whole ICP iteration in ONE launch (round 5; train.py:300-312 with icp_loss, loss.py:373-488) ----------------------------
+// p2plane_seq_kernel, p2plane_reduce_all_kernel and pose_train_finish_kernel were three dependent launches of 17 + 16 + 12 us for ~500
+// blocks of work: launch and dependency latency, not arithmetic.  Here every block writes its row, makes it visible and takes a
+// ticket; the block that draws the LAST one sums the rows (pair by pair, fixed order: each thread owns one of the 42 sums of a
+// sixth of the rows, the sixths joined in order), writes `out` as dc_p2plane_sequence does, and -- when the iteration has nothing
+// to wait for (one sequence in the loss, one rank) -- goes straight on with pose_train_finish_block: adjoint of the pose chain,
+// both Adam updates, next poses, record.  A few hundred tickets cost nothing here (the grid is resident at once; the C2 step
+// kernel's 7 800 blocks would queue on them).
+constexpr int kIcpPhases = 6;                 // kBlock / kIcpAcc row phases of a pair's sum
+static_assert(kIcpPhases * kIcpAcc <= kBlock, "one thread per (phase, sum)");
+constexpr int kIcpInFlight = 16;              // rows a thread requests before it adds any (a pair of ~15 k correspondences: 59 rows, 10 per phase)
+template <typename T, bool PLANE>
+__global__ __launch_bounds__(kBlock) void p2plane_seq_fused_kernel(IcpSeqArgs args, const double* __restrict__ poses, int model_kind, int n_terms,
+                                                                   const double* __restrict__ w, const double* __restrict__ e,
+                                                                   double* __restrict__ partials, IcpSeqReduce rq, double* __restrict__ out,
+                                                                   int n_scans, int32_t* __restrict__ ticket, PoseTrainArgs fin, int with_finish) {
+  __shared__ double lds[kWavesPerBlock * kIcpGroups * 8];
+  __shared__ double s_part[kIcpPhases][kIcpAcc];
+  __shared__ double s_pair[kIcpSeqPairs][kIcpAcc];
+  __shared__ int s_last;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < args.n_pairs; ++q)
+    if (b >= args.pairs[q].row0) p = q;
+  {
+    const IcpSeqPair& pr = args.pairs[p];
+    icp_pair_block<T, PLANE>(pr.A, pr.B, poses + 12 * pr.scan_a, poses + 12 * pr.scan_b, model_kind, n_terms, w, e, pr.idxA, pr.idxB, pr.m,
+                             b - pr.row0, partials + (int64_t)b * kIcpAcc, lds);
+  }
+  // Two levels of tickets: the last block of a PAIR sums that pair's rows (one round of loads: every thread owns one of the 42 sums
+  // of a sixth of the rows), the last pair to finish joins the pairs and goes on.  A row is written back to memory before its
+  // ticket says so -- a RELEASE only: an acquire here would invalidate this XCD's L2 under the blocks still gathering scan points
+  // through it (530 of them: the launch took 54 us).
+  double* pair_rows = partials + (int64_t)gridDim.x * kIcpAcc;          // [n_pairs][kIcpAcc] behind the block rows
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(ticket + 1 + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == rq.rows[p] - 1;
+    if (s_last) __hip_atomic_store(ticket + 1 + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the rows of the pair's other blocks, wherever they ran
+  const int c = tid % kIcpAcc, f = tid / kIcpAcc;
+  if (f < kIcpPhases) {
+    const double* rows = partials + (int64_t)rq.row0[p] * kIcpAcc;
+    const int n_r = rq.rows[p];
+    double v = 0.0;
+    for (int r0 = f; r0 < n_r; r0 += kIcpPhases * kIcpInFlight) {
+      double x[kIcpInFlight];
+#pragma unroll
+      for (int u = 0; u < kIcpInFlight; ++u) {
+        const int r = r0 + u * kIcpPhases;
+        x[u] = r < n_r ? rows[(int64_t)r * kIcpAcc + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kIcpInFlight; ++u) v += x[u];
+    }
+    s_part[f][c] = v;
+  }
+  __syncthreads();
+  if (tid < kIcpAcc) {
+    double t = 0.0;
+#pragma unroll
+    for (int ff = 0; ff < kIcpPhases; ++ff) t += s_part[ff][tid];
+    pair_rows[p * kIcpAcc + tid] = t * rq.weight[p];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == rq.n_pairs - 1;
+    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  for (int i = tid; i < rq.n_pairs * kIcpAcc; i += kBlock) s_pair[i / kIcpAcc][i % kIcpAcc] = pair_rows[i];
+  __syncthreads();
+  // out = { loss, dw[P], dexponent[P], d[R|t][S,12] }: one thread per destination, the pairs added in their order
+  const int pw = 2, pe = 2 + DC_MAX_MODEL_TERMS, pa = 2 + 2 * DC_MAX_MODEL_TERMS, pb = pa + 12;
+  const int n_out = 1 + 2 * n_terms + 12 * n_scans;
+  for (int dst = tid; dst < n_out; dst += kBlock) {
+    double x = 0.0;
+    if (dst == 0) {
+      for (int q = 0; q < rq.n_pairs; ++q) x += s_pair[q][0] + s_pair[q][1];
+    } else if (dst < 1 + n_terms) {
+      for (int q = 0; q < rq.n_pairs; ++q) x += s_pair[q][pw + dst - 1];
+    } else if (dst < 1 + 2 * n_terms) {
+      for (int q = 0; q < rq.n_pairs; ++q) x += s_pair[q][pe + dst - 1 - n_terms];
+    } else {
+      const int sc = (dst - 1 - 2 * n_terms) / 12, j = (dst - 1 - 2 * n_terms) % 12;
+      for (int q = 0; q < rq.n_pairs; ++q) {
+        if (rq.scan_a[q] == sc) x += s_pair[q][pa + j];
+        if (rq.scan_b[q] == sc) x += s_pair[q][pb + j];
+      }
+    }
+    out[dst] = x;
+  }
+  if (!with_finish) return;
+  __threadfence_block();
+  __syncthreads();                              // `out` is what the finishing step reads as its sums
+  pose_train_finish_block(fin, lds);
+}
+
 }  // namespace dc
 
 extern "C" {
+
+// dc_p2plane_sequence / dc_p2point_sequence as ONE launch, optionally followed IN THE SAME LAUNCH by dc_pose_train_finish (fin != NULL):
+// for sequences of at most kIcpSeqPairs pairs with at least one correspondence; DC_ERR_UNSUPPORTED otherwise (the caller then issues the
+// separate calls).  ticket: device int32, zero before the first call (the launch leaves it zero).
+int dc_icp_sequence_step(int plane, const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                         const double* poses, int model_kind, int n_terms, const double* w, const double* e, double* partials_ws,
+                         double* out, int32_t* ticket, const dcPoseTrainStep* fin, hipStream_t stream) {
+  if (n_scans < 1 || n_pairs < 1 || !scans || !pairs || !out || !ticket || !poses || !partials_ws) return DC_ERR_ARG;
+  if (dtype != DC_F32 && dtype != DC_F64) return DC_ERR_DTYPE;
+  if (model_kind < DC_MODEL_NONE || model_kind > DC_MODEL_LAST) return DC_ERR_ARG;
+  if (model_kind != DC_MODEL_NONE && (n_terms < 1 || n_terms > DC_MAX_MODEL_TERMS || !w || !e)) return DC_ERR_ARG;
+  const int nt_model = model_kind == DC_MODEL_NONE ? 0 : n_terms;
+  dc::IcpSeqArgs args{};
+  dc::IcpSeqReduce rq{};
+  int64_t row0 = 0;
+  int np = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    const dcIcpPair& q = pairs[p];
+    if (q.scan_a < 0 || q.scan_a >= n_scans || q.scan_b < 0 || q.scan_b >= n_scans || q.scan_a == q.scan_b) return DC_ERR_ARG;
+    if (q.m < 0 || (q.m > 0 && (!q.idx_a || !q.idx_b))) return DC_ERR_ARG;
+    if (q.m == 0) continue;
+    if (np == dc::kIcpSeqPairs) return DC_ERR_UNSUPPORTED;
+    const dcIcpScan &a = scans[q.scan_a], &b = scans[q.scan_b];
+    for (const dcIcpScan* c : {&a, &b})
+      if (!c->dirs || !c->depth || (plane && !c->normals) || (model_kind != DC_MODEL_NONE && !c->inc)) return DC_ERR_ARG;
+    dc::IcpSeqPair& t = args.pairs[np];
+    t.A = dc::ScanView{a.vps, a.dirs, a.depth, a.inc, a.lmask, plane ? a.normals : nullptr};
+    t.B = dc::ScanView{b.vps, b.dirs, b.depth, b.inc, b.lmask, plane ? b.normals : nullptr};
+    t.idxA = q.idx_a; t.idxB = q.idx_b; t.m = q.m; t.weight = q.weight; t.scan_a = q.scan_a; t.scan_b = q.scan_b;
+    const int64_t rows = (q.m + dc::kBlock - 1) / dc::kBlock;
+    if (row0 + rows > INT32_MAX) return DC_ERR_UNSUPPORTED;
+    t.row0 = (int32_t)row0; t.rows = (int32_t)rows;
+    rq.weight[np] = q.weight; rq.scan_a[np] = q.scan_a; rq.scan_b[np] = q.scan_b; rq.row0[np] = t.row0; rq.rows[np] = t.rows;
+    row0 += rows;
+    ++np;
+  }
+  if (np == 0) return DC_ERR_UNSUPPORTED;
+  args.n_pairs = rq.n_pairs = np;
+  dc::PoseTrainArgs fa{};
+  if (fin) {
+    if (nt_model < 1 || (fin->n_deltas != 1 && fin->n_deltas != n_scans) || !fin->poses0 || !fin->deltas || !fin->d_m || !fin->d_v || !fin->step ||
+        !fin->poses_used || !fin->poses_next || !fin->poses12_next || (fin->w && (!fin->w_m || !fin->w_v)) || (fin->record && fin->ring_rows < 1) ||
+        fin->n_record_extra < 0 || (fin->n_record_extra > 0 && !fin->record_extra))
+      return DC_ERR_ARG;
+    if (!(fin->lr_w >= 0.0) || !(fin->lr_d >= 0.0) || !(fin->beta1 >= 0.0 && fin->beta1 < 1.0) || !(fin->beta2 >= 0.0 && fin->beta2 < 1.0) ||
+        !(fin->eps >= 0.0))
+      return DC_ERR_ARG;
+    fa = dc::PoseTrainArgs{out, 1 + 2 * nt_model + 12 * n_scans, -1, 1, 1 + 2 * nt_model, nullptr, nt_model, n_scans, fin->n_deltas, fin->zero_first,
+                       fin->w, fin->w_m, fin->w_v, fin->poses0, fin->deltas, fin->d_m, fin->d_v, fin->step, fin->lr_w, fin->lr_d, fin->beta1,
+                       fin->beta2, fin->eps, fin->poses_used, fin->record, fin->ring_rows, fin->poses_next, fin->poses12_next, fin->record_extra,
+                       fin->n_record_extra};
+  }
+  const dim3 grid((unsigned)row0), block(dc::kBlock);
+#define ICP_FUSED(T, PLANE) hipLaunchKernelGGL((dc::p2plane_seq_fused_kernel<T, PLANE>), grid, block, 0, stream, args, poses, model_kind, nt_model, w, e, \
+                                              partials_ws, rq, out, n_scans, ticket, fa, fin ? 1 : 0)
+  if (dtype == DC_F32) { if (plane) ICP_FUSED(float, true); else ICP_FUSED(float, false); }
+  else { if (plane) ICP_FUSED(double, true); else ICP_FUSED(double, false); }
+#undef ICP_FUSED
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
 
 int dc_pose_correct_fwd(const double* poses, const double* deltas, int n_poses, int n_deltas, double* poses_out,
                         hipStream_t stream) {

@@ -866,6 +866,7 @@ class IcpSequence:
             max_m = max(max_m, m)
         self.part = torch.empty((lib().dc_p2plane_sequence_partial_count(ctypes.cast(self.pair_desc, ctypes.c_void_p), self.n_pairs),),
                                 dtype=torch.float64, device=self.device)
+        self.ticket = torch.zeros((32,), dtype=torch.int32, device=self.device)      # dc_icp_sequence_step's (left zero by every launch)
 
     @on_device
     def eval(self, poses12, model_kind=None, w=None, e=None, out=None):
@@ -884,3 +885,22 @@ class IcpSequence:
                  self.n_pairs, 0 if self.dtype == torch.float32 else 1, ptr(poses12), kind, nt, ptr(w), ptr(e),
                  ptr(self.part), ptr(out), stream_ptr()), 'dc_p2plane_sequence' if self.plane else 'dc_p2point_sequence')
         return out
+
+    @on_device
+    def step(self, poses12, model_kind, w, e, out, fin=None):
+        """``eval`` as ONE launch (dc_icp_sequence_step: the sums are finished by the block that takes the last ticket) and, with
+        ``fin`` (a _native.PoseTrainStepDesc), the finishing step of a training iteration -- dc_pose_train_finish's work -- by
+        that same block.  Returns False when the sequence cannot take it (more than sixteen pairs, no correspondence at all)."""
+        kind, nt, w, e = _model_args(model_kind, w, e, self._keep[0][0]) if self.n_scans else (0, 0, None, None)
+        if kind != 0 and not self.with_model:
+            raise ValueError('sequence was built without incidence angles')
+        need(poses12, (self.n_scans, 12), dtype=torch.float64, name='poses[S,12]', device=self.device)
+        need(out, (1 + 2 * nt + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        rc = lib().dc_icp_sequence_step(1 if self.plane else 0, ctypes.cast(self.scan_desc, ctypes.c_void_p), self.n_scans,
+                                        ctypes.cast(self.pair_desc, ctypes.c_void_p), self.n_pairs, 0 if self.dtype == torch.float32 else 1,
+                                        ptr(poses12), kind, nt, ptr(w), ptr(e), ptr(self.part), ptr(out), ptr(self.ticket),
+                                        None if fin is None else ctypes.byref(fin), stream_ptr())
+        if rc == nv.DC_ERR_UNSUPPORTED:
+            return False
+        check(rc, 'dc_icp_sequence_step')
+        return True

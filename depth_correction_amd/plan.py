@@ -72,7 +72,8 @@ class SequencePlan:
                           consecutive points of either kind -- and lay the wavefronts out in Morton order of their first point; a block
                           is four consecutive wavefronts.  The one-pass kernels skip a wavefront none of whose centres is inside the
                           mask, and with whole-block grouping alone only floor(outside / 64) wavefronts of a block qualify (C2: 26 % of
-                          the points are outside, 10.7 % of the wavefronts were skipped).  Default: on for [rows, K] tables with a mask.
+                          the points are outside, 10.7 % of the wavefronts were skipped).  Default: on for [rows, K <= 10] tables with
+                          a mask.
         :param degree_group: ball neighbourhoods without pose gradients: lanes of a block ordered by (mask, row length) instead of
                              (mask, scan).
         :param heavy_first: ball neighbourhoods: the blocks with the longest rows first in the grid (see below).
@@ -128,7 +129,8 @@ class SequencePlan:
                 order = order[pos[pos < self.n]]
             self.scan_seg, self.skipped_wavefronts, self.blk_skip = None, 0.0, None
             if wave_pack is None:
-                wave_pack = nbr.shape[1] <= 16 and not heavy_first and not degree_group
+                # (K = 16: a block's list under this layout can pass the 512 rows the pose kernel's tile holds -- left as it was)
+                wave_pack = nbr.shape[1] <= 10 and not heavy_first and not degree_group
             if wave_pack and mask is not None and not degree_sort and not active_only and not mask_first and self.n >= 4 * 256:
                 # wavefronts of one kind: the points inside the mask, in Morton order, cut into runs of 64, and likewise the points
                 # outside; the runs merged by the Morton position of their first point.  Every wavefront but the two at the ends of
@@ -408,7 +410,9 @@ class SequencePlan:
 
     def _build_pose_table(self):
         """dcPoseTable of this plan's forward table (dc_pose_table_build), or False when some block cannot take the pose kernel."""
-        ft, dev, nb = self.fwd_table, self.device, (self.n + 255) // 256
+        # (from the loss-only table when the plan has one: a centre outside the mask adds no edge gradient either, and its lists are
+        # the ones that fit the kernel's 512-row tile under the wave-packed layout)
+        ft, dev, nb = (getattr(self, 'fwd_table_loss', None) or self.fwd_table), self.device, (self.n + 255) // 256
         total = int(ft.blk_ptr[-1].item())
         t = dict(ids=torch.empty((max(total, 1),), dtype=torch.int32, device=dev),
                  loc=torch.empty((nb * self.k * 256,), dtype=torch.uint16, device=dev),
@@ -916,6 +920,28 @@ class PoseSequenceTrainer:
         check(lib().dc_pose_train_combine(ctypes.cast(arr, ctypes.c_void_p), len(trainers), 1 if t0.icp else 0, t0.nt, ptr(totals),
                                           stream_ptr()), 'dc_pose_train_combine')
         return totals
+
+    def evaluate_finish(self, w, exponent, w_step=None, w_m=None, w_v=None, lr_w=0.0, ring=None, rec_extra=None):
+        """``evaluate`` + ``finish`` of an ICP sequence whose loss waits for nobody (one sequence, one rank) in ONE launch
+        (dc_icp_sequence_step).  Returns False -- nothing launched -- when this sequence cannot take it."""
+        if not self.icp or not self.icp_kind or getattr(self, '_no_fused', False):
+            return False
+        f = getattr(self, '_fin', None)
+        if f is None:
+            f = self._fin = nv.PoseTrainStepDesc()
+            f.poses0, f.deltas, f.d_m, f.d_v = self.T0.data_ptr(), self.delta.data_ptr(), self.d_m.data_ptr(), self.d_v.data_ptr()
+            f.n_deltas, f.zero_first, f.step = self.nd, self.zero_first, self.step.data_ptr()
+            f.lr_d, f.beta1, f.beta2, f.eps = self.lr, self.betas[0], self.betas[1], self.eps
+            f.poses_used = f.poses_next = self.T.data_ptr()
+            f.poses12_next = self.P12.data_ptr()
+        p_ = lambda t: None if t is None else t.data_ptr()
+        f.w, f.w_m, f.w_v, f.lr_w = p_(w_step), p_(w_m), p_(w_v), float(lr_w)
+        f.record, f.ring_rows = p_(ring), (0 if ring is None else ring.shape[0])
+        f.record_extra, f.n_record_extra = p_(rec_extra), (0 if rec_extra is None else rec_extra.numel())
+        if not self.plan.step(self.P12, self.icp_kind, w, exponent, self.out, f):
+            self._no_fused = True
+            return False
+        return True
 
     @staticmethod
     def combine2(trainers, val_trainers, totals2):

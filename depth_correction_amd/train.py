@@ -729,6 +729,18 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
         book.end_batch()
 
     def body():
+        if totals2 is None and tr.icp:
+            # an ICP loss that waits for nobody (one sequence, one rank): evaluation, sums and the finishing step in ONE launch
+            # (dc_icp_sequence_step); the validation sequence first -- it reads the weights the training launch is about to step
+            done_v = [v.evaluate_finish(w, e, None, None, None, 0.0, vr) for v, vr in zip(vtr, vrings)]
+            for v, vr, ok_ in zip(vtr, vrings, done_v):
+                if not ok_:
+                    v.evaluate(w, e)
+                    v.finish(None, None, None, 0.0, vr)
+            if not tr.evaluate_finish(w, e, w, w_m, w_v, lr_w, rings[0]):
+                tr.evaluate(w, e)
+                tr.finish(w, w_m, w_v, lr_w, rings[0])
+            return
         for t_ in trs:
             t_.evaluate(w, e)
         for v in vtr:
@@ -744,32 +756,40 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
             v.finish(None, None, None, 0.0, vr, vtotals, extra)
 
     state = dict(launched=0, graph=None, tried=False)
+    G = max(1, min(int(getattr(cfg, 'loop_graph_iters', 8) or 1), R))     # iterations per captured graph
 
-    def run_one():
-        if callbacks is not None:
-            callbacks.iteration_started(state['launched'])
+    def run_some(left):
+        """Launch the next iteration(s), at most ``left``; returns how many."""
         # (sharded: launched eagerly -- a collective inside a captured graph is not something this path relies on)
-        if (state['launched'] >= 3 and not state['tried'] and n_it - state['launched'] >= 4 and getattr(cfg, 'loop_graph', True)
+        if (state['launched'] >= 3 and not state['tried'] and n_it - state['launched'] >= G + 3 and getattr(cfg, 'loop_graph', True)
                 and not sharded):
-            # every launch of an iteration takes the same pointers (the record's ring slot follows the device step counter): the
-            # iteration is captured once, after three eager ones (pose tables built, allocator warm), and replayed -- one graph
-            # launch per iteration instead of the host path of three library calls
+            # every launch of an iteration takes the same pointers (the record's ring slot follows the device step counter): G
+            # iterations are captured once, after three eager ones (pose tables built, allocator warm), and replayed -- one graph
+            # launch per G iterations.  (An iteration is one to three short launches: replayed one by one the HOST's ~45 us per
+            # graph launch would set the pace of an ICP iteration whose single launch takes half of that.)
             state['tried'] = True
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             try:
                 g_ = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_, stream=side):
-                    body()
+                    for _ in range(G):
+                        body()
                 state['graph'] = g_
+                # (a capture launches nothing: the G iterations it recorded have not run)
             except Exception as ex:                                   # not capturable here: keep launching eagerly
                 print('train(): the iteration could not be captured as a graph (%s); running eagerly' % (ex,))
             torch.cuda.current_stream(dev).wait_stream(side)
-        if state['graph'] is not None:
+        n = G if (state['graph'] is not None and left >= G) else 1
+        if callbacks is not None:
+            for q in range(n):
+                callbacks.iteration_started(state['launched'] + q)
+        if n == G and state['graph'] is not None:
             state['graph'].replay()
         else:
             body()
-        state['launched'] += 1
+        state['launched'] += n
+        return n
 
     # batches of R iterations: the records of a batch are fetched (one synchronisation) BEFORE the next batch is launched into the
     # same ring, and replayed through the reference's bookkeeping WHILE the device runs that next batch
@@ -778,8 +798,9 @@ def _native_pose_loop(cfg, model, optimizer, val_optimizer, plans, vplans, train
         while start < n_it:
             end = min(start + R, n_it)
             fetched = fetch() if prev is not None else None
-            for _ in range(start, end):
-                run_one()
+            it_ = start
+            while it_ < end:
+                it_ += run_some(end - it_)
             if prev is not None:
                 bookkeep(fetched, *prev)
             prev, start = (start, end), end

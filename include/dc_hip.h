@@ -423,6 +423,32 @@ int dc_p2point_sequence(const dcIcpScan* scans, int n_scans, const dcIcpPair* pa
                         const double* poses, int model_kind, int n_terms, const double* w, const double* e,
                         double* partials_ws, double* out, dcStream_t stream);
 
+/* ---- an ICP training iteration in ONE launch (round 5; train.py:300-312 with icp_loss, loss.py:373-488) --------------------------
+ * dc_p2plane_sequence / dc_p2point_sequence (plane = 1 / 0) with the sums finished inside the same launch -- every block takes a
+ * ticket, the one that draws the last sums the rows in fixed order -- and, with fin != NULL, dc_pose_train_finish (layout 1, no
+ * totals) run by that same block: adjoint of the pose chain, both Adam updates, next poses, record.  For sequences of at most 16
+ * pairs with at least one correspondence (DC_ERR_UNSUPPORTED otherwise: issue the separate calls).  ticket: device int32 [17], zero
+ * before the first call; the launch leaves it zero.  partials_ws: dc_p2plane_sequence_partial_count doubles.  fin's fields are dc_pose_train_finish's arguments of the same names
+ * (poses_used [S,16] may be poses_next: it is read first; poses12_next may be `poses`: every block has read it by then). */
+typedef struct dcPoseTrainStep {
+  double *w, *w_m, *w_v;
+  const double* poses0;
+  double *deltas, *d_m, *d_v;
+  int32_t n_deltas, zero_first;
+  int64_t* step;
+  double lr_w, lr_d, beta1, beta2, eps;
+  const double* poses_used;
+  double* record;
+  int32_t ring_rows, n_record_extra;
+  const double* record_extra;
+  double* poses_next;
+  double* poses12_next;
+} dcPoseTrainStep;
+int dc_icp_sequence_step(int plane, const dcIcpScan* scans, int n_scans, const dcIcpPair* pairs, int n_pairs, int dtype,
+                         const double* poses, int model_kind, int n_terms, const double* w, const double* e, double* partials_ws,
+                         double* out, int32_t* ticket, const dcPoseTrainStep* fin, dcStream_t stream);
+
+
 /* Quantile-inlier gating for the fused path (min_eigval_loss / trace_loss with inlier_ratio < 1 or inlier_max_loss,
  * loss.py:256-277).  raw_pointwise [n] (dtype): the forward's loss before relu / sqrt (dc_consistency_fwd with
  * loss_kind | DC_LOSS_RAW_POINTWISE); threshold: device fp64 scalar the caller derived from it (multiplier x quantile of

@@ -452,10 +452,11 @@ def test_round4_entry_points_reject_bad_arguments():
     step = torch.zeros((), dtype=torch.int64, device=dev)
     args = lambda **kw: [kw.get('sums', ptr(sums)), kw.get('layout', 0), kw.get('nt', P), kw.get('ns', S), ptr(w), ptr(m), ptr(v), ptr(T0),
                          ptr(d), ptr(dm), ptr(dv), kw.get('nd', S), 1, ptr(step), 1e-3, 1e-3, kw.get('b1', 0.9), 0.999, 1e-8, ptr(T),
-                         kw.get('rec', None), kw.get('rows', 0), ptr(T), ptr(P12), None, nv.stream_ptr()]
+                         kw.get('rec', None), kw.get('rows', 0), ptr(T), ptr(P12), None, kw.get('extra', None), kw.get('n_extra', 0),
+                         nv.stream_ptr()]
     assert lib.dc_pose_train_finish(*args()) == 0
     for bad in (dict(layout=2), dict(sums=None), dict(nt=0), dict(nt=99), dict(ns=0), dict(nd=2), dict(b1=1.0),
-                dict(rec=ptr(f64(4, 200)), rows=0)):
+                dict(rec=ptr(f64(4, 200)), rows=0), dict(n_extra=4), dict(extra=ptr(f64(4)), n_extra=-1)):
         assert lib.dc_pose_train_finish(*args(**bad)) == nv.DC_ERR_ARG, bad
     outs = (ctypes.c_void_p * 17)(*([sums.data_ptr()] * 17))
     tot = f64(2 + P)
@@ -463,6 +464,14 @@ def test_round4_entry_points_reject_bad_arguments():
     assert lib.dc_pose_train_combine(cast(outs), 2, 0, P, ptr(tot), nv.stream_ptr()) == 0
     for n_seq, layout, nt in ((0, 0, P), (17, 0, P), (2, 3, P), (2, 0, 0)):
         assert lib.dc_pose_train_combine(cast(outs), n_seq, layout, nt, ptr(tot), nv.stream_ptr()) == nv.DC_ERR_ARG
+    # the two-group form (training and validation sequences of an iteration): either group may be empty
+    tot2 = f64(2, 2 + P)
+    sums[:4] = torch.tensor([3.0, 2.0, 0.5, -0.25], dtype=torch.float64, device=dev)
+    assert lib.dc_pose_train_combine2(cast(outs), 2, cast(outs), 0, 0, P, ptr(tot2), nv.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert tot2.cpu().tolist() == [[6.0, 4.0, 1.0, -0.5], [0.0, 0.0, 0.0, 0.0]]
+    for n_a, n_b in ((17, 0), (2, 17), (-1, 0)):
+        assert lib.dc_pose_train_combine2(cast(outs), n_a, cast(outs), n_b, 0, P, ptr(tot2), nv.stream_ptr()) == nv.DC_ERR_ARG
     pts = torch.zeros((10, 3), dtype=torch.float32, device=dev)
     sp = torch.tensor([0, 4, 10], dtype=torch.int64, device=dev)
     xs, info = f64(10, 3), i32(1)
