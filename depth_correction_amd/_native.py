@@ -84,6 +84,8 @@ _SIGNATURES = {
                                   _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'dc_mask_bounds': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _f64, _f64, _vp, _vp]),
     'dc_valid_count': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'dc_nn1_corr_workspace_bytes': (_sz, [_i64]),
+    'dc_nn1_corr': (_i32, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_dispersion': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     'dc_sequence_eval': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'dc_sequence_step': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),

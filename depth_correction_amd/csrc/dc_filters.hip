@@ -209,6 +209,126 @@ __global__ __launch_bounds__(kBlock) void run_emit_kernel(const uint64_t* __rest
   if (head && !preserve_order) sort_key[r] = svals[p];        // first appearance in the processing sequence
 }
 
+
+// ---- K17: inlier correspondences of two scans (train.py:186-193, 202-209; loss.py:440-452) -------------------------------------
+// dists, ids = tree2.query(points1); th = np.quantile(dists[~isnan], ratio); mask1 = dists <= th; (mask1, ids[mask1]).  The 1-NN is
+// dc_knn_build's; here the quantile WITHOUT a sort: a radix select over the bit patterns of the non-negative fp64 distances (their
+// order is the numbers' order) finds the order statistic below the quantile position in eight passes of one byte -- a 256-bin
+// histogram per pass, kept in LDS per block and merged -- one more pass finds the next distinct value and how many elements lie
+// at or below, numpy's linear interpolation (lerp with its t >= 0.5 branch) gives the threshold, and the survivors' indices are
+// compacted in their order.  Nothing returns to the host in between.
+struct Nn1State {
+  unsigned long long prefix;      // the bits found so far
+  long long rank;                 // rank still to find among the elements that share the prefix
+  long long n_valid, lo;          // non-NaN elements; index of the order statistic below the quantile position
+  double gamma;                   // fractional part of the position
+  long long n_le;                 // elements <= a[lo]
+  unsigned long long next_bits;   // smallest value > a[lo] (bits), ~0 when none
+  unsigned int hist[256];
+};
+
+__global__ __launch_bounds__(kBlock) void nn1_hist_kernel(const double* __restrict__ dist, int64_t n, Nn1State* st, int shift, int first) {
+  __shared__ unsigned int s_hist[256];
+  s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long prefix = first ? 0ull : st->prefix;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double d = dist[i];
+    if (d != d) continue;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    if (!first && (b >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+    atomicAdd(&s_hist[(b >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (s_hist[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+__global__ void nn1_pick_kernel(Nn1State* st, int shift, int first, double ratio) {
+  if (threadIdx.x != 0) return;
+  if (first) {
+    long long total = 0;
+    for (int q = 0; q < 256; ++q) total += st->hist[q];
+    st->n_valid = total;
+    const double pos = (double)(total - 1) * ratio;                   // numpy: virtual_indexes = (n - 1) * q
+    const double fl = floor(pos);
+    st->lo = total > 0 ? (long long)fl : 0;
+    st->gamma = pos - fl;
+    st->rank = st->lo;
+    st->prefix = 0ull;
+    st->n_le = 0;
+    st->next_bits = ~0ull;
+  }
+  long long r = st->rank;
+  int bin = 255;
+  for (int q = 0; q < 256; ++q) {
+    const long long c = st->hist[q];
+    if (r < c) { bin = q; break; }
+    r -= c;
+  }
+  st->rank = r;
+  st->prefix |= (unsigned long long)bin << shift;
+  for (int q = 0; q < 256; ++q) st->hist[q] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void nn1_next_kernel(const double* __restrict__ dist, int64_t n, Nn1State* st) {
+  __shared__ long long s_cnt[kBlock / kWave];
+  __shared__ unsigned long long s_min[kBlock / kWave];
+  const unsigned long long v = st->prefix;
+  long long cnt = 0;
+  unsigned long long mn = ~0ull;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double d = dist[i];
+    if (d != d) continue;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    if (b <= v) ++cnt;
+    else mn = b < mn ? b : mn;
+  }
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, kWave);
+    const unsigned long long other = __shfl_xor(mn, o, kWave);
+    mn = other < mn ? other : mn;
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) { s_cnt[wave] = cnt; s_min[wave] = mn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < kBlock / kWave; ++wv) { cnt += s_cnt[wv]; mn = s_min[wv] < mn ? s_min[wv] : mn; }
+    atomicAdd((unsigned long long*)&st->n_le, (unsigned long long)cnt);
+    atomicMin(&st->next_bits, mn);
+  }
+}
+
+__global__ void nn1_threshold_kernel(Nn1State* st, double* __restrict__ threshold) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->n_valid <= 0) { *threshold = __longlong_as_double(0x7ff8000000000000ll); return; }      // np.quantile of nothing: NaN
+  const double a = __longlong_as_double((long long)st->prefix);
+  // a[lo + 1]: another copy of a[lo] when more than lo + 1 elements are <= it, else the next distinct value (a[lo] itself at the end)
+  double b = a;
+  if (st->lo + 1 < st->n_valid) b = (st->n_le >= st->lo + 2) ? a : __longlong_as_double((long long)st->next_bits);
+  const double t = st->gamma, diff = b - a;
+  *threshold = t >= 0.5 ? b - diff * (1.0 - t) : a + diff * t;       // numpy's _lerp
+}
+
+__global__ __launch_bounds__(kBlock) void nn1_flag_kernel(const double* __restrict__ dist, int64_t n, const double* __restrict__ threshold,
+                                                          uint8_t* __restrict__ mask, int32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const bool in = dist[i] <= *threshold;                               // (NaN compares false on either side, as in numpy)
+  mask[i] = in ? 1 : 0;
+  flags[i] = in ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void nn1_scatter_kernel(const int32_t* __restrict__ idx, const uint8_t* __restrict__ mask,
+                                                             const int32_t* __restrict__ pos, int64_t n, int32_t* __restrict__ idx_out,
+                                                             int64_t* __restrict__ count_out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (mask[i]) idx_out[pos[i]] = idx[i];
+  if (i == n - 1) *count_out = (int64_t)pos[i] + (mask[i] ? 1 : 0);
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -349,6 +469,49 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
   hipLaunchKernelGGL(run_emit_kernel, grid, block, 0, stream, skeys, svals, run_id, seq, n, preserve_order, skey, surv, count_out);
   err = sort_pairs_u32(tmp, tmp_bytes, skey, skey2, surv, out_idx, (size_t)n, 0, 32, stream);      // (keys never negative)
   if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
+  return err == hipSuccess ? DC_OK : (int)err;
+}
+
+
+size_t dc_nn1_corr_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  return 256 + ((sizeof(dc::Nn1State) + 255) / 256) * 256 + 2 * ((m * sizeof(int32_t) + 255) / 256) * 256 + dc::scan_bytes(m);
+}
+
+int dc_nn1_corr(const double* dist, const int32_t* idx, int64_t n, double ratio, uint8_t* mask_out, int32_t* idx_out, int64_t* count_out,
+                double* threshold_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || !(ratio >= 0.0 && ratio <= 1.0) || !count_out || !threshold_out) return DC_ERR_ARG;
+  if (n == 0) {
+    hipError_t e0 = hipMemsetAsync(count_out, 0, sizeof(int64_t), stream);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(threshold_out, 0xff, sizeof(double), stream);      // (a NaN)
+    return e0 == hipSuccess ? DC_OK : (int)e0;
+  }
+  if (!dist || !idx || !mask_out || !idx_out || !ws || n > 0x7fffffff) return DC_ERR_ARG;
+  if (ws_bytes < dc_nn1_corr_workspace_bytes(n)) return DC_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  dc::Nn1State* st = reinterpret_cast<dc::Nn1State*>(base);
+  const size_t st_bytes = ((sizeof(dc::Nn1State) + 255) / 256) * 256, arr = (((size_t)n * sizeof(int32_t) + 255) / 256) * 256;
+  int32_t* flags = reinterpret_cast<int32_t*>(base + st_bytes);
+  int32_t* pos = reinterpret_cast<int32_t*>(base + st_bytes + arr);
+  void* scan_ws = base + st_bytes + 2 * arr;
+  hipError_t err = hipMemsetAsync(st, 0, sizeof(dc::Nn1State), stream);
+  if (err != hipSuccess) return (int)err;
+  const unsigned blocks_all = (unsigned)((n + dc::kBlock - 1) / dc::kBlock);
+  const unsigned blocks = blocks_all < 512u ? blocks_all : 512u;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    hipLaunchKernelGGL(dc::nn1_hist_kernel, dim3(blocks), dim3(dc::kBlock), 0, stream, dist, n, st, shift, pass == 0 ? 1 : 0);
+    hipLaunchKernelGGL(dc::nn1_pick_kernel, dim3(1), dim3(64), 0, stream, st, shift, pass == 0 ? 1 : 0, ratio);
+  }
+  hipLaunchKernelGGL(dc::nn1_next_kernel, dim3(blocks), dim3(dc::kBlock), 0, stream, dist, n, st);
+  hipLaunchKernelGGL(dc::nn1_threshold_kernel, dim3(1), dim3(64), 0, stream, st, threshold_out);
+  hipLaunchKernelGGL(dc::nn1_flag_kernel, dim3(blocks_all), dim3(dc::kBlock), 0, stream, dist, n, (const double*)threshold_out, mask_out, flags);
+  err = dc::exclusive_scan_32(scan_ws, dc::scan_bytes((size_t)n), flags, pos, (size_t)n, stream);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(dc::nn1_scatter_kernel, dim3(blocks_all), dim3(dc::kBlock), 0, stream, idx, (const uint8_t*)mask_out, (const int32_t*)pos, n,
+                     idx_out, count_out);
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
 }

@@ -126,10 +126,9 @@ def icp_correspondences(points1, points2, ratio):
     """(mask1 bool [N1], idx2 int64 [M]): 1-NN of scan 1 in scan 2 on the GPU, inliers = dist <= quantile(dist, ratio)
     (train.py:186-193, loss.py:440-452)."""
     dist, idx = ops.knn(points2.detach().contiguous(), 1, query=points1.detach().to(points2.dtype).contiguous())
-    dist, idx = dist[:, 0], idx[:, 0].long()
-    th = torch.nanquantile(dist, ratio)
-    mask1 = dist <= th
-    return mask1, idx[mask1], dist
+    dist, idx = dist[:, 0].contiguous(), idx[:, 0].contiguous()
+    mask1, idx2, _ = ops.nn1_corr(dist, idx, ratio)                  # quantile select + compaction on the device (dc_nn1_corr)
+    return mask1, idx2.long(), dist
 
 
 def _pair_points(cloud):

@@ -59,6 +59,24 @@ def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
 
 
 @on_device
+def nn1_corr(dist, idx, ratio):
+    """(mask bool [n], idx[mask] int32 [m], threshold fp64 0-dim): the inlier correspondences of a scan pair from the 1-NN distances
+    (dc_nn1_corr: np.quantile by a radix select on the device, train.py:186-193).  One synchronisation: the survivors' count."""
+    need(dist, (None,), dtype=torch.float64, name='dist')
+    n = dist.shape[0]
+    need(idx, (n,), dtype=torch.int32, name='idx', device=dist.device)
+    mask = torch.empty((n,), dtype=torch.uint8, device=dist.device)
+    out = torch.empty((max(n, 1),), dtype=torch.int32, device=dist.device)
+    count = torch.zeros((1,), dtype=torch.int64, device=dist.device)
+    th = torch.empty((1,), dtype=torch.float64, device=dist.device)
+    nbytes = lib().dc_nn1_corr_workspace_bytes(n)
+    ws = _ws(nbytes, dist.device)
+    check(lib().dc_nn1_corr(ptr(dist), ptr(idx), n, float(ratio), ptr(mask), ptr(out), ptr(count), ptr(th), ptr(ws), nbytes, stream_ptr()),
+          'dc_nn1_corr')
+    return mask.view(torch.bool), out[:int(count.item())], th[0]
+
+
+@on_device
 def gather_rows(src, order):
     """src[order] for a contiguous per-point array [n, ...] and an int64 permutation (dc_gather_rows: one kernel family for every
     dtype and row shape)."""

@@ -299,6 +299,14 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
 int dc_mask_bounds(const void* num, int num_stride, int num_index, const void* den, int den_stride, int den_index,
                    int dtype, int64_t n, double lo, double hi, uint8_t* mask, dcStream_t stream);
 int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, dcStream_t stream);
+/* ---- K17: inlier correspondences of a scan pair (train.py:186-193, 202-209; loss.py:440-452) ---------------------------------------
+ * dist fp64 [n] / idx int32 [n]: the 1-NN of scan 1's points in scan 2 (dc_knn_build with k = 1 and a query).  threshold_out <-
+ * np.quantile(dist[~isnan(dist)], ratio) (linear interpolation, numpy's lerp) found by a radix select on the device -- no sort --,
+ * mask_out uint8 [n] <- dist <= threshold, idx_out int32 [n] <- idx[mask] in order (first *count_out valid; count_out device int64).
+ * Nothing returns to the host in between.  ws: dc_nn1_corr_workspace_bytes(n). */
+size_t dc_nn1_corr_workspace_bytes(int64_t n);
+int dc_nn1_corr(const double* dist, const int32_t* idx, int64_t n, double ratio, uint8_t* mask_out, int32_t* idx_out, int64_t* count_out,
+                double* threshold_out, void* ws, size_t ws_bytes, dcStream_t stream);
 /* out[i] = trace of the weighted covariance of vec[nbr[i]]; weights [n,k] or NULL (validity). */
 int dc_dispersion(const void* vec, int dtype, const int32_t* nbr, const void* weights, int64_t n, int k, void* out,
                   dcStream_t stream);

@@ -666,3 +666,25 @@ def test_one_pass_step_all_loss_variants_vs_oracle(golden, dev, tag, loss, norm,
     np.testing.assert_allclose(o[0], lo.item(), rtol=1e-11 if f64 else 1e-5)
     ref = wo.grad.numpy().ravel()
     np.testing.assert_allclose(o[2:4], ref, rtol=1e-8 if f64 else 1e-5, atol=(1e-10 if f64 else 2e-5) * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('n, ratio', [(1, 0.3), (2, 0.5), (257, 0.0), (5000, 0.3), (5000, 1.0), (100_003, 0.37), (100_003, 0.5)])
+def test_nn1_corr_quantile_select_vs_numpy(n, ratio):
+    """dc_nn1_corr (K17, train.py:186-193): threshold = np.quantile(dist[~isnan], ratio) bit for bit -- a radix select on the device,
+    numpy's lerp --, mask = dist <= threshold and the survivors' indices in order; with NaN distances, many equal distances (the
+    order statistics on either side of the position coincide) and the ends of the range."""
+    from depth_correction_amd import ops
+    rng = np.random.default_rng(n)
+    dist = np.abs(rng.normal(size=n)) * 0.1
+    if n > 100:
+        dist[rng.choice(n, n // 50, replace=False)] = np.nan
+        dist[rng.choice(n, n // 3, replace=False)] = np.round(dist[rng.choice(n, n // 3, replace=False)], 2)      # ties
+        dist[7] = 0.0
+    idx = rng.integers(0, 1 << 20, size=n).astype(np.int32)
+    mask, sel, th = ops.nn1_corr(torch.as_tensor(dist, device='cuda:0'), torch.as_tensor(idx, device='cuda:0'), ratio)
+    valid = dist[~np.isnan(dist)]
+    ref_th = np.quantile(valid, ratio)
+    assert float(th) == ref_th, (float(th), ref_th)
+    with np.errstate(invalid='ignore'):
+        ref_mask = dist <= ref_th
+    assert np.array_equal(mask.cpu().numpy(), ref_mask) and np.array_equal(sel.cpu().numpy(), idx[ref_mask])
