@@ -60,8 +60,6 @@ _SIGNATURES = {
     'dc_block_table_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_block_group': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'dc_pose_table_build': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dc_pose_table_ragged_count': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dc_pose_table_ragged_fill': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     'dc_points_local_basis': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     'dc_pose_train_finish': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f64, _f64, _f64, _f64, _f64,
                                     _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
@@ -132,8 +130,7 @@ class BlockTableDesc(ctypes.Structure):
 
 class PoseTableDesc(ctypes.Structure):
     """dcPoseTable of include/dc_hip.h."""
-    _fields_ = [('blk_ptr', _vp), ('ids', _vp), ('loc', _vp), ('own_pos', _vp), ('row_seg', _vp), ('row_scan', _vp), ('wseg', _vp),
-                ('slot_ptr', _vp)]
+    _fields_ = [('blk_ptr', _vp), ('ids', _vp), ('loc', _vp), ('own_pos', _vp), ('row_seg', _vp), ('row_scan', _vp)]
 
 
 class IcpScan(ctypes.Structure):

@@ -2446,8 +2446,6 @@ struct PoseTab {
   const uint16_t* __restrict__ own_pos;    // [N]: 16 x position of the point's own row in its block's list
   const uint16_t* __restrict__ row_seg;    // [blocks][S + 1]: first row of every scan in the block's list; [S] = the row count
   const uint8_t* __restrict__ row_scan;    // the scan of every listed row (parallel to ids)
-  const uint16_t* __restrict__ wseg;       // packed tables only: [blocks][4][S + 1] first slot of scan s in the slot rows of wavefront w (see
-                                           // pose_table_ragged_kernel); [S] = the wavefront's slot count
 };
 constexpr int kPoseCap = 512;              // rows of the static tile (the table builder refuses blocks with longer lists)
 
@@ -2501,120 +2499,6 @@ __global__ __launch_bounds__(kBlock) void pose_table_kernel(BlockTab tab, const 
   for (int q = 0; q < K; ++q) {
     const uint16_t l = lrow[q * kBlock];
     loc_out[((int64_t)b * K + q) * kBlock + tid] = l == 0xFFFF ? (uint16_t)0xFFFF : (uint16_t)(s_new[l >> 4] << 4);
-  }
-}
-
-// The same for a packed table of rows of any length (ball neighbourhoods; round 5): run-time slot count, lists of up to `cap` rows
-// (dynamic LDS: 7 bytes per row + 512 per scan), and a slot layout in which the wavefronts sweep their neighbours SCAN BY SCAN:
-// for wavefront w of the block the neighbours that belong to scan s sit in slot rows [wseg[w][s], wseg[w][s + 1]) of every lane
-// (as many rows as the lane with the most of them needs; the others are padded with empty slots).  The segment bounds are
-// wave-uniform, so the pose kernel sums a centre's edge gradients per scan in registers and joins the 64 lanes once per
-// (wavefront, scan) in a fixed order -- no per-edge atomics, no per-row gradient planes in LDS.  Two launches with an allocation
-// in between: this one orders the lists, counts and writes the remapped positions in the OLD slot layout (loc_tmp) and the
-// number of slot rows every block needs; pose_table_ragged_fill_kernel places them.  info[0] <- 1 when a block's list misses one
-// of its own rows.
-__global__ __launch_bounds__(kBlock) void pose_table_ragged_kernel(BlockTab tab, const int32_t* __restrict__ own_base,
-                                                                   const int32_t* __restrict__ scan_id, int64_t n, int n_scans, int cap,
-                                                                   int32_t* __restrict__ ids_out, uint16_t* __restrict__ loc_tmp,
-                                                                   uint16_t* __restrict__ own_pos, uint16_t* __restrict__ row_seg,
-                                                                   uint8_t* __restrict__ row_scan, uint16_t* __restrict__ wseg,
-                                                                   int32_t* __restrict__ slot_cnt, int32_t* __restrict__ info) {
-  extern __shared__ int32_t s_dyn[];
-  int32_t* s_id = s_dyn;                                              // [cap]
-  uint16_t* s_new = reinterpret_cast<uint16_t*>(s_dyn + cap);         // [cap]
-  uint16_t* s_cnt = s_new + cap;                                      // [n_scans][kBlock]
-  uint8_t* s_scan = reinterpret_cast<uint8_t*>(s_cnt + n_scans * kBlock);   // [cap]
-  __shared__ int s_start[kMaxBlockScans + 1];
-  __shared__ int s_wtot[kWavesPerBlock];
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int32_t base = tab.blk_ptr[b], nd = tab.blk_ptr[b + 1] - base;
-  const int32_t own = own_base[b];
-  if (nd > cap || own < 0) {                                          // block-uniform
-    if (tid == 0) { atomicMax(info, 1); slot_cnt[b] = 0; }
-    return;
-  }
-  if (tid <= n_scans) s_start[tid] = 0;
-  __syncthreads();
-  for (int t = tid; t < nd; t += kBlock) {
-    const int32_t id = tab.blk_ids[base + t];
-    const int sc = scan_id ? scan_id[id] : 0;
-    s_id[t] = id;
-    s_scan[t] = (uint8_t)sc;
-    atomicAdd(&s_start[sc + 1], 1);
-  }
-  __syncthreads();
-  if (tid == 0) for (int q = 0; q < n_scans; ++q) s_start[q + 1] += s_start[q];
-  __syncthreads();
-  for (int t = tid; t < nd; t += kBlock) {
-    const int sc = s_scan[t];
-    int rank = 0;
-    for (int t2 = 0; t2 < t; ++t2) rank += s_scan[t2] == sc ? 1 : 0;      // stable: ascending id inside a scan
-    const int p = s_start[sc] + rank;
-    s_new[t] = (uint16_t)p;
-    ids_out[base + p] = s_id[t];
-    row_scan[base + p] = (uint8_t)sc;
-  }
-  if (tid <= n_scans) row_seg[b * (n_scans + 1) + tid] = (uint16_t)s_start[tid];
-  __syncthreads();
-  const int64_t i = b * kBlock + tid;
-  if (i < n) own_pos[i] = (uint16_t)(s_new[own + tid] << 4);
-  // remapped positions in the old slot layout, and how many neighbours of every scan each lane has
-  const int32_t s0 = tab.slot_ptr[b], nslots = tab.slot_ptr[b + 1] - s0;
-  const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + tid;
-  uint16_t* ltmp = loc_tmp + (int64_t)s0 * kBlock + tid;
-  uint16_t* cnt = s_cnt + tid;                                          // [S][kBlock], this lane's column
-  for (int sc = 0; sc < n_scans; ++sc) cnt[sc * kBlock] = 0;
-  for (int q = 0; q < nslots; ++q) {
-    const uint16_t l = lrow[q * kBlock];
-    ltmp[q * kBlock] = l == 0xFFFF ? (uint16_t)0xFFFF : (uint16_t)(s_new[l >> 4] << 4);
-    if (l != 0xFFFF) ++cnt[s_scan[l >> 4] * kBlock];
-  }
-  __syncthreads();
-  // per wavefront and scan: the longest lane -> segment starts
-  const int lane = tid & (kWave - 1), wave = tid / kWave;
-  if (lane == 0) {
-    int at = 0;
-    uint16_t* ws = wseg + ((int64_t)b * kWavesPerBlock + wave) * (n_scans + 1);
-    for (int sc = 0; sc < n_scans; ++sc) {
-      int m = 0;
-      for (int l2 = 0; l2 < kWave; ++l2) m = max(m, (int)s_cnt[sc * kBlock + wave * kWave + l2]);
-      ws[sc] = (uint16_t)at;
-      at += (m + 1) & ~1;                                            // (even: the second sweep takes its slots two at a time)
-    }
-    ws[n_scans] = (uint16_t)at;
-    s_wtot[wave] = at;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int m = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) m = max(m, s_wtot[w]);
-    slot_cnt[b] = (m + kTrip - 1) / kTrip * kTrip;
-  }
-}
-
-// loc_out [slot_ptr2[blocks] + 8][256]: lane `tid`'s neighbours of scan s in slot rows wseg[w][s] .. of its wavefront, in their order;
-// everything else empty.  row_scan: the scan of every position of the block's (ordered) list.
-__global__ __launch_bounds__(kBlock) void pose_table_ragged_fill_kernel(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ slot_ptr,
-                                                                        const uint16_t* __restrict__ loc_tmp, const uint8_t* __restrict__ row_scan,
-                                                                        const uint16_t* __restrict__ wseg, const int32_t* __restrict__ slot_ptr2,
-                                                                        int n_scans, uint16_t* __restrict__ loc_out) {
-  __shared__ uint16_t s_at[kMaxBlockScans][kBlock];
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid / kWave;
-  const int32_t s0 = slot_ptr[b], nslots = slot_ptr[b + 1] - s0;
-  const int32_t d0 = slot_ptr2[b], nslots2 = slot_ptr2[b + 1] - d0;
-  const uint16_t* ltmp = loc_tmp + (int64_t)s0 * kBlock + tid;
-  uint16_t* lout = loc_out + (int64_t)d0 * kBlock + tid;
-  const uint16_t* ws = wseg + (b * kWavesPerBlock + wave) * (n_scans + 1);
-  const uint8_t* rsc = row_scan + blk_ptr[b];
-  for (int q = 0; q < nslots2; ++q) lout[q * kBlock] = 0xFFFF;
-  for (int sc = 0; sc < n_scans; ++sc) s_at[sc][tid] = ws[sc];
-  for (int q = 0; q < nslots; ++q) {
-    const uint16_t l = ltmp[q * kBlock];
-    if (l == 0xFFFF) continue;
-    const int sc = rsc[l >> 4];
-    lout[(int)(s_at[sc][tid]++) * kBlock] = l;
   }
 }
 
@@ -2877,213 +2761,6 @@ __global__ __launch_bounds__(kBlock, 4) void consistency_step_pose_kernel(
     }
   }
   // {sum loss, count, dL/dw} of the wavefront; the exponent-gradient columns [P, 2P) of this evaluation are zero
-  if (tid < P) p_bwd[(P + tid) * rs + blockIdx.x] = 0.0;
-  step_partials<P, true>(acc2, gw, p_fwd, p_bwd, true, 0);
-}
-
-// ---- pose mode in one launch for ball neighbourhoods (round 5) ----------------------------------------------------------------
-// config.py:187-189 defaults to ball neighbourhoods and scripts/model_poses_learning:61,71 trains pose corrections on them; with
-// rows of 70-200 neighbours those evaluations took the three-kernel general path (dc_points_fwd -> slots forward with a record per
-// centre -> backward over the transposed run table: three sweeps over the (centre, neighbour) pairs, 101 / 205 us at r = 0.25 /
-// 0.4 m).  This kernel is the ragged one-pass kernel (consistency_step_ragged_q32_kernel: dynamic tile, trips of eight slots) with
-// the reverse mode inside the wavefront: the slot rows of a wavefront hold its neighbours SCAN BY SCAN (dcPoseTable.wseg), so a
-// centre sums its edges' gradients g_ij and g_ij (x) (x_j - x_i) for one scan in registers, the 64 lanes are joined once per
-// (wavefront, scan) by shuffles, and dL/d[R|t]_s = (sum g (x) (x - t_s)) R_s | sum g follows per block from 4 x S small rows --
-// all fixed-order fp64 sums: bit-reproducible without integer tricks.  (First version: the fixed-K pose kernel's per-row integer
-// sums through LDS atomics -- 555 atomics per centre on rows its neighbours in the wavefront hit at the same time, and 56 B of LDS per
-// staged row = one block per CU: 283 us at r = 0.4 m against 209 for the general path.)  The rows are staged from basis rows
-// {X0, u, c} that dc_points_basis forms for the CURRENT poses once per evaluation (a pass over N points: 6 us at 282 k).
-template <int P, int CAP>
-// (wavefronts per SIMD = blocks per CU as the tile + ~5 KB of per-scan sums allow them: the register budget follows, nothing spills)
-__global__ __launch_bounds__(kBlock, (CAP <= 1024 ? 3 : 2)) void consistency_step_pose_ragged_kernel(
-    PointBasis pb, PoseTab tab, const int32_t* __restrict__ slot_ptr, const int32_t* __restrict__ row_ptr, const double* __restrict__ poses,
-    int n_scans, int64_t n, const uint8_t* __restrict__ mask, LossParams lp, QParams qp, double* __restrict__ p_fwd, double* __restrict__ p_bwd) {
-  using Row = StepRow<q32, P>;
-  static_assert(Row::kPieces == 2, "one or two weights");
-  extern __shared__ int4 tile[];                                    // [2 * CAP], then the per-scan arrays sized by n_scans
-  double* s_pose = reinterpret_cast<double*>(tile + 2 * CAP);       // [S][12]
-  double* s_part = s_pose + n_scans * 12;                           // [4][S][12] per wavefront and scan: sum g (x) q [9], sum g [3]
-  __shared__ double s_w[DC_MAX_MODEL_TERMS];
-  __shared__ uint16_t s_ws[kWavesPerBlock][kLdsScans + 1];          // dcPoseTable.wseg of this block
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int64_t nblocks = (n + kBlock - 1) / kBlock;
-  const int64_t blk = xcd_block(nblocks);
-  const int64_t rs = (int64_t)gridDim.x;
-  double* pcol = p_bwd + 2 * P * rs + (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  double acc2[2] = {0.0, 0.0}, gw[P];
-#pragma unroll
-  for (int k = 0; k < P; ++k) gw[k] = 0.0;
-  if (blk < 0) {                                                    // padding block of the last round (block-uniform): zero rows
-    for (int item = tid; item < 12 * n_scans; item += kBlock) pcol[item * rs] = 0.0;
-  } else {
-    for (int t = tid; t < n_scans * 12; t += kBlock) s_pose[t] = poses[t];
-    for (int t = tid; t < kWavesPerBlock * n_scans * 12; t += kBlock) s_part[t] = 0.0;
-    for (int t = tid; t < kWavesPerBlock * (n_scans + 1); t += kBlock)
-      s_ws[t / (n_scans + 1)][t % (n_scans + 1)] = tab.wseg[blk * kWavesPerBlock * (n_scans + 1) + t];
-    stage_weights(pb, s_w);
-    const int64_t i = blk * kBlock + tid;
-    const bool live = i < n;
-    const bool in_mask = live && (mask ? mask[i] != 0 : true);
-    const int32_t s0 = slot_ptr[blk];
-    const uint16_t* lrow = tab.loc + (int64_t)s0 * kBlock + tid;
-    const uint16_t* ws = tab.wseg + (blk * kWavesPerBlock + wave) * (n_scans + 1);
-    const int wtot = __builtin_amdgcn_readfirstlane((int)ws[n_scans]);      // slot rows of this wavefront
-    const int32_t deg = live ? row_ptr[i + 1] - row_ptr[i] : 0;
-    const uint32_t own_off = live ? (uint32_t)tab.own_pos[i] : 0u;
-    const int32_t base = tab.blk_ptr[blk], nd = tab.blk_ptr[blk + 1] - base;
-    __syncthreads();
-    double wq[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) wq[k] = s_w[k];
-    for (int t = tid; t < nd; t += kBlock) Row::stage(pb, wq, tab.ids[base + t], tile, CAP, t);
-    __syncthreads();
-    const char* tb = reinterpret_cast<const char*>(tile);
-    if (!mask || __any((int)in_mask)) {                             // (a wavefront of masked-out centres only: nothing to add)
-      const Pt<q32>::Raw ci = Pt<q32>::from_row(reinterpret_cast<const int4*>(tb + own_off));
-      // ---- first sweep over all the wavefront's slot rows (empty slots read the lane's own row: a zero difference) ----
-      CovAcc acc;
-      cov_init(acc);
-      uint32_t nx[kTrip];                                           // the next trip's positions, requested a trip ahead
-#pragma unroll
-      for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)lrow[u_ * kBlock];                // (slot counts are multiples of eight,
-      for (int q0 = 0; q0 < wtot; q0 += kTrip) {                                              //  and the table ends with eight rows of slack)
-        uint32_t l[kTrip];
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; ++u_) l[u_] = nx[u_];
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)lrow[(q0 + kTrip + u_) * kBlock];
-        int4 r[kTrip];
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; ++u_) r[u_] = *reinterpret_cast<const int4*>(tb + (l[u_] == kNoLoc ? own_off : l[u_]));
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; ++u_)
-          cov_add_d(acc, (double)(r[u_].x - ci.v[0]), (double)(r[u_].y - ci.v[1]), (double)(r[u_].z - ci.v[2]));
-      }
-      acc.W = (double)deg;
-      double cm[3], v0[3], c1, c2;
-      step_point2<q32, 2>(acc, deg, false, in_mask, lp, qp, acc2, cm, v0, &c1, &c2);
-      // ---- second sweep: dL/dw of the centre and its edges' gradients, summed per scan.  Two neighbours per packed float32
-      //      instruction (as consistency_step_ragged_q32_kernel's second sweep); a wavefront's slot rows change scan at even, wave-
-      //      uniform positions (s_ws), where the lanes' sums are joined and set down ----
-      float cmf[3], vs[3], vu[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { cmf[a] = (float)cm[a]; vs[a] = (float)(c1 * v0[a]); vu[a] = (float)v0[a]; }
-      const float c2f = (float)c2;
-      const bool on = live && (c1 != 0.0 || c2 != 0.0);
-      const double qi[3] = {(double)ci.v[0], (double)ci.v[1], (double)ci.v[2]};
-      double gwd[P];
-#pragma unroll
-      for (int k = 0; k < P; ++k) gwd[k] = 0.0;
-      float2v M2[9], gs2[3];
-#pragma unroll
-      for (int a = 0; a < 9; ++a) M2[a] = float2v{0.0f, 0.0f};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) gs2[a] = float2v{0.0f, 0.0f};
-      int sc = 0;
-      int nb = __builtin_amdgcn_readfirstlane((int)s_ws[wave][1]);   // first slot row of scan sc + 1
-      auto flush = [&]() {
-        // the lane's sums of scan sc about the grid origin, then the wavefront's: values a * 3 + c of sum g (x) q, then sum g
-        double M[9], gsd[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) gsd[a] = (double)gs2[a].x + (double)gs2[a].y;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) M[3 * a + c] = fma(gsd[a], qi[c], (double)M2[3 * a + c].x + (double)M2[3 * a + c].y);
-        }
-        double v8[8], v4[4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v8[q] = M[q];
-        v4[0] = M[8]; v4[1] = gsd[0]; v4[2] = gsd[1]; v4[3] = gsd[2];
-        const double t8 = wave_sum_packed<8>(v8);
-        const double t4 = wave_sum_packed<4>(v4);
-        double* dstp = s_part + (wave * n_scans + sc) * 12;
-        if (lane < 8) dstp[packed_value_of_lane<8>(lane)] = t8;
-        if (lane < 4) dstp[8 + packed_value_of_lane<4>(lane)] = t4;
-#pragma unroll
-        for (int a = 0; a < 9; ++a) M2[a] = float2v{0.0f, 0.0f};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) gs2[a] = float2v{0.0f, 0.0f};
-      };
-#pragma unroll
-      for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)lrow[u_ * kBlock];
-      for (int q0 = 0; q0 < wtot; q0 += kTrip) {
-        uint32_t l[kTrip];
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; ++u_) l[u_] = nx[u_];
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; ++u_) nx[u_] = (uint32_t)lrow[(q0 + kTrip + u_) * kBlock];
-        float2v g2[P];
-#pragma unroll
-        for (int k = 0; k < P; ++k) g2[k] = float2v{0.0f, 0.0f};
-#pragma unroll
-        for (int u_ = 0; u_ < kTrip; u_ += 2) {
-          while (q0 + u_ == nb && sc < n_scans - 1) {               // (wave-uniform: a scalar branch)
-            if (nb > (int)s_ws[wave][sc]) flush();
-            ++sc;
-            nb = __builtin_amdgcn_readfirstlane((int)s_ws[wave][sc + 1]);
-          }
-          const bool ha = on && l[u_] != kNoLoc, hb = on && l[u_ + 1] != kNoLoc;
-          const char* ra = tb + (ha ? l[u_] : own_off);
-          const char* rb = tb + (hb ? l[u_ + 1] : own_off);
-          const int4 a0 = *reinterpret_cast<const int4*>(ra), a1 = *reinterpret_cast<const int4*>(ra + CAP * 16);
-          const int4 b0 = *reinterpret_cast<const int4*>(rb), b1 = *reinterpret_cast<const int4*>(rb + CAP * 16);
-          const float2v d0 = float2v{(float)(a0.x - ci.v[0]), (float)(b0.x - ci.v[0])};       // (exact: |x_j - x_i| < 2^24 grid steps)
-          const float2v d1 = float2v{(float)(a0.y - ci.v[1]), (float)(b0.y - ci.v[1])};
-          const float2v d2 = float2v{(float)(a0.z - ci.v[2]), (float)(b0.z - ci.v[2])};
-          const float2v e0 = d0 - float2v{cmf[0], cmf[0]}, e1 = d1 - float2v{cmf[1], cmf[1]}, e2 = d2 - float2v{cmf[2], cmf[2]};
-          const float2v u0 = float2v{__int_as_float(a0.w), __int_as_float(b0.w)};
-          const float2v u1 = float2v{__int_as_float(a1.x), __int_as_float(b1.x)};
-          const float2v u2 = float2v{__int_as_float(a1.y), __int_as_float(b1.y)};
-          const float2v al = __builtin_elementwise_fma(float2v{vs[2], vs[2]}, e2, __builtin_elementwise_fma(float2v{vs[1], vs[1]}, e1, float2v{vs[0], vs[0]} * e0));
-          float2v g0 = __builtin_elementwise_fma(al, float2v{vu[0], vu[0]}, -(float2v{c2f, c2f} * e0));
-          float2v g1 = __builtin_elementwise_fma(al, float2v{vu[1], vu[1]}, -(float2v{c2f, c2f} * e1));
-          float2v g2v = __builtin_elementwise_fma(al, float2v{vu[2], vu[2]}, -(float2v{c2f, c2f} * e2));
-          g0 = float2v{ha ? g0.x : 0.0f, hb ? g0.y : 0.0f};          // an empty slot (the lane's own row) is not a neighbour
-          g1 = float2v{ha ? g1.x : 0.0f, hb ? g1.y : 0.0f};
-          g2v = float2v{ha ? g2v.x : 0.0f, hb ? g2v.y : 0.0f};
-          const float2v tj = __builtin_elementwise_fma(g2v, u2, __builtin_elementwise_fma(g1, u1, g0 * u0));      // g_ij . u_j
-          g2[0] = __builtin_elementwise_fma(tj, float2v{__int_as_float(a1.z), __int_as_float(b1.z)}, g2[0]);
-          if constexpr (P > 1) g2[1] = __builtin_elementwise_fma(tj, float2v{__int_as_float(a1.w), __int_as_float(b1.w)}, g2[1]);
-          gs2[0] += g0; gs2[1] += g1; gs2[2] += g2v;
-          M2[0] = __builtin_elementwise_fma(g0, d0, M2[0]); M2[1] = __builtin_elementwise_fma(g0, d1, M2[1]); M2[2] = __builtin_elementwise_fma(g0, d2, M2[2]);
-          M2[3] = __builtin_elementwise_fma(g1, d0, M2[3]); M2[4] = __builtin_elementwise_fma(g1, d1, M2[4]); M2[5] = __builtin_elementwise_fma(g1, d2, M2[5]);
-          M2[6] = __builtin_elementwise_fma(g2v, d0, M2[6]); M2[7] = __builtin_elementwise_fma(g2v, d1, M2[7]); M2[8] = __builtin_elementwise_fma(g2v, d2, M2[8]);
-        }
-#pragma unroll
-        for (int k = 0; k < P; ++k) gwd[k] += (double)(g2[k].x + g2[k].y);       // (a trip's float32 sums join the fp64 sums trip by trip)
-      }
-      // what is left: the scan the sweep ended in (later scans have no slot rows in this wavefront: their sums stay zero)
-      if (wtot > (int)s_ws[wave][sc]) flush();
-#pragma unroll
-      for (int k = 0; k < P; ++k) gw[k] = gwd[k] * qp.scale;
-    }
-    __syncthreads();
-    // ---- dL/d[R|t]_s of the block: the four wavefronts' sums in order, then (sum g (x) (x - t_s)) R_s | sum g ----
-    {
-      const int sc = tid >> 2, part = tid & 3;
-      if (sc < n_scans && part < 3) {
-        double m[3], ga;
-        {
-          double t[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int col = c < 3 ? part * 3 + c : 9 + part;
-            const int S12 = n_scans * 12, at = sc * 12 + col;
-            t[c] = (s_part[at] + s_part[S12 + at]) + (s_part[2 * S12 + at] + s_part[3 * S12 + at]);
-          }
-          const double* Tp = s_pose + sc * 12;
-          ga = t[3] * qp.scale;                                     // gradients per grid step -> per metre
-#pragma unroll
-          for (int c = 0; c < 3; ++c) m[c] = fma(t[c] * qp.scale, qp.scale, ga * (qp.origin[c] - Tp[4 * c + 3]));
-          double* dst = pcol + (sc * 12 + part * 4) * rs;
-#pragma unroll
-          for (int b2 = 0; b2 < 3; ++b2) dst[b2 * rs] = fma(m[2], Tp[8 + b2], fma(m[1], Tp[4 + b2], m[0] * Tp[b2]));
-          dst[3 * rs] = ga;
-        }
-      }
-    }
-  }
   if (tid < P) p_bwd[(P + tid) * rs + blockIdx.x] = 0.0;
   step_partials<P, true>(acc2, gw, p_fwd, p_bwd, true, 0);
 }
@@ -3387,27 +3064,6 @@ static int ragged_launch(dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent
   return DC_OK;
 }
 
-template <int P, int CAP>
-static int pose_ragged_launch(dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, const PointBasis& pb, const PoseTab& tab,
-                              const int32_t* slot_ptr, const int32_t* row_ptr, const double* poses, int n_scans, int64_t n, const uint8_t* mask,
-                              const LossParams& lp, const QParams& qp, double* p_fwd, double* p_bwd) {
-  const size_t bytes = (size_t)CAP * 2 * 16 + (size_t)n_scans * 12 * 8 * (1 + kWavesPerBlock);
-  static std::atomic<uint64_t> attr_set{0};
-  if (bytes > 48 * 1024) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (!(attr_set.fetch_or(bit) & bit)) {
-      hipError_t err = hipFuncSetAttribute((const void*)consistency_step_pose_ragged_kernel<P, CAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)((size_t)CAP * 2 * 16 + (size_t)kLdsScans * 12 * 8 * (1 + kWavesPerBlock)));
-      if (err != hipSuccess) { attr_set.fetch_and(~bit); return (int)err; }
-    }
-  }
-  hipExtLaunchKernelGGL((consistency_step_pose_ragged_kernel<P, CAP>), grid, dim3(kBlock), bytes, stream, ev0, ev1, 0, pb, tab, slot_ptr, row_ptr, poses,
-                        n_scans, n, mask, lp, qp, p_fwd, p_bwd);
-  return DC_OK;
-}
-
 // a usable table of the wanted layout -> LDS bytes / rows of the staged tile (+ `extra_rows`), which must fit `lds_limit`
 static bool use_table(const dcBlockTable* t, int layout, int stride, uint32_t row_bytes, int extra_rows, size_t lds_limit,
                       size_t* lds_bytes, int* lds_rows) {
@@ -3559,36 +3215,6 @@ int dc_pose_table_build(const dcBlockTable* fwd, const int32_t* scan_id, int64_t
 }
 
 // `reduce` = false leaves the block partials in partials_ws for a later combined reduction (dc_sequence_eval).
-int dc_pose_table_ragged_count(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int32_t* ids_out, uint16_t* loc_tmp,
-                               uint16_t* own_pos, uint16_t* row_seg, uint8_t* row_scan, uint16_t* wseg, int32_t* slot_cnt, int32_t* info,
-                               hipStream_t stream) {
-  if (!fwd || fwd->layout != DC_TABLE_SLOTS || !fwd->blk_ptr || !fwd->blk_ids || !fwd->slot_ptr || !fwd->loc || !fwd->own_base) return DC_ERR_ARG;
-  if (n < 1 || n_scans < 1 || n_scans > kLdsScans || !ids_out || !loc_tmp || !own_pos || !row_seg || !row_scan || !wseg || !slot_cnt || !info)
-    return DC_ERR_ARG;
-  if (fwd->packed != 1 || fwd->max_rows < 1 || fwd->max_rows > 4095) return DC_ERR_UNSUPPORTED;
-  const int cap = fwd->max_rows;
-  const size_t lds = (size_t)cap * 7 + (size_t)n_scans * kBlock * 2 + 16;
-  if (lds > 60 * 1024) return DC_ERR_UNSUPPORTED;
-  hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), stream);
-  if (err != hipSuccess) return (int)err;
-  BlockTab tab{fwd->blk_ptr, fwd->blk_ids, fwd->slot_ptr, fwd->loc};
-  hipLaunchKernelGGL(pose_table_ragged_kernel, dim3((unsigned)n_blocks(n)), dim3(kBlock), lds, stream, tab, fwd->own_base, scan_id, n, n_scans, cap,
-                     ids_out, loc_tmp, own_pos, row_seg, row_scan, wseg, slot_cnt, info);
-  DC_CHECK_LAUNCH();
-  return DC_OK;
-}
-
-int dc_pose_table_ragged_fill(const dcBlockTable* fwd, const uint16_t* loc_tmp, const uint8_t* row_scan, const uint16_t* wseg,
-                              const int32_t* slot_ptr2, int64_t n, int n_scans, uint16_t* loc_out, hipStream_t stream) {
-  if (!fwd || !fwd->blk_ptr || !fwd->slot_ptr || !loc_tmp || !row_scan || !wseg || !slot_ptr2 || !loc_out || n < 1 || n_scans < 1 ||
-      n_scans > kLdsScans)
-    return DC_ERR_ARG;
-  hipLaunchKernelGGL(pose_table_ragged_fill_kernel, dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, fwd->blk_ptr, fwd->slot_ptr, loc_tmp, row_scan,
-                     wseg, slot_ptr2, n_scans, loc_out);
-  DC_CHECK_LAUNCH();
-  return DC_OK;
-}
-
 static int consistency_fwd_impl(const void* points, int stride, int dtype, int point_fmt, const double* qparams,
                                 const int32_t* nbr, const int32_t* centre_idx, const dcBlockTable* table, int64_t n, int k,
                                 const uint8_t* mask,
@@ -3981,41 +3607,6 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   const bool pose_one_pass = want_grad && want_pose_grad && !want_exponent_grad && d->pose_table && d->local_basis && !d->vps && !d->centre_idx &&
                              d->point_fmt == DC_Q32 && d->dtype == DC_F32 && (n_terms == 1 || n_terms == 2) && d->n_scans <= kLdsScans && w &&
                              (d->k == 4 || d->k == 8 || d->k == 10 || d->k == 16) && !g_pose_three_pass.load();
-  // the same for ball neighbourhoods (a packed table with its pose table, dc_pose_table_build(k = 0)): the rows come from basis rows
-  // the caller formed for THESE poses (dc_points_basis), consistency_step_pose_ragged_kernel
-  const bool pose_ragged = want_grad && want_pose_grad && !want_exponent_grad && d->pose_table && d->pose_table->wseg && d->pose_table->slot_ptr &&
-                           !d->local_basis && d->basis && !d->centre_idx &&
-                           q32_pts && (n_terms == 1 || n_terms == 2) && d->n_scans <= kLdsScans && w && d->fwd_table &&
-                           d->fwd_table->layout == DC_TABLE_SLOTS && d->fwd_table->packed == 1 && d->fwd_table->row_ptr && d->fwd_table->max_rows > 0 &&
-                           d->fwd_table->max_rows <= 2048 && !g_pose_three_pass.load() && !g_no_tab.load();
-  if (pose_ragged) {
-    QParams qp;
-    int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp);
-    if (rc) return rc;
-    PointBasis pb{d->basis, w, n_terms, qp.inv_scale};
-    const dcPoseTable* pt = d->pose_table;
-    PoseTab tab{pt->blk_ptr, pt->ids, pt->loc, pt->own_pos, pt->row_seg, pt->row_scan, pt->wseg};
-    const LossParams lp = make_loss_params(d->loss_kind & ~DC_LOSS_RAW_POINTWISE, d->normalization, d->sqrt_);
-    const dim3 grid((unsigned)xcd_grid(n_blocks(d->n)));
-    const int mr = d->fwd_table->max_rows;
-    {
-      ProfScope prof(1);
-#define POSE_RAG(P, CAP) (prof.name("(consistency_step_pose_ragged_kernel<" #P ", " #CAP ">)"), \
-                          pose_ragged_launch<P, CAP>(grid, stream, prof.start(), prof.stop(), pb, tab, pt->slot_ptr, d->fwd_table->row_ptr, poses, \
-                                                     d->n_scans, d->n, d->mask, lp, qp, p_fwd, p_bwd))
-#define POSE_RAG_CAPS(P) (mr <= 1024 ? POSE_RAG(P, 1024) : mr <= 1600 ? POSE_RAG(P, 1600) : POSE_RAG(P, 2048))
-      rc = n_terms == 2 ? POSE_RAG_CAPS(2) : POSE_RAG_CAPS(1);
-#undef POSE_RAG_CAPS
-#undef POSE_RAG
-      if (rc) return rc;
-    }
-    DC_CHECK_LAUNCH();
-    const int64_t rows_b = xcd_grid(n_blocks(d->n));         // one row per block, every column contiguous
-    hipLaunchKernelGGL(reduce_eval_kernel, dim3(2 + n_acc), dim3(kRedBlock), 0, stream, p_fwd, p_bwd, rows_b, rows_b, n_acc, 2 + n_acc, out, adam,
-                       (const int32_t*)d->status, -1, 0);
-    DC_CHECK_LAUNCH();
-    return DC_OK;
-  }
   // every other way to a gradient walks the transposed neighbour lists: the caller provides them on demand
   if (want_grad && !one_pass && !pose_one_pass && (!d->csr_ptr || !d->csr_src)) return DC_ERR_BACKWARD_TABLES;
   const bool basis = basis_fwd &&
@@ -4151,7 +3742,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
     int rc = make_qparams(d->point_fmt, d->dtype, stride, d->qparams, &qp, d->status);
     if (rc) return rc;
     const dcPoseTable* pt = d->pose_table;
-    PoseTab tab{pt->blk_ptr, pt->ids, pt->loc, pt->own_pos, pt->row_seg, pt->row_scan, nullptr};
+    PoseTab tab{pt->blk_ptr, pt->ids, pt->loc, pt->own_pos, pt->row_seg, pt->row_scan};
     const LossParams lp = make_loss_params(d->loss_kind & ~DC_LOSS_RAW_POINTWISE, d->normalization, d->sqrt_);
     const dim3 grid((unsigned)xcd_grid(n_blocks(d->n))), block(kBlock);
     {

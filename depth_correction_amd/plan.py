@@ -381,34 +381,14 @@ class SequencePlan:
             self._desc = d
         return self._desc
 
-    def _set_pose_tables(self, d, w, exponent, want_grad, want_exponent, want_pose, poses12=None):
+    def _set_pose_tables(self, d, w, exponent, want_grad, want_exponent, want_pose):
         """Point the descriptor at the pose tables (built once, on the first evaluation that asks for pose gradients) and at the
         local basis rows valid for ``exponent`` (rebuilt when the exponent tensor changes identity or version), or clear the
         fields: pose-gradient evaluations then run as one launch (consistency_step_pose_kernel)."""
-        common = (self.use_pose_kernel and want_grad and want_pose and not want_exponent and w is not None and w.numel() in (1, 2)
-                  and self.qfmt is not None and self.centre_idx is None and self.fwd_table is not None
-                  and self.fwd_table.own_base is not None and self.n_scans <= 32 and d.model_kind != 0 and self._block_tables)
-        ft = self.fwd_table
-        if common and ft.packed and ft.row_ptr is not None and 0 < ft.max_rows <= 2048 and self._bwd_layout == 'runs':
-            # ball neighbourhoods (a packed table of rows of any length): consistency_step_pose_ragged_kernel stages its rows from
-            # basis rows formed for THIS evaluation's poses (one pass over the points, dc_points_basis) through the block lists of a
-            # pose table built once
-            if self._pose_table is None:
-                self._pose_table = self._build_pose_table(ragged=True)
-            if self._pose_table is not False:
-                nt = w.numel()
-                rows = getattr(self, '_pose_basis_rows', None)
-                if rows is None or rows.shape[1] != 6 + nt:
-                    rows = self._pose_basis_rows = torch.empty((self.n, 6 + nt), dtype=torch.int32, device=self.device)
-                ps = self.ps
-                check(lib().dc_points_basis(ptr(ps.vps), ptr(ps.dirs), ptr(ps.depth), ptr(ps.inc), ptr(ps.lmask), ptr(ps.scan_id),
-                                            ptr(poses12), self.n_scans, d.model_kind, nt, ptr(exponent), self.n, nv.DC_F32, self.qfmt._c,
-                                            ptr(rows), ptr(self.status), stream_ptr()), 'dc_points_basis')
-                d.pose_table = ctypes.cast(ctypes.pointer(self._pose_table[0]), ctypes.c_void_p)
-                d.local_basis = None
-                d.basis = rows.data_ptr()
-                return
-        ok = (common and self.ps.vps is None and self.k in (4, 8, 10, 16) and self.nbr.shape[1] == self.k and not ft.packed)
+        ok = (self.use_pose_kernel and want_grad and want_pose and not want_exponent and w is not None and w.numel() in (1, 2)
+              and self.qfmt is not None and self.ps.vps is None and self.centre_idx is None and self.fwd_table is not None
+              and self.fwd_table.own_base is not None and self.k in (4, 8, 10, 16) and self.n_scans <= 32
+              and d.model_kind != 0 and self._block_tables and self.nbr.shape[1] == self.k)
         if ok and self._pose_table is None:
             self._pose_table = self._build_pose_table()
         if not ok or self._pose_table is False:
@@ -428,49 +408,25 @@ class SequencePlan:
         d.pose_table = ctypes.cast(ctypes.pointer(self._pose_table[0]), ctypes.c_void_p)
         d.local_basis = lb[1].data_ptr()
 
-    def _build_pose_table(self, ragged=False):
-        """dcPoseTable of this plan's forward table (dc_pose_table_build), or False when some block cannot take the pose kernel.
-        ``ragged``: a packed table of rows of any length (ball neighbourhoods): dc_pose_table_ragged_count / _fill, the slot rows of
-        every wavefront grouped by scan."""
+    def _build_pose_table(self):
+        """dcPoseTable of this plan's forward table (dc_pose_table_build), or False when some block cannot take the pose kernel."""
         # (from the loss-only table when the plan has one: a centre outside the mask adds no edge gradient either, and its lists are
         # the ones that fit the kernel's 512-row tile under the wave-packed layout)
         ft, dev, nb = (getattr(self, 'fwd_table_loss', None) or self.fwd_table), self.device, (self.n + 255) // 256
         total = int(ft.blk_ptr[-1].item())
         t = dict(ids=torch.empty((max(total, 1),), dtype=torch.int32, device=dev),
+                 loc=torch.empty((nb * self.k * 256,), dtype=torch.uint16, device=dev),
                  own_pos=torch.empty((self.n,), dtype=torch.uint16, device=dev),
                  row_seg=torch.empty((nb * (self.n_scans + 1),), dtype=torch.uint16, device=dev),
                  row_scan=torch.empty((max(total, 1),), dtype=torch.uint8, device=dev))
         info = torch.zeros((1,), dtype=torch.int32, device=dev)
-        if ragged:
-            loc_tmp = torch.empty_like(ft.loc)
-            t['wseg'] = torch.empty((nb * 4 * (self.n_scans + 1),), dtype=torch.uint16, device=dev)
-            slot_cnt = torch.zeros((nb,), dtype=torch.int32, device=dev)
-            rc = lib().dc_pose_table_ragged_count(ft.ref(), ptr(self.ps.scan_id), self.n, self.n_scans, ptr(t['ids']), ptr(loc_tmp),
-                                                  ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['row_scan']), ptr(t['wseg']), ptr(slot_cnt),
-                                                  ptr(info), stream_ptr())
-            if rc == nv.DC_ERR_UNSUPPORTED:
-                return False
-            check(rc, 'dc_pose_table_ragged_count')
-            if int(info.item()) != 0:
-                return False
-            t['slot_ptr'] = torch.zeros((nb + 1,), dtype=torch.int32, device=dev)
-            t['slot_ptr'][1:] = torch.cumsum(slot_cnt, 0)
-            # (eight slot rows of slack: the sweeps read whole trips)
-            t['loc'] = torch.empty(((int(t['slot_ptr'][-1].item()) + 8) * 256,), dtype=torch.uint16, device=dev)
-            check(lib().dc_pose_table_ragged_fill(ft.ref(), ptr(loc_tmp), ptr(t['row_scan']), ptr(t['wseg']), ptr(t['slot_ptr']), self.n,
-                                                  self.n_scans, ptr(t['loc']), stream_ptr()), 'dc_pose_table_ragged_fill')
-            self.pose_slot_rows = (int(t['slot_ptr'][-1].item()), int(ft.slot_ptr[-1].item()))      # (with the per-scan padding, without)
-            desc = nv.PoseTableDesc(ptr(ft.blk_ptr), ptr(t['ids']), ptr(t['loc']), ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['row_scan']),
-                                    ptr(t['wseg']), ptr(t['slot_ptr']))
-            return desc, t
-        t['loc'] = torch.empty((nb * self.k * 256,), dtype=torch.uint16, device=dev)
         check(lib().dc_pose_table_build(ft.ref(), ptr(self.ps.scan_id), self.n, self.n_scans, self.k, ptr(t['ids']), ptr(t['loc']),
                                         ptr(t['own_pos']), ptr(t['row_seg']), ptr(t['row_scan']), ptr(info), stream_ptr()),
               'dc_pose_table_build')
         if int(info.item()) != 0:
             return False
         desc = nv.PoseTableDesc(ptr(ft.blk_ptr), ptr(t['ids']), ptr(t['loc']), ptr(t['own_pos']), ptr(t['row_seg']),
-                                ptr(t['row_scan']), None, None)
+                                ptr(t['row_scan']))
         return desc, t
 
     def _set_basis(self, d, w, exponent, poses12, want_exponent, want_pose):
@@ -512,7 +468,7 @@ class SequencePlan:
             need(exponent, (nt,), dtype=torch.float64, name='exponent', device=self.device)
         for attempt in (0, 1):
             self._set_basis(d, w, exponent, poses12, want_exponent, want_pose)
-            self._set_pose_tables(d, w, exponent, want_grad, want_exponent, want_pose, poses12)
+            self._set_pose_tables(d, w, exponent, want_grad, want_exponent, want_pose)
             rc = lib().dc_sequence_eval(ctypes.byref(d), ptr(w), ptr(exponent), ptr(poses12), int(want_grad),
                                         int(want_exponent), int(want_pose), ptr(out), stream_ptr())
             if rc != nv.DC_ERR_BACKWARD_TABLES or attempt:

@@ -480,15 +480,7 @@ int dc_consistency_gate(const void* raw_pointwise, int dtype, int point_fmt, con
  * scan's rows start and the scan of every listed row.  dc_pose_table_build fills caller-allocated arrays: ids int32
  * [blk_ptr[blocks]], loc uint16 [blocks * K * 256], own_pos uint16 [n], row_seg uint16 [blocks * (n_scans + 1)], row_scan uint8
  * [blk_ptr[blocks]]; info int32 [1] <- 1 when some block cannot take the pose kernel (more than 512 distinct rows, or a block
- * whose list misses one of its own rows).
- * Packed tables of rows of any length (ball neighbourhoods, the reference's default nn_type, config.py:187-189; round 5):
- * dc_pose_table_ragged_count orders the lists by (scan, id) as above, writes the remapped positions in the forward table's slot
- * layout (loc_tmp, the shape of its loc), own_pos, row_seg, row_scan, and a slot layout in which the wavefronts of a block sweep
- * their neighbours scan by scan: wseg uint16 [blocks][4][n_scans + 1] = first slot row of every scan for wavefront w, slot_cnt
- * int32 [blocks] = slot rows the block needs (a multiple of 8).  The caller forms slot_ptr2 = exclusive prefix of slot_cnt,
- * allocates loc_out uint16 [(slot_ptr2[blocks] + 8) * 256] and calls dc_pose_table_ragged_fill.  Evaluations with pose gradients then
- * run as ONE launch (consistency_step_pose_ragged_kernel) when dcSequenceDesc.basis holds dc_points_basis rows formed for the poses
- * of the call (local_basis NULL) and no list is longer than 2 048 rows (n_scans <= 32). */
+ * whose list misses one of its own rows). */
 typedef struct dcPoseTable {
   const int32_t* blk_ptr;          /* the forward table's */
   const int32_t* ids;
@@ -496,16 +488,9 @@ typedef struct dcPoseTable {
   const uint16_t* own_pos;
   const uint16_t* row_seg;
   const uint8_t* row_scan;
-  const uint16_t* wseg;            /* packed tables (dc_pose_table_ragged_*) only, else NULL: [blocks][4][n_scans + 1] */
-  const int32_t* slot_ptr;         /* packed tables only: [blocks + 1] first slot row of every block in `loc` */
 } dcPoseTable;
 int dc_pose_table_build(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int k, int32_t* ids_out,
                         uint16_t* loc_out, uint16_t* own_pos, uint16_t* row_seg, uint8_t* row_scan, int32_t* info, dcStream_t stream);
-int dc_pose_table_ragged_count(const dcBlockTable* fwd, const int32_t* scan_id, int64_t n, int n_scans, int32_t* ids_out, uint16_t* loc_tmp,
-                               uint16_t* own_pos, uint16_t* row_seg, uint8_t* row_scan, uint16_t* wseg, int32_t* slot_cnt, int32_t* info,
-                               dcStream_t stream);
-int dc_pose_table_ragged_fill(const dcBlockTable* fwd, const uint16_t* loc_tmp, const uint8_t* row_scan, const uint16_t* wseg,
-                              const int32_t* slot_ptr2, int64_t n, int n_scans, uint16_t* loc_out, dcStream_t stream);
 /* Pose-independent rows of the rays (sensor frame, viewpoints at the sensor origin): {d0, dir, c_k = dd'/dw_k} as 6 float32 words
  * per row for float32 clouds and models of one or two weights (model.py:113-349 are affine in their weights); valid for the
  * exponents `e`.  Stored per block of `table`, in the order of its list: rows_out [blk_ptr[blocks], 6], block b's row t at

@@ -592,22 +592,18 @@ def test_ball_pose_backward_with_large_lds_tiles(room):
     e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
     P = plan.poses12(info['poses'])
     res = []
-    nv.check(nv.lib().dc_set_option(7, 1), 'dc_set_option')           # (the general path: the one-launch kernel has its own test below)
-    try:
-        for no_tab in (0, 1):
-            nv.check(nv.lib().dc_set_option(0, no_tab), 'dc_set_option')
-            try:
-                out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
-                with KernelTimer(every=1) as kt:
-                    plan.eval_native(w, e, P, out, want_grad=True, want_pose=True)
-                    torch.cuda.synchronize()
-                    name = kt.kernels()['consistency_bwd']
-                assert name.startswith('consistency_bwd_runs_kernel') == (no_tab == 0), name
-                res.append(npy(out).copy())
-            finally:
-                nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
-    finally:
-        nv.check(nv.lib().dc_set_option(7, 0), 'dc_set_option')
+    for no_tab in (0, 1):
+        nv.check(nv.lib().dc_set_option(0, no_tab), 'dc_set_option')
+        try:
+            out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
+            with KernelTimer(every=1) as kt:
+                plan.eval_native(w, e, P, out, want_grad=True, want_pose=True)
+                torch.cuda.synchronize()
+                name = kt.kernels()['consistency_bwd']
+            assert name.startswith('consistency_bwd_runs_kernel') == (no_tab == 0), name
+            res.append(npy(out).copy())
+        finally:
+            nv.check(nv.lib().dc_set_option(0, 0), 'dc_set_option')
     assert plan.bwd_table.max_rows * 32 > 44 * 1024                    # the case this test is about
     a, b = res
     assert a[1] == b[1] > 10000
@@ -616,70 +612,6 @@ def test_ball_pose_backward_with_large_lds_tiles(room):
     ga, gb = a[6:].reshape(-1, 3, 4), b[6:].reshape(-1, 3, 4)
     for s_ in range(plan.n_scans):
         np.testing.assert_allclose(ga[s_], gb[s_], rtol=1e-6, atol=1e-7 * np.abs(gb[s_]).max())
-
-
-@pytest.mark.parametrize('r, n_scans, oracle', [(0.4, 10, False), (0.25, 10, False), (0.3, 3, True)])
-def test_ball_pose_kernel_vs_general_path_and_oracle(room, r, n_scans, oracle):
-    """Pose gradients on ball neighbourhoods (the reference's default nn_type, config.py:187-189; scripts/model_poses_learning:61,71)
-    in ONE launch -- consistency_step_pose_ragged_kernel: the ragged one-pass kernel with the edges' gradients summed per staged row
-    as integers in LDS and per scan in the world frame -- against the three-kernel general path on the same plan (loss, count,
-    dL/dw, dL/d[R|t] of every scan, perturbed poses; both run their sweeps in float32 on the q32 grid, in different orders: 1e-6 of
-    each scan's largest entry) and, on three scans, against the oracle's autograd (north_star's 1e-5)."""
-    from depth_correction_amd import _native as nv
-    from depth_correction_amd.filters import filter_grid
-    from depth_correction_amd.pipeline import build_sequence
-    from depth_correction_amd.plan import KernelTimer
-    from depth_correction_amd.transform import corrected_poses
-    scans, poses = room
-    rng = np.random.default_rng(77)
-    kept = [filter_grid(s, 0.2, keep='random', rng=rng) for s in scans[:n_scans]]
-    plan, info = build_sequence(kept, poses[:n_scans], k=None, r=r, dtype=torch.float32)
-    dev = plan.device
-    w = torch.tensor([1e-3, 2e-3], dtype=torch.float64, device=dev)
-    e = torch.tensor([2.0, 4.0], dtype=torch.float64, device=dev)
-    deltas = torch.as_tensor(rng.normal(size=(plan.n_scans, 6)) * 2e-3, dtype=torch.float64, device=dev)
-    T = corrected_poses(info['poses'], deltas)
-    P = plan.poses12(T)
-    res = []
-    for three in (0, 1):
-        nv.check(nv.lib().dc_set_option(7, three), 'dc_set_option')
-        try:
-            out = torch.zeros(2 + 4 + 12 * plan.n_scans, dtype=torch.float64, device=dev)
-            with KernelTimer(every=1) as kt:
-                plan.eval_native(w, e, P, out, want_grad=True, want_pose=True)
-                torch.cuda.synchronize()
-                names = kt.kernels()
-            assert ('consistency_step_pose_ragged_kernel<2, ' in names['consistency_fwd']) == (three == 0), names
-            res.append(npy(out).copy())
-        finally:
-            nv.check(nv.lib().dc_set_option(7, 0), 'dc_set_option')
-    a, b = res
-    assert a[1] == b[1] > 1000 and plan.status_bits() == 0
-    # (the staged rows carry c_k rounded to float32, as the step kernel's basis rows do: d' differs from the general path's by
-    #  ~1e-9 m and a few points round to the next grid value)
-    np.testing.assert_allclose(a[0], b[0], rtol=1e-7)
-    np.testing.assert_allclose(a[2:4], b[2:4], rtol=1e-6, atol=1e-7 * np.abs(b[2:4]).max())
-    ga, gb = a[6:].reshape(-1, 3, 4), b[6:].reshape(-1, 3, 4)
-    for s_ in range(plan.n_scans):
-        np.testing.assert_allclose(ga[s_], gb[s_], rtol=1e-6, atol=1e-6 * np.abs(gb[s_]).max())
-    # a second evaluation gives the same bits (integer sums in LDS: no order enters)
-    out2 = torch.zeros_like(out)
-    plan.eval_native(w, e, P, out2, want_grad=True, want_pose=True)
-    assert np.array_equal(npy(out2), a)
-    if not oracle:
-        return
-    oc = [dict(vps=c['vps'].double().cpu(), dirs=c['dirs'].double().cpu(), depth=c['depth'].double().cpu(),
-               inc=c['inc_angles'].double().cpu(), mask=c['mask'].cpu()) for c in info['clouds']]
-    wo = torch.tensor([[1e-3, 2e-3]], dtype=torch.float64, requires_grad=True)
-    To = T.detach().cpu().clone().requires_grad_(True)
-    lo, _ = O.eval_sequence(oc, To, wo, e.cpu().reshape(1, -1), info['neighbors'].long().cpu(), info['mask'].cpu(), reduction='sum')
-    lo.backward()
-    np.testing.assert_allclose(a[0], lo.item(), rtol=1e-5)
-    g = npy(wo.grad).ravel()
-    np.testing.assert_allclose(a[2:4], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
-    gT = npy(To.grad)[:, :3, :]
-    for s_ in range(plan.n_scans):
-        np.testing.assert_allclose(ga[s_], gT[s_], rtol=1e-5, atol=1e-5 * np.abs(gT[s_]).max())
 
 
 def test_chained_wait_that_expires_is_reported_not_just_nan(room):
