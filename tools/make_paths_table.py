@@ -10,7 +10,7 @@ import os
 import sys
 
 WANT = {   # workload -> (kernel name fragments, units per launch as text, unit count)
-    'c4': (['p2plane_seq_kernel', 'p2plane_reduce_all_kernel', 'pose_train_finish_kernel', 'pose_correct_kernel'], '9 scan pairs of ~15 k correspondences', 131980),
+    'c4': (['p2plane_seq_fused_kernel', 'p2plane_seq_kernel', 'p2plane_reduce_all_kernel', 'pose_train_finish_kernel', 'pose_correct_kernel'], '9 scan pairs of ~15 k correspondences', 131980),
     'pose': (['consistency_step_pose_kernel', 'reduce_eval_kernel', 'consistency_bwd_runs_kernel<float, dc::q32, false, true>', 'consistency_fwd_fixed_kernel', 'points_fwd_kernel<float, dc::q32, 4>'], 'N = 2 000 000 points', 2000000),
     'knn2m': (['knn_group_kernel', 'knn_query_kernel<10>', 'knn_tail_kernel'], 'N = 2 000 000 queries', 2000000),
     'knn200k': (['knn_group_kernel', 'knn_query_kernel<10>', 'knn_tail_kernel'], 'N = 200 000 queries', 200000),
