@@ -554,7 +554,9 @@ def main():
             'sequences': S, 'points': int(sum(p_.n for p_ in mplans)), 'working_set_bytes': int(sum(compulsory_bytes(p_)['consistency_step'] for p_ in mplans)),
             'ms_per_step': ms_multi, 'us_per_sequence_step': ms_multi / S * 1e3, 'points_per_s': sum(p_.n for p_ in mplans) / (ms_multi * 1e-3),
             'kernel': kname_m, 'kernel_ms': km[0], 'timed_launches': km[1],
-            'launches_per_step': '%d evaluations (the first takes the previous Adam update in its launch) + %d reductions + the sum of the sequences\' sums' % (S, S),
+            'launches_per_step': ('%d: one per sequence (a chain over the sequences, dc_sequence_step_linked: every launch finishes the one before it)' % S)
+                                 if getattr(trm, 'linked', False) else
+                                 ('%d evaluations (the first takes the previous Adam update in its launch) + %d reductions + the sum of the sequences\' sums' % (S, S)),
             'design_bytes_per_launch': comp_m,
             'design_GBps': comp_m / (km[0] * 1e-3) / 1e9 if km[0] else None,
             'traffic_per_launch': prof_m['hbm_bytes'] if prof_m else None,

@@ -92,6 +92,9 @@ _SIGNATURES = {
     'dc_sequence_step_chained': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
     'dc_sequence_step_chained_rec': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     'dc_sequence_eval_after_update': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    'dc_sequence_step_linked': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp,
+                                       _vp, _vp]),
+    'dc_sequence_chain_flush_linked': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
     'dc_sequence_chain_flush': (_i32, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp, _vp]),
     'dc_adam_step': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _vp]),
     'dc_adam_step_device': (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _vp]),

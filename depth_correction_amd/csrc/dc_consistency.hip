@@ -1367,6 +1367,9 @@ struct StepChain {
   int32_t* status;           // bit 0: a point left the q32 extent (read); bit 1: a wait for the weights ran out (raised here)
   int spin_limit;            // polls a waiting block makes before it gives up (dc_set_option(5, n); 0: gives up at once)
   const double* w_now;       // the caller's weights (what a launch with nothing to finish publishes)
+  const int32_t* prev_status;  // linked chains: the status word of the sequence whose rows are finished (nullptr: `status`)
+  const double* acc_in;      // [2 + P] or nullptr: added to the previous launch's sums (the sequences of ONE loss evaluated launch after
+                             // launch: the running sums of the step's earlier sequences)
   AdamArgs adam;             // the update the previous evaluation's gradient feeds (bias corrections of ITS step)
   const uint8_t* blk_skip;   // [blocks] or nullptr: blocks none of whose centres is inside the loss mask (dcSequenceDesc.blk_skip): they add
                              // nothing to the loss, the count or dL/dw and are treated like the padding blocks of the last round
@@ -1415,8 +1418,9 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* l
     return;
   }
   const bool step = ch.has_prev && ch.adam.p && a >= 2 && threadIdx.x == 0;
-  const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && ch.status &&
-                       __hip_atomic_load(ch.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  const int32_t* st_prev = ch.prev_status ? ch.prev_status : ch.status;
+  const bool flagged = ch.has_prev && a == 0 && threadIdx.x == 0 && st_prev &&
+                       __hip_atomic_load(st_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   double p0 = 0.0, m0 = 0.0, v0 = 0.0;
   if (step) {
     p0 = ch.adam.p[a - 2]; m0 = ch.adam.m[a - 2]; v0 = ch.adam.v[a - 2];
@@ -1446,6 +1450,7 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* l
     if (ch.has_prev) {
       double t = 0.0;
       for (int wv = 0; wv < kBlock / kWave; ++wv) t += lds[wv];
+      if (ch.acc_in) t += ch.acc_in[a];                      // (read before out_prev is written: the two may be one buffer)
       if (flagged) t = __longlong_as_double(0x7ff8000000000000ll);
       ch.out_prev[a] = t;
       if (step) adam_apply(ch.adam, a - 2, t, p0, m0, v0);
@@ -1453,6 +1458,13 @@ __device__ __forceinline__ void chain_front_block(const StepChain& ch, double* l
     // weight a - 2 is final for this launch (the value just stored, or the caller's when there was nothing to finish)
     if (a >= 2) chain_publish(ch, a - 2, step ? ch.adam.p[a - 2] : ch.w_now[a - 2]);
   }
+}
+
+// chain_front_block on its own: finishes the last launch of a linked chain (dc_sequence_chain_flush_linked)
+template <int P>
+__global__ __launch_bounds__(kBlock) void chain_front_only_kernel(StepChain ch) {
+  __shared__ double s_front[kBlock / kWave];
+  chain_front_block<P>(ch, s_front);
 }
 
 // s_w[k] <- w_k * w_scale of this launch for the lanes of the block, as soon as its leading blocks have published them
@@ -3539,6 +3551,10 @@ struct ChainCall {
   bool reduce_now;           // also launch the ordinary reduction of THIS evaluation's rows into `out` (no Adam)
   double* w_prev_out = nullptr;
   uint32_t stamp = 0;        // the launch's number (its step): marks the weights it publishes
+  const double* prev_rows = nullptr;   // linked chains: the PREVIOUS launch's partial rows when that was another sequence's (else this
+  int64_t prev_count = 0;              // sequence's other buffer), how many there are, and the running sums they are added to
+  const double* acc_in = nullptr;
+  const int32_t* prev_status = nullptr;
 };
 // the two partial-row buffers of a chain: behind the columns ordinary evaluations use, so that an evaluation of the same
 // sequence between two chained steps (a validation pass, a lazily produced loss cloud) cannot overwrite a pending step
@@ -3631,6 +3647,8 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
         p_bwd = p_fwd + 2 * g_blocks;
         ch.ready = chain->ready; ch.parity = chain->parity; ch.has_prev = chain->has_prev; ch.n_front = kChainFront;
         ch.n_out = 2 + n_acc; ch.prev = chain_buffer(d, n_terms, chain->parity ^ 1); ch.prev_rows = g_blocks;
+        if (chain->prev_rows) { ch.prev = chain->prev_rows; ch.prev_rows = chain->prev_count; }
+        ch.acc_in = chain->acc_in; ch.prev_status = chain->prev_status;
         ch.out_prev = chain->out_prev; ch.w_prev_out = chain->w_prev_out; ch.status = d->status; ch.spin_limit = g_chain_spin.load(); ch.adam = chain->adam_prev;
         ch.grad_sum = chain->grad_sum;
         ch.stamp = chain->stamp; ch.w_now = w;
@@ -3853,6 +3871,65 @@ int dc_sequence_step_chained_rec(const dcSequenceDesc* d, double* w, const doubl
     if (rc) return rc;
   }
   return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out_prev, stream, AdamArgs{}, &c);
+}
+
+// ---- a chain over the SEVERAL sequences of one loss (train.py:172-175; eval.py:85-112 pools their sums) ---------------------------
+// Launch (step, i) evaluates sequence i and first finishes the launch before it -- sequence i - 1 of this step, or the last sequence
+// of the previous step -- by summing ITS rows (d_prev, parity prev_parity) onto the running sums of the step (acc_in, NULL for the
+// step's second launch).  finish: 0 nothing is pending (the very first launch), 1 sum into out_prev (the running sums; may be
+// acc_in itself), 2 the sums complete a step: Adam update `step - 1` on w, out_prev <- the step's totals, w_used_prev.
+static int linked_call(const dcSequenceDesc* d, const dcSequenceDesc* d_prev, int prev_parity, int finish, const double* acc_in, int n_terms,
+                       ChainCall* c) {
+  if (finish == 0) return DC_OK;
+  if (!d_prev || !d_prev->partials || d_prev->n_terms != n_terms || d_prev->n < 1) return DC_ERR_ARG;
+  if (d_prev->partials_count < dc_sequence_partials_count(d_prev->n, n_terms, d_prev->n_scans)) return DC_ERR_WORKSPACE;
+  const int64_t n_rows = d_prev->centre_idx ? d_prev->n_centres : d_prev->n;
+  c->prev_rows = chain_buffer(d_prev, n_terms, prev_parity & 1);
+  c->prev_count = xcd_grid(n_blocks(n_rows));
+  c->acc_in = acc_in;
+  c->prev_status = d_prev->status;
+  (void)d;
+  return DC_OK;
+}
+
+int dc_sequence_step_linked(const dcSequenceDesc* d, const dcSequenceDesc* d_prev, int prev_parity, int finish, const double* acc_in,
+                            double* w, const double* e, const double* poses, double* exp_avg, double* exp_avg_sq, int64_t step,
+                            int64_t stamp, double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
+                            int32_t* ready, double* out_prev, double* w_used_prev, hipStream_t stream) {
+  if (!d || d->model_kind == DC_MODEL_NONE || d->n_terms < 1 || d->n == 0 || !ready || !out_prev || step < 1 || stamp < 1) return DC_ERR_ARG;
+  if (finish < 0 || finish > 2 || (finish == 2 && step < 2)) return DC_ERR_ARG;
+  ChainCall c{ready, (int)(step & 1), finish ? 1 : 0, out_prev, AdamArgs{}, nullptr, false, finish == 2 ? w_used_prev : nullptr};
+  c.stamp = (uint32_t)stamp;
+  int rc = linked_call(d, d_prev, prev_parity, finish, acc_in, d->n_terms, &c);
+  if (rc) return rc;
+  if (finish == 2) {
+    rc = make_adam(w, exp_avg, exp_avg_sq, d->n_terms, step - 1, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
+    if (rc) return rc;
+  }
+  return sequence_eval_impl(d, w, e, poses, 1, 0, 0, out_prev, stream, AdamArgs{}, &c);
+}
+
+// the last launch of a linked chain finished on its own: d_prev's rows (+ acc_in) -> out, Adam update `step` (one small launch)
+int dc_sequence_chain_flush_linked(const dcSequenceDesc* d_prev, int prev_parity, const double* acc_in, double* w, double* exp_avg,
+                                   double* exp_avg_sq, int64_t step, int64_t stamp, double grad_scale, double lr, double beta1, double beta2,
+                                   double eps, double weight_decay, int32_t* ready, double* out, hipStream_t stream) {
+  if (!d_prev || d_prev->model_kind == DC_MODEL_NONE || d_prev->n_terms < 1 || d_prev->n_terms > 3 || !ready || !out || step < 1) return DC_ERR_ARG;
+  ChainCall c{ready, 0, 1, out, AdamArgs{}, nullptr, false, nullptr};
+  int rc = linked_call(d_prev, d_prev, prev_parity, 2, acc_in, d_prev->n_terms, &c);
+  if (rc) return rc;
+  rc = make_adam(w, exp_avg, exp_avg_sq, d_prev->n_terms, step, grad_scale, lr, beta1, beta2, eps, weight_decay, &c.adam_prev);
+  if (rc) return rc;
+  StepChain ch{};
+  ch.ready = ready; ch.stamp = (uint32_t)stamp; ch.parity = 0; ch.has_prev = 1; ch.n_front = kChainFront;
+  ch.n_out = 2 + 2 * d_prev->n_terms + 12 * d_prev->n_scans;
+  ch.prev = c.prev_rows; ch.prev_rows = c.prev_count; ch.acc_in = acc_in; ch.out_prev = out; ch.w_prev_out = nullptr; ch.status = d_prev->status;
+  ch.spin_limit = 0; ch.adam = c.adam_prev; ch.grad_sum = nullptr; ch.w_now = w; ch.prev_status = d_prev->status;
+  const int P = d_prev->n_terms;
+  if (P == 1) hipLaunchKernelGGL(chain_front_only_kernel<1>, dim3(kChainFront), dim3(kBlock), 0, stream, ch);
+  else if (P == 2) hipLaunchKernelGGL(chain_front_only_kernel<2>, dim3(kChainFront), dim3(kBlock), 0, stream, ch);
+  else hipLaunchKernelGGL(chain_front_only_kernel<3>, dim3(kChainFront), dim3(kBlock), 0, stream, ch);
+  DC_CHECK_LAUNCH();
+  return DC_OK;
 }
 
 int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg, double* exp_avg_sq, int64_t step, double grad_scale,

@@ -540,6 +540,41 @@ class SequencePlan:
         return True
 
     @on_device
+    def step_linked(self, prev_plan, prev_parity, finish, acc_in, w, exponent, poses12, exp_avg, exp_avg_sq, step, stamp, ready, out_prev,
+                    grad_scale, lr, betas, eps, weight_decay, w_used_prev=None):
+        """One launch of a chain over the SEVERAL sequences of one loss (dc_sequence_step_linked): this sequence is evaluated and the
+        launch before it -- ``prev_plan``'s, buffer ``prev_parity`` -- is finished first: its rows summed onto ``acc_in`` into
+        ``out_prev`` (finish = 1), with the Adam update when they complete a step (finish = 2); finish = 0: nothing pending.
+        Returns False when this plan / model cannot chain."""
+        nt = w.numel()
+        d = self.desc(nt)
+        need(poses12, (self.n_scans, 12), dtype=torch.float64, name='poses12', device=self.device)
+        need(out_prev, (None,), dtype=torch.float64, name='out_prev', device=self.device)
+        assert out_prev.numel() >= 2 + 2 * nt + 12 * self.n_scans
+        need(ready, (16,), dtype=torch.int32, name='ready', device=self.device)
+        self._set_basis(d, w, exponent, poses12, False, False)
+        dp = None if (prev_plan is None or not finish) else prev_plan.desc(nt)
+        rc = lib().dc_sequence_step_linked(ctypes.byref(d), None if dp is None else ctypes.byref(dp), int(prev_parity), int(finish), ptr(acc_in),
+                                           ptr(w), ptr(exponent), ptr(poses12), ptr(exp_avg), ptr(exp_avg_sq), int(step), int(stamp),
+                                           float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                           ptr(ready), ptr(out_prev), ptr(w_used_prev), stream_ptr())
+        if rc in (-4, nv.DC_ERR_BACKWARD_TABLES):
+            return False
+        check(rc, 'dc_sequence_step_linked')
+        self.version += 1
+        return True
+
+    @on_device
+    def flush_linked(self, parity, acc_in, w, exp_avg, exp_avg_sq, step, stamp, ready, out, grad_scale, lr, betas, eps, weight_decay):
+        """Finish the last launch of a linked chain (this plan's rows, buffer ``parity``, + ``acc_in`` -> out; Adam update ``step``)."""
+        d = self.desc(w.numel())
+        need(out, (2 + 2 * w.numel() + 12 * self.n_scans,), dtype=torch.float64, name='out', device=self.device)
+        check(lib().dc_sequence_chain_flush_linked(ctypes.byref(d), int(parity), ptr(acc_in), ptr(w), ptr(exp_avg), ptr(exp_avg_sq), int(step),
+                                                   int(stamp), float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                   float(weight_decay), ptr(ready), ptr(out), stream_ptr()), 'dc_sequence_chain_flush_linked')
+        return out
+
+    @on_device
     def eval_after_update(self, w, exponent, poses12, out, exp_avg, exp_avg_sq, t, grad_sum, ready, grad_scale, lr, betas, eps,
                           weight_decay, w_used=None):
         """Evaluation number ``t`` whose launch first takes Adam update ``t - 1`` from ``grad_sum`` (the previous evaluation's
@@ -1005,11 +1040,15 @@ class SequenceTrainer:
         # t + 1 (dc_sequence_eval_after_update), three launches per step instead of four; the returned sums are current, only
         # the weights lag by the one update flush() applies
         self.update_in_next = (bool(chained) and not self.fused_step and evaluate is None and adam is None
-                               and len(self.plans) >= 1 and self.nt > 0)
+                               and len(self.plans) >= 1 and self.nt > 0 and (distributed or len(self.plans) == 1))
+        # several local sequences in one loss, one rank: a chain over the sequences -- ONE launch per sequence and step, each launch
+        # finishing the one before it (dc_sequence_step_linked); step() returns the PREVIOUS step's sums like ``chained``
+        self.linked = (bool(chained) and evaluate is None and adam is None and len(self.plans) > 1 and self.nt > 0 and not distributed)
         self._pending = False
         self._grad_prev = None         # update_in_next: the summed gradient of the last step when the caller reduced it (use_sums)
         self.ready = torch.zeros((16,), dtype=torch.int32, device=dev)      # 64 bytes: the chain's published weights
         self.outs = [torch.zeros((2 + 2 * self.nt + 12 * p.n_scans,), dtype=torch.float64, device=dev) for p in self.plans]
+        self.link_acc = torch.zeros((max(o.numel() for o in self.outs),), dtype=torch.float64, device=dev)      # linked: the step's running sums
         self.acc = torch.zeros((2 + self.nt,), dtype=torch.float64, device=dev)       # [sum loss, count, dL/dw]
         self.distributed, self.group = distributed, process_group
         self.count = float(sum(p.count for p in self.plans))
@@ -1027,6 +1066,15 @@ class SequenceTrainer:
         """Chained mode: finish the last launched step (its sums -> ``out`` or the trainer's own buffer, and its Adam
         update); returns the sums.  No-op otherwise."""
         buf = self.outs[0] if out is None else out
+        if self._pending and self.linked:
+            S = len(self.plans)
+            self.plans[-1].flush_linked(self.t & 1, self.link_acc, self.w, self.exp_avg, self.exp_avg_sq, self.t, self.t * S + S + 1,
+                                        self.ready, buf if buf.numel() == self.outs[-1].numel() else self.outs[-1], self._grad_scale(), self.lr,
+                                        self.betas, self.eps, self.weight_decay)
+            if buf.numel() != self.outs[-1].numel():
+                buf[:2 + self.nt].copy_(self.outs[-1][:2 + self.nt])
+            self._pending = False
+            return buf[:2 + self.nt]
         if self._pending and self.update_in_next:
             g = self._grad_prev if self._grad_prev is not None else (self.acc if len(self.plans) > 1 else self.outs[0])[2:2 + self.nt]
             self.adam(g)                                          # the last evaluation's (all-reduced) gradient, step self.t
@@ -1035,7 +1083,7 @@ class SequenceTrainer:
             self.plans[0].chain_flush(self.w, buf, self.exp_avg, self.exp_avg_sq, self.t, self._grad_scale(), self.lr,
                                       self.betas, self.eps, self.weight_decay)
             self._pending = False
-        return buf[:2 + self.nt] if len(self.outs) == 1 else self.acc
+        return buf[:2 + self.nt] if (len(self.outs) == 1 or self.linked) else self.acc
 
     def use_sums(self, acc):
         """``acc`` [2 + P] = {sum loss, count, dL/dw} of the last step over all sequences and ranks (step(defer_reduce=True)): the
@@ -1055,6 +1103,29 @@ class SequenceTrainer:
         evaluation used -- a training log's record of an iteration, written by the launch itself.  ``update_in_next`` mode: the
         sums are current, ``w_used_prev`` takes the weights THIS evaluation uses; ``defer_reduce``: the sequences' sums stay in
         ``self.outs`` and the caller hands the joint (all-reduced) sums back with use_sums() before the next step."""
+        if self.linked:
+            T, S = self.t + 1, len(self.plans)
+            buf = self.outs[0] if out_prev is None else out_prev
+            for i, (plan, P) in enumerate(zip(self.plans, self.poses12)):
+                if i == 0:                       # finishes the last sequence of step T - 1: its totals, the Adam update, the record
+                    ok = plan.step_linked(self.plans[-1], (T - 1) & 1, 2 if self._pending else 0, self.link_acc if self._pending else None,
+                                          self.w, self.exponent, P, self.exp_avg, self.exp_avg_sq, T, T * S + 1, self.ready, buf,
+                                          self._grad_scale(), self.lr, self.betas, self.eps, self.weight_decay, w_used_prev=w_used_prev)
+                else:                            # finishes sequence i - 1 of this step: its sums onto the step's running sums
+                    ok = plan.step_linked(self.plans[i - 1], T & 1, 1, None if i == 1 else self.link_acc, self.w, self.exponent, P,
+                                          self.exp_avg, self.exp_avg_sq, T, T * S + 1 + i, self.ready, self.link_acc,
+                                          self._grad_scale(), self.lr, self.betas, self.eps, self.weight_decay)
+                if not ok:
+                    if i or self._pending:
+                        raise RuntimeError('a sequence plan refused a linked step in the middle of a chain')
+                    self.linked = False
+                    break
+            if self.linked:
+                self.t += 1
+                self._pending = True
+                return buf[:2 + self.nt]
+            if require_chain:
+                return None                      # (nothing was launched)
         if self.chained:
             buf = self.outs[0] if out_prev is None else out_prev
             ok = self.plans[0].step_chained(self.w, self.exponent, self.poses12[0], buf, self.exp_avg, self.exp_avg_sq,

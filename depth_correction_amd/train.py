@@ -270,8 +270,8 @@ def _train(cfg: Config, callbacks=None, train_datasets=None, val_datasets=None):
         if sharded:
             code = _agree(code, cfg.device)
         if code == 1:
-            if not sharded and len(native[0]) == 1:
-                ran, best = _native_loop(cfg, model, optimizer, native[0][0], native[1], train_poses, val_poses, batch, callbacks)
+            if not sharded:
+                ran, best = _native_loop(cfg, model, optimizer, native[0], native[1], train_poses, val_poses, batch, callbacks)
             else:
                 ran, best = _native_shared_loop(cfg, model, optimizer, native[0], native[1], train_poses, val_poses, batch, shard, callbacks)
             if ran:
@@ -957,20 +957,23 @@ def _native_shared_loop(cfg, model, optimizer, plans, vplans, train_poses, val_p
     return True, book.best
 
 
-def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, batch, callbacks=None):
-    """train()'s loop for the model-only case on the library's own step: ONE launch per iteration (dc_sequence_step_chained_rec:
-    the launch of iteration t evaluates loss and dL/dw with the weights Adam update t - 1 left, and its leading blocks first
-    finish iteration t - 1 -- sums, update, and the record {sums, weights used} of that iteration straight into the log's ring
-    slot), plus one evaluation-only launch pair per validation sequence.  The weights ARE ``model.w`` (the trainer works on
-    the parameter's storage).  Bookkeeping as in _batched_loop: one synchronisation per ``batch`` iterations.  Returns
-    (ran, best config); ran = False, nothing touched, when the plan turns out not to chain."""
+def _native_loop(cfg, model, optimizer, plans, vplans, train_poses, val_poses, batch, callbacks=None):
+    """train()'s loop for the model-only case on the library's own step: ONE launch per (sequence and) iteration.  One training
+    sequence: dc_sequence_step_chained_rec -- the launch of iteration t evaluates loss and dL/dw with the weights Adam update t - 1
+    left, and its leading blocks first finish iteration t - 1: sums, update, and the record {sums, weights used} of that iteration
+    straight into the log's ring slot.  Several training sequences in the loss (train.py:172-175; round 5): a chain over the
+    sequences, dc_sequence_step_linked -- every launch finishes the one before it, the first launch of an iteration completes the
+    previous iteration.  Plus one evaluation-only launch pair per validation sequence.  The weights ARE ``model.w`` (the trainer
+    works on the parameter's storage).  Bookkeeping as in _batched_loop: one synchronisation per ``batch`` iterations.  Returns
+    (ran, best config); ran = False, nothing touched, when the plans turn out not to chain."""
     from .plan import SequenceTrainer
     dev = torch.device(cfg.device)
     n_it, R = cfg.n_opt_iters, batch
     g = optimizer.param_groups[0]
     w_param = model.w
     e = model.kernel_params()[1].detach()
-    tr = SequenceTrainer([plan], w_param.detach(), e, [train_poses[0]], lr=g['lr'], betas=g['betas'], eps=g['eps'], chained=True)
+    plan = plans[0]
+    tr = SequenceTrainer(plans, w_param.detach(), e, train_poses, lr=g['lr'], betas=g['betas'], eps=g['eps'], chained=True)
     assert tr.w.data_ptr() == w_param.data_ptr()
     nt = tr.nt
     ring = torch.zeros((R, 2 + 2 * nt + 12 * plan.n_scans), dtype=torch.float64, device=dev)
@@ -979,7 +982,7 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
     vP = [vp.poses12(T) for vp, T in zip(vplans, val_poses)]
     sd_const = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     w_key = [k for k, v in model.state_dict().items() if v.data_ptr() == w_param.data_ptr()][0]
-    poses_cpu = [train_poses[0].detach().cpu().clone()]
+    poses_cpu = [T.detach().cpu().clone() for T in train_poses]
     book = _Bookkeeper(cfg, model)
     snap = None                      # optimiser state after the last fetched iteration: where a batch can be started again
 
@@ -1005,7 +1008,7 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
         """Iterations first .. n_it - 1 with ordinary (two-launch) steps and one synchronisation each: where the loop goes on
         after a chained launch gave up waiting for its weights (status bit 1: its sums are NaN, and so is every weight the
         Adam updates after it produced)."""
-        tr.chained = False
+        tr.chained = tr.linked = False
         for it in range(first, n_it):
             w_used = tr.w.clone()
             vs = [vp.eval_native(tr.w, tr.exponent, P, vr[0], want_grad=False).cpu() for vp, P, vr in zip(vplans, vP, vrings)]
@@ -1022,11 +1025,14 @@ def _native_loop(cfg, model, optimizer, plan, vplans, train_poses, val_poses, ba
         tr.flush(out=ring[(upto - 1) % R])
         h, hw = ring.cpu(), ring_w.cpu()                            # synchronises
         hv = [v.cpu() for v in vrings]
-        bits = plan.status_bits()                                   # (free: the copies above have synchronised)
+        bits = 0
+        for p_ in plans:
+            bits |= p_.status_bits()                                # (free: the copies above have synchronised)
         if bits & plan.STATUS_CHAIN_TIMEOUT:
             warnings.warn('train(): a chained step gave up waiting for its weights (iterations %d..%d); repeating them and '
                           'finishing the run with ordinary steps' % (first, upto - 1))
-            plan.clear_status()
+            for p_ in plans:
+                p_.clear_status()
             w0_, m0_, v0_, t0_ = snap
             tr.w.copy_(w0_); tr.exp_avg.copy_(m0_); tr.exp_avg_sq.copy_(v0_); tr.t = t0_
             plain_iterations(first)

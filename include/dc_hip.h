@@ -588,6 +588,22 @@ int dc_sequence_step_chained_rec(const dcSequenceDesc* d, double* w, const doubl
                                  dcStream_t stream);
 int dc_sequence_chain_flush(const dcSequenceDesc* d, double* w, double* exp_avg, double* exp_avg_sq, int64_t step, double grad_scale,
                             double lr, double beta1, double beta2, double eps, double weight_decay, double* out, dcStream_t stream);
+/* A chain over the SEVERAL sequences of one loss on one GPU (train.py:172-175 loops over them, eval.py:85-112 pools their sums and
+ * counts): one launch per sequence and step and nothing else.  Launch (step, i) evaluates sequence i -- its rows go to buffer
+ * `step & 1` of ITS descriptor -- and first finishes the launch before it by summing that launch's rows (d_prev, buffer prev_parity:
+ * sequence i - 1 of this step, or the last sequence of step - 1) onto the running sums acc_in (device fp64 [2 + P]; NULL for the
+ * step's second launch).  finish: 0 = nothing is pending (the chain's very first launch), 1 = the sums go on into out_prev (which may
+ * be acc_in itself), 2 = they complete step - 1: out_prev <- its totals, torch.optim.Adam's update step - 1 on w, w_used_prev.
+ * stamp: a number that grows with every launch of the chain (marks the published weights); ready as for dc_sequence_step_chained.
+ * dc_sequence_chain_flush_linked finishes the chain's last launch on its own (one small launch): d_prev's rows + acc_in -> out, Adam
+ * update `step`. */
+int dc_sequence_step_linked(const dcSequenceDesc* d, const dcSequenceDesc* d_prev, int prev_parity, int finish, const double* acc_in,
+                            double* w, const double* e, const double* poses, double* exp_avg, double* exp_avg_sq, int64_t step,
+                            int64_t stamp, double grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay,
+                            int32_t* ready, double* out_prev, double* w_used_prev, dcStream_t stream);
+int dc_sequence_chain_flush_linked(const dcSequenceDesc* d_prev, int prev_parity, const double* acc_in, double* w, double* exp_avg,
+                                   double* exp_avg_sq, int64_t step, int64_t stamp, double grad_scale, double lr, double beta1, double beta2,
+                                   double eps, double weight_decay, int32_t* ready, double* out, dcStream_t stream);
 /* The same idea when several sequences / ranks share the weights (an all-reduce of the sums sits between an evaluation and
  * its update, so a launch cannot sum the previous rows itself): evaluation `step`, whose leading blocks first take Adam update
  * step - 1 from grad_sum (device fp64 [P]: the previous evaluation's dL/dw summed over all ranks; NULL for the first call),

@@ -60,6 +60,42 @@ VARIANTS = [('mineig_norm', 'min_eigval_loss', True, False), ('mineig_raw', 'min
             ('trace_sqrt', 'trace_loss', False, True)]
 
 
+def test_linked_chain_over_several_sequences_equals_plain_trainer(golden):
+    """Several sequences in ONE loss on one GPU (train.py:172-175; eval.py:85-112 pools their sums and counts): a chain over the
+    sequences -- dc_sequence_step_linked: one launch per sequence and step, every launch first finishes the one before it (its
+    rows onto the step's running sums; the first launch of a step completes the previous step: totals, Adam update) -- against the
+    plain trainer (evaluate all -> sum -> dc_adam_step).  Sums are handed out one step late, as in a single-sequence chain; a flush
+    in the middle; sequences with different masks and numbers of scans."""
+    from depth_correction_amd.plan import SequencePlan, SequenceTrainer
+    g = golden('room_k10')
+    cfg = _cfg(g)
+    clouds, poses, _, ns, mask = _setup(g, cfg)
+    mask2 = mask & (torch.arange(len(mask), device=mask.device) % 3 != 0)
+    mk = lambda: [SequencePlan(clouds, poses, ns[0], mask), SequencePlan(clouds, poses, ns[0].clone(), mask2),
+                  SequencePlan(clouds, poses, ns[0].clone(), mask)]
+    plain = SequenceTrainer(mk(), g['w'], g['exponent'], 3 * [poses], lr=1e-2)
+    chain = SequenceTrainer(mk(), g['w'], g['exponent'], 3 * [poses], lr=1e-2, chained=True)
+    assert chain.linked and not chain.update_in_next and not plain.linked
+    ref, got = [], []
+    for it in range(9):
+        ref.append(npy(plain.step()).copy())
+        prev = npy(chain.step()).copy()
+        assert chain.linked
+        if it not in (0, 5):
+            got.append(prev)
+        if it == 4:
+            got.append(npy(chain.flush()).copy())
+            np.testing.assert_allclose(npy(chain.w), npy(plain.w), rtol=1e-10)
+    got.append(npy(chain.flush()).copy())
+    assert len(got) == 9
+    for a, b in zip(got, ref):
+        assert a[1] == b[1] == float(2 * mask.sum() + mask2.sum())
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-11)
+        np.testing.assert_allclose(a[2:], b[2:], rtol=1e-9, atol=1e-12 * np.abs(b[2:]).max())
+    np.testing.assert_allclose(npy(chain.w), npy(plain.w), rtol=1e-10)
+    assert abs(npy(chain.w)[0] - g['w'][0]) > 1e-3
+
+
 @pytest.mark.parametrize('fused', [True, False])
 def test_iteration_golden(golden, fused):
     """eval_loss_clouds + backward for every loss variant, fused kernels and un-fused DepthCloud operators."""
@@ -1111,6 +1147,30 @@ def test_train_native_pose_loop_short_runs_and_small_batches(golden, tmp_path, c
     np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-9, atol=1e-12)
     da, db = torch.load(b0.train_pose_deltas), torch.load(b1.train_pose_deltas)
     np.testing.assert_allclose(db[0].cpu().numpy(), da[0].cpu().numpy(), rtol=1e-7, atol=1e-10)
+
+
+def test_train_model_only_over_two_sequences_takes_the_linked_chain(golden, tmp_path, capsys, monkeypatch):
+    """train() with TWO training sequences in the loss and only the model optimised (train.py:172-175): train._native_loop on the
+    chain over the sequences (one launch per sequence and iteration, dc_sequence_step_linked) against the reference's
+    per-iteration loop -- the same progress lines and final checkpoint; a validation sequence included."""
+    from depth_correction_amd import train as train_mod
+    g = golden('room_k10')
+    took = []
+    fn = train_mod._native_loop
+    monkeypatch.setattr(train_mod, '_native_loop', lambda *a, **k: (took.append(1), fn(*a, **k))[1])
+    mk = lambda d, **kw: _cfg(g, n_opt_iters=13, lr=5e-3, log_dir=str(d), model_kwargs={'w': g['w'].tolist(), 'exponent': g['exponent'].tolist()}, **kw)
+    ds = list(zip(_scan_arrays(g), g['poses']))
+    tr_ds, va_ds = [ds, ds[1:]], [ds[:2]]
+    (tmp_path / 'plain').mkdir()
+    (tmp_path / 'fast').mkdir()
+    b0, l0, v0, f0, _ = _train_and_collect(mk(tmp_path / 'plain', loop_batch=1), tr_ds, va_ds, capsys)
+    assert took == []
+    b1, l1, v1, f1, _ = _train_and_collect(mk(tmp_path / 'fast', loop_batch=5), tr_ds, va_ds, capsys)
+    assert took == [1] and len(l0) == len(l1) == 13 and f0 == f1 and any(f0)
+    np.testing.assert_allclose(np.array(v1), np.array(v0), rtol=1e-8, atol=1e-12)
+    sa, sb = torch.load(b0.model_state_dict), torch.load(b1.model_state_dict)
+    for k in sa:
+        np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-9, atol=1e-15)
 
 
 @pytest.mark.parametrize('plane, multi', [(True, False), (False, False), (True, True)])
