@@ -1503,7 +1503,7 @@ __device__ __forceinline__ void chain_weights(const StepChain& ch, double w_scal
 // are the ones the backward kernel adds up, grouped by centre instead of by point, with c1 / c2 / cmean in fp64.
 // Staged row (piece-major, 16-B pieces; piece 0 starts with the point in its usual row format, so the first sweep and the
 // centre read it as before):  q32: {x0, x1, x2, u0 | u1, u2, c0, c1 | c2}, x on the grid, u / c float32 bits;
-// double: {x0, x1 | x2, u0 | u1, u2 | c0, c1 | c2, -}.
+// double: {x0, x1 | x2, u0' u1' | u2', c0', c1', c2'} (u', c': float32 copies for the second sweep).
 template <typename PT, int P> struct StepRow;
 template <int P> struct StepRow<q32, P> {
   static constexpr int kPieces = (6 + P + 3) / 4;
@@ -1548,7 +1548,13 @@ template <int P> struct StepRow<q32, P> {
   }
 };
 template <int P> struct StepRow<double, P> {
-  static constexpr int kPieces = (6 + P + 1) / 2;
+  // Staged row of a float64 cloud (round 5): {x0, x1 | x2, u0' u1' | u2', c0', c1', c2'} -- the point in fp64 as before (the first
+  // sweep and the centre read pieces 0 and 1: the loss is what it was, bit for bit), u and c as float32 COPIES for the second sweep:
+  // 48 B instead of 64, three LDS reads per neighbour there instead of four.  The kernel is bound by LDS reads at random rows
+  // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.62, LDS busy two thirds of the launch).  The point itself is formed from the
+  // fp64 basis row; the float32 copies enter dL/dw only: a relative rounding of 6e-8 per term, of random sign over 2e7 terms.
+  static constexpr int kPieces = 3;
+  static_assert(P <= 3, "three float32 weights' terms fit the third piece");
   static __device__ __forceinline__ int4 pack(double a, double b) {
     return make_int4(__double2loint(a), __double2hiint(a), __double2loint(b), __double2hiint(b));
   }
@@ -1564,17 +1570,17 @@ template <int P> struct StepRow<double, P> {
     place(fetch(pb, row), wq, tile, cap, t);
   }
   static __device__ __forceinline__ void place(const Raw& raw, const double* wq, int4* tile, int cap, int t) {
-    double q[6 + P + 1];
+    double q[9];
 #pragma unroll
-    for (int c = 0; c < 6 + P; ++c) q[c] = raw.q[c];
-    q[6 + P] = 0.0;
+    for (int c = 0; c < 9; ++c) q[c] = c < 6 + P ? raw.q[c] : 0.0;
     double sc = 0.0;
 #pragma unroll
     for (int k = 0; k < P; ++k) sc += wq[k] * q[6 + k];
 #pragma unroll
     for (int a = 0; a < 3; ++a) q[a] += sc * q[3 + a];
-#pragma unroll
-    for (int a = 0; a < kPieces; ++a) tile[a * cap + t] = pack(q[2 * a], q[2 * a + 1]);
+    tile[t] = pack(q[0], q[1]);
+    tile[cap + t] = make_int4(__double2loint(q[2]), __double2hiint(q[2]), __float_as_int((float)q[3]), __float_as_int((float)q[4]));
+    tile[2 * cap + t] = make_int4(__float_as_int((float)q[5]), __float_as_int((float)q[6]), __float_as_int((float)q[7]), __float_as_int((float)q[8]));
   }
   static __device__ __forceinline__ void mean_of(const Pt<double>::Raw& ci, const double* cm, double* mean) {
 #pragma unroll
@@ -1582,16 +1588,14 @@ template <int P> struct StepRow<double, P> {
   }
   static __device__ __forceinline__ void load(const int4* tile, int cap, uint32_t off, const double* mean, double* e, double* u, double* c) {
     const char* row = reinterpret_cast<const char*>(tile) + off;
-    double q[2 * kPieces];
-#pragma unroll
-    for (int a = 0; a < kPieces; ++a) {
-      const int4 p = *reinterpret_cast<const int4*>(row + (size_t)a * cap * 16);
-      q[2 * a] = __hiloint2double(p.y, p.x); q[2 * a + 1] = __hiloint2double(p.w, p.z);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { e[a] = q[a] - mean[a]; u[a] = q[3 + a]; }
-#pragma unroll
-    for (int k = 0; k < P; ++k) c[k] = q[6 + k];
+    const int4 p0 = *reinterpret_cast<const int4*>(row);
+    const int4 p1 = *reinterpret_cast<const int4*>(row + (size_t)cap * 16);
+    const int4 p2 = *reinterpret_cast<const int4*>(row + (size_t)cap * 32);
+    e[0] = __hiloint2double(p0.y, p0.x) - mean[0]; e[1] = __hiloint2double(p0.w, p0.z) - mean[1]; e[2] = __hiloint2double(p1.y, p1.x) - mean[2];
+    u[0] = (double)__int_as_float(p1.z); u[1] = (double)__int_as_float(p1.w); u[2] = (double)__int_as_float(p2.x);
+    c[0] = (double)__int_as_float(p2.y);
+    if constexpr (P > 1) c[1] = (double)__int_as_float(p2.z);
+    if constexpr (P > 2) c[2] = (double)__int_as_float(p2.w);
   }
 };
 
@@ -3609,7 +3613,7 @@ static int sequence_eval_impl(const dcSequenceDesc* d, const double* w, const do
   // loss and dL/dw in ONE pass (forward-mode) for up to three weights: no record, no backward launch, no transposed table
   size_t lds_s = 0;
   int rows_s = 0;
-  const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : (6 + n_terms + 1) / 2);
+  const unsigned step_row_bytes = 16u * (unsigned)(q32_pts ? (6 + n_terms + 3) / 4 : 3);        // StepRow<PT, P>::kPieces
   // (the one-pass kernels never stage the blocks they skip: their tile is sized by the longest list among the others)
   dcBlockTable ft_active{};
   if (d->fwd_table) {

@@ -199,7 +199,9 @@ def test_train_matches_oracle_adam_loop(golden, tmp_path):
         loss, _ = O.eval_sequence(scans, t(g['poses']), w, t(g['exponent'].reshape(1, -1)), t(g['g_neighbors']).long(),
                                   t(g['g_mask']), reduction='mean')
         np.testing.assert_allclose(seen[it][0], loss.item(), rtol=1e-8)
-        np.testing.assert_allclose(seen[it][1], npy(w), rtol=1e-8)
+        # (the bar on fp64 device data: 1e-9 on the loss, 1e-7 on gradients -- the staged rows carry float32 copies of u and c for the
+        #  second sweep, 6e-8 per term; Adam normalises the gradient, so its error is the weights' error)
+        np.testing.assert_allclose(seen[it][1], npy(w), rtol=1e-7)
         loss.backward()
         opt.step()
     assert best is not None and best.model_state_dict.endswith('_state_dict.pth')

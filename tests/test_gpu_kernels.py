@@ -624,8 +624,14 @@ def test_basis_form_equals_general_path(golden, dev, model, n_terms, active_only
             # (1.5e-8 m against mm-sized plane distances), which leaves ~1e-4 of the largest component where the terms
             # cancel most (Polynomial at w = 0 here); the one-pass kernel keeps the mean in fp64
             loose = not f64 and not (path == 'default' and one_pass_expected)
-            np.testing.assert_allclose(o[2:2 + nt], ref_g, rtol=1e-8 if f64 else 1e-5,
-                                       atol=(1e-10 if f64 else (2e-4 if loose else 2e-5)) * np.abs(ref_g).max(), err_msg=path)
+            # fp64 clouds: the two-kernel and general forms are fp64 throughout (1e-8); the one-pass kernel's second sweep reads
+            # float32 copies of u and c from its 48-byte staged rows -- 6e-8 on each term of a sum of both signs, 1.3e-7 of the
+            # result measured here, held to 1e-6, and 8e-8 of the largest component on one that cancels to 3 % of it (atol 2e-7 of
+            # the largest) -- the loss itself, first sweep, stays fp64: 1e-11 above
+            staged32 = f64 and path == 'default' and one_pass_expected
+            np.testing.assert_allclose(o[2:2 + nt], ref_g, rtol=(1e-6 if staged32 else 1e-8) if f64 else 1e-5,
+                                       atol=((2e-7 if staged32 else 1e-10) if f64 else (2e-4 if loose else 2e-5)) * np.abs(ref_g).max(),
+                                       err_msg=path)
     if one_pass_expected:
         # the same points: the same pointwise losses, summed in another order -- and, for float32 clouds, from another form of the
         # eigen-solver (the one-pass kernel's eig3_smallest_unit leaves the eigenvalue at its Newton iterate: ~1e-12 of the spread)
@@ -665,7 +671,8 @@ def test_one_pass_step_all_loss_variants_vs_oracle(golden, dev, tag, loss, norm,
     assert o[1] == float(g['g_mask'].sum())
     np.testing.assert_allclose(o[0], lo.item(), rtol=1e-11 if f64 else 1e-5)
     ref = wo.grad.numpy().ravel()
-    np.testing.assert_allclose(o[2:4], ref, rtol=1e-8 if f64 else 1e-5, atol=(1e-10 if f64 else 2e-5) * np.abs(ref).max())
+    # (fp64 clouds: float32 copies of u and c in the second sweep -- see test_basis_form_equals_general_path -- 1.1e-8 measured here)
+    np.testing.assert_allclose(o[2:4], ref, rtol=1e-6 if f64 else 1e-5, atol=(1e-8 if f64 else 2e-5) * np.abs(ref).max())
 
 
 @pytest.mark.parametrize('n, ratio', [(1, 0.3), (2, 0.5), (257, 0.0), (5000, 0.3), (5000, 1.0), (100_003, 0.37), (100_003, 0.5)])
