@@ -722,7 +722,7 @@ def main():
         for it in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out_cloud = correct_cloud(cloud_on_device(raw, dtype=dtype, device=dev), model, cfg)
+            out_cloud = correct_cloud(raw, model, cfg)          # (the uploaded rows: dc_scan_prefilter, then neighbourhoods, features, model)
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t0) * 1e3)
         extras['online_correction'] = {'points_in': int(raw.shape[0]), 'points_out': len(out_cloud),

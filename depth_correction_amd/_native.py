@@ -34,6 +34,7 @@ _SIGNATURES = {
     'dc_knn_set_shell_budget': (_i32, [_i32]),
     'dc_knn_set_fine_cell_count': (_i32, [_i32]),
     'dc_knn_build': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _sz, _vp]),
+    'dc_knn_build_i64': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_count': (_i32, [_vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
     'dc_radius_fill': (_i32, [_i64, _f64, _i32, _vp, _vp, _sz, _vp]),
     'dc_radius_count_query': (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _i64, _f64, _vp, _vp, _vp, _sz, _vp]),
@@ -84,6 +85,13 @@ _SIGNATURES = {
                                   _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'dc_mask_bounds': (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _f64, _f64, _vp, _vp]),
     'dc_valid_count': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'dc_mask_bounds_multi': (_i32, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'dc_compact_rows_workspace_bytes': (_sz, [_i64]),
+    'dc_compact_rows': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'dc_to_points': (_i32, [_vp, _i32, _vp, _vp, _i32, _i64, _vp, _vp]),
+    'dc_valid_weights': (_i32, [_vp, _i64, _vp, _vp]),
+    'dc_scan_prefilter_workspace_bytes': (_sz, [_i64]),
+    'dc_scan_prefilter': (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_nn1_corr_workspace_bytes': (_sz, [_i64]),
     'dc_nn1_corr': (_i32, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'dc_dispersion': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),

@@ -8,6 +8,7 @@
 #include "../../include/dc_hip.h"
 #include "dc_device.h"
 #include <cstring>
+#include "dc_hostutil.h"
 #include "dc_sort.h"
 
 namespace dc {
@@ -329,6 +330,146 @@ __global__ __launch_bounds__(kBlock) void nn1_scatter_kernel(const int32_t* __re
   if (i == n - 1) *count_out = (int64_t)pos[i] + (mask[i] ? 1 : 0);
 }
 
+
+// ---- stable compaction of the rows of several arrays by one mask (depth_cloud.py:126-134: cloud[mask] slices every per-point field) ----
+// torch does this per field -- nonzero (count, partition, prefix sums) and one index_select each: ~25 launches for the four fields of
+// an incoming scan.  Here: one counting kernel (kept rows of every 512-row block) and one kernel that places every field of the
+// kept rows (a block's first output row = the sum of the counts before it, read by the block itself; beyond kCompactSelfScan blocks a
+// prefix sum over the counts runs in between).
+constexpr int kCompactPer = 2;                    // rows per lane
+constexpr int kCompactRows = kCompactPer * kBlock; // rows of one block
+constexpr int kCompactFields = 8;
+constexpr int kCompactSelfScan = 4096;             // blocks up to which a block sums the counts before it by itself (2 M rows)
+struct CompactFields {
+  const void* src[kCompactFields];
+  void* dst[kCompactFields];
+  int32_t row_bytes[kCompactFields];
+  int32_t n_fields;
+};
+
+__device__ __forceinline__ int block_sum_i32(int v, int* lds /* [kBlock / kWave] */) {
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = v;
+  __syncthreads();
+  int s = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) s += lds[w];
+  __syncthreads();
+  return s;
+}
+
+// (row = block base + q * kBlock + lane, q < kCompactPer: consecutive lanes read consecutive rows and, where they are kept, write consecutive rows)
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(const uint8_t* __restrict__ mask, int64_t n, int32_t* __restrict__ counts) {
+  __shared__ int lds[kBlock / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kCompactRows + threadIdx.x;
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < kCompactPer; ++q) { const int64_t i = base + q * kBlock; c += (i < n && mask[i]) ? 1 : 0; }
+  const int tot = block_sum_i32(c, lds);
+  if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+template <bool SCANNED>
+__global__ __launch_bounds__(kBlock) void compact_place_kernel(const uint8_t* __restrict__ mask, int64_t n, const int32_t* __restrict__ counts,
+                                                               CompactFields f, int32_t* __restrict__ index_out, int64_t* __restrict__ count_out) {
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ int lds[kWaves];
+  __shared__ int s_cnt[kCompactPer * kWaves];
+  int before = 0;
+  if (SCANNED) before = counts[blockIdx.x];                      // (exclusive prefix sums of the counts)
+  else {
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) part += counts[b];
+    before = block_sum_i32(part, lds);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int64_t base = (int64_t)blockIdx.x * kCompactRows + threadIdx.x;
+  bool keep[kCompactPer];
+  int below[kCompactPer];
+#pragma unroll
+  for (int q = 0; q < kCompactPer; ++q) {
+    const int64_t i = base + q * kBlock;
+    keep[q] = i < n && mask[i] != 0;
+    const unsigned long long bal = __ballot(keep[q]);
+    below[q] = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[q * kWaves + wave] = __popcll(bal);
+  }
+  __syncthreads();
+  int run = before;
+#pragma unroll
+  for (int q = 0; q < kCompactPer; ++q) {
+    int mine = run;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { const int c = s_cnt[q * kWaves + w]; if (w < wave) mine += c; run += c; }
+    if (!keep[q]) continue;
+    const int64_t i = base + q * kBlock, o = mine + below[q];
+    if (index_out) index_out[o] = (int32_t)i;
+    for (int a = 0; a < f.n_fields; ++a) {
+      const int rb = f.row_bytes[a];
+      if ((rb & 3) == 0) {
+        const int words = rb >> 2;
+        const uint32_t* sp = static_cast<const uint32_t*>(f.src[a]) + i * words;
+        uint32_t* dp = static_cast<uint32_t*>(f.dst[a]) + o * words;
+        // (the usual rows -- [N,1], [N,3] of float32 / float64 -- with their loads issued together)
+        if (words == 1) dp[0] = sp[0];
+        else if (words == 2) { const uint32_t v0 = sp[0], v1 = sp[1]; dp[0] = v0; dp[1] = v1; }
+        else if (words == 3) { const uint32_t v0 = sp[0], v1 = sp[1], v2 = sp[2]; dp[0] = v0; dp[1] = v1; dp[2] = v2; }
+        else if (words == 6) {
+          uint32_t v[6];
+#pragma unroll
+          for (int w = 0; w < 6; ++w) v[w] = sp[w];
+#pragma unroll
+          for (int w = 0; w < 6; ++w) dp[w] = v[w];
+        } else for (int w = 0; w < words; ++w) dp[w] = sp[w];
+      } else {
+        const uint8_t* sp = static_cast<const uint8_t*>(f.src[a]) + i * rb;
+        uint8_t* dp = static_cast<uint8_t*>(f.dst[a]) + o * rb;
+        for (int w = 0; w < rb; ++w) dp[w] = sp[w];
+      }
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && count_out) *count_out = (int64_t)run;
+}
+
+// points = vps + depth * dirs (depth_cloud.py:251-252), product and sum rounded separately like the two tensor operations
+template <typename T>
+__global__ __launch_bounds__(kBlock) void to_points_kernel(const T* __restrict__ vps, int vps_rows, const T* __restrict__ dirs,
+                                                           const T* __restrict__ depth, int64_t n, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= 3 * n) return;
+  const int64_t i = e / 3;
+  const T prod = depth[i] * dirs[e];
+  out[e] = vps[vps_rows == 1 ? e - 3 * i : e] + prod;
+}
+
+// weights = valid_neighbor_mask().float() (depth_cloud.py:341-343)
+__global__ __launch_bounds__(kBlock) void valid_weights_kernel(const int32_t* __restrict__ nbr, int64_t count, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e < count) out[e] = nbr[e] >= 0 ? 1.0f : 0.0f;
+}
+
+// every bound on the columns (and column ratios) of one array in one pass: mask = [mask &] AND_b lo_b <= v[i, num_b] (/ v[i, den_b]) <= hi_b
+constexpr int kMaxBounds = 8;
+struct BoundSpecs {
+  int32_t num[kMaxBounds], den[kMaxBounds];        // den < 0: the plain value
+  double lo[kMaxBounds], hi[kMaxBounds];
+  int32_t n_bounds;
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mask_bounds_multi_kernel(const T* __restrict__ v, int stride, int64_t n, BoundSpecs b, int init,
+                                                                   uint8_t* __restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  bool keep = init ? true : mask[i] != 0;
+  for (int q = 0; q < b.n_bounds; ++q) {
+    T x = v[i * stride + b.num[q]];
+    if (b.den[q] >= 0) x = x / v[i * stride + b.den[q]];          // in storage precision, like the reference's tensor division
+    keep = keep && in_bounds((double)x, b.lo[q], b.hi[q]);
+  }
+  mask[i] = keep ? 1 : 0;
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -514,6 +655,137 @@ int dc_nn1_corr(const double* dist, const int32_t* idx, int64_t n, double ratio,
                      idx_out, count_out);
   err = hipGetLastError();
   return err == hipSuccess ? DC_OK : (int)err;
+}
+
+size_t dc_compact_rows_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  const size_t nb = (size_t)((n + dc::kCompactRows - 1) / dc::kCompactRows) + 1;
+  return 512 + 2 * ((nb * sizeof(int32_t) + 255) / 256) * 256 + dc::scan_bytes(nb);
+}
+
+int dc_compact_rows(const uint8_t* mask, int64_t n, int n_fields, const void* const* src, void* const* dst, const int32_t* row_bytes,
+                    int32_t* index_out, int64_t* count_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || n_fields < 0 || n_fields > dc::kCompactFields || !count_out) return DC_ERR_ARG;
+  if (n == 0) { hipError_t e0 = hipMemsetAsync(count_out, 0, sizeof(int64_t), stream); return e0 == hipSuccess ? DC_OK : (int)e0; }
+  if (!mask || !ws || n > 0x7fffffff || (n_fields > 0 && (!src || !dst || !row_bytes))) return DC_ERR_ARG;
+  if (ws_bytes < dc_compact_rows_workspace_bytes(n)) return DC_ERR_WORKSPACE;
+  dc::CompactFields f;
+  memset(&f, 0, sizeof(f));
+  f.n_fields = n_fields;
+  for (int a = 0; a < n_fields; ++a) {
+    if (!src[a] || !dst[a] || row_bytes[a] < 1) return DC_ERR_ARG;
+    // (word copies need 4-byte aligned rows)
+    f.src[a] = src[a]; f.dst[a] = dst[a]; f.row_bytes[a] = row_bytes[a];
+    if ((row_bytes[a] & 3) == 0 && ((((uintptr_t)src[a]) | ((uintptr_t)dst[a])) & 3) != 0) return DC_ERR_ARG;
+  }
+  const unsigned nb = (unsigned)((n + dc::kCompactRows - 1) / dc::kCompactRows);
+  dc::Carver c(ws);
+  int32_t* counts = c.take<int32_t>(nb + 1);
+  int32_t* offsets = c.take<int32_t>(nb + 1);
+  void* scan_ws = c.take<char>(dc::scan_bytes(nb + 1));
+  hipLaunchKernelGGL(dc::compact_count_kernel, dim3(nb), dim3(dc::kBlock), 0, stream, mask, n, counts);
+  if ((int)nb <= dc::kCompactSelfScan) {
+    hipLaunchKernelGGL((dc::compact_place_kernel<false>), dim3(nb), dim3(dc::kBlock), 0, stream, mask, n, (const int32_t*)counts, f, index_out,
+                       count_out);
+  } else {
+    hipError_t err = dc::exclusive_scan_32(scan_ws, dc::scan_bytes(nb + 1), counts, offsets, (size_t)nb, stream);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL((dc::compact_place_kernel<true>), dim3(nb), dim3(dc::kBlock), 0, stream, mask, n, (const int32_t*)offsets, f, index_out,
+                       count_out);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DC_OK : (int)e;
+}
+
+int dc_to_points(const void* vps, int vps_rows, const void* dirs, const void* depth, int dtype, int64_t n, void* points_out, hipStream_t stream) {
+  if (n == 0) return DC_OK;
+  if (n < 0 || !vps || !dirs || !depth || !points_out || (vps_rows != 1 && vps_rows != n)) return DC_ERR_ARG;
+  const dim3 grid((unsigned)((3 * n + dc::kBlock - 1) / dc::kBlock)), block(dc::kBlock);
+  if (3 * n > (int64_t)0x7fffffff * dc::kBlock) return DC_ERR_UNSUPPORTED;
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((dc::to_points_kernel<float>), grid, block, 0, stream, (const float*)vps, vps_rows, (const float*)dirs, (const float*)depth, n,
+                       (float*)points_out);
+  else if (dtype == DC_F64)
+    hipLaunchKernelGGL((dc::to_points_kernel<double>), grid, block, 0, stream, (const double*)vps, vps_rows, (const double*)dirs,
+                       (const double*)depth, n, (double*)points_out);
+  else return DC_ERR_DTYPE;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DC_OK : (int)e;
+}
+
+int dc_valid_weights(const int32_t* nbr, int64_t count, float* weights_out, hipStream_t stream) {
+  if (count == 0) return DC_OK;
+  if (count < 0 || !nbr || !weights_out) return DC_ERR_ARG;
+  if (count > (int64_t)0x7fffffff * dc::kBlock) return DC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(dc::valid_weights_kernel, dim3((unsigned)((count + dc::kBlock - 1) / dc::kBlock)), dim3(dc::kBlock), 0, stream, nbr, count,
+                     weights_out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DC_OK : (int)e;
+}
+
+int dc_mask_bounds_multi(const void* values, int stride, int dtype, int64_t n, int n_bounds, const int32_t* num_index, const int32_t* den_index,
+                         const double* lo, const double* hi, int init, uint8_t* mask, hipStream_t stream) {
+  if (n == 0) return DC_OK;
+  if (n < 0 || !values || !mask || stride < 1 || n_bounds < 0 || n_bounds > dc::kMaxBounds) return DC_ERR_ARG;
+  if (n_bounds > 0 && (!num_index || !den_index || !lo || !hi)) return DC_ERR_ARG;
+  dc::BoundSpecs b;
+  memset(&b, 0, sizeof(b));
+  b.n_bounds = n_bounds;
+  for (int q = 0; q < n_bounds; ++q) {
+    if (num_index[q] < 0 || num_index[q] >= stride || den_index[q] >= stride) return DC_ERR_ARG;
+    b.num[q] = num_index[q]; b.den[q] = den_index[q]; b.lo[q] = lo[q]; b.hi[q] = hi[q];
+  }
+  const dim3 grid((unsigned)((n + dc::kBlock - 1) / dc::kBlock)), block(dc::kBlock);
+  if (dtype == DC_F32)
+    hipLaunchKernelGGL((dc::mask_bounds_multi_kernel<float>), grid, block, 0, stream, (const float*)values, stride, n, b, init, mask);
+  else if (dtype == DC_F64)
+    hipLaunchKernelGGL((dc::mask_bounds_multi_kernel<double>), grid, block, 0, stream, (const double*)values, stride, n, b, init, mask);
+  else return DC_ERR_DTYPE;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DC_OK : (int)e;
+}
+
+// ---- first stage of the online node in one call (scripts/depth_correction:31-58 -> preproc.py:44-47): from_points, points, the
+// scan-shadow mask off the direction grid, cloud[mask].  A composition of the entry points above and in dc_knn.hip / dc_scanio.hip
+// -- what it saves is the host's time between their launches (five Python calls, ~150 us during which the device waits).
+static size_t prefilter_field_bytes(int64_t n, int out_dtype) { return (((size_t)n * 3 * (out_dtype == DC_F32 ? 4 : 8)) + 255) / 256 * 256; }
+
+size_t dc_scan_prefilter_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  size_t sub = dc_knn_workspace_bytes((int64_t)m, 0);
+  const size_t b = dc_cloud_from_points_workspace_bytes((int64_t)m), c = dc_compact_rows_workspace_bytes((int64_t)m);
+  sub = sub > b ? sub : b;
+  sub = sub > c ? sub : c;
+  return 4 * prefilter_field_bytes((int64_t)m, DC_F64) + ((m + 255) / 256) * 256 + 512 + sub;
+}
+
+int dc_scan_prefilter(const void* points, int stride, int in_dtype, const void* vps, int64_t n, int out_dtype, double shadow_r,
+                      double shadow_lo, double shadow_hi, void* vps_out, void* dirs_out, void* depth_out, void* points_out,
+                      int64_t* count_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || stride < 3 || !count_out || !(shadow_r > 0.0)) return DC_ERR_ARG;
+  if ((in_dtype != DC_F32 && in_dtype != DC_F64) || (out_dtype != DC_F32 && out_dtype != DC_F64)) return DC_ERR_DTYPE;
+  if (n == 0) { hipError_t e0 = hipMemsetAsync(count_out, 0, sizeof(int64_t), stream); return e0 == hipSuccess ? DC_OK : (int)e0; }
+  if (!points || !vps_out || !dirs_out || !depth_out || !points_out || !ws) return DC_ERR_ARG;
+  if (ws_bytes < dc_scan_prefilter_workspace_bytes(n)) return DC_ERR_WORKSPACE;
+  char* base = static_cast<char*>(ws);
+  const size_t fb = prefilter_field_bytes(n, DC_F64);
+  void* t_vps = base; void* t_dirs = base + fb; void* t_depth = base + 2 * fb; void* t_pts = base + 3 * fb;
+  uint8_t* mask = reinterpret_cast<uint8_t*>(base + 4 * fb);
+  int64_t* count_all = reinterpret_cast<int64_t*>(base + 4 * fb + (((size_t)n + 255) / 256) * 256);
+  void* sub = base + 4 * fb + (((size_t)n + 255) / 256) * 256 + 512;
+  const size_t sub_bytes = ws_bytes - (size_t)((char*)sub - base);
+  const double nan = __builtin_nan("");
+  int rc = dc_cloud_from_points(points, stride, in_dtype, vps, n, 0.0, nan, nan, out_dtype, t_dirs, t_depth, t_vps, nullptr, count_all, sub,
+                                sub_bytes, stream);
+  if (rc) return rc;
+  if ((rc = dc_to_points(t_vps, (int)n, t_dirs, t_depth, out_dtype, n, t_pts, stream))) return rc;
+  if ((rc = dc_shadow_filter(t_pts, t_vps, (int)n, t_dirs, out_dtype, n, shadow_r, shadow_lo, shadow_hi, mask, sub, sub_bytes, stream))) return rc;
+  const int es = out_dtype == DC_F32 ? 4 : 8;
+  const void* src[4] = {t_vps, t_dirs, t_depth, t_pts};
+  void* dst[4] = {vps_out, dirs_out, depth_out, points_out};
+  const int32_t rb[4] = {3 * es, 3 * es, es, 3 * es};
+  return dc_compact_rows(mask, n, 4, src, dst, rb, nullptr, count_out, sub, sub_bytes, stream);
 }
 
 }  // extern "C"

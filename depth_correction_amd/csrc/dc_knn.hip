@@ -48,7 +48,7 @@ __device__ __forceinline__ uint64_t morton3(int32_t x, int32_t y, int32_t z) {
 // TWO LEVELS.  The cell edge h is chosen from the cloud's AVERAGE areal density, but lidar density is anything but uniform: weighted
 // by query, the 27 cells around a query hold 110 points on the 2 M-point test cloud (median 77, 90th percentile 245) for k = 10.  So
 // the grid has a second, fine level of edge h / 2: the points are ordered by the 30-bit Morton code of their FINE cell (10 bits per
-// axis; grid_setup_kernel keeps the coarse level below 512 cells per axis), a coarse cell is then eight consecutive fine cells --
+// axis; grid_from_box keeps the coarse level below 512 cells per axis), a coarse cell is then eight consecutive fine cells --
 // one sorted array serves both levels -- and the hash table's entry of a coarse cell carries the starts of its eight fine cells.
 // knn_group_kernel searches at the fine level where the query's own coarse cell holds at least g_knn_fine_min points (mean
 // candidates 110 -> 53 at 16, 11.6 % instead of 11.2 % of the queries need a second stage); every other kernel uses the coarse level.
@@ -193,11 +193,7 @@ __device__ __forceinline__ void combine_box_partials(const double* __restrict__ 
 //   otherwise     : lidar points lie on surfaces; with areal density sigma ~ N / A(bbox) a cell of edge
 //                   h holds ~ sigma h^2 points and a ball of radius h ~ pi sigma h^2, so h = sqrt(A k / (2N))
 //                   lets most queries finish after the first shell.
-__global__ void grid_setup_kernel(const double* __restrict__ part, int n_part, int64_t n, int k, double cell_hint,
-                                  Grid* __restrict__ g) {
-  __shared__ double tot[kBoxVals];
-  combine_box_partials(part, n_part, tot);
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void grid_from_box(const double* tot, int64_t n, int k, double cell_hint, Grid* g) {
   double lo[3] = {tot[0], tot[1], tot[2]}, hi[3] = {tot[3], tot[4], tot[5]};
   const double sum[3] = {tot[6], tot[7], tot[8]}, sq[3] = {tot[9], tot[10], tot[11]}, cnt = tot[12];
   // The grid covers the bulk of the cloud: the bounding box cut to mean +- 6 sigma per axis.  A few far outliers
@@ -236,13 +232,26 @@ __global__ void grid_setup_kernel(const double* __restrict__ part, int n_part, i
   }
 }
 
+// Every block finishes the box itself (a few hundred partial rows) and derives the grid from it -- the launch of a one-block set-up
+// kernel between two passes over the points costs more than the 20 MB of cached re-reads --; block 0 stores the grid for the kernels
+// that follow.  The blocks also clear the hash table of the cells (filled after the sort) and the pending-query counter.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__ xyz, int stride, int64_t n,
-                                                           const Grid* __restrict__ gp, GridKey* __restrict__ keys,
-                                                           int32_t* __restrict__ ids) {
+__global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__ xyz, int stride, int64_t n, const double* __restrict__ part,
+                                                           int n_part, int k, double cell_hint, Grid* __restrict__ gp,
+                                                           GridKey* __restrict__ keys, int32_t* __restrict__ ids,
+                                                           uint64_t* __restrict__ tab_key, uint32_t tab_n, int32_t* __restrict__ n_pending) {
+  __shared__ double tot[kBoxVals];
+  __shared__ Grid s_g;
+  combine_box_partials(part, n_part, tot);
+  if (threadIdx.x == 0) {
+    grid_from_box(tot, n, k, cell_hint, &s_g);
+    if (blockIdx.x == 0) { *gp = s_g; *n_pending = 0; }
+  }
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < tab_n; e += (uint64_t)gridDim.x * kBlock) tab_key[e] = kEmptyKey;
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const Grid g = *gp;
+  const Grid g = s_g;
   double p[3];
   int32_t c[3];
   load_xyz(xyz, i, stride, p);
@@ -296,53 +305,39 @@ struct CellTable {
   uint32_t mask;
 };
 
-// Gather the sorted fp64 coordinates and insert the key of every coarse cell (at its first point) into the hash table.
+// Gather the sorted fp64 coordinates and fill the hash table: the first point of every FINE cell and the last point of every coarse
+// cell find -- or claim -- the table slot of their coarse cell (one compare-and-swap serves both) and write the positions they know:
+// the first point of a fine cell its position into s[i] of its coarse cell and into the entries of the empty fine cells before it
+// (back to the previous point's fine cell, or to 0 at the coarse cell's first point); the last point of the coarse cell the end into
+// the rest.  (Two kernels until round 5: all keys first, then the positions.)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void sorted_points_kernel(const T* __restrict__ xyz, int stride, int64_t n,
-                                                               const GridKey* __restrict__ skeys,
-                                                               const int32_t* __restrict__ sids,
-                                                               double* __restrict__ sp, uint64_t* __restrict__ tab_key, uint32_t tab_mask) {
+__global__ __launch_bounds__(kBlock) void sorted_cells_kernel(const T* __restrict__ xyz, int stride, int64_t n,
+                                                              const GridKey* __restrict__ skeys, const int32_t* __restrict__ sids,
+                                                              double* __restrict__ sp, uint64_t* __restrict__ tab_key,
+                                                              int32_t* __restrict__ tab_s, uint32_t tab_mask) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   double x[3];
   load_xyz(xyz, sids[p], stride, x);
   sp[p * 3] = x[0]; sp[p * 3 + 1] = x[1]; sp[p * 3 + 2] = x[2];
   const GridKey mk = skeys[p];
-  if (p == 0 || (skeys[p - 1] >> 3) != (mk >> 3)) {
-    const int32_t cx = (int32_t)compact10(mk) >> 1, cy = (int32_t)compact10(mk >> 1) >> 1, cz = (int32_t)compact10(mk >> 2) >> 1;
-    const uint64_t key = cell_key(cx, cy, cz);
-    uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
-    while (true) {
-      const unsigned long long prev = atomicCAS((unsigned long long*)&tab_key[slot], (unsigned long long)kEmptyKey,
-                                                (unsigned long long)key);
-      if (prev == kEmptyKey || prev == key) break;
-      slot = (slot + 1) & tab_mask;
-    }
-  }
-}
-
-// The fine-cell starts of every coarse cell (second pass: all keys are in the table).  The first point of a fine cell writes its
-// position into s[i] of its coarse cell and into the entries of the empty fine cells before it (back to the previous point's
-// fine cell, or to 0 at the coarse cell's first point); the last point of the coarse cell writes the end into the rest.
-__global__ __launch_bounds__(kBlock) void cell_end_kernel(int64_t n, const GridKey* __restrict__ skeys,
-                                                          const uint64_t* __restrict__ tab_key, int32_t* __restrict__ tab_s,
-                                                          uint32_t tab_mask) {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n) return;
-  const GridKey mk = skeys[p];
-  const bool c_head = p == 0 || (skeys[p - 1] >> 3) != (mk >> 3);
-  const bool f_head = p == 0 || skeys[p - 1] != mk;
-  const bool c_tail = p == n - 1 || (skeys[p + 1] >> 3) != (mk >> 3);
+  const GridKey prev_k = p > 0 ? skeys[p - 1] : 0u, next_k = p < n - 1 ? skeys[p + 1] : 0u;
+  const bool c_head = p == 0 || (prev_k >> 3) != (mk >> 3);
+  const bool f_head = p == 0 || prev_k != mk;
+  const bool c_tail = p == n - 1 || (next_k >> 3) != (mk >> 3);
   if (!f_head && !c_tail) return;
-  const int32_t fx = (int32_t)compact10(mk), fy = (int32_t)compact10(mk >> 1), fz = (int32_t)compact10(mk >> 2);
-  const int32_t cx = fx >> 1, cy = fy >> 1, cz = fz >> 1;
+  const int32_t cx = (int32_t)compact10(mk) >> 1, cy = (int32_t)compact10(mk >> 1) >> 1, cz = (int32_t)compact10(mk >> 2) >> 1;
   const uint64_t key = cell_key(cx, cy, cz);
   uint32_t slot = cell_hash(cx, cy, cz) & tab_mask;
-  while (tab_key[slot] != key) slot = (slot + 1) & tab_mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS((unsigned long long*)&tab_key[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) break;
+    slot = (slot + 1) & tab_mask;
+  }
   int32_t* s = tab_s + (int64_t)slot * kCellStride;
   const int i = (int)(mk & 7u);                    // Morton sub-index of the fine cell: x | y << 1 | z << 2
   if (f_head) {
-    const int from = c_head ? 0 : (int)(skeys[p - 1] & 7u) + 1;
+    const int from = c_head ? 0 : (int)(prev_k & 7u) + 1;
     for (int j = from; j <= i; ++j) s[j] = (int32_t)p;
   }
   if (c_tail) {
@@ -450,7 +445,8 @@ __global__ __launch_bounds__(kBlock, KMAX <= 16 ? 4 : 1) void knn_query_kernel(c
                                                            const Grid* __restrict__ gp, CellTable tab, int k, double r_max,
                                                            int64_t n_points, int r_exhaust,
                                                            int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                           int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending) {
+                                                           int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending,
+                                                           int64_t* __restrict__ idx64_out) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= n_query) return;
   const Grid g = *gp;
@@ -631,6 +627,7 @@ __global__ __launch_bounds__(kBlock, KMAX <= 16 ? 4 : 1) void knn_query_kernel(c
     if (s < k) {
       const bool ok = bi[s] != 0x7fffffff;
       idx_out[row * k + s] = ok ? bi[s] : -1;
+      if (idx64_out) idx64_out[row * k + s] = ok ? (int64_t)bi[s] : -1;
       if (dist_out) dist_out[row * k + s] = ok ? sqrt(bd[s]) : INFINITY;
     }
   }
@@ -680,7 +677,8 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
                                                           const double* __restrict__ queries, const int32_t* __restrict__ qids,
                                                           const int32_t* __restrict__ pending, const int32_t* __restrict__ n_pending,
                                                           const Grid* __restrict__ gp, CellTable tab, int k, double r_max, int64_t n_points,
-                                                          int r_exhaust, int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                          int r_exhaust, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                          int64_t* __restrict__ idx64_out) {
   __shared__ double s_d[kWavesPerBlock][KMAX + kTailCap];
   __shared__ int32_t s_i[kWavesPerBlock][KMAX + kTailCap];
   __shared__ double s_nd[kWavesPerBlock][KMAX];
@@ -795,6 +793,7 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
     for (int s = lane; s < k; s += kWave) {
       const bool ok = pi[s] != 0x7fffffff;
       idx_out[row * k + s] = ok ? pi[s] : -1;
+      if (idx64_out) idx64_out[row * k + s] = ok ? (int64_t)pi[s] : -1;
       if (dist_out) dist_out[row * k + s] = ok ? sqrt(pd[s]) : INFINITY;
     }
     wave_sync();
@@ -864,7 +863,7 @@ __global__ __launch_bounds__(kBlock, 5) void knn_group_kernel(const double* __re
                                                            int64_t n_query, const Grid* __restrict__ gp, CellTable tab, int k,
                                                            double r_max, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                            int r_budget, int32_t* __restrict__ pending, int32_t* __restrict__ n_pending,
-                                                           int fine_min, const uint8_t* __restrict__ fine_flag) {
+                                                           int fine_min, const uint8_t* __restrict__ fine_flag, int64_t* __restrict__ idx64_out) {
   __shared__ int32_t s_hist[kGrpPerBlock][kGrp];
   __shared__ double s_pd[kGrpPerBlock][kGrpPool];
   __shared__ int32_t s_pi[kGrpPerBlock][kGrpPool];
@@ -1085,6 +1084,7 @@ __global__ __launch_bounds__(kBlock, 5) void knn_group_kernel(const double* __re
   if (valid && !unsettled && sub < k) {
     const bool ok = bi != kNone;
     idx_out[row * k + sub] = ok ? bi : -1;
+    if (idx64_out) idx64_out[row * k + sub] = ok ? (int64_t)bi : -1;
     if (dist_out) dist_out[row * k + sub] = ok ? sqrt(bd) : INFINITY;
   }
 }
@@ -1381,13 +1381,15 @@ static GridWs carve_grid(void* ws, int64_t n, int64_t n_query_extra) {
 template <typename T>
 static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hint, GridWs& w, hipStream_t st) {
   const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL((bbox_partial_kernel<T>), dim3(kBoxBlocks), dim3(kBlock), 0, st, xyz, stride, n, w.part);
-  hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(kBlock), 0, st, w.part, kBoxBlocks, n, k, cell_hint, w.grid);
-  hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.grid, w.keys, w.ids);
+  // (the box in at most kBoxBlocks partial rows, four points per lane: every block of cell_keys_kernel re-reads them)
+  const int64_t want_box = (n + 4 * kBlock - 1) / (4 * kBlock);
+  const int n_box = (int)(want_box < 1 ? 1 : (want_box > kBoxBlocks ? kBoxBlocks : want_box));
+  hipLaunchKernelGGL((bbox_partial_kernel<T>), dim3(n_box), dim3(kBlock), 0, st, xyz, stride, n, w.part);
+  hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, (const double*)w.part, n_box, k, cell_hint, w.grid,
+                     w.keys, w.ids, w.tab_key, w.tab_n, w.n_pending);
   DC_HIP(sort_pairs_u32(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, kGridKeyBits, st));
-  DC_HIP(hipMemsetAsync(w.tab_key, 0xff, (size_t)w.tab_n * sizeof(uint64_t), st));
-  hipLaunchKernelGGL((sorted_points_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp, w.tab_key, w.tab_n - 1);
-  hipLaunchKernelGGL(cell_end_kernel, dim3(nb), dim3(kBlock), 0, st, n, w.skeys, w.tab_key, w.tab_s, w.tab_n - 1);
+  hipLaunchKernelGGL((sorted_cells_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp, w.tab_key, w.tab_s,
+                     w.tab_n - 1);
   DC_HIP(hipGetLastError());
   return DC_OK;
 }
@@ -1404,7 +1406,7 @@ static bool knn_rows_per_query(int k) {
 
 static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, const double* q, const int32_t* qids, int64_t nq,
                       const Grid* g, CellTable tab, double r, int32_t* idx, double* dist, int32_t* pending, int32_t* n_pending,
-                      const uint8_t* fine_flag, hipStream_t st) {
+                      const uint8_t* fine_flag, int64_t* idx64, hipStream_t st) {
   const dim3 grid((unsigned)((nq + kBlock - 1) / kBlock)), block(kBlock);
   // shells 0..R hold (2R+1)^3 cells at ~4 candidates' worth of work each; a scan of all n points costs n candidates
   int r_exhaust = (int)(cbrt((double)n * 0.25) * 0.5);
@@ -1417,14 +1419,14 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
   if (raw == kKnnBudgetAuto) raw = nq >= 1000000 ? 4 : 2;
   const int budget = raw >= 100 ? raw - 100 : raw;
   if (budget < 0) pending = nullptr;
-  if (pending) DC_HIP(hipMemsetAsync(n_pending, 0, sizeof(int32_t), st));
+  // (n_pending was zeroed by cell_keys_kernel of the grid build that precedes every call)
   if (pending && knn_rows_per_query(k)) {
     const dim3 ggrid((unsigned)((nq + kGrpPerBlock - 1) / kGrpPerBlock));
     hipLaunchKernelGGL(knn_group_kernel, ggrid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist, budget, pending, n_pending,
-                       g_knn_fine_min.load(), fine_flag);
+                       g_knn_fine_min.load(), fine_flag, idx64);
   } else {
 #define LK(KM) hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, n, r_exhaust, idx, dist, \
-                                  budget, pending, n_pending)
+                                  budget, pending, n_pending, idx64)
     // the sorted insertion costs ~12 instructions per slot and runs for a whole wavefront whenever one lane accepts a
     // candidate, so the slot count follows k closely (10 = the reference's default nn_k)
     if (k <= 4) LK(4); else if (k <= 8) LK(8); else if (k <= 10) LK(10); else if (k <= 16) LK(16); else if (k <= 32) LK(32); else LK(64);
@@ -1434,7 +1436,7 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
     // one wavefront per pending query; their number stays on the device (the grid is fixed, wavefronts stride over the list)
     const int64_t want = (nq + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 tgrid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048));
-#define LT(KM) hipLaunchKernelGGL((knn_tail_kernel<KM>), tgrid, block, 0, st, sp, sids, q, qids, pending, n_pending, g, tab, k, r, n, r_exhaust, idx, dist)
+#define LT(KM) hipLaunchKernelGGL((knn_tail_kernel<KM>), tgrid, block, 0, st, sp, sids, q, qids, pending, n_pending, g, tab, k, r, n, r_exhaust, idx, dist, idx64)
     if (k <= 16) LT(16); else LT(64);
 #undef LT
   }
@@ -1552,6 +1554,14 @@ size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
 int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride, int64_t n_query,
                  int k, double r, double cell_hint, int32_t* idx_out, double* dist_out, void* ws, size_t ws_bytes,
                  hipStream_t stream) {
+  return dc_knn_build_i64(points, stride, dtype, n, query, q_stride, n_query, k, r, cell_hint, idx_out, nullptr, dist_out, ws, ws_bytes, stream);
+}
+
+// The same, with the table written a second time as int64 (the index type of the reference's tensors, nearest_neighbors.py:78): the
+// conversion pass over the table -- a launch of its own per build -- folds into the kernels' stores.
+int dc_knn_build_i64(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride, int64_t n_query,
+                     int k, double r, double cell_hint, int32_t* idx_out, int64_t* idx64_out, double* dist_out, void* ws, size_t ws_bytes,
+                     hipStream_t stream) {
   if (n == 0 && !query) return DC_OK;
   if (!points || n < 0 || k < 1 || k > 64 || !idx_out || !ws || stride < 3) return DC_ERR_ARG;
   if (n >= (int64_t)0x7fffffff) return DC_ERR_UNSUPPORTED;
@@ -1562,6 +1572,7 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
   if (n == 0) {
     if (query && n_query > 0) {
       DC_HIP(hipMemsetAsync(idx_out, 0xff, (size_t)n_query * k * sizeof(int32_t), stream));
+      if (idx64_out) DC_HIP(hipMemsetAsync(idx64_out, 0xff, (size_t)n_query * k * sizeof(int64_t), stream));
       // dist = inf is not a byte pattern; callers treat idx = -1 as authoritative
     }
     return DC_OK;
@@ -1580,13 +1591,13 @@ int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const voi
                          w.tab_n - 1, fine_min, w.fine);
       flags = w.fine;
     }
-    return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, flags, stream);
+    return launch_knn(k, w.sp, w.sids, n, w.sp, w.sids, n, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, flags, idx64_out, stream);
   }
   if (n_query == 0) return DC_OK;
   const dim3 grid((unsigned)((n_query + kBlock - 1) / kBlock)), block(kBlock);
   if (dtype == DC_F32) hipLaunchKernelGGL((to_f64_kernel<float>), grid, block, 0, stream, (const float*)query, q_stride, n_query, w.qf64);
   else hipLaunchKernelGGL((to_f64_kernel<double>), grid, block, 0, stream, (const double*)query, q_stride, n_query, w.qf64);
-  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, nullptr, stream);
+  return launch_knn(k, w.sp, w.sids, n, w.qf64, nullptr, n_query, w.grid, tab, r, idx_out, dist_out, w.pending, w.n_pending, nullptr, idx64_out, stream);
 }
 
 // Radius search, pass 1: per-point neighbour counts and their maximum (device scalars).

@@ -78,6 +78,28 @@ __global__ __launch_bounds__(kBlock) void scan_compact_kernel(const TI* __restri
   if (index_out) index_out[o] = (int32_t)i;
 }
 
+// no crop and no depth bounds: every row is kept -- one kernel, no flags, no prefix sums
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kBlock) void scan_direct_kernel(const TI* __restrict__ pts, int stride, const TI* __restrict__ vps, int64_t n,
+                                                             TO* __restrict__ dirs, TO* __restrict__ depth, TO* __restrict__ vps_out,
+                                                             int32_t* __restrict__ index_out, int64_t* __restrict__ count_out) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0) *count_out = n;
+  TO ray[3], vp[3];
+  ray_of<TI, TO>(pts, stride, vps, i, ray, vp);
+  const TO d = sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+  depth[i] = d;
+  const bool unit = d > (TO)0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    dirs[i * 3 + a] = unit ? ray[a] / d : ray[a];
+    if (vps_out) vps_out[i * 3 + a] = vp[a];
+  }
+  if (index_out) index_out[i] = (int32_t)i;
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -109,8 +131,14 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
   void* tmp = c.take<char>(cb);
   const double lo = (min_depth == min_depth) ? min_depth : -INFINITY, hi = (max_depth == max_depth) ? max_depth : INFINITY;   // NaN = unbounded
   const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  const bool unfiltered = !(ego_box > 0.0) && lo == -INFINITY && hi == INFINITY;
 #define RUN(TI, TO)                                                                                                          \
   do {                                                                                                                       \
+    if (unfiltered) {                                                                                                        \
+      hipLaunchKernelGGL((scan_direct_kernel<TI, TO>), grid, block, 0, stream, (const TI*)points, stride, (const TI*)vps, n,  \
+                         (TO*)dirs_out, (TO*)depth_out, (TO*)vps_out, index_out, count_out);                                 \
+      break;                                                                                                                 \
+    }                                                                                                                        \
     hipLaunchKernelGGL((scan_flags_kernel<TI, TO>), grid, block, 0, stream, (const TI*)points, stride, (const TI*)vps, n,     \
                        (TI)ego_box, (TI)lo, (TI)hi, keep);                                                                   \
     DC_HIP(exclusive_scan_32(tmp, cb, keep, pos, (size_t)n, stream));                                                        \

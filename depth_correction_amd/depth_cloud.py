@@ -93,10 +93,17 @@ class DepthCloud(object):
         if isinstance(item, list) and len(item) > 0 and isinstance(item[0], str):
             return DepthCloud(**{f: getattr(self, f) for f in item})
         if isinstance(item, torch.Tensor) and item.dtype == torch.bool and item.dim() == 1 and item.is_cuda:
-            # x[mask] runs a count + a partition + a gather per FIELD; the surviving rows are found once here
+            # x[mask] runs a count + a partition + a gather per FIELD; here every field's kept rows are placed by one pair of launches
+            # (dc_compact_rows) -- outside autograd; fields that carry a gradient take the index_select they can differentiate
+            names = [f for f in DepthCloud.sliced_fields if getattr(self, f) is not None]
+            fields = [getattr(self, f) for f in names]
+            n = len(self)
+            plain = [f.shape[0] == n and not (f.requires_grad and torch.is_grad_enabled()) for f in fields]
+            if item.shape[0] == n and all(plain) and len(fields) <= 8:
+                kept = ops.compact_rows(item, [f.detach() for f in fields])
+                return DepthCloud(**dict(zip(names, kept)))
             item = item.nonzero().squeeze(1)
-            return DepthCloud(**{f: getattr(self, f).index_select(0, item) for f in DepthCloud.sliced_fields
-                                 if getattr(self, f) is not None})
+            return DepthCloud(**{f: x.index_select(0, item) if x.shape[0] == n else x[item] for f, x in zip(names, fields)})
         return DepthCloud(**{f: getattr(self, f)[item] for f in DepthCloud.sliced_fields if getattr(self, f) is not None})
 
     def __add__(self, other):
@@ -188,8 +195,8 @@ class DepthCloud(object):
             # device tensors: one kernel (dc_cloud_from_points) instead of five elementwise passes
             vps_t = None if vps is None else torch.as_tensor(vps, dtype=pts.dtype, device=pts.device).contiguous()
             assert vps_t is None or vps_t.shape == pts.shape
-            v, dirs, depth, _ = ops.cloud_from_points(pts.contiguous(), vps_t, dtype=dtype or pts.dtype)
-            kwargs = dict(vps=torch.zeros_like(dirs) if v is None else v, dirs=dirs, depth=depth)
+            v, dirs, depth, _ = ops.cloud_from_points(pts.contiguous(), vps_t, dtype=dtype or pts.dtype, want_zero_vps=True)
+            kwargs = dict(vps=v, dirs=dirs, depth=depth)
         else:
             pts = pts.to(dtype) if dtype is not None else pts
             vps = torch.zeros_like(pts) if vps is None else torch.as_tensor(vps, dtype=dtype, device=device)
@@ -221,6 +228,11 @@ class DepthCloud(object):
 
     # ---- K2 / K3 ------------------------------------------------------------------------------------
     def to_points(self):
+        v, d, r = self.vps, self.dirs, self.depth
+        if d.is_cuda and d.dtype in (torch.float32, torch.float64) and v.dtype == d.dtype == r.dtype and d.dim() == 2 and d.is_contiguous() \
+                and v.is_contiguous() and r.is_contiguous() and v.device == d.device == r.device \
+                and not (torch.is_grad_enabled() and (v.requires_grad or d.requires_grad or r.requires_grad)):
+            return ops.to_points(v, d, r)          # the same two roundings in one kernel (dc_to_points)
         return self.vps + self.depth * self.dirs
 
     def update_points(self):
@@ -247,10 +259,17 @@ class DepthCloud(object):
         assert self.neighbors is not None
         return self.neighbors >= 0
 
-    def update_neighbors(self, k=None, r=None):
+    def update_neighbors(self, k=None, r=None, _weights=True):
         assert self.points is not None
         self._distances, self.neighbors = nearest_neighbors(self.get_points(), self.get_points(), k=k, r=r)
-        self.weights = (self.graph().nbr >= 0).float()[..., None]          # valid_neighbor_mask() read off the int32 table
+        self.neighbor_points = None
+        self._feat = None
+        if not _weights:            # update_all: update_features writes the same validity weights a moment later
+            self.weights = None
+            return
+        nbr = self.graph().nbr
+        # valid_neighbor_mask() read off the int32 table (one kernel on the device)
+        self.weights = ops.valid_weights(nbr) if nbr.is_cuda and nbr.is_contiguous() else (nbr >= 0).float()[..., None]
         self.weights._dc_validity = True
         self.neighbor_points = None
         self._feat = None
@@ -364,7 +383,7 @@ class DepthCloud(object):
         if keep_neighbors:
             self.update_distances()
         else:
-            self.update_neighbors(k=k, r=r)
+            self.update_neighbors(k=k, r=r, _weights=False)
         self.update_features(scale=scale)
 
     # ---- K13 helpers ------------------------------------------------------------------------------------------

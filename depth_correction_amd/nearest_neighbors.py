@@ -36,15 +36,15 @@ def nearest_neighbors(points, query, k=None, r=None, n_jobs=-1):
         pts, qry = pts.double(), qry.double()
     same = qry.data_ptr() == pts.data_ptr() and qry.shape == pts.shape
     if k:
-        dist, ind = ops.knn(pts, int(k), r=r, query=None if same else qry.to(pts.dtype))
-        return dist, _as_reference_index(ind)
+        dist, ind, ind64 = ops.knn(pts, int(k), r=r, query=None if same else qry.to(pts.dtype), want_index64=True)
+        return dist, _as_reference_index(ind, ind64)
     return None, _as_reference_index(ops.radius_neighbors(pts, float(r), query=None if same else qry.to(pts.dtype)))
 
 
-def _as_reference_index(ind32):
+def _as_reference_index(ind32, ind64=None):
     """int64 copy of the builder's int32 table (the reference's index dtype, nearest_neighbors.py:78) that REMEMBERS the int32
     table it came from: the kernels behind DepthCloud take int32, and converting back cost a pass per consumer."""
     from .autograd import NeighborhoodGraph
-    ind = ind32.long()
+    ind = ind32.long() if ind64 is None else ind64        # (the k-NN kernels write both tables)
     ind._dc_graph = NeighborhoodGraph(ind, nbr=ind32)
     return ind

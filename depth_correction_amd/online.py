@@ -5,7 +5,8 @@
     dc.update_points()
 
 ``correct_cloud`` is that sequence under ``torch.no_grad()``; the input is a structured / plain array as ``numpify`` of a
-PointCloud2 yields, or a DepthCloud already on the device (scan_io.cloud_on_device).  Message conversion (ros_numpy)
+PointCloud2 yields, the uploaded rows [N, >=3] as a device tensor (the fastest way in: from_points, shadow filter and
+``cloud[mask]`` are then one native call, dc_scan_prefilter), or a DepthCloud already on the device (scan_io.cloud_on_device).  Message conversion (ros_numpy)
 and publishing stay outside (ROS is out of scope); ``to_structured_array`` on the result gives the fields the
 node publishes.
 """

@@ -15,7 +15,7 @@ from ._native import lib, check, need, ptr, stream_ptr, dtype_code, on_device
 __all__ = [
     'knn', 'radius_neighbors', 'knn_transpose', 'BlockTable', 'block_table', 'table_to_csr', 'spatial_order', 'points_fwd', 'points_bwd', 'features_fwd',
     'features_bwd', 'consistency_fwd', 'consistency_bwd', 'mask_bounds', 'valid_count', 'dispersion', 'p2plane_pair', 'p2point_pair',
-    'IcpSequence', 'shadow_mask', 'shadow_filter', 'correct_depth', 'cloud_from_points',
+    'IcpSequence', 'shadow_mask', 'shadow_filter', 'correct_depth', 'cloud_from_points', 'mask_bounds_all', 'compact_rows', 'to_points', 'valid_weights', 'scan_prefilter',
     'as_index32', 'scan_ids', 'points_extent', 'gather_rows', 'cat_rows',
 ]
 
@@ -36,8 +36,9 @@ def as_index32(neighbors):
 # neighbourhood builder
 # ------------------------------------------------------------------------------------------------
 @on_device
-def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
-    """k-NN of ``query`` (default: ``points`` itself) in ``points``: (dist f64 [M,k] | None, idx i32 [M,k])."""
+def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True, want_index64=False):
+    """k-NN of ``query`` (default: ``points`` itself) in ``points``: (dist f64 [M,k] | None, idx i32 [M,k]); with
+    ``want_index64`` a third result, the same table as int64 written by the same kernels (dc_knn_build_i64)."""
     need(points, (None, 3), name='points')
     n = points.shape[0]
     if not (1 <= k <= 64):
@@ -46,16 +47,18 @@ def knn(points, k, r=None, query=None, cell_hint=0.0, want_dist=True):
         need(query, (None, 3), dtype=points.dtype, name='query', device=points.device)
     m = n if query is None else query.shape[0]
     idx = torch.empty((m, k), dtype=torch.int32, device=points.device)
-    dist = torch.full((m, k), float('inf'), dtype=torch.float64, device=points.device) if want_dist else None
+    # (the kernels write every entry of both tables -- inf beside a missing neighbour --; only the empty cloud needs the fill)
+    dist = (torch.empty if n else torch.full)((m, k), *(() if n else (float('inf'),)), dtype=torch.float64, device=points.device) if want_dist else None
     if n == 0:
         idx.fill_(-1)
-        return dist, idx
+        return (dist, idx, idx.long()) if want_index64 else (dist, idx)
+    idx64 = torch.empty((m, k), dtype=torch.int64, device=points.device) if want_index64 else None
     nbytes = lib().dc_knn_workspace_bytes(n, 0 if query is None else m)
     ws = _ws(nbytes, points.device)
-    check(lib().dc_knn_build(ptr(points), 3, dtype_code(points), n, ptr(query), 3, 0 if query is None else m, k,
-                             float(r) if r else 0.0, float(cell_hint), ptr(idx), ptr(dist), ptr(ws), nbytes,
-                             stream_ptr()), 'dc_knn_build')
-    return dist, idx
+    check(lib().dc_knn_build_i64(ptr(points), 3, dtype_code(points), n, ptr(query), 3, 0 if query is None else m, k,
+                                 float(r) if r else 0.0, float(cell_hint), ptr(idx), ptr(idx64), ptr(dist), ptr(ws), nbytes,
+                                 stream_ptr()), 'dc_knn_build_i64')
+    return (dist, idx, idx64) if want_index64 else (dist, idx)
 
 
 @on_device
@@ -659,6 +662,109 @@ def mask_bounds(mask, num, num_index=0, den=None, den_index=0, lo=None, hi=None)
 
 
 @on_device
+def mask_bounds_all(values, bounds, mask=None):
+    """bool [N]: every ``(num_index, den_index | None, lo, hi)`` of ``bounds`` on the columns of ``values`` [N, C] in ONE pass
+    (dc_mask_bounds_multi), ANDed into ``mask`` when given (in place), else into a new mask."""
+    n = values.shape[0]
+    v2 = values.reshape(n, -1)
+    need(v2, (n, None), name='values')
+    init = mask is None
+    if init:
+        mask = torch.empty((n,), dtype=torch.bool, device=v2.device)
+    need(mask, (n,), dtype=torch.bool, name='mask', device=v2.device)
+    nb = len(bounds)
+    if nb > 8:
+        raise ValueError('at most 8 bounds per pass')
+    num = (ctypes.c_int32 * max(nb, 1))(*[int(b[0]) for b in bounds])
+    den = (ctypes.c_int32 * max(nb, 1))(*[-1 if b[1] is None else int(b[1]) for b in bounds])
+    lo = (ctypes.c_double * max(nb, 1))(*[_bound(b[2], float('-inf')) for b in bounds])
+    hi = (ctypes.c_double * max(nb, 1))(*[_bound(b[3], float('inf')) for b in bounds])
+    check(lib().dc_mask_bounds_multi(ptr(v2), v2.shape[1], dtype_code(v2), n, nb, num, den, lo, hi, 1 if init else 0, ptr(mask),
+                                     stream_ptr()), 'dc_mask_bounds_multi')
+    return mask
+
+
+@on_device
+def compact_rows(mask, fields, want_index=False):
+    """``[f[mask] for f in fields]`` (and the kept row numbers, int32) for up to 8 contiguous arrays of N rows on the device: two
+    launches and ONE synchronisation (the number of kept rows) for all of them (dc_compact_rows; depth_cloud.py:126-134)."""
+    n = mask.shape[0]
+    need(mask, (n,), dtype=torch.bool, name='mask')
+    dev = mask.device
+    if len(fields) > 8:
+        raise ValueError('at most 8 fields per call')
+    srcs, outs, rb = [], [], []
+    for f in fields:
+        if f.shape[0] != n or f.device != dev:
+            raise ValueError('every field needs %d rows on %s' % (n, dev))
+        f = f.contiguous()
+        srcs.append(f)
+        outs.append(torch.empty_like(f))
+        rb.append(f.element_size() * (f.numel() // n if n else 1))
+    index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
+    count = torch.empty((1,), dtype=torch.int64, device=dev)
+    nf = len(srcs)
+    a_src = (ctypes.c_void_p * max(nf, 1))(*[ptr(f) for f in srcs])
+    a_dst = (ctypes.c_void_p * max(nf, 1))(*[ptr(f) for f in outs])
+    a_rb = (ctypes.c_int32 * max(nf, 1))(*rb)
+    nbytes = lib().dc_compact_rows_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    check(lib().dc_compact_rows(ptr(mask), n, nf, a_src, a_dst, a_rb, ptr(index), ptr(count), ptr(ws), nbytes, stream_ptr()),
+          'dc_compact_rows')
+    m = int(count.item())
+    outs = [o[:m] for o in outs]
+    return (outs, index[:m]) if want_index else outs
+
+
+@on_device
+def scan_prefilter(points, vps, dtype, r, lo, hi):
+    """Raw rows [N, >=3] (and viewpoints [N,3] | None) on the device -> (vps, dirs, depth [M,1], points) of the rays the scan-shadow
+    filter keeps: from_points, to_points, dc_shadow_filter and cloud[mask] launched by ONE call (dc_scan_prefilter), one
+    synchronisation (M)."""
+    need(points, (None, None), name='points')
+    n, stride = points.shape
+    if stride < 3:
+        raise ValueError('points need at least 3 columns')
+    dev = points.device
+    dtype = points.dtype if dtype is None else dtype
+    if vps is not None:
+        need(vps, (n, 3), dtype=points.dtype, name='vps', device=dev)
+    outs = [torch.empty((n, c), dtype=dtype, device=dev) for c in (3, 3, 1, 3)]
+    count = torch.empty((1,), dtype=torch.int64, device=dev)
+    nbytes = lib().dc_scan_prefilter_workspace_bytes(n)
+    ws = _ws(nbytes, dev)
+    check(lib().dc_scan_prefilter(ptr(points), stride, dtype_code(points), ptr(vps), n, nv.DC_F32 if dtype == torch.float32 else nv.DC_F64,
+                                  float(r), float(lo), float(hi), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(count),
+                                  ptr(ws), nbytes, stream_ptr()), 'dc_scan_prefilter')
+    m = int(count.item())
+    return tuple(o[:m] for o in outs)
+
+
+@on_device
+def to_points(vps, dirs, depth):
+    """``vps + depth * dirs`` in one kernel, bit-equal to the two tensor operations (dc_to_points; no autograd)."""
+    n = dirs.shape[0]
+    need(dirs, (n, 3), name='dirs')
+    need(depth, (n, 1), dtype=dirs.dtype, name='depth', device=dirs.device)
+    vps = vps.reshape(-1, 3)
+    need(vps, (None, 3), dtype=dirs.dtype, name='vps', device=dirs.device)
+    if vps.shape[0] not in (1, n):
+        raise ValueError('vps must have 1 or %d rows' % n)
+    out = torch.empty_like(dirs)
+    check(lib().dc_to_points(ptr(vps), vps.shape[0], ptr(dirs), ptr(depth), dtype_code(dirs), n, ptr(out), stream_ptr()), 'dc_to_points')
+    return out
+
+
+@on_device
+def valid_weights(nbr):
+    """float32 [N, K, 1]: 1 where the table holds a neighbour (``valid_neighbor_mask().float()[..., None]``)."""
+    need(nbr, (None, None), dtype=torch.int32, name='neighbors')
+    out = torch.empty(tuple(nbr.shape) + (1,), dtype=torch.float32, device=nbr.device)
+    check(lib().dc_valid_weights(ptr(nbr), nbr.numel(), ptr(out), stream_ptr()), 'dc_valid_weights')
+    return out
+
+
+@on_device
 def valid_count(nbr):
     need(nbr, (None, None), dtype=torch.int32, name='neighbors')
     cnt = torch.empty((nbr.shape[0],), dtype=torch.int32, device=nbr.device)
@@ -682,7 +788,7 @@ def dispersion(vec, nbr, weights=None):
 
 
 @on_device
-def cloud_from_points(points, vps=None, dtype=None, ego_box=None, min_depth=None, max_depth=None, want_index=False):
+def cloud_from_points(points, vps=None, dtype=None, ego_box=None, min_depth=None, max_depth=None, want_index=False, want_zero_vps=False):
     """Raw rows [N, >=3] on the device -> (vps [M,3] | None, dirs [M,3], depth [M,1], index int64 [M] | None) of the rows
     that survive the ego-box crop and the depth bounds, in their original order (dc_cloud_from_points: kitti360.py:101-105,
     filters.py:116-141, depth_cloud.py:592-638).  One synchronisation (the number of kept rows) when a filter is active."""
@@ -696,13 +802,14 @@ def cloud_from_points(points, vps=None, dtype=None, ego_box=None, min_depth=None
         need(vps, (n, 3), dtype=points.dtype, name='vps', device=dev)
     dirs = torch.empty((n, 3), dtype=dtype, device=dev)
     depth = torch.empty((n, 1), dtype=dtype, device=dev)
-    vps_out = torch.empty((n, 3), dtype=dtype, device=dev) if vps is not None else None
+    filtered = bool(ego_box and ego_box > 0) or min_depth is not None or max_depth is not None
+    # (want_zero_vps: the kernel that writes the fields also writes the zero viewpoints of a cloud without any)
+    vps_out = torch.empty((n, 3), dtype=dtype, device=dev) if (vps is not None or want_zero_vps) else None
     index = torch.empty((n,), dtype=torch.int32, device=dev) if want_index else None
     count = torch.empty((1,), dtype=torch.int64, device=dev)
     nbytes = lib().dc_cloud_from_points_workspace_bytes(n)
     ws = _ws(nbytes, dev)
     nan = float('nan')
-    filtered = bool(ego_box and ego_box > 0) or min_depth is not None or max_depth is not None
     check(lib().dc_cloud_from_points(ptr(points), stride, dtype_code(points), ptr(vps), n, float(ego_box or 0.0),
                                      nan if min_depth is None else float(min_depth), nan if max_depth is None else float(max_depth),
                                      nv.DC_F32 if dtype == torch.float32 else nv.DC_F64, ptr(dirs), ptr(depth), ptr(vps_out),

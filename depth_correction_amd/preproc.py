@@ -40,6 +40,13 @@ def _and_mask(cloud, mask):
 
 def local_feature_cloud(cloud, cfg: Config):
     """Scan -> DepthCloud with neighbours, features and the planarity mask (preproc.py:35-64)."""
+    if isinstance(cloud, torch.Tensor):
+        # raw rows [N, >=3] already on the device (what the node holds after the upload of a message)
+        if cloud.is_cuda and cloud.dim() == 2 and cloud.dtype in (torch.float32, torch.float64) and cfg.shadow_angle_bounds:
+            cloud = _prefiltered_cloud(cloud.detach(), cfg)
+        else:
+            cloud = DepthCloud.from_points(cloud[:, :3], dtype=cfg.numpy_float_type(), device=cfg.device)
+        return _with_features(cloud, cfg)
     if isinstance(cloud, np.ndarray):
         make = DepthCloud.from_structured_array if cloud.dtype.names else DepthCloud.from_points
         cloud = make(cloud, dtype=cfg.numpy_float_type(), device=cfg.device)
@@ -51,16 +58,52 @@ def local_feature_cloud(cloud, cfg: Config):
         else:
             cloud.update_dir_neighbors(angle=cfg.shadow_neighborhood_angle)
             cloud = filter_shadow_points(cloud, cfg.shadow_angle_bounds, log=cfg.log_filters)
+    return _with_features(cloud, cfg)
+
+
+_chords = {}
+
+
+def _chord(angle):
+    from .nearest_neighbors import ball_angle_to_distance
+    if angle not in _chords:
+        _chords[angle] = float(ball_angle_to_distance(torch.as_tensor(angle)))
+    return _chords[angle]
+
+
+def _prefiltered_cloud(raw, cfg: Config):
+    """from_points + shadow filter + cloud[mask] of raw device rows in one native call (dc_scan_prefilter): the first statements of
+    local_feature_cloud (preproc.py:36-47) without the host between their launches; the same kernels, the same cloud."""
+    from . import ops
+    from .filters import _shadow_bounds
+    lo, hi, _ = _shadow_bounds(cfg.shadow_angle_bounds)
+    # (the reference evaluates the chord in float32 tensor arithmetic, nearest_neighbors.py:13-19: kept, once per configuration value)
+    r = _chord(float(cfg.shadow_neighborhood_angle))
+    dtype = cfg.torch_float_type()
+    n = raw.shape[0]
+    vps, dirs, depth, points = ops.scan_prefilter(raw.contiguous(), None, dtype, r, lo, hi)
+    if cfg.log_filters:
+        print('%.3f = %i / %i points kept (shadow points removed).' % (len(dirs) / max(n, 1), len(dirs), n))
+    return DepthCloud(vps, dirs, depth, points=points)
+
+
+def _with_features(cloud, cfg: Config):
+    """Neighbourhoods, features and the planarity mask (preproc.py:48-63)."""
     cloud.update_all(k=cfg.nn_k, r=cfg.nn_r)
     if cloud.eigvals.is_cuda and not cfg.log_filters and (cfg.eigenvalue_bounds or cfg.eigenvalue_ratio_bounds):
         # the same masks ANDed in place, one kernel per bound (dc_mask_bounds): no ones / and passes between them
         from . import ops
+        bounds = [(int(e), None, lo, hi) for e, lo, hi in (cfg.eigenvalue_bounds or [])] + \
+                 [(int(i), int(j), lo, hi) for i, j, lo, hi in (cfg.eigenvalue_ratio_bounds or [])]
+        if len(bounds) <= 8:
+            # every bound in one pass over the eigenvalues (dc_mask_bounds_multi), written or ANDed into the mask
+            cloud.mask = ops.mask_bounds_all(cloud.eigvals.detach().contiguous(), bounds,
+                                             mask=None if cloud.mask is None else cloud.mask.clone())
+            return cloud
         mask = torch.ones((len(cloud),), dtype=torch.bool, device=cloud.device()) if cloud.mask is None else cloud.mask.clone()
         ev = cloud.eigvals.detach().contiguous()
-        for e, lo, hi in (cfg.eigenvalue_bounds or []):
-            ops.mask_bounds(mask, ev, int(e), lo=lo, hi=hi)
-        for i, j, lo, hi in (cfg.eigenvalue_ratio_bounds or []):
-            ops.mask_bounds(mask, ev, int(i), ev, int(j), lo, hi)
+        for i, j, lo, hi in bounds:
+            ops.mask_bounds(mask, ev, i, None if j is None else ev, 0 if j is None else j, lo, hi)
         cloud.mask = mask
         return cloud
     if cfg.eigenvalue_bounds:

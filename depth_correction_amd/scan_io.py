@@ -116,8 +116,8 @@ def cloud_on_device(raw, vps=None, dtype=None, device='cuda:0', ego_box=None, mi
     if vps is not None:
         vps = (vps if isinstance(vps, torch.Tensor) else upload(vps, device)).to(raw_t.dtype).contiguous()
     v, dirs, depth, _ = ops.cloud_from_points(raw_t.contiguous(), vps, dtype=dtype, ego_box=ego_box, min_depth=min_depth,
-                                              max_depth=max_depth)
-    return DepthCloud(torch.zeros_like(dirs) if v is None else v, dirs, depth)
+                                              max_depth=max_depth, want_zero_vps=True)
+    return DepthCloud(v, dirs, depth)
 
 
 def load_kitti_bin_device(path, device='cuda:0', dtype=None, filter_ego_pts_depth=1.0, min_depth=None, max_depth=None):

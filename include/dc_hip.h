@@ -72,6 +72,11 @@ int dc_knn_set_fine_cell_count(int points);
 int dc_knn_build(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride,
                  int64_t n_query, int k, double r, double cell_hint, int32_t* idx_out, double* dist_out, void* ws,
                  size_t ws_bytes, dcStream_t stream);
+/* dc_knn_build that also writes the table as int64 [., k] (idx64_out, optional): the reference's index dtype (nearest_neighbors.py:78)
+ * without a conversion pass. */
+int dc_knn_build_i64(const void* points, int stride, int dtype, int64_t n, const void* query, int q_stride,
+                 int64_t n_query, int k, double r, double cell_hint, int32_t* idx_out, int64_t* idx64_out, double* dist_out, void* ws,
+                 size_t ws_bytes, dcStream_t stream);
 
 /* Radius search (query_ball_point, nearest_neighbors.py:50-51,69-73), two passes over one workspace
  * (size dc_knn_workspace_bytes(n, 0)): counts + their maximum, then rows of ascending indices padded with -1. */
@@ -299,6 +304,33 @@ int dc_consistency_bwd(const void* points, int stride, int dtype, int point_fmt,
 int dc_mask_bounds(const void* num, int num_stride, int num_index, const void* den, int den_stride, int den_index,
                    int dtype, int64_t n, double lo, double hi, uint8_t* mask, dcStream_t stream);
 int dc_valid_count(const int32_t* nbr, int64_t n, int k, int32_t* count_out, dcStream_t stream);
+/* All bounds on the columns of ONE array [n, stride] in one pass (preproc.py:57-62: eigenvalue_bounds then
+ * eigenvalue_ratio_bounds on cloud.eigvals): mask = (init ? 1 : mask) & AND_b lo[b] <= v[i, num_index[b]] (/ v[i, den_index[b]] when
+ * den_index[b] >= 0) <= hi[b]; the arrays of the n_bounds <= 8 bounds are HOST arrays; +-inf = unbounded; NaN fails. */
+int dc_mask_bounds_multi(const void* values, int stride, int dtype, int64_t n, int n_bounds, const int32_t* num_index,
+                         const int32_t* den_index, const double* lo, const double* hi, int init, uint8_t* mask, dcStream_t stream);
+/* cloud[mask] (depth_cloud.py:126-134: every per-point field sliced by one boolean mask): the rows i with mask[i] != 0 of up to 8
+ * arrays, in their order, in two launches.  src / dst / row_bytes: HOST arrays of n_fields device pointers and row sizes in bytes
+ * (rows of a multiple of 4 bytes are copied by words and need 4-byte aligned arrays); every dst holds n rows.  index_out int32 [n]
+ * (optional): the kept row numbers.  *count_out (device int64) = number of kept rows.  ws: dc_compact_rows_workspace_bytes(n). */
+size_t dc_compact_rows_workspace_bytes(int64_t n);
+int dc_compact_rows(const uint8_t* mask, int64_t n, int n_fields, const void* const* src, void* const* dst, const int32_t* row_bytes,
+                    int32_t* index_out, int64_t* count_out, void* ws, size_t ws_bytes, dcStream_t stream);
+/* DepthCloud.to_points outside autograd (depth_cloud.py:251-252): points[i] = vps[i or 0] + depth[i] * dirs[i], the product and the sum
+ * rounded separately like the reference's two tensor operations (bit-equal to them).  vps_rows 1 or n. */
+int dc_to_points(const void* vps, int vps_rows, const void* dirs, const void* depth, int dtype, int64_t n, void* points_out,
+                 dcStream_t stream);
+/* The online node's first stage in one call (scripts/depth_correction:31-58, preproc.py:44-47): DepthCloud.from_points of the raw rows
+ * (no crop, no depth bounds: the node's input has passed them, scripts/depth_correction:42), points = vps + depth * dirs, the scan-shadow
+ * mask over the direction neighbourhoods of chord radius shadow_r with angle bounds [shadow_lo, shadow_hi] (dc_shadow_filter), and
+ * cloud[mask]: vps_out / dirs_out / points_out [m,3], depth_out [m] of the kept rays in their order (buffers of n rows), *count_out = m
+ * (device int64).  The same kernels as the separate calls -- bit-equal results --, launched without the host in between. */
+size_t dc_scan_prefilter_workspace_bytes(int64_t n);
+int dc_scan_prefilter(const void* points, int stride, int in_dtype, const void* vps, int64_t n, int out_dtype, double shadow_r,
+                      double shadow_lo, double shadow_hi, void* vps_out, void* dirs_out, void* depth_out, void* points_out,
+                      int64_t* count_out, void* ws, size_t ws_bytes, dcStream_t stream);
+/* weights = valid_neighbor_mask().float() (depth_cloud.py:341-343): weights_out[e] = nbr[e] >= 0 over `count` table entries. */
+int dc_valid_weights(const int32_t* nbr, int64_t count, float* weights_out, dcStream_t stream);
 /* ---- K17: inlier correspondences of a scan pair (train.py:186-193, 202-209; loss.py:440-452) ---------------------------------------
  * dist fp64 [n] / idx int32 [n]: the 1-NN of scan 1's points in scan 2 (dc_knn_build with k = 1 and a query).  threshold_out <-
  * np.quantile(dist[~isnan(dist)], ratio) (linear interpolation, numpy's lerp) found by a radix select on the device -- no sort --,
@@ -650,7 +682,8 @@ int dc_voxel_filter(const void* points, int stride, int dtype, int64_t n, double
  *   DepthCloud.from_points depth_cloud.py:592-638 in out_dtype: depth = |p - vp|, dirs = (p - vp) / depth, rays of zero
  *                         depth left un-normalised (:626-627),
  * and write dirs_out [m,3], depth_out [m], vps_out [m,3] (optional), index_out int32 [m] = kept source rows (optional),
- * *count_out = m (device int64).  Outputs must hold n rows.  ws: dc_cloud_from_points_workspace_bytes(n). */
+ * *count_out = m (device int64).  Outputs must hold n rows.  ws: dc_cloud_from_points_workspace_bytes(n).  With neither crop nor
+ * bounds every row is kept and one kernel writes the fields (vps_out of a NULL vps: zeros). */
 size_t dc_cloud_from_points_workspace_bytes(int64_t n);
 int dc_cloud_from_points(const void* points, int stride, int in_dtype, const void* vps, int64_t n, double ego_box,
                          double min_depth, double max_depth, int out_dtype, void* dirs_out, void* depth_out, void* vps_out,

@@ -1329,8 +1329,11 @@ def test_online_correction_sequence_golden(golden, tag):
         arr = unstructured_to_structured(np.concatenate([xyz + vp, vp], axis=1), names=['x', 'y', 'z', 'vp_x', 'vp_y', 'vp_z'])
         inputs = [arr]
     else:
+        # (a structured array, a DepthCloud on the device, and the uploaded raw rows: the last takes dc_scan_prefilter -- from_points,
+        #  shadow filter and cloud[mask] in one native call)
         inputs = [unstructured_to_structured(xyz, names=['x', 'y', 'z']),
-                  cloud_on_device(torch.as_tensor(xyz, device='cuda:0'), dtype=torch.float64)]
+                  cloud_on_device(torch.as_tensor(xyz, device='cuda:0'), dtype=torch.float64),
+                  torch.as_tensor(xyz, device='cuda:0')]
     for inp in inputs:
         dc = correct_cloud(inp, model, cfg)
         assert len(dc) == len(g[tag + '_depth']) < len(xyz)                                   # the shadow filter removed the same rays

@@ -695,3 +695,50 @@ def test_nn1_corr_quantile_select_vs_numpy(n, ratio):
     with np.errstate(invalid='ignore'):
         ref_mask = dist <= ref_th
     assert np.array_equal(mask.cpu().numpy(), ref_mask) and np.array_equal(sel.cpu().numpy(), idx[ref_mask])
+
+
+@pytest.mark.parametrize('n', [0, 1, 5, 511, 512, 513, 200_003, 2_200_000])
+def test_compact_rows_equals_boolean_indexing(dev, n):
+    """dc_compact_rows (cloud[mask], depth_cloud.py:126-134): the kept rows of several arrays in their order, bit for bit what torch's
+    boolean indexing returns -- rows of 1, 4, 12, 24, 36 and 6 bytes, block boundaries of the 512-row blocks, and beyond 4 096 blocks
+    (the prefix sum over the block counts instead of the blocks' own sums)."""
+    from depth_correction_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(n + 3)
+    mask = (torch.rand((n,), generator=g) < 0.8).to(dev)
+    fields = [torch.randn((n, 3), generator=g).to(dev), torch.randn((n, 1), generator=g).double().to(dev)]
+    if n < 1_000_000:
+        fields += [torch.randn((n, 3), generator=g).double().to(dev), (torch.rand((n,), generator=g) < 0.5).to(dev),
+                   torch.randint(0, 255, (n, 6), generator=g, dtype=torch.uint8).to(dev), torch.randn((n, 3, 3), generator=g).to(dev)]
+    outs, index = ops.compact_rows(mask, fields, want_index=True)
+    assert torch.equal(index.long(), mask.nonzero().squeeze(1))
+    for f, o in zip(fields, outs):
+        assert o.dtype == f.dtype and torch.equal(o, f[mask])
+    for m in (torch.zeros_like(mask), torch.ones_like(mask)):
+        o, = ops.compact_rows(m, fields[:1])
+        assert torch.equal(o, fields[0][m])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_to_points_valid_weights_and_bounds_in_one_pass(dev, dtype):
+    """dc_to_points = vps + depth * dirs with torch's two roundings (bit-equal), per-point and single viewpoints; dc_valid_weights =
+    (neighbors >= 0).float(); dc_mask_bounds_multi = the bounds of dc_mask_bounds one after the other, written or ANDed."""
+    from depth_correction_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(11)
+    n = 70_001
+    dirs = torch.nn.functional.normalize(torch.randn((n, 3), generator=g), dim=1).to(dtype).to(dev)
+    depth = (torch.rand((n, 1), generator=g) * 30).to(dtype).to(dev)
+    for vps in (torch.randn((n, 3), generator=g).to(dtype).to(dev), torch.tensor([[0.1, -0.2, 0.3]], dtype=dtype, device=dev)):
+        assert torch.equal(ops.to_points(vps, dirs, depth), vps + depth * dirs)
+    nbr = torch.randint(-1, 50, (n, 7), generator=g, dtype=torch.int32).to(dev)
+    w = ops.valid_weights(nbr)
+    assert w.shape == (n, 7, 1) and torch.equal(w, (nbr >= 0).float()[..., None])
+    ev = torch.rand((n, 3), generator=g).to(dtype).to(dev)
+    ev[5, 1] = float('nan')
+    bounds = [(0, None, 0.05, None), (1, None, None, 0.9), (0, 1, 0.0, 0.25), (1, 2, float('nan'), 4.0)]
+    want = torch.ones((n,), dtype=torch.bool, device=dev)
+    for i, j, lo, hi in bounds:
+        ops.mask_bounds(want, ev, i, None if j is None else ev, 0 if j is None else j, lo, hi)
+    assert torch.equal(ops.mask_bounds_all(ev, bounds), want) and 0 < int(want.sum()) < n
+    prior = torch.rand((n,), generator=g).to(dev) < 0.5
+    assert torch.equal(ops.mask_bounds_all(ev, bounds, mask=prior.clone()), want & prior)
+    assert torch.equal(ops.mask_bounds_all(ev, []), torch.ones_like(want))

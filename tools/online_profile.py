@@ -24,18 +24,42 @@ cfg = Config(nn_k=10, nn_r=None, device='cuda:0', float_type='float32', shadow_n
              shadow_angle_bounds=[float(np.radians(5.0)), float('inf')], log_filters=False)
 model = ScaledPolynomial(w=[1e-3, 2e-3], exponent=[2.0, 4.0], device=dev)
 for _ in range(5):
-    correct_cloud(cloud_on_device(raw, dtype=torch.float32, device=dev), model, cfg)
+    correct_cloud(raw, model, cfg)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(50):
-    out = correct_cloud(cloud_on_device(raw, dtype=torch.float32, device=dev), model, cfg)
+    out = correct_cloud(raw, model, cfg)
     torch.cuda.synchronize()
 print('wall per call: %.3f ms' % ((time.perf_counter() - t0) / 50 * 1e3))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(50):
-    out = correct_cloud(cloud_on_device(raw, dtype=torch.float32, device=dev), model, cfg)
+    out = correct_cloud(raw, model, cfg)
     torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats('cumulative').print_stats(28)
+
+# ---- the host's time line of one call: when the mid-way synchronisation (the number of rows the shadow filter kept) returns, when
+# the last launch is queued, when the device is done
+from depth_correction_amd import ops as _ops
+marks = []
+_orig = _ops.scan_prefilter
+def _marked(*a, **k):
+    marks.append(('before scan_prefilter', time.perf_counter()))
+    r = _orig(*a, **k)
+    marks.append(('scan_prefilter returned (sync)', time.perf_counter()))
+    return r
+_ops.scan_prefilter = _marked
+rows = []
+for _ in range(30):
+    del marks[:]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = correct_cloud(raw, model, cfg)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    rows.append([(m[1] - t0) * 1e6 for m in marks] + [(t1 - t0) * 1e6, (t2 - t0) * 1e6])
+med = np.median(np.array(rows), axis=0)
+print('host time line (us, medians of 30): before scan_prefilter %.0f | its synchronisation returned %.0f | all launches queued %.0f | device done %.0f' % tuple(med))

@@ -79,8 +79,15 @@ def main():
                      shadow_angle_bounds=[float(np.radians(5.0)), float('inf')], log_filters=False)
         model = ScaledPolynomial(w=[1e-3, 2e-3], exponent=[2.0, 4.0], device=dev)
         raw = torch.as_tensor(scans[0], device=dev)
+        import time
+        lat = []
         for _ in range(args.reps):
-            correct_cloud(cloud_on_device(raw, dtype=torch.float32, device=dev), model, cfg)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            correct_cloud(raw, model, cfg)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        print('online latency ms: median %.4f  min %.4f  (of %d, the first %.3f)' % (np.median(lat[1:]), min(lat), len(lat), lat[0]))
     elif args.what in ('radius', 'radius25'):
         # ball neighbourhoods (the reference's default): ten room scans, voxel grid 0.2 m, r = 0.4 m / 0.25 m
         from depth_correction_amd.filters import filter_grid
