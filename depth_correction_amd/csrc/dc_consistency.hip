@@ -3462,7 +3462,12 @@ int dc_debug_block_trace(void* buf) {        // diagnostic build only: [4 x grid
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(dc::g_block_trace), &p, sizeof(p));
 }
 #endif
+// The switches exist for A-B measurements and for the tests that hold one path against another; a process that has not asked for them
+// (DC_ENABLE_ABLATIONS=1 in its environment when the library is first used) cannot change them: the product has no mutable
+// process-wide state.
 int dc_set_option(int option, int value) {
+  static const bool enabled = [] { const char* e = getenv("DC_ENABLE_ABLATIONS"); return e && atoi(e) != 0; }();
+  if (!enabled) return DC_ERR_UNSUPPORTED;
   if (option == 0) { g_no_tab.store(value != 0); return DC_OK; }
   if (option == 1) { g_fwd_generic.store(value); return DC_OK; }
   if (option == 3) { g_no_basis.store(value != 0); return DC_OK; }

@@ -1542,8 +1542,17 @@ using namespace dc;
 
 extern "C" {
 
-int dc_knn_set_shell_budget(int shells) { g_knn_budget.store(shells); return DC_OK; }
-int dc_knn_set_fine_cell_count(int points) { g_knn_fine_min.store(points < 1 ? 0x7fffffff : points); return DC_OK; }      // default 14
+// (A-B switches: refused unless the process asked for them with DC_ENABLE_ABLATIONS=1, like dc_set_option)
+static bool knn_ablations_enabled() {
+  static const bool enabled = [] { const char* e = getenv("DC_ENABLE_ABLATIONS"); return e && atoi(e) != 0; }();
+  return enabled;
+}
+int dc_knn_set_shell_budget(int shells) { if (!knn_ablations_enabled()) return DC_ERR_UNSUPPORTED; g_knn_budget.store(shells); return DC_OK; }
+int dc_knn_set_fine_cell_count(int points) {       // default 14
+  if (!knn_ablations_enabled()) return DC_ERR_UNSUPPORTED;
+  g_knn_fine_min.store(points < 1 ? 0x7fffffff : points);
+  return DC_OK;
+}
 
 size_t dc_knn_workspace_bytes(int64_t n, int64_t n_query) {
   if (n < 0 || n_query < 0) return 0;

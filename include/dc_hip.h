@@ -705,7 +705,9 @@ int dc_cloud_from_points(const void* points, int stride, int in_dtype, const voi
 /* NOT thread-safe against launches: the switches are process-wide (one value for every plan and stream).  They exist for A-B
  * measurements and tests in a process that does nothing else meanwhile; a thread flipping one while another thread evaluates gets
  * either variant for that launch (each launch reads them once; results are the same to the stated tolerances, timings are not).
- * Product code never calls dc_set_option. */
+ * Product code never calls dc_set_option -- and cannot: the switches (and dc_knn_set_shell_budget / dc_knn_set_fine_cell_count) return
+ * DC_ERR_UNSUPPORTED unless the process had DC_ENABLE_ABLATIONS=1 in its environment when the library was first used (tests/conftest.py,
+ * bench.py's ablation extras and the tools under tools/ set it); without it the library has no mutable process-wide state. */
 int dc_set_option(int option, int value);
 
 /* ---- kernel timer: when enabled, dc_points_fwd / dc_consistency_fwd / dc_consistency_bwd (kinds 0 / 1 / 2)

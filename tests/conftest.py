@@ -6,6 +6,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the tests hold one path of the library against another (dc_set_option): the switches are locked unless a process asks for them
+os.environ.setdefault('DC_ENABLE_ABLATIONS', '1')
 for p in (ROOT, os.path.join(ROOT, 'oracle')):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -92,3 +92,22 @@ def test_missing_library_fails_loudly(monkeypatch, built):
     monkeypatch.setattr(built, 'lib_path', lambda: '/nonexistent/libdc_hip.so')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         built.lib()
+
+
+def test_ab_switches_are_locked_unless_the_process_asks_for_them():
+    """dc_set_option / dc_knn_set_shell_budget / dc_knn_set_fine_cell_count (A-B measurements, path-against-path tests) are refused
+    (DC_ERR_UNSUPPORTED) in a process without DC_ENABLE_ABLATIONS=1: the product library has no mutable process-wide state.  Host
+    functions: no GPU needed."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); "
+            "print(lib.dc_set_option(3, 0), lib.dc_knn_set_shell_budget(1000), lib.dc_knn_set_fine_cell_count(14))")
+    from depth_correction_amd import _native as nv
+    path = nv.lib_path()
+    for flag, want in ((None, '-4 -4 -4'), ('0', '-4 -4 -4'), ('1', '0 0 0')):
+        env = {k: v for k, v in os.environ.items() if k != 'DC_ENABLE_ABLATIONS'}
+        if flag is not None:
+            env['DC_ENABLE_ABLATIONS'] = flag
+        out = subprocess.run([sys.executable, '-c', code, path], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want, (flag, out.stdout, out.stderr)

@@ -2,6 +2,7 @@
 """k-NN build times (dc_knn_build incl. grid set-up) for the shell budget values given: one 200k-point scan and the 2 M-point
 global cloud, k = 10; and online.correct_cloud on the scan.   python3 tools/knn_bench.py --budget -1 1 2 3"""
 import argparse, json, os, sys, time
+os.environ.setdefault('DC_ENABLE_ABLATIONS', '1')          # this tool flips the library's A-B switches (dc_knn_set_shell_budget)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
