@@ -729,8 +729,8 @@ def main():
             lat.append((time.perf_counter() - t0) * 1e3)
         extras['online_correction'] = {'points_in': int(raw.shape[0]), 'points_out': len(out_cloud),
                                        'latency_ms': float(np.median(lat[1:])), 'first_call_ms': lat[0],
-                                       'what': 'from_points + dir neighbours + shadow filter + k-NN + features + mask + model, '
-                                               'scan resident on the device; median of 5'}
+                                       'what': 'correct_cloud on the uploaded rows: from_points + shadow filter + cloud[mask] (dc_scan_prefilter), k-NN, '
+                                               'features, mask, model, points; scan resident on the device; median of 5'}
 
     if rank == 0:
         timed_region_kernel_ms = {name: v[0] for name, v in kernel_ms.items()}

@@ -1134,7 +1134,11 @@ __global__ __launch_bounds__(kBlock) void shadow_group_kernel(const double* __re
   const T na = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
   const T da = na > eps ? na : eps;
   a0 /= da; a1 /= da; a2 /= da;
-  T amin = (T)INFINITY, amax = -(T)INFINITY;
+  // The extreme ANGLES are the arc cosines of the extreme COSINES (acos does not increase anywhere): the walk keeps the largest and the
+  // smallest cosine and takes two arc cosines per ray at the end instead of one per neighbour (a fifth of the kernel's instructions,
+  // which it issues at 0.86 of the VALU rate).  A cosine an ulp outside [-1, 1] or a NaN -- whose arc cosine is NaN in the reference's
+  // row -- removes the ray as before.
+  T cmax = -(T)INFINITY, cmin = (T)INFINITY;
   bool bad = false;
   int32_t c[3];
   cell_of(g, q, c);
@@ -1181,16 +1185,17 @@ __global__ __launch_bounds__(kBlock) void shadow_group_kernel(const double* __re
           const T db = nb > eps ? nb : eps;
           b0 /= db; b1 /= db; b2 /= db;
           const T cs = a0 * b0 + a1 * b1 + a2 * b2;
-          const T ang = acos(cs);
-          bad = bad || (ang != ang);
-          amin = ang < amin ? ang : amin;
-          amax = ang > amax ? ang : amax;
+          bad = bad || !(cs >= (T)-1 && cs <= (T)1);
+          cmax = cs > cmax ? cs : cmax;
+          cmin = cs < cmin ? cs : cmin;
         }
       }
     }
     if (!done && (shell_bound(g, q, c, r) > rad || !shell_in_grid(g, c, r + 1))) done = true;
   }
-  row_min_max(amin, amax);
+  row_min_max(cmin, cmax);
+  const bool none = cmin > cmax;                     // no neighbour met
+  const T amin = none ? (T)INFINITY : (T)acos(cmax), amax = none ? -(T)INFINITY : (T)acos(cmin);
   const unsigned long long bm = __ballot(bad);
   const bool row_bad = ((unsigned)(bm >> row_lane0) & 0xffffu) != 0u;
   // a ray with no neighbour at all (not even itself: non-finite direction) has an all-fill row in the reference: kept

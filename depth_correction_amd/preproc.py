@@ -43,10 +43,8 @@ def local_feature_cloud(cloud, cfg: Config):
     if isinstance(cloud, torch.Tensor):
         # raw rows [N, >=3] already on the device (what the node holds after the upload of a message)
         if cloud.is_cuda and cloud.dim() == 2 and cloud.dtype in (torch.float32, torch.float64) and cfg.shadow_angle_bounds:
-            cloud = _prefiltered_cloud(cloud.detach(), cfg)
-        else:
-            cloud = DepthCloud.from_points(cloud[:, :3], dtype=cfg.numpy_float_type(), device=cfg.device)
-        return _with_features(cloud, cfg)
+            return _with_features(_prefiltered_cloud(cloud.detach(), cfg), cfg, points_current=True)
+        return _with_features(DepthCloud.from_points(cloud[:, :3], dtype=cfg.numpy_float_type(), device=cfg.device), cfg)
     if isinstance(cloud, np.ndarray):
         make = DepthCloud.from_structured_array if cloud.dtype.names else DepthCloud.from_points
         cloud = make(cloud, dtype=cfg.numpy_float_type(), device=cfg.device)
@@ -87,9 +85,14 @@ def _prefiltered_cloud(raw, cfg: Config):
     return DepthCloud(vps, dirs, depth, points=points)
 
 
-def _with_features(cloud, cfg: Config):
-    """Neighbourhoods, features and the planarity mask (preproc.py:48-63)."""
-    cloud.update_all(k=cfg.nn_k, r=cfg.nn_r)
+def _with_features(cloud, cfg: Config, points_current=False):
+    """Neighbourhoods, features and the planarity mask (preproc.py:48-63).  ``points_current``: cloud.points already are
+    vps + depth * dirs of its fields (dc_scan_prefilter wrote them): update_all's first statement is skipped."""
+    if points_current and cloud.points is not None:
+        cloud.update_neighbors(k=cfg.nn_k, r=cfg.nn_r, _weights=False)
+        cloud.update_features(scale=None)
+    else:
+        cloud.update_all(k=cfg.nn_k, r=cfg.nn_r)
     if cloud.eigvals.is_cuda and not cfg.log_filters and (cfg.eigenvalue_bounds or cfg.eigenvalue_ratio_bounds):
         # the same masks ANDed in place, one kernel per bound (dc_mask_bounds): no ones / and passes between them
         from . import ops

@@ -17,7 +17,8 @@ WANT = {   # workload -> (kernel name fragments, units per launch as text, unit 
     'radius': (['consistency_step_ragged_q32_kernel', 'consistency_step_basis_slots_kernel', 'radius_kernel', 'radius_sort_rows_kernel', 'radius_group_kernel'], '282 303 points, 52.1 M (point, neighbour) pairs (grid 0.2 m, r = 0.4 m)', 52089021),
     'radius25': (['consistency_step_ragged_q32_kernel', 'consistency_step_basis_slots_kernel', 'radius_kernel', 'radius_sort_rows_kernel', 'radius_group_kernel'], '282 303 points, 20.3 M (point, neighbour) pairs (grid 0.2 m, r = 0.25 m)', 20290615),
     'c1': (['features_fwd_tile_kernel<float, 3, 10>', 'features_fwd_kernel<float, 3>'], 'N = 200 000 points', 200000),
-    'online': (['shadow_group_kernel', 'knn_group_kernel', 'knn_tail_kernel', 'features_fwd_tile_kernel', 'features_fwd_kernel', 'correct_depth_kernel', 'mask_bounds_kernel'], 'one 200 000-point scan', 200000),
+    'online': (['shadow_group_kernel', 'knn_group_kernel', 'knn_tail_kernel', 'features_fwd_tile_kernel', 'features_fwd_kernel', 'correct_depth_kernel', 'mask_bounds_multi_kernel', 'cell_keys_kernel', 'sorted_cells_kernel', 'compact_place_kernel', 'scan_direct_kernel',
+               'to_points_kernel'], 'one 200 000-point scan', 200000),
 }
 
 
