@@ -99,8 +99,10 @@ class DepthCloud(object):
             fields = [getattr(self, f) for f in names]
             n = len(self)
             plain = [f.shape[0] == n and not (f.requires_grad and torch.is_grad_enabled()) for f in fields]
-            if item.shape[0] == n and all(plain) and len(fields) <= 8:
-                kept = ops.compact_rows(item, [f.detach() for f in fields])
+            if item.shape[0] == n and all(plain):
+                kept = []
+                for c0 in range(0, len(fields), 8):              # (eight arrays per call)
+                    kept += ops.compact_rows(item, [f.detach() for f in fields[c0:c0 + 8]])
                 return DepthCloud(**dict(zip(names, kept)))
             item = item.nonzero().squeeze(1)
             return DepthCloud(**{f: x.index_select(0, item) if x.shape[0] == n else x[item] for f, x in zip(names, fields)})
