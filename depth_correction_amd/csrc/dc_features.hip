@@ -3,6 +3,7 @@
 // update_normals :409-415, update_incidence_angles :417-424) in one launch, and the hand-derived backward of
 // (mean, cov, eigvals) for the torch.autograd.Function behind it.  C ABI at the bottom (include/dc_hip.h).
 #include <atomic>
+#include <cstdlib>
 #include "dc_common.h"
 #include "dc_device.h"
 #include "dc_pointmath.h"
@@ -319,7 +320,12 @@ static std::atomic<int> g_features_tiled{1};
 
 extern "C" {
 
-int dc_features_set_tiled(int on) { return g_features_tiled.exchange(on ? 1 : 0, std::memory_order_relaxed); }
+// (an A-B switch like dc_set_option: refused -- the setting reported, nothing changed -- unless the process asked for the switches)
+int dc_features_set_tiled(int on) {
+  static const bool enabled = [] { const char* e = getenv("DC_ENABLE_ABLATIONS"); return e && atoi(e) != 0; }();
+  if (!enabled) return g_features_tiled.load(std::memory_order_relaxed);
+  return g_features_tiled.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
 
 int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nbr, int64_t n, int k,
                     const void* mean_weights, double scale, const void* dirs, void* mean, void* cov, void* eigvals,

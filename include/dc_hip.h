@@ -178,7 +178,7 @@ int dc_features_fwd(const void* points, int stride, int dtype, const int32_t* nb
  * of other threads): 0 sends every dc_features_fwd call to the general run-time-k kernel, 1 (default) lets calls with
  * k = 4 / 8 / 10 / 16, validity weights and 16-B aligned arrays take the tiled kernel (features_fwd_tile_kernel: coalesced index
  * tile, k gathers in flight, outputs through LDS).  Same reference lines as dc_features_fwd; results agree to round-off. */
-int dc_features_set_tiled(int on);   /* returns the previous setting */
+int dc_features_set_tiled(int on);   /* returns the previous setting; changes nothing unless DC_ENABLE_ABLATIONS=1 (see dc_set_option) */
 
 /* dL/dpoints from dL/d(mean, cov, eigvals) (any may be NULL); grec_ws: dtype [n,12] scratch. */
 int dc_features_bwd(const void* points, int stride, int dtype, const int32_t* csr_ptr, const int32_t* csr_src,

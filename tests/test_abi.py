@@ -95,16 +95,17 @@ def test_missing_library_fails_loudly(monkeypatch, built):
 
 
 def test_ab_switches_are_locked_unless_the_process_asks_for_them():
-    """dc_set_option / dc_knn_set_shell_budget / dc_knn_set_fine_cell_count (A-B measurements, path-against-path tests) are refused
+    """dc_set_option / dc_knn_set_shell_budget / dc_knn_set_fine_cell_count / dc_features_set_tiled (A-B measurements, path-against-path tests) are refused
     (DC_ERR_UNSUPPORTED) in a process without DC_ENABLE_ABLATIONS=1: the product library has no mutable process-wide state.  Host
     functions: no GPU needed."""
     import subprocess
     import sys
     code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); "
-            "print(lib.dc_set_option(3, 0), lib.dc_knn_set_shell_budget(1000), lib.dc_knn_set_fine_cell_count(14))")
+            "print(lib.dc_set_option(3, 0), lib.dc_knn_set_shell_budget(1000), lib.dc_knn_set_fine_cell_count(14)); "
+            "lib.dc_features_set_tiled(0); print(lib.dc_features_set_tiled(1))")       # (the second call reports what the first left)
     from depth_correction_amd import _native as nv
     path = nv.lib_path()
-    for flag, want in ((None, '-4 -4 -4'), ('0', '-4 -4 -4'), ('1', '0 0 0')):
+    for flag, want in ((None, '-4 -4 -4\n1'), ('0', '-4 -4 -4\n1'), ('1', '0 0 0\n0')):
         env = {k: v for k, v in os.environ.items() if k != 'DC_ENABLE_ABLATIONS'}
         if flag is not None:
             env['DC_ENABLE_ABLATIONS'] = flag

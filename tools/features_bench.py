@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import torch
 
+os.environ.setdefault('DC_ENABLE_ABLATIONS', '1')          # this tool flips the library's A-B switches (dc_features_set_tiled)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
