@@ -639,6 +639,16 @@ __global__ __launch_bounds__(kBlock, KMAX <= 16 ? 4 : 1) void knn_query_kernel(c
 // shell (or when the buffer fills) the k smallest of {current best, buffer} by (distance, index) are extracted by k rounds of a
 // wave-wide lexicographic minimum -- the order knn_query_kernel's sorted insertion produces, so indices and distances are
 // bit-identical.  Same termination rule, same fall-back to a scan of all points beyond r_exhaust shells.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ bool lex_less(double ad, int32_t ai, double bd, int32_t bi) { return ad < bd || (ad == bd && ai < bi); }
+// one step of a row-wide (16 lanes) lexicographic minimum of (distance, index) over DPP
+template <int CTRL>
+__device__ __forceinline__ void lex_min_dpp(double& md, int32_t& mi) {
+  const double od = __hiloint2double(dpp_i32<CTRL>(__double2hiint(md)), dpp_i32<CTRL>(__double2loint(md)));
+  const int32_t oi = dpp_i32<CTRL>(mi);
+  if (lex_less(od, oi, md, mi)) { md = od; mi = oi; }
+}
 constexpr int kTailCap = 320;            // candidate entries per wavefront behind the KMAX best ones
 __device__ __forceinline__ int udiv_small(int a, int d, float inv_d) {      // a / d for 0 <= a < 2^22, d > 0
   int q = (int)((float)a * inv_d);
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
                                                           const int32_t* __restrict__ pending, const int32_t* __restrict__ n_pending,
                                                           const Grid* __restrict__ gp, CellTable tab, int k, double r_max, int64_t n_points,
                                                           int r_exhaust, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
-                                                          int64_t* __restrict__ idx64_out) {
+                                                          int64_t* __restrict__ idx64_out, int seeded_stages) {
   __shared__ double s_d[kWavesPerBlock][KMAX + kTailCap];
   __shared__ int32_t s_i[kWavesPerBlock][KMAX + kTailCap];
   __shared__ double s_nd[kWavesPerBlock][KMAX];
@@ -691,7 +701,10 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
   const int n_pend = *n_pending;
   const double ub2 = r_max > 0.0 ? r_max * r_max : INFINITY;
   for (int wq = blockIdx.x * kWavesPerBlock + wave; wq < n_pend; wq += total_waves) {
-    const int64_t t = pending[wq];
+    // (knn_group_kernel marks the queries it searched at the fine level by the complement of their number)
+    const int32_t tv = pending[wq];
+    const bool fine = tv < 0;
+    const int64_t t = fine ? (int64_t)~tv : (int64_t)tv;
     const double q[3] = {queries[t * 3], queries[t * 3 + 1], queries[t * 3 + 2]};
     const int64_t row = qids ? qids[t] : t;
     int32_t c[3];
@@ -700,34 +713,64 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
     int nc = 0;                                   // candidates behind the k best (wave-uniform)
     double worst_d = INFINITY;
     int32_t worst_i = 0x7fffffff;
-    // the k smallest of pool [0, k + nc) by (distance, index) -> pool [0, k)
+    // the k smallest DISTINCT entries of pool [0, k + nc) by (distance, index) -> pool [0, k).  Every lane takes its (up to kPer) entries
+    // into registers and orders them; every round then pops the wave-wide minimum of the lanes' heads -- four DPP steps inside the rows
+    // of 16, the four row results read lane by lane.  An entry equal to the one before it (a member of the list handed over by
+    // knn_group_kernel met again in its cell) is popped without being written.  (Until round 5 every round re-read the pool from
+    // LDS and reduced over six ds_bpermute steps: 13 us per selection, 21 of the 37 us of a pending query -- timed on the device.)
     auto select = [&]() {
       const int np = k + nc;
-      double last_d = -1.0;
-      int32_t last_i = -1;
-      for (int s = 0; s < k; ++s) {
-        double md = INFINITY;
-        int32_t mi = 0x7fffffff;
-        for (int e = lane; e < np; e += kWave) {
-          const double d = pd[e];
-          const int32_t i = pi[e];
-          const bool gt = d > last_d || (d == last_d && i > last_i);
-          const bool lt = d < md || (d == md && i < mi);
-          if (gt && lt) { md = d; mi = i; }
-        }
+      constexpr int kPer = (KMAX + kTailCap + kWave - 1) / kWave;
+      double hd[kPer];
+      int32_t hi[kPer];
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-          const double od = __shfl_xor(md, off, kWave);
-          const int32_t oi = __shfl_xor(mi, off, kWave);
-          if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
-        }
-        if (lane == 0) { s_nd[wave][s] = md; s_ni[wave][s] = mi; }
-        last_d = md; last_i = mi;
-        if (!(md < INFINITY)) {                    // nothing finite is left: the remaining slots are empty
-          for (int s2 = s + 1 + lane; s2 < k; s2 += kWave) { s_nd[wave][s2] = INFINITY; s_ni[wave][s2] = 0x7fffffff; }
-          break;
+      for (int u = 0; u < kPer; ++u) {
+        const int e = lane + u * kWave;
+        const bool in = e < np;
+        hd[u] = in ? pd[e] : INFINITY;
+        hi[u] = in ? pi[e] : 0x7fffffff;
+      }
+#pragma unroll
+      for (int a = 1; a < kPer; ++a) {
+#pragma unroll
+        for (int b = a; b > 0; --b) {
+          if (lex_less(hd[b], hi[b], hd[b - 1], hi[b - 1])) {
+            const double td = hd[b]; hd[b] = hd[b - 1]; hd[b - 1] = td;
+            const int32_t ti = hi[b]; hi[b] = hi[b - 1]; hi[b - 1] = ti;
+          }
         }
       }
+      double last_d = -1.0;
+      int32_t last_i = -1;
+      int s = 0;
+      for (int round = 0; round < 2 * k + 2 && s < k; ++round) {
+        double md = hd[0];
+        int32_t mi = hi[0];
+        lex_min_dpp<0xB1>(md, mi);
+        lex_min_dpp<0x4E>(md, mi);
+        lex_min_dpp<0x124>(md, mi);
+        lex_min_dpp<0x128>(md, mi);
+        double gd = __shfl(md, 0, kWave);
+        int32_t gi = __shfl(mi, 0, kWave);
+#pragma unroll
+        for (int r = 1; r < kWave / 16; ++r) {
+          const double od = __shfl(md, 16 * r, kWave);
+          const int32_t oi = __shfl(mi, 16 * r, kWave);
+          if (lex_less(od, oi, gd, gi)) { gd = od; gi = oi; }
+        }
+        if (!(gd < INFINITY)) break;               // nothing finite is left: the remaining slots are empty
+        if (!(gd == last_d && gi == last_i)) {
+          if (lane == 0) { s_nd[wave][s] = gd; s_ni[wave][s] = gi; }
+          ++s;
+          last_d = gd; last_i = gi;
+        }
+        if (hd[0] == gd && hi[0] == gi) {          // the lane(s) that held it move on to their next entry
+#pragma unroll
+          for (int u = 0; u + 1 < kPer; ++u) { hd[u] = hd[u + 1]; hi[u] = hi[u + 1]; }
+          hd[kPer - 1] = INFINITY; hi[kPer - 1] = 0x7fffffff;
+        }
+      }
+      for (int s2 = s + lane; s2 < k; s2 += kWave) { s_nd[wave][s2] = INFINITY; s_ni[wave][s2] = 0x7fffffff; }
       wave_sync();
       for (int s = lane; s < k; s += kWave) { pd[s] = s_nd[wave][s]; pi[s] = s_ni[wave][s]; }
       wave_sync();
@@ -747,7 +790,22 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(const double* __restri
     };
     const bool finite_q = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]);
     bool exhaustive = false;
-    for (int r = 0; finite_q && shell_in_grid(g, c, r); ++r) {
+    // seeded_stages > 0: the row of the output tables holds the k best (index, SQUARED distance) knn_group_kernel found in its stages
+    // without settling the query.  A query searched at the coarse level goes on with the first shell those stages did not cover;
+    // one searched at the fine level (half-size cells: less ground covered) walks the coarse shells from its own cell again, the
+    // list only as the threshold that keeps nearly every candidate out of the pool -- its members met again are dropped by select().
+    int r_first = 0;
+    if (seeded_stages > 0) {
+      for (int s = lane; s < k; s += kWave) {
+        const int32_t id = idx_out[row * k + s];
+        pd[s] = id >= 0 ? dist_out[row * k + s] : INFINITY;
+        pi[s] = id >= 0 ? id : 0x7fffffff;
+      }
+      wave_sync();
+      worst_d = pd[k - 1]; worst_i = pi[k - 1];
+      r_first = fine ? 0 : seeded_stages + 1;
+    }
+    for (int r = r_first; finite_q && shell_in_grid(g, c, r); ++r) {
       if (r > r_exhaust) { exhaustive = true; break; }
       const int side = 2 * r + 1, ring = 4 * side - 4;
       const int n_cells = r == 0 ? 1 : 2 * side * side + (side - 2) * ring;
@@ -825,8 +883,6 @@ constexpr int kGrpPerBlock = kBlock / kGrp;
 constexpr int kGrpPool = 64;                       // pool entries per query: four per lane in the selection
 
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
 __device__ __forceinline__ float row_all_min(float m) {
   m = fminf(m, dpp_f32<0xB1>(m));                  // quad_perm [1,0,3,2]
@@ -842,7 +898,6 @@ __device__ __forceinline__ int row_incl_scan(int v) {          // inclusive pref
   v += dpp_i32<0x118>(v);
   return v;
 }
-__device__ __forceinline__ bool lex_less(double ad, int32_t ai, double bd, int32_t bi) { return ad < bd || (ad == bd && ai < bi); }
 template <int CTRL>
 __device__ __forceinline__ int rot_less(double md, int32_t mi) {          // 1 when the entry CTRL lanes away sorts before mine
   const double od = __hiloint2double(dpp_i32<CTRL>(__double2hiint(md)), dpp_i32<CTRL>(__double2loint(md)));
@@ -1079,7 +1134,14 @@ __global__ __launch_bounds__(kBlock, 5) void knn_group_kernel(const double* __re
     int32_t base = 0;
     if (lane == leader) base = atomicAdd(n_pending, (int32_t)__popcll(pm));
     base = __shfl(base, leader, kWave);
-    if (pend) pending[base + (int32_t)__popcll(pm & ((1ull << lane) - 1ull))] = (int32_t)t;
+    if (pend) pending[base + (int32_t)__popcll(pm & ((1ull << lane) - 1ull))] = lv ? (int32_t)~t : (int32_t)t;     // (< 0: fine level)
+  }
+  // an unsettled row hands its best list to knn_tail_kernel through its rows of the output tables: indices as they will stand,
+  // distances SQUARED (the tail kernel writes the roots); without a distance table the tail kernel starts from nothing
+  if (valid && unsettled && dist_out && sub < k) {
+    const bool ok = bi != kNone;
+    idx_out[row * k + sub] = ok ? bi : -1;
+    dist_out[row * k + sub] = ok ? bd : INFINITY;
   }
   if (valid && !unsettled && sub < k) {
     const bool ok = bi != kNone;
@@ -1425,7 +1487,9 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
   const int budget = raw >= 100 ? raw - 100 : raw;
   if (budget < 0) pending = nullptr;
   // (n_pending was zeroed by cell_keys_kernel of the grid build that precedes every call)
+  int seeded = 0;            // stages whose best list knn_group_kernel hands to knn_tail_kernel (through the distance table)
   if (pending && knn_rows_per_query(k)) {
+    seeded = (dist && budget > 0) ? budget : 0;
     const dim3 ggrid((unsigned)((nq + kGrpPerBlock - 1) / kGrpPerBlock));
     hipLaunchKernelGGL(knn_group_kernel, ggrid, block, 0, st, sp, sids, q, qids, nq, g, tab, k, r, idx, dist, budget, pending, n_pending,
                        g_knn_fine_min.load(), fine_flag, idx64);
@@ -1441,7 +1505,7 @@ static int launch_knn(int k, const double* sp, const int32_t* sids, int64_t n, c
     // one wavefront per pending query; their number stays on the device (the grid is fixed, wavefronts stride over the list)
     const int64_t want = (nq + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 tgrid((unsigned)(want < 2048 ? (want < 1 ? 1 : want) : 2048));
-#define LT(KM) hipLaunchKernelGGL((knn_tail_kernel<KM>), tgrid, block, 0, st, sp, sids, q, qids, pending, n_pending, g, tab, k, r, n, r_exhaust, idx, dist, idx64)
+#define LT(KM) hipLaunchKernelGGL((knn_tail_kernel<KM>), tgrid, block, 0, st, sp, sids, q, qids, pending, n_pending, g, tab, k, r, n, r_exhaust, idx, dist, idx64, seeded)
     if (k <= 16) LT(16); else LT(64);
 #undef LT
   }
