@@ -334,6 +334,10 @@ def test_knn_row_per_query_kernel_corner_cases():
             out.append((npy(d), npy(i)))
         for d, i in out[1:]:
             assert np.array_equal(out[0][1], i) and np.array_equal(out[0][0], d)
+        # without a distance table knn_group_kernel has nowhere to hand its best lists over: knn_tail_kernel starts the pending queries
+        # from nothing -- the same table
+        _, i_nd = ops.knn(x, k, r=r, query=query, want_dist=False)
+        assert np.array_equal(out[0][1], npy(i_nd))
         return out[0]
 
     # repeated points: every query has 40 candidates at distance 0 and 40 more at each next distance
