@@ -94,7 +94,8 @@ def _with_features(cloud, cfg: Config, points_current=False):
     else:
         cloud.update_all(k=cfg.nn_k, r=cfg.nn_r)
     if cloud.eigvals.is_cuda and not cfg.log_filters and (cfg.eigenvalue_bounds or cfg.eigenvalue_ratio_bounds):
-        # the same masks ANDed in place, one kernel per bound (dc_mask_bounds): no ones / and passes between them
+        # the same masks without the ones / and passes between them: every bound in one kernel (dc_mask_bounds_multi), or one kernel per
+        # bound ANDed in place (dc_mask_bounds) beyond eight
         from . import ops
         bounds = [(int(e), None, lo, hi) for e, lo, hi in (cfg.eigenvalue_bounds or [])] + \
                  [(int(i), int(j), lo, hi) for i, j, lo, hi in (cfg.eigenvalue_ratio_bounds or [])]
