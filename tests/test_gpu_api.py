@@ -1462,3 +1462,29 @@ def test_polynomial_models_without_gradients_run_one_kernel(golden, name, dtype)
             assert rel <= 2 * eps, rel
             if mask is not None:
                 assert torch.equal(fast[~mask], dc.depth[~mask]) and not torch.equal(fast[mask], dc.depth[mask])
+
+
+@pytest.mark.parametrize('float_type', ['float32', 'float64'])
+def test_local_feature_cloud_of_raw_device_rows_equals_the_cloud_path(golden, float_type):
+    """local_feature_cloud on the uploaded rows [N, 3] (dc_scan_prefilter: from_points, points, shadow mask and cloud[mask] launched by
+    one native call, update_points skipped, the validity weights left to update_features) against the same function on a DepthCloud
+    (the separate calls): every field bit for bit, float32 and float64 clouds, with the eigenvalue bounds of the default
+    configuration and with none."""
+    from depth_correction_amd.config import Config
+    from depth_correction_amd.preproc import local_feature_cloud
+    from depth_correction_amd.scan_io import cloud_on_device
+    g = golden('online')
+    xyz = torch.as_tensor(np.concatenate([g['xyz'], g['xyz'][::7] * 1.01]), device='cuda:0')
+    for bounds in (None, []):
+        kw = {} if bounds is None else dict(eigenvalue_bounds=[], eigenvalue_ratio_bounds=[])
+        cfg = Config(nn_k=8, nn_r=None, float_type=float_type, device='cuda:0', log_filters=False, shadow_neighborhood_angle=0.02,
+                     shadow_angle_bounds=[float(np.radians(4.0)), float('inf')], **kw)
+        a = local_feature_cloud(xyz, cfg)
+        b = local_feature_cloud(cloud_on_device(xyz, dtype=cfg.torch_float_type()), cfg)
+        assert 0 < len(a) == len(b) < len(xyz)
+        for f in ('vps', 'dirs', 'depth', 'points', 'mean', 'cov', 'eigvals', 'eigvecs', 'normals', 'inc_angles', 'mask', 'neighbors',
+                  'weights', 'distances'):
+            x, y = getattr(a, f), getattr(b, f)
+            assert (x is None) == (y is None), f
+            if x is not None:
+                assert x.dtype == y.dtype and torch.equal(x, y), f
