@@ -232,6 +232,12 @@ __device__ void grid_from_box(const double* tot, int64_t n, int k, double cell_h
   }
 }
 
+__global__ void grid_setup_kernel(const double* __restrict__ part, int n_part, int64_t n, int k, double cell_hint, Grid* __restrict__ g) {
+  __shared__ double tot[kBoxVals];
+  combine_box_partials(part, n_part, tot);
+  if (threadIdx.x == 0 && blockIdx.x == 0) grid_from_box(tot, n, k, cell_hint, g);
+}
+
 // Every block finishes the box itself (a few hundred partial rows) and derives the grid from it -- the launch of a one-block set-up
 // kernel between two passes over the points costs more than the 20 MB of cached re-reads --; block 0 stores the grid for the kernels
 // that follow.  The blocks also clear the hash table of the cells (filled after the sort) and the pending-query counter.
@@ -242,11 +248,14 @@ __global__ __launch_bounds__(kBlock) void cell_keys_kernel(const T* __restrict__
                                                            uint64_t* __restrict__ tab_key, uint32_t tab_n, int32_t* __restrict__ n_pending) {
   __shared__ double tot[kBoxVals];
   __shared__ Grid s_g;
-  combine_box_partials(part, n_part, tot);
-  if (threadIdx.x == 0) {
-    grid_from_box(tot, n, k, cell_hint, &s_g);
-    if (blockIdx.x == 0) { *gp = s_g; *n_pending = 0; }
-  }
+  if (n_part > 0) {
+    combine_box_partials(part, n_part, tot);
+    if (threadIdx.x == 0) {
+      grid_from_box(tot, n, k, cell_hint, &s_g);
+      if (blockIdx.x == 0) *gp = s_g;
+    }
+  } else if (threadIdx.x == 0) s_g = *gp;          // (large clouds: grid_setup_kernel ran before -- thousands of blocks re-reading the partials cost more than its launch)
+  if (threadIdx.x == 0 && blockIdx.x == 0) *n_pending = 0;
   for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < tab_n; e += (uint64_t)gridDim.x * kBlock) tab_key[e] = kEmptyKey;
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1452,8 +1461,11 @@ static int build_grid(const T* xyz, int stride, int64_t n, int k, double cell_hi
   const int64_t want_box = (n + 4 * kBlock - 1) / (4 * kBlock);
   const int n_box = (int)(want_box < 1 ? 1 : (want_box > kBoxBlocks ? kBoxBlocks : want_box));
   hipLaunchKernelGGL((bbox_partial_kernel<T>), dim3(n_box), dim3(kBlock), 0, st, xyz, stride, n, w.part);
-  hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, (const double*)w.part, n_box, k, cell_hint, w.grid,
-                     w.keys, w.ids, w.tab_key, w.tab_n, w.n_pending);
+  // (one scan: every key block derives the grid itself, a launch saved; from half a million points on the set-up kernel is the cheaper way)
+  const bool own_setup = n <= 500000;
+  if (!own_setup) hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(kBlock), 0, st, (const double*)w.part, n_box, n, k, cell_hint, w.grid);
+  hipLaunchKernelGGL((cell_keys_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, (const double*)w.part, own_setup ? n_box : 0, k, cell_hint,
+                     w.grid, w.keys, w.ids, w.tab_key, w.tab_n, w.n_pending);
   DC_HIP(sort_pairs_u32(w.sort_tmp, w.sort_bytes, w.keys, w.skeys, w.ids, w.sids, (size_t)n, 0, kGridKeyBits, st));
   hipLaunchKernelGGL((sorted_cells_kernel<T>), dim3(nb), dim3(kBlock), 0, st, xyz, stride, n, w.skeys, w.sids, w.sp, w.tab_key, w.tab_s,
                      w.tab_n - 1);
