@@ -657,8 +657,34 @@ __device__ __forceinline__ double adam_one(double p0, double& m, double& v, doub
 __device__ __forceinline__ void pose_train_finish_block(const PoseTrainArgs& a, double* lds) {
   const int S = a.n_scans, P = a.n_terms, tid = threadIdx.x;
   const int n_sums = a.n_sums;
+  // Everything a thread needs is requested up front -- its pose's correction, reference pose, gradient rows and Adam moments, the
+  // step counter, the weights' state -- and held in registers: the block is ONE wavefront's worth of work at the end of an
+  // iteration, and every dependent round trip to memory (there were six: the counter for the record's row, the record, the inputs,
+  // the moments, the corrections after the update, T_next read back for P12_next) is a microsecond of the loop's critical path.
+  const int64_t step0 = *a.step;
+  const bool per_pose = a.n_deltas != 1;
+  const bool mine = tid < S;                                   // (S <= kBlock poses take the register path; more: the loops below)
+  double dl[6] = {0, 0, 0, 0, 0, 0}, Av[16], Gv[12], mv[6], vv[6];
+  const double* gT = a.sums + a.grad_T_off;
+  if (mine) {
+    const double* d6 = a.delta + (per_pose ? (int64_t)tid * 6 : 0);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dl[q] = d6[q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Av[q] = a.T0[(int64_t)tid * 16 + q];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) Gv[q] = gT[(int64_t)tid * 12 + q];
+    if (per_pose) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { mv[q] = a.d_m[(int64_t)tid * 6 + q]; vv[q] = a.d_v[(int64_t)tid * 6 + q]; }
+    }
+  }
+  const bool step_w = a.w && tid < P && a.lr_w != 0.0;         // (lr_w = 0: weights that are recorded, not optimised)
+  double w0 = 0.0, wm = 0.0, wv = 0.0, gw = 0.0;
+  if (step_w) { w0 = a.w[tid]; wm = a.w_m[tid]; wv = a.w_v[tid]; gw = a.totals ? a.totals[2 + tid] : a.sums[a.grad_w_off + tid]; }
+  const double divisor = a.totals ? a.totals[1] : (a.count_index >= 0 ? a.sums[a.count_index] : 1.0);
   if (a.record) {
-    double* r = a.record + (*a.step % a.ring_rows) * (int64_t)(n_sums + P + 6 * a.n_deltas + 12 * S + a.n_rec_extra);
+    double* r = a.record + (step0 % a.ring_rows) * (int64_t)(n_sums + P + 6 * a.n_deltas + 12 * S + a.n_rec_extra);
     for (int q = tid; q < n_sums; q += kBlock) r[q] = a.sums[q];
     r += n_sums;
     for (int q = tid; q < P; q += kBlock) r[q] = a.w ? a.w[q] : 0.0;
@@ -670,43 +696,54 @@ __device__ __forceinline__ void pose_train_finish_block(const PoseTrainArgs& a, 
     for (int q = tid; q < a.n_rec_extra; q += kBlock) r[q] = a.rec_extra[q];
   }
   __syncthreads();                                             // the record holds what this iteration USED: copied before any update
-  const double t = (double)(*a.step + 1);
+  const double t = (double)(step0 + 1);
   const double bias1 = 1.0 - pow(a.b1, t), bias2_sqrt = sqrt(1.0 - pow(a.b2, t));
-  const double gscale = a.totals ? 1.0 / a.totals[1] : (a.count_index >= 0 ? 1.0 / a.sums[a.count_index] : 1.0);
-  const double* gT = a.sums + a.grad_T_off;
+  const double gscale = (a.totals || a.count_index >= 0) ? 1.0 / divisor : 1.0;
   double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int p = tid; p < S; p += kBlock) {
-    const double* d6 = a.delta + (a.n_deltas == 1 ? 0 : (int64_t)p * 6);
-    const double* A = a.T0 + (int64_t)p * 16;
-    const double* G = gT + (int64_t)p * 12;                    // rows 0..2 of dL/dT (its last row is zero)
+    if (p != tid) {                                            // (a pose beyond the first kBlock: fetched here)
+      const double* d6 = a.delta + (per_pose ? (int64_t)p * 6 : 0);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dl[q] = d6[q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Av[q] = a.T0[(int64_t)p * 16 + q];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) Gv[q] = gT[(int64_t)p * 12 + q];
+      if (per_pose) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { mv[q] = a.d_m[(int64_t)p * 6 + q]; vv[q] = a.d_v[(int64_t)p * 6 + q]; }
+      }
+    }
+    const double* A = Av;
+    const double* G = Gv;                                      // rows 0..2 of dL/dT (its last row is zero)
     double R[9], gR[9], g6[6];
     PoseChain c;
-    pose_chain_fwd(d6, R, c);
+    pose_chain_fwd(dl, R, c);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) gR[i * 3 + b] = (A[i] * G[b] + A[4 + i] * G[4 + b] + A[8 + i] * G[8 + b]) * gscale;
       g6[i] = (A[i] * G[3] + A[4 + i] * G[7] + A[8 + i] * G[11]) * gscale;
     }
-    pose_chain_bwd(d6, c, gR, g6 + 3);
+    pose_chain_bwd(dl, c, gR, g6 + 3);
     if (a.zero_first && p == 0) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) g6[q] = 0.0;
     }
-    if (a.n_deltas == 1) {
+    if (!per_pose) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) acc[q] += g6[q];
     } else {
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const int64_t i = (int64_t)p * 6 + q;
-        double m = a.d_m[i], v = a.d_v[i];
-        a.delta[i] = adam_one(a.delta[i], m, v, g6[q], a.lr_d, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
-        a.d_m[i] = m; a.d_v[i] = v;
+        dl[q] = adam_one(dl[q], mv[q], vv[q], g6[q], a.lr_d, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+        a.delta[i] = dl[q];
+        a.d_m[i] = mv[q]; a.d_v[i] = vv[q];
       }
     }
   }
-  if (a.n_deltas == 1) {                                       // one correction for the whole sequence: its gradient is the sum
+  if (!per_pose) {                                             // one correction for the whole sequence: its gradient is the sum
     block_sum<6>(acc, lds);                                      // (the totals are thread 0's)
     if (tid == 0) {
 #pragma unroll
@@ -717,27 +754,35 @@ __device__ __forceinline__ void pose_train_finish_block(const PoseTrainArgs& a, 
       }
     }
   }
-  if (a.w && tid < P && a.lr_w != 0.0) {                       // (lr_w = 0: weights that are recorded, not optimised)
-    double m = a.w_m[tid], v = a.w_v[tid];
-    const double gw = a.totals ? a.totals[2 + tid] : a.sums[a.grad_w_off + tid];
-    a.w[tid] = adam_one(a.w[tid], m, v, gw * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
-    a.w_m[tid] = m; a.w_v[tid] = v;
+  if (step_w) {
+    a.w[tid] = adam_one(w0, wm, wv, gw * gscale, a.lr_w, a.b1, a.b2, a.eps, bias1, bias2_sqrt);
+    a.w_m[tid] = wm; a.w_v[tid] = wv;
   }
   __syncthreads();                                             // the corrections are updated; the step counter and T_used have been read
   if (tid == 0) *a.step = (int64_t)t;
   for (int p = tid; p < S; p += kBlock) {
-    const double* d6 = a.delta + (a.n_deltas == 1 ? 0 : (int64_t)p * 6);
-    const double* A = a.T0 + (int64_t)p * 16;
-    double R[9];
+    // (the registers still hold this pose's updated correction and reference pose when every thread had one pose at most)
+    if (!per_pose || S > kBlock) {                             // the shared correction, or more poses than threads: as stored
+      const double* d6 = a.delta + (per_pose ? (int64_t)p * 6 : 0);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dl[q] = d6[q];
+    }
+    if (S > kBlock) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Av[q] = a.T0[(int64_t)p * 16 + q];
+    }
+    const double* A = Av;
+    double R[9], o[16];
     PoseChain c;
-    pose_chain_fwd(d6, R, c);
-    double* o = a.T_next + (int64_t)p * 16;
+    pose_chain_fwd(dl, R, c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) o[i * 4 + b] = A[i * 4] * R[b] + A[i * 4 + 1] * R[3 + b] + A[i * 4 + 2] * R[6 + b];
-      o[i * 4 + 3] = A[i * 4] * d6[0] + A[i * 4 + 1] * d6[1] + A[i * 4 + 2] * d6[2] + A[i * 4 + 3];
+      o[i * 4 + 3] = A[i * 4] * dl[0] + A[i * 4 + 1] * dl[1] + A[i * 4 + 2] * dl[2] + A[i * 4 + 3];
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a.T_next[(int64_t)p * 16 + q] = o[q];
 #pragma unroll
     for (int q = 0; q < 12; ++q) a.P12_next[(int64_t)p * 12 + q] = o[q];
   }
@@ -767,6 +812,8 @@ __global__ __launch_bounds__(kBlock) void p2plane_seq_fused_kernel(IcpSeqArgs ar
   __shared__ double lds[kWavesPerBlock * kIcpGroups * 8];
   __shared__ double s_part[kIcpPhases][kIcpAcc];
   __shared__ double s_pair[kIcpSeqPairs][kIcpAcc];
+  constexpr int kOutLds = 1 + 2 * DC_MAX_MODEL_TERMS + 12 * 32;      // `out` of up to 32 scans, kept for the finishing step
+  __shared__ double s_out[kOutLds];
   __shared__ int s_last;
   const int b = blockIdx.x, tid = threadIdx.x;
   int p = 0;
@@ -848,10 +895,12 @@ __global__ __launch_bounds__(kBlock) void p2plane_seq_fused_kernel(IcpSeqArgs ar
       }
     }
     out[dst] = x;
+    if (n_out <= kOutLds) s_out[dst] = x;
   }
   if (!with_finish) return;
   __threadfence_block();
-  __syncthreads();                              // `out` is what the finishing step reads as its sums
+  __syncthreads();                              // `out` is what the finishing step reads as its sums -- from LDS where it fits: reading
+  if (n_out <= kOutLds) fin.sums = s_out;       // back what this block has just stored is a round trip to memory on the critical path
   pose_train_finish_block(fin, lds);
 }
 
