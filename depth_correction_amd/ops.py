@@ -666,6 +666,8 @@ def mask_bounds_all(values, bounds, mask=None):
     """bool [N]: every ``(num_index, den_index | None, lo, hi)`` of ``bounds`` on the columns of ``values`` [N, C] in ONE pass
     (dc_mask_bounds_multi), ANDed into ``mask`` when given (in place), else into a new mask."""
     n = values.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.bool, device=values.device) if mask is None else mask
     v2 = values.reshape(n, -1)
     need(v2, (n, None), name='values')
     init = mask is None

@@ -1488,3 +1488,8 @@ def test_local_feature_cloud_of_raw_device_rows_equals_the_cloud_path(golden, fl
             assert (x is None) == (y is None), f
             if x is not None:
                 assert x.dtype == y.dtype and torch.equal(x, y), f
+    # an empty scan and one with a single ray go through both ways in
+    for n in (0, 1):
+        few = xyz[:n].contiguous()
+        a, b = local_feature_cloud(few, cfg), local_feature_cloud(cloud_on_device(few, dtype=cfg.torch_float_type()), cfg)
+        assert len(a) == len(b) == n and a.neighbors.shape == b.neighbors.shape == (n, 8)
